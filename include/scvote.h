@@ -1,0 +1,164 @@
+/*
+ * scvote.h -- C ABI of the MI355X-native self-consistency aggregation engine.
+ *
+ * This is the drop-in boundary for ONE hot path of hughbzhang/o1_inference_scaling_laws:
+ * the majority-vote / tie-aware scoring / per-budget reduction behind
+ *
+ *     o1.py:167  process_single_example(example, token_limit, cache, N) -> (score, total_tokens)
+ *     o1.py:216  run_experiments(dataset, cache, token_limit, N)        -> (accuracy, avg_tokens_used)
+ *
+ * The reference has no FFI of its own (it is 421 lines of Python); these entry points are what a
+ * ctypes binding for that path binds (see INTEGRATION.md for the stub a maintainer adds to o1.py).
+ * Everything here is plain C: pointers, sizes, fixed-width integers.  No torch / numpy types.
+ *
+ * Data model:
+ *   answers  int32 [P, B, N]  row-major, N contiguous.  One element = one sample-vote.
+ *                             Value domain: bins 0..1023 (AIME answers 0..999 + 24 spare bins the
+ *                             host-side extractor uses to dictionary-encode out-of-domain ints).
+ *   tokens   int32 [P, B, N]  optional second stream (completion tokens of each sample).
+ *   n_valid  int32 [B]        optional: budget b votes over the prefix answers[p,b,0:n_valid[b]]
+ *                             (o1.py:274-276: N = token_limit // min(2**11, token_limit)).
+ *   truth    int32 [P]        ground-truth bin of each problem (o1.py:206 int(example['answer'])).
+ *
+ * Per (problem, budget) cell the engine produces one scv_cell; per budget it produces integer
+ * counters from which the host computes the reference's floats in ONE canonical order
+ * (o1.py:244-245).  All device outputs are integers => bit-exact at any GPU count.
+ */
+#ifndef SCVOTE_H
+#define SCVOTE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCV_NUM_BINS 1024         /* histogram bins per cell (0..999 answers + 24 spare)        */
+#define SCV_TIE_CLASSES 1025      /* tie_class_hits[b][m], m = n_modes in 0..1024               */
+
+/* mem_kind: where every pointer argument of a call lives. */
+#define SCV_MEM_HOST 0            /* host pointers; the library stages through HBM and syncs    */
+#define SCV_MEM_DEVICE 1          /* device pointers; async on the ctx stream, caller syncs     */
+
+/* scv_create flags */
+#define SCV_FLAG_TIMING 0x1u      /* record hipEvents around every aggregation kernel launch    */
+#define SCV_FLAG_CLAMP_TO_INVALID_BIN 0x2u /* out-of-domain votes go to bin 1023, no error      */
+
+/* synthetic distributions */
+#define SCV_DIST_UNIFORM 0        /* D0: uniform over 0..999                                    */
+#define SCV_DIST_PEAKED 1         /* D1: truth w.p. q_p in {.1...7}, 4 distractors at .05, rest uniform */
+#define SCV_DIST_DEGENERATE 2     /* D2: every vote == truth[p]                                 */
+#define SCV_DIST_TIE 3            /* D3: exact 2-/3-way ties, with and without truth among them */
+
+/* error codes: 0 ok; -(hipError_t) for HIP failures; the following for argument/data errors. */
+#define SCV_OK 0
+#define SCV_ERR_ARG (-2001)           /* null/negative/oversized argument                       */
+#define SCV_ERR_DOMAIN (-2002)        /* a vote outside 0..1023 was seen (results are invalid)  */
+#define SCV_ERR_NO_DEVICE (-2003)     /* no HIP device visible                                  */
+#define SCV_ERR_NOT_TIMED (-2004)     /* scv_last_kernel_ns without SCV_FLAG_TIMING / no launch */
+#define SCV_ERR_ALLOC (-2005)         /* device allocation failed                               */
+
+/*
+ * Result of one (problem, budget) cell.  Replaces the return value of
+ * statistics.multimode(answers) + the scoring at o1.py:202-213:
+ *   score = hit ? 1.0 / n_modes : 0          (o1.py:206,210)
+ * truth_count (= histogram[truth]) is the c of the pass@k estimator.
+ */
+typedef struct scv_cell {
+    uint32_t max_count;   /* count of the modal value(s); 0 iff the cell had no valid votes   */
+    uint32_t truth_count; /* votes equal to truth[p]                                           */
+    uint16_t n_modes;     /* len(statistics.multimode(answers)); 0 iff max_count == 0          */
+    int16_t  min_mode;    /* smallest modal bin, -1 iff max_count == 0                         */
+    uint8_t  hit;         /* truth[p] in multimode(answers)                                    */
+    uint8_t  pad[3];
+} scv_cell;               /* 16 bytes */
+
+typedef struct scv_ctx scv_ctx;   /* opaque: device, stream, scratch, timing events           */
+
+/* Create a context bound to `device` (-1 = current HIP device).  One ctx per GPU per process. */
+int scv_create(scv_ctx** out, int device, uint32_t flags);
+int scv_destroy(scv_ctx* ctx);
+
+/* Borrow an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+int scv_set_stream(scv_ctx* ctx, void* hip_stream);
+/* Block until everything queued on the ctx stream has finished; reports SCV_ERR_DOMAIN if a
+ * DEVICE-mode aggregation since the last sync saw an out-of-domain vote. */
+int scv_sync(scv_ctx* ctx);
+
+/*
+ * Kernel tuning knobs (for A/B measurement; 0 / negative = keep current):
+ *   copies        LDS sub-histogram replication R in {4,8,16,32}
+ *   threads       workgroup size in {256,512,1024}
+ *   wg_per_cu     persistent workgroups per CU
+ *   unroll        16-byte loads in flight per lane in {1,2,4,8}
+ */
+int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unroll);
+
+/*
+ * The hot path.  Replaces, for all P problems and B budgets at once,
+ *   o1.py:181-195 (vote collection + token sum), o1.py:202 (statistics.multimode),
+ *   o1.py:204-213 (tie-aware score) and the integer part of o1.py:229-245 (per-budget sums).
+ *
+ * Outputs (any may be NULL):
+ *   cells_out            scv_cell [P, B]
+ *   cell_tokens_out      int64    [P, B]   sum of tokens over the valid prefix (o1.py:195)
+ *   tie_class_hits_out   int64    [B, 1025] #problems with hit and n_modes == m  (o1.py:238-239)
+ *   token_sum_out        int64    [B]       sum over problems of cell_tokens     (o1.py:240,245)
+ *   truth_count_sum_out  int64    [B]       sum over problems of truth_count
+ * In DEVICE mode the three per-budget outputs are ACCUMULATED INTO (+=), so a caller streaming
+ * problem-chunks (or ranks before an all-reduce) zeroes them once; in HOST mode they are overwritten.
+ */
+int scv_aggregate_i32(scv_ctx* ctx,
+                      const int32_t* answers, const int32_t* tokens,
+                      const int32_t* n_valid, const int32_t* truth,
+                      int64_t P, int32_t B, int64_t N, int mem_kind,
+                      scv_cell* cells_out, int64_t* cell_tokens_out,
+                      int64_t* tie_class_hits_out, int64_t* token_sum_out,
+                      int64_t* truth_count_sum_out);
+
+/*
+ * Problem-level bootstrap (new semantics, not in the reference).  For resample
+ * r in [r_begin, r_end): draw P problem indices idx_j = mulhi32(hi32(mix64(seed + G*(r*P+j+1))), P)
+ * and count, per budget, hits by tie class.  counts_out int64 [r_end-r_begin, B, M]; a drawn hit
+ * with n_modes >= M returns SCV_ERR_ARG (pick M = 1 + largest class present in tie_class_hits).
+ * cells is scv_cell [P, B].  Pointers follow mem_kind.
+ */
+int scv_bootstrap(scv_ctx* ctx, const scv_cell* cells, int64_t P, int32_t B,
+                  int32_t r_begin, int32_t r_end, uint64_t seed, int32_t M, int mem_kind,
+                  int64_t* counts_out);
+
+/*
+ * Closed-form integer synthetic generator, evaluated ON DEVICE (config C3 is 335.5 GB and cannot
+ * be shipped).  Element (p, b, i) depends only on (seed, dist, p_offset + p, b, i, B, N), so shards
+ * and the CPU mirror (o1_inference_scaling_laws_amd/synth.py) produce identical tensors.
+ *   mix64 = splitmix64 finaliser, G = 0x9E3779B97F4A7C15, mulhi32(a, n) = (a * n) >> 32
+ *   k_p   = mix64((seed ^ 0x5851F42D4C957F2D) + G * (p + 1))
+ *   truth = mulhi32(lo32(k_p), 1000);  q_num = 1 + hi32(k_p) % 7;  d_j = mulhi32(lo32(mix64(k_p + G*(j+1))), 1000)
+ *   u     = mix64(seed + G * (((p*B + b) * N + i) + 1)),  uv = mulhi32(lo32(u), 1000)
+ *   D0: uv.  D1: x = hi32(u); x < q_num*429496729 -> truth; else (x - that) < 4*214748364 -> d_[(x-that)/214748364]; else uv.
+ *   D2: truth.  D3: m = 2 + (p & 1); base = ((p >> 1) & 1) ? (truth + 500) % 1000 : truth;
+ *       i < (N / m) * m -> (base + 37 * (i % m)) % 1000, else (base + 999) % 1000.
+ *   tokens: 100 + mulhi32(hi32(mix64(u ^ G)), 11901)                       (100..12000)
+ * All pointers are DEVICE pointers (any may be NULL); async on the ctx stream.
+ */
+int scv_synth_fill_i32(scv_ctx* ctx, int32_t* answers, int32_t* tokens, int32_t* truth,
+                       int64_t P, int32_t B, int64_t N, int64_t p_offset,
+                       uint64_t seed, int dist);
+
+/* Duration of the most recent aggregation kernel launch on this ctx, from hipEvents recorded on
+ * the launch stream (needs SCV_FLAG_TIMING).  Blocks until that launch has finished. */
+int scv_last_kernel_ns(scv_ctx* ctx, uint64_t* ns_out);
+/* Sum and count of all timed launches since the previous call (resets the accumulators). */
+int scv_drain_kernel_ns(scv_ctx* ctx, uint64_t* total_ns_out, uint64_t* launches_out);
+
+int scv_device_count(void);
+/* Static properties of the ctx device: [0]=CU count, [1]=LDS bytes per workgroup max, [2]=clock kHz, [3]=HBM bytes. */
+int scv_device_info(scv_ctx* ctx, int64_t info_out[4]);
+const char* scv_last_error(void);   /* thread-local, never NULL */
+const char* scv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCVOTE_H */

@@ -1,0 +1,70 @@
+"""ctypes binding of include/scvote.h.  Fails loudly when the HIP library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from ._build import LIB_PATH
+
+_lib = None
+
+# include/scvote.h constants
+MEM_HOST, MEM_DEVICE = 0, 1
+FLAG_TIMING, FLAG_CLAMP = 0x1, 0x2
+DIST_UNIFORM, DIST_PEAKED, DIST_DEGENERATE, DIST_TIE = 0, 1, 2, 3
+NUM_BINS, TIE_CLASSES = 1024, 1025
+OK, ERR_ARG, ERR_DOMAIN, ERR_NO_DEVICE, ERR_NOT_TIMED, ERR_ALLOC = 0, -2001, -2002, -2003, -2004, -2005
+
+
+class ScvError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"scvote error {code}: {message}")
+        self.code = code
+
+
+class DomainError(ScvError, ValueError):
+    """A vote outside bins 0..1023 reached the engine (SCV_ERR_DOMAIN)."""
+
+
+def load():
+    """dlopen csrc/libscvote.so and declare every entry point of include/scvote.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    p, i32, i64, u32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
+    L.scv_create.argtypes = [C.POINTER(p), C.c_int, u32]
+    L.scv_destroy.argtypes = [p]
+    L.scv_set_stream.argtypes = [p, p]
+    L.scv_sync.argtypes = [p]
+    L.scv_set_tuning.argtypes = [p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.scv_aggregate_i32.argtypes = [p, p, p, p, p, i64, i32, i64, C.c_int, p, p, p, p, p]
+    L.scv_bootstrap.argtypes = [p, p, i64, i32, i32, i32, u64, i32, C.c_int, p]
+    L.scv_synth_fill_i32.argtypes = [p, p, p, p, i64, i32, i64, i64, u64, C.c_int]
+    L.scv_last_kernel_ns.argtypes = [p, C.POINTER(u64)]
+    L.scv_drain_kernel_ns.argtypes = [p, C.POINTER(u64), C.POINTER(u64)]
+    L.scv_device_count.argtypes = []
+    L.scv_device_info.argtypes = [p, C.POINTER(i64 * 4)]
+    L.scv_last_error.argtypes = []
+    L.scv_last_error.restype = C.c_char_p
+    L.scv_version.argtypes = []
+    L.scv_version.restype = C.c_char_p
+    for name in ("scv_create", "scv_destroy", "scv_set_stream", "scv_sync", "scv_set_tuning", "scv_aggregate_i32",
+                 "scv_bootstrap", "scv_synth_fill_i32", "scv_last_kernel_ns", "scv_drain_kernel_ns",
+                 "scv_device_count", "scv_device_info"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc == OK:
+        return
+    msg = load().scv_last_error().decode("utf-8", "replace")
+    if rc == ERR_DOMAIN:
+        raise DomainError(rc, msg)
+    raise ScvError(rc, msg)

@@ -1,0 +1,445 @@
+// scvote.hip -- C ABI (include/scvote.h) over the gfx950 kernels in scvote_kernels.hip.h.
+//
+// Host-side responsibilities: argument validation, launch geometry (persistent grid sized from
+// the CU count), variant dispatch for A/B tuning, hipEvent timing on the launch stream, and the
+// HOST-memory staging path.  No C++ exception crosses the ABI; every entry returns 0 or a
+// negative code and sets a thread-local message.
+#include "scvote_kernels.hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define SCV_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? SCV_ERR_ALLOC : -(int)e_, "%s: %s", #expr,     \
+                        hipGetErrorString(e_));                                                    \
+    } while (0)
+
+struct EventPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct scv_ctx {
+    int device = 0;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    int64_t lds_max = 65536;
+    int64_t clock_khz = 0;
+    int64_t hbm_bytes = 0;
+    // tuning
+    int copies = 16, threads = 512, wg_per_cu = 2, unroll = 4;
+    // device scratch
+    uint32_t* d_err = nullptr;
+    bool err_dirty = false;
+    // timing
+    std::vector<EventPair> events;
+    size_t events_used = 0;
+    // HOST-mode staging (grown on demand)
+    void* d_stage = nullptr;
+    size_t d_stage_bytes = 0;
+};
+
+namespace {
+
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+bool valid_copies(int c) { return c == 8 || c == 16 || c == 32; }
+bool valid_threads(int t) { return t == 256 || t == 512 || t == 1024; }
+bool valid_unroll(int u) { return u == 2 || u == 4 || u == 8; }
+
+using KernelFn = void (*)(const scv::AggArgs);
+
+template <int RL2, int T, int U>
+KernelFn pick_tok(bool tok) {
+    return tok ? (KernelFn)scv::scv_hist_argmax<RL2, T, U, true> : (KernelFn)scv::scv_hist_argmax<RL2, T, U, false>;
+}
+template <int RL2, int T>
+KernelFn pick_u(int u, bool tok) {
+    switch (u) {
+    case 2: return pick_tok<RL2, T, 2>(tok);
+    case 8: return pick_tok<RL2, T, 8>(tok);
+    default: return pick_tok<RL2, T, 4>(tok);
+    }
+}
+template <int RL2>
+KernelFn pick_t(int t, int u, bool tok) {
+    switch (t) {
+    case 256: return pick_u<RL2, 256>(u, tok);
+    case 1024: return pick_u<RL2, 1024>(u, tok);
+    default: return pick_u<RL2, 512>(u, tok);
+    }
+}
+KernelFn pick_kernel(int copies, int t, int u, bool tok) {
+    switch (copies) {
+    case 8: return pick_t<3>(t, u, tok);
+    case 32: return pick_t<5>(t, u, tok);
+    default: return pick_t<4>(t, u, tok);
+    }
+}
+
+int set_device(scv_ctx* ctx) {
+    SCV_HIP(hipSetDevice(ctx->device));
+    return SCV_OK;
+}
+
+// Launch the hot-path kernel on device pointers.  Accumulates into the per-budget counters.
+int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
+                     const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells,
+                     int64_t* cell_tokens, int64_t* tie, int64_t* tok_sum, int64_t* truth_sum) {
+    const int64_t ncells = P * (int64_t)B;
+    if (ncells == 0) return SCV_OK;
+    scv::AggArgs a;
+    a.answers = answers; a.tokens = tokens; a.n_valid = n_valid; a.truth = truth;
+    a.ncells = ncells; a.N = N; a.B = B;
+    a.cells = cells; a.cell_tokens = cell_tokens;
+    a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
+    a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
+    a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
+    a.err_flag = ctx->d_err;
+
+    int copies = ctx->copies, threads = ctx->threads;
+    size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords) * sizeof(uint32_t);
+    if ((int64_t)lds > ctx->lds_max) return fail(SCV_ERR_ARG, "LDS request %zu exceeds device limit %lld", lds, (long long)ctx->lds_max);
+    // a workgroup needs lds bytes; cap residency so the persistent grid is what actually runs
+    int wg_per_cu = ctx->wg_per_cu;
+    const int by_lds = (int)((160 * 1024) / lds);
+    const int by_waves = 2048 / threads;
+    if (wg_per_cu > by_lds) wg_per_cu = by_lds;
+    if (wg_per_cu > by_waves) wg_per_cu = by_waves;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    int64_t grid = (int64_t)ctx->num_cus * wg_per_cu;
+    if (grid > ncells) grid = ncells;
+
+    KernelFn fn = pick_kernel(copies, threads, ctx->unroll, tokens != nullptr);
+    SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+
+    EventPair* ev = nullptr;
+    if (ctx->flags & SCV_FLAG_TIMING) {
+        if (ctx->events_used == ctx->events.size()) {
+            EventPair np;
+            SCV_HIP(hipEventCreate(&np.a));
+            SCV_HIP(hipEventCreate(&np.b));
+            ctx->events.push_back(np);
+        }
+        ev = &ctx->events[ctx->events_used++];
+        SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)threads), lds, ctx->stream, a);
+    SCV_HIP(hipGetLastError());
+    if (ev) SCV_HIP(hipEventRecord(ev->b, ctx->stream));
+    ctx->err_dirty = true;
+    return SCV_OK;
+}
+
+// Read and clear the device error word (stream must be idle).
+int fetch_err(scv_ctx* ctx, uint32_t* out) {
+    *out = 0;
+    if (!ctx->err_dirty) return SCV_OK;
+    SCV_HIP(hipMemcpyAsync(out, ctx->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SCV_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+    SCV_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->err_dirty = false;
+    return SCV_OK;
+}
+
+int check_err_word(scv_ctx* ctx, uint32_t w) {
+    if ((w & 1u) && !(ctx->flags & SCV_FLAG_CLAMP_TO_INVALID_BIN))
+        return fail(SCV_ERR_DOMAIN, "a vote outside bins 0..1023 was seen; results are invalid");
+    if (w & 2u) return fail(SCV_ERR_ARG, "bootstrap: a drawn hit had n_modes >= M");
+    return SCV_OK;
+}
+
+int ensure_stage(scv_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->d_stage_bytes) return SCV_OK;
+    if (ctx->d_stage) { SCV_HIP(hipFree(ctx->d_stage)); ctx->d_stage = nullptr; ctx->d_stage_bytes = 0; }
+    SCV_HIP(hipMalloc(&ctx->d_stage, bytes));
+    ctx->d_stage_bytes = bytes;
+    return SCV_OK;
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+const char* scv_last_error(void) { return g_err; }
+const char* scv_version(void) { return "scvote 0.1 (gfx950)"; }
+
+int scv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int scv_create(scv_ctx** out, int device, uint32_t flags) {
+    if (!out) return fail(SCV_ERR_ARG, "scv_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SCV_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0) { SCV_HIP(hipGetDevice(&device)); }
+    if (device >= n) return fail(SCV_ERR_ARG, "device %d out of range (%d visible)", device, n);
+    scv_ctx* ctx = new (std::nothrow) scv_ctx();
+    if (!ctx) return fail(SCV_ERR_ALLOC, "out of host memory");
+    ctx->device = device;
+    ctx->flags = flags;
+    hipError_t e = hipSetDevice(device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) { ctx->own_stream = true; e = hipMalloc((void**)&ctx->d_err, 256); }
+    if (e == hipSuccess) e = hipMemset(ctx->d_err, 0, 256);
+    if (e != hipSuccess) {
+        int code = fail(-(int)e, "scv_create: %s", hipGetErrorString(e));
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return code;
+    }
+    ctx->num_cus = prop.multiProcessorCount;
+    ctx->lds_max = 160 * 1024;  // gfx950: a single workgroup may declare all 160 KiB
+    ctx->clock_khz = prop.clockRate;
+    ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    ctx->copies = env_int("SCV_COPIES", ctx->copies);
+    ctx->threads = env_int("SCV_THREADS", ctx->threads);
+    ctx->wg_per_cu = env_int("SCV_WG_PER_CU", ctx->wg_per_cu);
+    ctx->unroll = env_int("SCV_UNROLL", ctx->unroll);
+    if (!valid_copies(ctx->copies) || !valid_threads(ctx->threads) || !valid_unroll(ctx->unroll) || ctx->wg_per_cu < 1) {
+        int code = fail(SCV_ERR_ARG, "bad SCV_* tuning environment");
+        scv_destroy(ctx);
+        return code;
+    }
+    *out = ctx;
+    return SCV_OK;
+}
+
+int scv_destroy(scv_ctx* ctx) {
+    if (!ctx) return SCV_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_err) (void)hipFree(ctx->d_err);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SCV_OK;
+}
+
+int scv_set_stream(scv_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+    if (int rc = set_device(ctx)) return rc;
+    SCV_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) { SCV_HIP(hipStreamDestroy(ctx->stream)); ctx->own_stream = false; }
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        SCV_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return SCV_OK;
+}
+
+int scv_sync(scv_ctx* ctx) {
+    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+    if (int rc = set_device(ctx)) return rc;
+    SCV_HIP(hipStreamSynchronize(ctx->stream));
+    uint32_t w = 0;
+    if (int rc = fetch_err(ctx, &w)) return rc;
+    return check_err_word(ctx, w);
+}
+
+int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unroll) {
+    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+    if (copies > 0) { if (!valid_copies(copies)) return fail(SCV_ERR_ARG, "copies must be 8, 16 or 32"); ctx->copies = copies; }
+    if (threads > 0) { if (!valid_threads(threads)) return fail(SCV_ERR_ARG, "threads must be 256, 512 or 1024"); ctx->threads = threads; }
+    if (wg_per_cu > 0) ctx->wg_per_cu = wg_per_cu;
+    if (unroll > 0) { if (!valid_unroll(unroll)) return fail(SCV_ERR_ARG, "unroll must be 2, 4 or 8"); ctx->unroll = unroll; }
+    return SCV_OK;
+}
+
+int scv_aggregate_i32(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
+                      const int32_t* truth, int64_t P, int32_t B, int64_t N, int mem_kind, scv_cell* cells_out,
+                      int64_t* cell_tokens_out, int64_t* tie_class_hits_out, int64_t* token_sum_out,
+                      int64_t* truth_count_sum_out) {
+    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+    if (P < 0 || B < 0 || N < 0) return fail(SCV_ERR_ARG, "negative shape P=%lld B=%d N=%lld", (long long)P, B, (long long)N);
+    if (N > 0x7fffffffll) return fail(SCV_ERR_ARG, "N=%lld exceeds 2^31-1 (cell counts are u32)", (long long)N);
+    if (P > 0 && B > 0 && !truth) return fail(SCV_ERR_ARG, "truth is NULL");
+    if (P > 0 && B > 0 && N > 0 && !answers) return fail(SCV_ERR_ARG, "answers is NULL");
+    if (mem_kind != SCV_MEM_HOST && mem_kind != SCV_MEM_DEVICE) return fail(SCV_ERR_ARG, "bad mem_kind %d", mem_kind);
+    if (int rc = set_device(ctx)) return rc;
+
+    if (mem_kind == SCV_MEM_DEVICE)
+        return launch_aggregate(ctx, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
+                                tie_class_hits_out, token_sum_out, truth_count_sum_out);
+
+    // ---- HOST: stage problem-chunks through HBM ------------------------------------------------
+    const size_t row_bytes = (size_t)B * (size_t)N * sizeof(int32_t);           // one problem
+    const size_t budget = (size_t)env_int("SCV_STAGE_MB", 2048) << 20;           // votes (+tokens) per chunk
+    const size_t per_problem = row_bytes * (tokens ? 2 : 1);
+    int64_t chunk = per_problem ? (int64_t)(budget / per_problem) : P;
+    if (chunk < 1) chunk = 1;
+    if (chunk > P) chunk = P;
+    const size_t counters_bytes = ((size_t)B * SCV_TIE_CLASSES + 2 * (size_t)B) * sizeof(int64_t);
+    // layout of the staging block
+    size_t off = 0;
+    const size_t o_ans = off; off = align_up(off + (size_t)chunk * row_bytes, 256);
+    const size_t o_tok = off; off = align_up(off + (tokens ? (size_t)chunk * row_bytes : 0), 256);
+    const size_t o_truth = off; off = align_up(off + (size_t)chunk * sizeof(int32_t), 256);
+    const size_t o_nv = off; off = align_up(off + (size_t)B * sizeof(int32_t), 256);
+    const size_t o_cells = off; off = align_up(off + (size_t)chunk * B * sizeof(scv_cell), 256);
+    const size_t o_ctok = off; off = align_up(off + (size_t)chunk * B * sizeof(int64_t), 256);
+    const size_t o_cnt = off; off = align_up(off + counters_bytes, 256);
+    if (int rc = ensure_stage(ctx, off > 0 ? off : 256)) return rc;
+    char* base = static_cast<char*>(ctx->d_stage);
+    int64_t* d_tie = reinterpret_cast<int64_t*>(base + o_cnt);
+    int64_t* d_tok = d_tie + (size_t)B * SCV_TIE_CLASSES;
+    int64_t* d_ts = d_tok + B;
+    hipStream_t s = ctx->stream;
+    SCV_HIP(hipMemsetAsync(base + o_cnt, 0, counters_bytes > 0 ? counters_bytes : 1, s));
+    if (n_valid && B > 0) SCV_HIP(hipMemcpyAsync(base + o_nv, n_valid, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    for (int64_t p0 = 0; p0 < P; p0 += chunk) {
+        const int64_t pc = (P - p0 < chunk) ? (P - p0) : chunk;
+        if (row_bytes) SCV_HIP(hipMemcpyAsync(base + o_ans, answers + (size_t)p0 * B * N, (size_t)pc * row_bytes, hipMemcpyHostToDevice, s));
+        if (tokens && row_bytes) SCV_HIP(hipMemcpyAsync(base + o_tok, tokens + (size_t)p0 * B * N, (size_t)pc * row_bytes, hipMemcpyHostToDevice, s));
+        SCV_HIP(hipMemcpyAsync(base + o_truth, truth + p0, (size_t)pc * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        if (int rc = launch_aggregate(ctx, reinterpret_cast<const int32_t*>(base + o_ans),
+                                      tokens ? reinterpret_cast<const int32_t*>(base + o_tok) : nullptr,
+                                      n_valid ? reinterpret_cast<const int32_t*>(base + o_nv) : nullptr,
+                                      reinterpret_cast<const int32_t*>(base + o_truth), pc, B, N,
+                                      reinterpret_cast<scv_cell*>(base + o_cells),
+                                      reinterpret_cast<int64_t*>(base + o_ctok), d_tie, d_tok, d_ts))
+            return rc;
+        if (cells_out && B > 0) SCV_HIP(hipMemcpyAsync(cells_out + (size_t)p0 * B, base + o_cells, (size_t)pc * B * sizeof(scv_cell), hipMemcpyDeviceToHost, s));
+        if (cell_tokens_out && B > 0) SCV_HIP(hipMemcpyAsync(cell_tokens_out + (size_t)p0 * B, base + o_ctok, (size_t)pc * B * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        SCV_HIP(hipStreamSynchronize(s));  // the single staging block is reused by the next chunk
+    }
+    if (B > 0) {
+        if (tie_class_hits_out) SCV_HIP(hipMemcpyAsync(tie_class_hits_out, d_tie, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        if (token_sum_out) SCV_HIP(hipMemcpyAsync(token_sum_out, d_tok, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        if (truth_count_sum_out) SCV_HIP(hipMemcpyAsync(truth_count_sum_out, d_ts, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    }
+    SCV_HIP(hipStreamSynchronize(s));
+    uint32_t w = 0;
+    if (int rc = fetch_err(ctx, &w)) return rc;
+    return check_err_word(ctx, w);
+}
+
+int scv_bootstrap(scv_ctx* ctx, const scv_cell* cells, int64_t P, int32_t B, int32_t r_begin, int32_t r_end,
+                  uint64_t seed, int32_t M, int mem_kind, int64_t* counts_out) {
+    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+    if (!cells || !counts_out) return fail(SCV_ERR_ARG, "bootstrap: NULL pointer");
+    if (P <= 0 || P > 0xFFFFFFFFll || B <= 0 || M <= 0 || r_end < r_begin || r_begin < 0)
+        return fail(SCV_ERR_ARG, "bootstrap: bad shape P=%lld B=%d M=%d r=[%d,%d)", (long long)P, B, M, r_begin, r_end);
+    const size_t lds = (size_t)B * M * sizeof(uint32_t);
+    if (lds > 64 * 1024) return fail(SCV_ERR_ARG, "bootstrap: B*M=%lld counters exceed 64 KiB of LDS", (long long)B * M);
+    if (mem_kind != SCV_MEM_HOST && mem_kind != SCV_MEM_DEVICE) return fail(SCV_ERR_ARG, "bad mem_kind %d", mem_kind);
+    if (int rc = set_device(ctx)) return rc;
+    const int32_t R = r_end - r_begin;
+    if (R == 0) return SCV_OK;
+    hipStream_t s = ctx->stream;
+    const size_t out_bytes = (size_t)R * B * M * sizeof(int64_t);
+    if (mem_kind == SCV_MEM_DEVICE) {
+        hipLaunchKernelGGL(scv::scv_bootstrap_k, dim3((unsigned)R), dim3(256), lds, s, cells, P, B, r_begin, seed, M,
+                           reinterpret_cast<unsigned long long*>(counts_out), ctx->d_err);
+        SCV_HIP(hipGetLastError());
+        ctx->err_dirty = true;
+        return SCV_OK;
+    }
+    const size_t cells_bytes = (size_t)P * B * sizeof(scv_cell);
+    const size_t o_out = align_up(cells_bytes, 256);
+    if (int rc = ensure_stage(ctx, o_out + out_bytes)) return rc;
+    char* base = static_cast<char*>(ctx->d_stage);
+    SCV_HIP(hipMemcpyAsync(base, cells, cells_bytes, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(scv::scv_bootstrap_k, dim3((unsigned)R), dim3(256), lds, s,
+                       reinterpret_cast<const scv_cell*>(base), P, B, r_begin, seed, M,
+                       reinterpret_cast<unsigned long long*>(base + o_out), ctx->d_err);
+    SCV_HIP(hipGetLastError());
+    ctx->err_dirty = true;
+    SCV_HIP(hipMemcpyAsync(counts_out, base + o_out, out_bytes, hipMemcpyDeviceToHost, s));
+    SCV_HIP(hipStreamSynchronize(s));
+    uint32_t w = 0;
+    if (int rc = fetch_err(ctx, &w)) return rc;
+    return check_err_word(ctx, w);
+}
+
+int scv_synth_fill_i32(scv_ctx* ctx, int32_t* answers, int32_t* tokens, int32_t* truth, int64_t P, int32_t B,
+                       int64_t N, int64_t p_offset, uint64_t seed, int dist) {
+    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+    if (P < 0 || B < 0 || N < 0 || p_offset < 0) return fail(SCV_ERR_ARG, "synth_fill: negative shape");
+    if (dist < SCV_DIST_UNIFORM || dist > SCV_DIST_TIE) return fail(SCV_ERR_ARG, "synth_fill: unknown dist %d", dist);
+    if (int rc = set_device(ctx)) return rc;
+    if (P == 0) return SCV_OK;
+    int64_t grid = P * (int64_t)B;
+    if (B == 0) grid = (P + 255) / 256;
+    const int64_t cap = (int64_t)ctx->num_cus * 16;
+    if (grid > cap) grid = cap;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(scv::scv_synth_fill_k, dim3((unsigned)grid), dim3(256), 0, ctx->stream, answers, tokens, truth, P,
+                       B, N, p_offset, seed, dist);
+    SCV_HIP(hipGetLastError());
+    return SCV_OK;
+}
+
+int scv_last_kernel_ns(scv_ctx* ctx, uint64_t* ns_out) {
+    if (!ctx || !ns_out) return fail(SCV_ERR_ARG, "NULL argument");
+    if (!(ctx->flags & SCV_FLAG_TIMING) || ctx->events_used == 0)
+        return fail(SCV_ERR_NOT_TIMED, "no timed launch (create the ctx with SCV_FLAG_TIMING)");
+    if (int rc = set_device(ctx)) return rc;
+    EventPair& ev = ctx->events[ctx->events_used - 1];
+    SCV_HIP(hipEventSynchronize(ev.b));
+    float ms = 0.f;
+    SCV_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
+    *ns_out = (uint64_t)((double)ms * 1e6);
+    return SCV_OK;
+}
+
+int scv_drain_kernel_ns(scv_ctx* ctx, uint64_t* total_ns_out, uint64_t* launches_out) {
+    if (!ctx || !total_ns_out || !launches_out) return fail(SCV_ERR_ARG, "NULL argument");
+    if (!(ctx->flags & SCV_FLAG_TIMING)) return fail(SCV_ERR_NOT_TIMED, "ctx was created without SCV_FLAG_TIMING");
+    if (int rc = set_device(ctx)) return rc;
+    double total = 0;
+    for (size_t i = 0; i < ctx->events_used; ++i) {
+        SCV_HIP(hipEventSynchronize(ctx->events[i].b));
+        float ms = 0.f;
+        SCV_HIP(hipEventElapsedTime(&ms, ctx->events[i].a, ctx->events[i].b));
+        total += (double)ms * 1e6;
+    }
+    *total_ns_out = (uint64_t)total;
+    *launches_out = ctx->events_used;
+    ctx->events_used = 0;
+    return SCV_OK;
+}
+
+int scv_device_info(scv_ctx* ctx, int64_t info_out[4]) {
+    if (!ctx || !info_out) return fail(SCV_ERR_ARG, "NULL argument");
+    info_out[0] = ctx->num_cus;
+    info_out[1] = ctx->lds_max;
+    info_out[2] = ctx->clock_khz;
+    info_out[3] = ctx->hbm_bytes;
+    return SCV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,390 @@
+// scvote_kernels.hip.h -- gfx950 (CDNA4 / MI355X) device code of the self-consistency engine.
+//
+// Kernel 1  scv_hist_argmax   THE hot path.  Replaces, per (problem, budget) cell,
+//           /root/reference/o1.py:181-195 (collect N votes, sum tokens), o1.py:202
+//           (statistics.multimode) and o1.py:204-213 (tie-aware score), and accumulates the integer
+//           part of the per-budget reduction o1.py:229-245.
+// Kernel 2  scv_bootstrap_k   problem-level bootstrap over the per-cell table.
+// Kernel 0  scv_synth_fill_k  closed-form synthetic generator (spec: include/scvote.h).
+//
+// Design (DESIGN.md has the numbers):
+//  * Pure integer/indexing work, HBM-bound: 4 algorithmic bytes per vote, nothing written per vote.
+//    No MFMA.  The only on-chip resource that can undercut HBM is the LDS atomic unit.
+//  * One persistent workgroup streams whole cells: lane l of every wave issues 16-byte
+//    (global_load_dwordx4) loads at consecutive addresses, so a wave instruction covers 1 KiB
+//    contiguous and U of them are in flight per lane.
+//  * The 1024-bin histogram lives in LDS, replicated R times and indexed [bin][lane % R]:
+//    word address = bin*R + (lane & (R-1)).  A ds_add_u32 wave instruction is serviced in two
+//    32-lane groups over 32 banks; with this layout the bank is (bin*R + lane) % 32, so for R = 32
+//    every lane of a group owns its bank (conflict-free for ANY data, including all-equal votes);
+//    for R = 16 at most 2 lanes share a bank (free: the 4-cycle issue already covers 2 array
+//    cycles), R = 8 -> <= 4-way.  Throughput is therefore independent of the answer distribution:
+//    peaked / degenerate inputs (the realistic case: 40-70 % of votes on one bin) cost the same as
+//    uniform ones.  This is what a 64-wide wavefront + 160 KiB LDS buys; it is not a warp-shaped
+//    design.
+//  * Cell epilogue: fold the R copies (ds_read_b128, rotated so the 16-lane groups of a b128 read
+//    hit 16 distinct 16-byte slots), zero them in the same pass, then wave-reduce (64 lanes)
+//    max / #modes / min-mode, one LDS hop across waves, one 16-byte cell record.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/scvote.h"
+
+namespace scv {
+
+constexpr int kBins = SCV_NUM_BINS;
+constexpr int kRedWords = 96;  // cross-wave scratch behind the histogram
+
+struct AggArgs {
+    const int32_t* answers;
+    const int32_t* tokens;
+    const int32_t* n_valid;
+    const int32_t* truth;
+    int64_t ncells;
+    int64_t N;
+    int32_t B;
+    scv_cell* cells;
+    int64_t* cell_tokens;
+    unsigned long long* tie_hits;
+    unsigned long long* token_sum;
+    unsigned long long* truth_sum;
+    uint32_t* err_flag;
+};
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int RL2>
+__device__ __forceinline__ void vote(uint32_t* hist, uint32_t copy, uint32_t v, uint32_t& bad) {
+    bad |= v;
+    const uint32_t bin = v < 1023u ? v : 1023u;  // out-of-domain -> bin 1023 (+ error flag)
+    atomicAdd(&hist[(bin << RL2) | copy], 1u);   // ds_add_u32, no return
+}
+
+template <int RL2>
+__device__ __forceinline__ void vote4(uint32_t* hist, uint32_t copy, const int4& x, uint32_t& bad) {
+    vote<RL2>(hist, copy, (uint32_t)x.x, bad);
+    vote<RL2>(hist, copy, (uint32_t)x.y, bad);
+    vote<RL2>(hist, copy, (uint32_t)x.z, bad);
+    vote<RL2>(hist, copy, (uint32_t)x.w, bad);
+}
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int4 stream_load(const int4* p) {
+    // read-once stream: non-temporal so the line is not kept for a reuse that never comes
+    const v4i32 v = __builtin_nontemporal_load(reinterpret_cast<const v4i32*>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+
+// RL2 = log2(copies), T = threads per workgroup, U = 16-byte loads in flight per lane.
+template <int RL2, int T, int U, bool TOK>
+__global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
+    constexpr int R = 1 << RL2;
+    constexpr int NB = kBins / T;        // bins folded per thread in the epilogue
+    constexpr int NW = T / 64;           // waves per workgroup
+    constexpr int CH = R / 4;            // 16-byte chunks per bin
+    constexpr int BPR = 64 / R;          // bins per 256-byte LDS row
+    static_assert(NB >= 1 && NW <= 16, "workgroup shape");
+
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* hist = smem;
+    uint32_t* red = smem + kBins * R;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const uint32_t copy = (uint32_t)lane & (R - 1);
+
+    {   // zero the replicated histogram once; afterwards the epilogue leaves it zeroed
+        uint4* h4 = reinterpret_cast<uint4*>(hist);
+        for (int i = tid; i < kBins * R / 4; i += T) h4[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
+    uint32_t bad = 0;
+    for (int64_t cell = blockIdx.x; cell < a.ncells; cell += gridDim.x) {
+        const int64_t p = cell / a.B;
+        const int32_t b = (int32_t)(cell - p * a.B);
+        int64_t n = a.N;
+        if (a.n_valid) {
+            const int64_t nv = a.n_valid[b];
+            n = nv < 0 ? 0 : (nv > a.N ? a.N : nv);
+        }
+        const int32_t* row = a.answers + cell * a.N;
+        const int32_t* trow = TOK ? a.tokens + cell * a.N : nullptr;
+        long long tsum = 0;
+
+        // ---- o1.py:181-195: stream the votes ------------------------------------------------
+        // head: scalars up to the first 16-byte boundary (rows are unaligned when N % 4 != 0)
+        int64_t head = (int64_t)(((16u - (uint32_t)((uintptr_t)row & 15u)) & 15u) >> 2);
+        if (head > n) head = n;
+        if (tid < head) {
+            vote<RL2>(hist, copy, (uint32_t)row[tid], bad);
+            if (TOK) tsum += trow[tid];
+        }
+        const int4* v4 = reinterpret_cast<const int4*>(row + head);
+        const int64_t nvec = (n - head) >> 2;
+        int64_t i = tid;
+        if (!TOK) {
+            for (; i + (int64_t)(U - 1) * T < nvec; i += (int64_t)U * T) {
+                int4 x[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[u] = stream_load(v4 + i + (int64_t)u * T);
+#pragma unroll
+                for (int u = 0; u < U; ++u) vote4<RL2>(hist, copy, x[u], bad);
+            }
+            for (; i < nvec; i += T) {
+                const int4 x = stream_load(v4 + i);
+                vote4<RL2>(hist, copy, x, bad);
+            }
+        } else {
+            // the token row has the same misalignment as the vote row only if both bases agree
+            // mod 16; they do for the [P,B,N] layouts the ABI accepts (both rows start at
+            // base + cell*N*4 and hipMalloc / torch bases are 256-byte aligned).  A token base
+            // that is not 16-byte congruent takes the scalar route.
+            const bool tok_vec = (((uintptr_t)(trow + head)) & 15u) == 0;
+            if (tok_vec) {
+                const int4* t4 = reinterpret_cast<const int4*>(trow + head);
+                constexpr int UT = U > 1 ? U / 2 : 1;
+                for (; i + (int64_t)(UT - 1) * T < nvec; i += (int64_t)UT * T) {
+                    int4 x[UT], y[UT];
+#pragma unroll
+                    for (int u = 0; u < UT; ++u) {
+                        x[u] = stream_load(v4 + i + (int64_t)u * T);
+                        y[u] = stream_load(t4 + i + (int64_t)u * T);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UT; ++u) {
+                        vote4<RL2>(hist, copy, x[u], bad);
+                        tsum += (long long)y[u].x + (long long)y[u].y + (long long)y[u].z + (long long)y[u].w;
+                    }
+                }
+                for (; i < nvec; i += T) {
+                    const int4 x = stream_load(v4 + i);
+                    const int4 y = stream_load(t4 + i);
+                    vote4<RL2>(hist, copy, x, bad);
+                    tsum += (long long)y.x + (long long)y.y + (long long)y.z + (long long)y.w;
+                }
+            } else {
+                for (; i < nvec; i += T) {
+                    const int4 x = stream_load(v4 + i);
+                    vote4<RL2>(hist, copy, x, bad);
+                    const int32_t* ts = trow + head + 4 * i;
+                    tsum += (long long)ts[0] + (long long)ts[1] + (long long)ts[2] + (long long)ts[3];
+                }
+            }
+        }
+        {   // tail: the < 4 votes after the last full 16-byte vector
+            const int64_t t0 = head + (nvec << 2);
+            if (tid < n - t0) {
+                vote<RL2>(hist, copy, (uint32_t)row[t0 + tid], bad);
+                if (TOK) tsum += trow[t0 + tid];
+            }
+        }
+        if (tid == 0) red[48] = 0;
+        __syncthreads();  // B1: all votes of this cell are in LDS
+
+        // ---- statistics.multimode (statistics.py:599-601): fold copies, find max count -------
+        const int32_t truth = a.truth[p];
+        uint32_t cnt[NB];
+        uint32_t lmax = 0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int bin = tid + k * T;
+            uint4* h4 = reinterpret_cast<uint4*>(hist + (bin << RL2));
+            uint32_t s = 0;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int jj = (j + bin / BPR) & (CH - 1);
+                const uint4 x = h4[jj];
+                s += x.x + x.y + x.z + x.w;
+                h4[jj] = make_uint4(0, 0, 0, 0);
+            }
+            cnt[k] = s;
+            lmax = s > lmax ? s : lmax;
+            if (bin == truth) red[48] = s;  // truth_count = histogram[truth] (pass@k's c)
+        }
+        const uint32_t wmax = wave_max_u32(lmax);
+        if (lane == 0) red[wid] = wmax;
+        if (TOK) {
+            const long long wt = wave_sum_i64(tsum);
+            if (lane == 0) {
+                red[64 + 2 * wid] = (uint32_t)((unsigned long long)wt & 0xffffffffull);
+                red[65 + 2 * wid] = (uint32_t)((unsigned long long)wt >> 32);
+            }
+        }
+        __syncthreads();  // B2: per-wave maxima visible; histogram is zero again
+
+        uint32_t maxc = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const uint32_t m = red[w]; maxc = m > maxc ? m : maxc; }
+        uint32_t nm = 0, mm = 1024u;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const uint32_t bin = (uint32_t)(tid + k * T);
+            if (cnt[k] == maxc) { nm += 1; mm = bin < mm ? bin : mm; }
+        }
+        nm = wave_sum_u32(nm);
+        mm = wave_min_u32(mm);
+        if (lane == 0) { red[16 + wid] = nm; red[32 + wid] = mm; }
+        __syncthreads();  // B3
+
+        if (tid == 0) {
+            uint32_t n_modes = 0, min_mode = 1024u;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                n_modes += red[16 + w];
+                const uint32_t m = red[32 + w];
+                min_mode = m < min_mode ? m : min_mode;
+            }
+            const uint32_t tc = red[48];
+            long long tok = 0;
+            if (TOK) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    tok += (long long)(((unsigned long long)red[65 + 2 * w] << 32) | red[64 + 2 * w]);
+            }
+            // o1.py:204-213: hit = truth in modes; multimode([]) == [] -> no hit when max_count == 0
+            const bool any = maxc > 0;
+            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;
+            if (!any) { n_modes = 0; }
+            if (a.cells) {
+                uint4 rec;
+                rec.x = maxc;
+                rec.y = tc;
+                rec.z = (n_modes & 0xffffu) | ((any ? (min_mode & 0xffffu) : 0xffffu) << 16);
+                rec.w = hit;
+                reinterpret_cast<uint4*>(a.cells)[cell] = rec;
+            }
+            if (a.cell_tokens) a.cell_tokens[cell] = tok;
+            // o1.py:238-240 as integers: tie-class counter, token sum, truth-count sum
+            if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
+            if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
+            if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
+        }
+        // the next cell's votes may start: the histogram was re-zeroed before B2, and `red` is
+        // next written after the next B1, which thread 0 only reaches after this block.
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+}
+
+// ---- synthetic generator ------------------------------------------------------------------------
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__device__ __forceinline__ uint32_t mulhi32(uint32_t x, uint32_t n) { return __umulhi(x, n); }
+
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+
+struct ProblemParams { uint32_t truth, q_num, d[4]; };
+
+__device__ __forceinline__ ProblemParams problem_params(uint64_t seed, int64_t p) {
+    ProblemParams r;
+    const uint64_t k = mix64((seed ^ 0x5851F42D4C957F2Dull) + kGolden * (uint64_t)(p + 1));
+    r.truth = mulhi32((uint32_t)k, 1000u);
+    r.q_num = 1u + (uint32_t)(k >> 32) % 7u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.d[j] = mulhi32((uint32_t)mix64(k + kGolden * (uint64_t)(j + 1)), 1000u);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void scv_synth_fill_k(int32_t* answers, int32_t* tokens, int32_t* truth,
+                                                        int64_t P, int32_t B, int64_t N, int64_t p_offset,
+                                                        uint64_t seed, int dist) {
+    const int64_t ncells = P * B;
+    for (int64_t cell = blockIdx.x; cell < ncells; cell += gridDim.x) {
+        const int64_t pl = cell / B;
+        const int32_t b = (int32_t)(cell - pl * B);
+        const int64_t p = p_offset + pl;
+        const ProblemParams pp = problem_params(seed, p);
+        if (truth && b == 0 && threadIdx.x == 0) truth[pl] = (int32_t)pp.truth;
+        if (!answers && !tokens) continue;
+        const uint32_t t0 = pp.q_num * 429496729u;
+        const uint32_t T5 = 214748364u;
+        const uint32_t m = 2u + (uint32_t)(p & 1);
+        const uint32_t base = ((p >> 1) & 1) ? (pp.truth + 500u) % 1000u : pp.truth;
+        const int64_t full = (N / m) * m;
+        const uint64_t e0 = ((uint64_t)p * (uint64_t)B + (uint64_t)b) * (uint64_t)N;
+        int32_t* arow = answers ? answers + cell * N : nullptr;
+        int32_t* trow = tokens ? tokens + cell * N : nullptr;
+        for (int64_t i = threadIdx.x; i < N; i += blockDim.x) {
+            const uint64_t u = mix64(seed + kGolden * (e0 + (uint64_t)i + 1));
+            if (arow) {
+                const uint32_t hi = (uint32_t)(u >> 32), uv = mulhi32((uint32_t)u, 1000u);
+                uint32_t v;
+                if (dist == SCV_DIST_UNIFORM) v = uv;
+                else if (dist == SCV_DIST_PEAKED) {
+                    if (hi < t0) v = pp.truth;
+                    else {
+                        const uint32_t x = hi - t0;
+                        const uint32_t j = (x >= T5) + (x >= 2u * T5) + (x >= 3u * T5);
+                        v = (x < 4u * T5) ? pp.d[j] : uv;
+                    }
+                } else if (dist == SCV_DIST_DEGENERATE) v = pp.truth;
+                else v = (i < full) ? (base + 37u * (uint32_t)(i % m)) % 1000u : (base + 999u) % 1000u;
+                arow[i] = (int32_t)v;
+            }
+            if (trow) trow[i] = (int32_t)(100u + mulhi32((uint32_t)(mix64(u ^ kGolden) >> 32), 11901u));
+        }
+    }
+    // problems with B == 0 or no cells still need their truth
+    if (truth && B == 0)
+        for (int64_t pl = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; pl < P; pl += (int64_t)gridDim.x * blockDim.x)
+            truth[pl] = (int32_t)problem_params(seed, p_offset + pl).truth;
+}
+
+// ---- problem-level bootstrap --------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void scv_bootstrap_k(const scv_cell* cells, int64_t P, int32_t B, int32_t r_begin,
+                                                       uint64_t seed, int32_t M, unsigned long long* out,
+                                                       uint32_t* err_flag) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];
+    const int32_t r = r_begin + (int32_t)blockIdx.x;
+    for (int i = threadIdx.x; i < B * M; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    bool overflow = false;
+    const uint4* c4 = reinterpret_cast<const uint4*>(cells);
+    for (int64_t j = threadIdx.x; j < P; j += blockDim.x) {
+        const uint64_t u = mix64(seed + kGolden * ((uint64_t)r * (uint64_t)P + (uint64_t)j + 1));
+        const int64_t idx = (int64_t)mulhi32((uint32_t)(u >> 32), (uint32_t)P);
+        for (int32_t b = 0; b < B; ++b) {
+            const uint4 c = c4[idx * B + b];
+            if (c.w & 0xffu) {
+                const uint32_t nm = c.z & 0xffffu;
+                if (nm >= (uint32_t)M) overflow = true;
+                else atomicAdd(&cnt[b * M + nm], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B * M; i += blockDim.x)
+        out[(int64_t)blockIdx.x * B * M + i] = cnt[i];
+    if (overflow) atomicOr(err_flag, 2u);
+}
+
+}  // namespace scv

@@ -1,0 +1,224 @@
+"""Python face of the HIP engine (ctypes over include/scvote.h).
+
+Two calling modes, mirroring ``mem_kind`` of the ABI:
+
+* numpy arrays  -> SCV_MEM_HOST: the library stages problem-chunks through HBM and returns numpy.
+* torch CUDA tensors -> SCV_MEM_DEVICE: zero-copy, asynchronous on torch's current stream; outputs
+  are torch tensors on the same device (PyTorch is used for device memory and streams only).
+
+There is no CPU implementation here.  Without the compiled library or a HIP device, constructing
+an ``Engine`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import TIE_CLASSES, check
+from .scoring import accuracy_from_tie_classes, avg_tokens_used, exact_accuracy_from_tie_classes
+
+CELL_DTYPE = np.dtype(
+    [("max_count", "<u4"), ("truth_count", "<u4"), ("n_modes", "<u2"), ("min_mode", "<i2"),
+     ("hit", "u1"), ("pad", "u1", (3,))]
+)
+assert CELL_DTYPE.itemsize == 16
+
+
+def counters_size(B: int) -> int:
+    """int64 words of the packed per-budget counters: tie_class_hits[B,1025] | token_sum[B] | truth_count_sum[B]."""
+    return B * TIE_CLASSES + 2 * B
+
+
+@dataclass
+class AggregateResult:
+    """Integer outputs of one aggregation (host copies) + the reference's floats derived from them."""
+    P: int
+    B: int
+    cells: np.ndarray | None            # CELL_DTYPE [P, B]
+    cell_tokens: np.ndarray | None      # int64 [P, B]
+    tie_class_hits: np.ndarray          # int64 [B, 1025]
+    token_sum: np.ndarray               # int64 [B]
+    truth_count_sum: np.ndarray         # int64 [B]
+    num_problems: int | None = None     # denominator for accuracy (global P when sharded)
+
+    def _den(self):
+        return self.num_problems if self.num_problems is not None else self.P
+
+    def accuracy(self, b: int = 0) -> float:
+        return accuracy_from_tie_classes(self.tie_class_hits[b], self._den())
+
+    def exact_accuracy(self, b: int = 0):
+        return exact_accuracy_from_tie_classes(self.tie_class_hits[b], self._den())
+
+    def avg_tokens_used(self, b: int = 0) -> np.float64:
+        return avg_tokens_used(self.token_sum[b], self._den())
+
+    @staticmethod
+    def from_counters(counters: np.ndarray, P: int, B: int, cells=None, cell_tokens=None, num_problems=None):
+        counters = np.asarray(counters, dtype=np.int64)
+        tie = counters[: B * TIE_CLASSES].reshape(B, TIE_CLASSES)
+        tok = counters[B * TIE_CLASSES: B * TIE_CLASSES + B]
+        tcs = counters[B * TIE_CLASSES + B:]
+        return AggregateResult(P, B, cells, cell_tokens, tie, tok, tcs, num_problems)
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One context per GPU per process (one process per GPU under torch.distributed)."""
+
+    def __init__(self, device: int | None = None, timing: bool = False, clamp_to_invalid_bin: bool = False):
+        self._L = _lib.load()            # raises ImportError when csrc/libscvote.so is missing
+        self._ctx = C.c_void_p()
+        flags = (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_CLAMP if clamp_to_invalid_bin else 0)
+        check(self._L.scv_create(C.byref(self._ctx), -1 if device is None else int(device), flags))
+        info = (C.c_int64 * 4)()
+        check(self._L.scv_device_info(self._ctx, C.byref(info)))
+        self.num_cus, self.lds_bytes, self.clock_khz, self.hbm_bytes = (int(x) for x in info)
+        self._bound_stream = None
+        self.timing = timing
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._L.scv_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- configuration ----------------------------------------------------------------------
+
+    def set_tuning(self, copies: int = 0, threads: int = 0, wg_per_cu: int = 0, unroll: int = 0):
+        check(self._L.scv_set_tuning(self._ctx, copies, threads, wg_per_cu, unroll))
+
+    def use_torch_stream(self):
+        """Launch on torch's current stream so engine work orders with torch / RCCL ops."""
+        import torch
+        s = torch.cuda.current_stream().cuda_stream
+        if s != self._bound_stream:
+            check(self._L.scv_set_stream(self._ctx, C.c_void_p(s) if s else None))
+            self._bound_stream = s
+
+    def sync(self):
+        check(self._L.scv_sync(self._ctx))
+
+    def drain_kernel_ns(self):
+        """(total_ns, launches) of the timed hot-path launches since the previous drain."""
+        tot, n = C.c_uint64(), C.c_uint64()
+        check(self._L.scv_drain_kernel_ns(self._ctx, C.byref(tot), C.byref(n)))
+        return int(tot.value), int(n.value)
+
+    # ---- HOST mode ------------------------------------------------------------------------------
+
+    def aggregate(self, answers, truth, tokens=None, n_valid=None, want_cells=True) -> AggregateResult:
+        """answers int32 [P,B,N] (numpy) -> AggregateResult.  Blocking.  See scv_aggregate_i32."""
+        answers = np.ascontiguousarray(answers, dtype=np.int32)
+        if answers.ndim != 3:
+            raise ValueError("answers must be [P, B, N]")
+        P, B, N = answers.shape
+        truth = np.ascontiguousarray(truth, dtype=np.int32)
+        if truth.shape != (P,):
+            raise ValueError("truth must be [P]")
+        if tokens is not None:
+            tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+            if tokens.shape != answers.shape:
+                raise ValueError("tokens must match answers")
+        if n_valid is not None:
+            n_valid = np.ascontiguousarray(n_valid, dtype=np.int32)
+            if n_valid.shape != (B,):
+                raise ValueError("n_valid must be [B]")
+        cells = np.zeros((P, B), dtype=CELL_DTYPE) if want_cells else None
+        cell_tokens = np.zeros((P, B), dtype=np.int64) if (want_cells and tokens is not None) else None
+        tie = np.zeros((B, TIE_CLASSES), dtype=np.int64)
+        tok = np.zeros((B,), dtype=np.int64)
+        tcs = np.zeros((B,), dtype=np.int64)
+        check(self._L.scv_aggregate_i32(self._ctx, _np_ptr(answers), _np_ptr(tokens), _np_ptr(n_valid),
+                                        _np_ptr(truth), P, B, N, _lib.MEM_HOST, _np_ptr(cells),
+                                        _np_ptr(cell_tokens), _np_ptr(tie), _np_ptr(tok), _np_ptr(tcs)))
+        return AggregateResult(P, B, cells, cell_tokens, tie, tok, tcs)
+
+    def bootstrap(self, cells: np.ndarray, r_begin: int, r_end: int, seed: int, M: int) -> np.ndarray:
+        """cells CELL_DTYPE [P,B] -> int64 [r_end-r_begin, B, M].  Blocking.  See scv_bootstrap."""
+        cells = np.ascontiguousarray(cells)
+        if cells.dtype != CELL_DTYPE or cells.ndim != 2:
+            raise ValueError("cells must be CELL_DTYPE [P, B]")
+        P, B = cells.shape
+        out = np.zeros((r_end - r_begin, B, M), dtype=np.int64)
+        check(self._L.scv_bootstrap(self._ctx, _np_ptr(cells), P, B, r_begin, r_end, seed, M, _lib.MEM_HOST, _np_ptr(out)))
+        return out
+
+    # ---- DEVICE mode (torch tensors; asynchronous on torch's current stream) --------------------
+
+    def aggregate_device(self, answers, truth, tokens=None, n_valid=None, counters=None, cells=None,
+                         cell_tokens=None):
+        """answers torch.int32 cuda [P,B,N].  Accumulates into ``counters`` (int64 [counters_size(B)],
+        allocated zeroed if None) and writes ``cells`` (uint8 [P,B,16], allocated if None; pass False
+        to skip).  Returns (counters, cells, cell_tokens).  Does not synchronise."""
+        import torch
+        if not (answers.is_cuda and answers.dtype == torch.int32 and answers.is_contiguous() and answers.dim() == 3):
+            raise ValueError("answers must be a contiguous CUDA int32 tensor [P, B, N]")
+        P, B, N = answers.shape
+        dev = answers.device
+        for name, t, shape in (("truth", truth, (P,)), ("tokens", tokens, (P, B, N)), ("n_valid", n_valid, (B,))):
+            if t is None:
+                continue
+            if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == shape and t.device == dev):
+                raise ValueError(f"{name} must be a contiguous CUDA int32 tensor {shape} on {dev}")
+        if truth is None:
+            raise ValueError("truth is required")
+        self.use_torch_stream()
+        if counters is None:
+            counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
+        elif not (counters.is_cuda and counters.dtype == torch.int64 and counters.numel() == counters_size(B)
+                  and counters.is_contiguous()):
+            raise ValueError("counters must be int64 [counters_size(B)] on the device")
+        if cells is None:
+            cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
+        elif cells is False:
+            cells = None
+        if cell_tokens is None and tokens is not None and cells is not None:
+            cell_tokens = torch.empty((P, B), dtype=torch.int64, device=dev)
+        base = counters.data_ptr()
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        check(self._L.scv_aggregate_i32(
+            self._ctx, ptr(answers), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, _lib.MEM_DEVICE,
+            ptr(cells), ptr(cell_tokens),
+            C.c_void_p(base), C.c_void_p(base + 8 * B * TIE_CLASSES), C.c_void_p(base + 8 * (B * TIE_CLASSES + B))))
+        return counters, cells, cell_tokens
+
+    def synth_fill_device(self, answers=None, tokens=None, truth=None, *, P, B, N, seed, dist, p_offset=0):
+        """Fill preallocated CUDA int32 tensors with the closed-form synthetic data (asynchronous)."""
+        self.use_torch_stream()
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        check(self._L.scv_synth_fill_i32(self._ctx, ptr(answers), ptr(tokens), ptr(truth), P, B, N, p_offset, seed, dist))
+
+    def bootstrap_device(self, cells, r_begin: int, r_end: int, seed: int, M: int, out=None):
+        """cells uint8 cuda [P,B,16] -> int64 cuda [r_end-r_begin, B, M] (asynchronous)."""
+        import torch
+        P, B = cells.shape[0], cells.shape[1]
+        self.use_torch_stream()
+        if out is None:
+            out = torch.empty((r_end - r_begin, B, M), dtype=torch.int64, device=cells.device)
+        check(self._L.scv_bootstrap(self._ctx, C.c_void_p(cells.data_ptr()), P, B, r_begin, r_end, seed, M,
+                                    _lib.MEM_DEVICE, C.c_void_p(out.data_ptr())))
+        return out
+
+
+def cells_from_torch(cells_u8) -> np.ndarray:
+    """uint8 cuda/cpu [P,B,16] -> CELL_DTYPE [P,B] on the host."""
+    arr = cells_u8.detach().cpu().numpy()
+    return np.ascontiguousarray(arr).view(CELL_DTYPE).reshape(arr.shape[0], arr.shape[1])

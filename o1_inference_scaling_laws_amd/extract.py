@@ -1,0 +1,125 @@
+"""response_cache.json -> dense vote tensors.
+
+Resolves every (problem, token_limit, idx) through the SAME cache-key scheme as the reference
+(/root/reference/o1.py:85-88 generation key, :119 extraction key) and applies its failure rule:
+any sample the reference could not obtain from the cache -- missing generation (the reference then
+raises NameError at o1.py:94), extraction cached as None (AssertionError at o1.py:163), missing
+extraction (network call) -- becomes a vote for answer 0 with 0 tokens (o1.py:190-192).
+
+Value domain: the engine histograms bins 0..1023.  AIME answers 0..999 map to themselves; any other
+value the cache holds (negative, >= 1000, non-integral) is an ordinary candidate for
+statistics.multimode, so it is dictionary-encoded per problem into the spare
+bins 1000..1023.  More than 24 distinct such values in one problem raises DomainOverflow (there is
+no CPU fallback).
+
+O1_MODEL and PROMPT are parameters: they are part of the key (o1.py:86) and are read from the
+reference module at install time (o1_dropin.install), never copied into this repository.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+SPARE_BASE, SPARE_COUNT = 1000, 24
+FAILED_VOTE = (0, 0)  # o1.py:192
+
+
+class DomainOverflow(ValueError):
+    """A problem has more than 24 distinct out-of-domain answers."""
+
+
+def generation_key(model: str, prompt: str, problem: str, token_limit: int, idx: int) -> str:
+    """o1.py:85-88.  ``prompt`` is the UNFORMATTED template, as in the reference."""
+    if idx > 0:
+        return f"{model}_{prompt}_{problem}_{token_limit}_{idx}"
+    return f"{model}_{prompt}_{problem}_{token_limit}"
+
+
+def extraction_key(response_content: str) -> str:
+    """o1.py:119."""
+    return f"extract_answer_{response_content}"
+
+
+def resolve_vote(cache: dict, model: str, prompt: str, problem: str, token_limit: int, idx: int):
+    """generate_single_response (o1.py:148-164) restricted to cache hits -> (answer, tokens)."""
+    gk = generation_key(model, prompt, problem, token_limit, idx)
+    response = cache.get(gk)
+    if response is None:
+        return FAILED_VOTE
+    try:
+        content, tokens = response["content"], response["tokens"]
+    except (KeyError, TypeError):
+        return FAILED_VOTE
+    ek = extraction_key(content)
+    if ek not in cache:
+        return FAILED_VOTE
+    answer = cache[ek]
+    if answer is None:      # o1.py:163 assert answer is not None
+        return FAILED_VOTE
+    return answer, tokens
+
+
+def _canonical(v):
+    """Python equality classes as Counter sees them: 3 == 3.0 == Fraction(3); True == 1."""
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    if isinstance(v, float) and v == v and v not in (float("inf"), float("-inf")) and v == int(v):
+        return int(v)
+    return v
+
+
+class ProblemEncoder:
+    """Per-problem dictionary: in-domain ints -> themselves, anything else -> spare bins."""
+
+    def __init__(self):
+        self._codes = {}
+
+    def encode(self, v) -> int:
+        v = _canonical(v)
+        if isinstance(v, int) and 0 <= v < SPARE_BASE:
+            return v
+        code = self._codes.get(v)
+        if code is None:
+            if len(self._codes) >= SPARE_COUNT:
+                raise DomainOverflow(f"more than {SPARE_COUNT} distinct out-of-domain answers in one problem")
+            code = SPARE_BASE + len(self._codes)
+            self._codes[v] = code
+        return code
+
+
+@dataclass
+class VoteTensors:
+    answers: np.ndarray   # int32 [P, B, Nmax]
+    tokens: np.ndarray    # int32 [P, B, Nmax]
+    n_valid: np.ndarray   # int32 [B]
+    truth: np.ndarray     # int32 [P]
+
+
+def build_vote_tensors(dataset, cache: dict, budgets, model: str, prompt: str) -> VoteTensors:
+    """budgets: [(key_token_limit, N)] -- the (actual_token_limit, N) pairs of o1.py:274-277 / :302.
+
+    Budget b of problem p votes over samples idx = 0..N_b-1 of key_token_limit_b (prefix of one
+    sample pool when several budgets share a key_token_limit).
+    """
+    P, B = len(dataset), len(budgets)
+    nmax = max([n for _, n in budgets], default=0)
+    answers = np.zeros((P, B, max(nmax, 1)), dtype=np.int32)
+    tokens = np.zeros((P, B, max(nmax, 1)), dtype=np.int32)
+    n_valid = np.array([n for _, n in budgets], dtype=np.int32).reshape(B)
+    truth = np.zeros((P,), dtype=np.int32)
+    for p, example in enumerate(dataset):
+        enc = ProblemEncoder()
+        truth[p] = enc.encode(int(example["answer"]))          # o1.py:206
+        memo = {}
+        for b, (key_limit, n) in enumerate(budgets):
+            for idx in range(n):
+                k = (key_limit, idx)
+                if k not in memo:
+                    ans, tok = resolve_vote(cache, model, prompt, example["problem"], key_limit, idx)
+                    tok = int(tok)
+                    if not -2 ** 31 <= tok < 2 ** 31:
+                        raise ValueError(f"token count {tok} does not fit int32")
+                    memo[k] = (enc.encode(ans), tok)
+                answers[p, b, idx], tokens[p, b, idx] = memo[k]
+    return VoteTensors(answers, tokens, n_valid, truth)

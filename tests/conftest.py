@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+    with open(os.path.join(REPO, "tests", "golden", "golden_o1.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle_engine():
+    from tests._adapters import OracleEngine
+    return OracleEngine()
+
+
+@pytest.fixture(scope="session")
+def hip_engine():
+    """The product engine.  On the GPU box a missing library must FAIL, never skip or fall back."""
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
+    from o1_inference_scaling_laws_amd.engine import Engine
+    eng = Engine(timing=True)
+    yield eng
+    eng.close()

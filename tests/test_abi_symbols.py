@@ -1,0 +1,72 @@
+"""The C-ABI library loads and exports every symbol include/scvote.h declares.  No compute calls
+(no GPU here); on a GPU-less box the product must refuse loudly, never fall back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from o1_inference_scaling_laws_amd import _build, _lib
+from o1_inference_scaling_laws_amd.engine import CELL_DTYPE
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(REPO, "include", "scvote.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(scv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_boundary():
+    names = declared_functions()
+    for must in ("scv_create", "scv_destroy", "scv_aggregate_i32", "scv_bootstrap", "scv_synth_fill_i32",
+                 "scv_last_error", "scv_device_count", "scv_last_kernel_ns"):
+        assert must in names
+
+
+def test_library_is_built_in_tree_and_exports_every_declared_symbol():
+    assert os.path.exists(_build.LIB_PATH), "run __graft_entry__.build() first"
+    assert os.path.commonpath([REPO, _build.LIB_PATH]) == REPO
+    L = ctypes.CDLL(_build.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(L, name), f"{name} declared in include/scvote.h but not exported"
+
+
+def test_binding_declares_every_symbol():
+    L = _lib.load()
+    for name in declared_functions():
+        fn = getattr(L, name)
+        assert fn.argtypes is not None, name
+
+
+def test_cell_struct_layout_matches_header():
+    src = open(os.path.join(REPO, "include", "scvote.h")).read()
+    body = re.search(r"typedef struct scv_cell \{(.*?)\} scv_cell;", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(u?int\d+_t)\s+(\w+)(\[\d+\])?;", body)
+    assert [f[1] for f in fields] == list(CELL_DTYPE.names)
+    assert CELL_DTYPE.itemsize == 16 and CELL_DTYPE.fields["min_mode"][1] == 10 and CELL_DTYPE.fields["hit"][1] == 12
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from o1_inference_scaling_laws_amd.engine import Engine
+    with pytest.raises(_lib.ScvError) as ei:
+        Engine()
+    assert ei.value.code == _lib.ERR_NO_DEVICE
+    assert _lib.load().scv_device_count() == 0
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "o1_inference_scaling_laws_amd")
+    for root, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "libscv_oracle" not in text and "scv_oracle.c" not in text, f
+    _ = np

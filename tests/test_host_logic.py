@@ -1,0 +1,171 @@
+"""Host-side logic: bucketing, key scheme, failure rule, domain encoding, scoring, generator mirror,
+sharding algebra.  CPU only."""
+import math
+import random
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from o1_inference_scaling_laws_amd import dist as scv_dist
+from o1_inference_scaling_laws_amd import extract, o1_dropin, scoring, synth
+from oracle import coracle, pyoracle
+from tests._adapters import TEST_MODEL, TEST_PROMPT, OracleEngine, assert_results_equal
+
+
+def test_bucketing_matches_reference_restatement():
+    for flag in (False, True):
+        assert o1_dropin.majority_vote_budgets(flag) == pyoracle.majority_vote_budgets(flag)
+        assert o1_dropin.just_ask_nicely_budgets(flag) == pyoracle.just_ask_nicely_budgets(flag)
+    b = o1_dropin.majority_vote_budgets(False)
+    assert [t for t, _, _ in b] == [2 ** i for i in range(4, 15)]
+    assert [n for _, _, n in b] == [1] * 8 + [2, 4, 8]
+    assert [n for _, _, n in o1_dropin.majority_vote_budgets(True)][-4:] == [16, 32, 64, 128]
+    assert all(k == 2048 for t, k, _ in b if t >= 2048)
+
+
+def test_key_scheme():
+    assert extract.generation_key("m", "PR", "prob", 2048, 0) == "m_PR_prob_2048"
+    assert extract.generation_key("m", "PR", "prob", 2048, 3) == "m_PR_prob_2048_3"
+    assert extract.extraction_key("xyz") == "extract_answer_xyz"
+
+
+def test_failure_rule_votes_zero_with_zero_tokens():
+    gk = extract.generation_key(TEST_MODEL, TEST_PROMPT, "p", 64, 0)
+    full = {gk: {"content": "c", "tokens": 17}, extract.extraction_key("c"): 42}
+    assert extract.resolve_vote(full, TEST_MODEL, TEST_PROMPT, "p", 64, 0) == (42, 17)
+    assert extract.resolve_vote({}, TEST_MODEL, TEST_PROMPT, "p", 64, 0) == (0, 0)
+    none = {gk: {"content": "c", "tokens": 17}, extract.extraction_key("c"): None}
+    assert extract.resolve_vote(none, TEST_MODEL, TEST_PROMPT, "p", 64, 0) == (0, 0)
+    noext = {gk: {"content": "c", "tokens": 17}}
+    assert extract.resolve_vote(noext, TEST_MODEL, TEST_PROMPT, "p", 64, 0) == (0, 0)
+
+
+def test_domain_encoding_and_overflow():
+    enc = extract.ProblemEncoder()
+    assert enc.encode(0) == 0 and enc.encode(999) == 999 and enc.encode(7.0) == 7 and enc.encode(True) == 1
+    a, b = enc.encode(-3), enc.encode(10 ** 12)
+    assert (a, b) == (1000, 1001) and enc.encode(-3) == 1000 and enc.encode(1000) == 1002
+    assert enc.encode("forty-two") == 1003
+    for i in range(20):
+        enc.encode(5000 + i)
+    with pytest.raises(extract.DomainOverflow):
+        enc.encode(99999)
+
+
+def test_encoded_cells_agree_with_multimode_on_arbitrary_ints():
+    rng = random.Random(3)
+    eng = OracleEngine()
+    for _ in range(50):
+        N = rng.randint(1, 12)
+        pool = [rng.choice([-5, -1, 0, 3, 999, 1000, 1001, 10 ** 9, 2 ** 40]) for _ in range(4)]
+        votes = [rng.choice(pool) for _ in range(N)]
+        truth = rng.choice(pool + [17])
+        enc = extract.ProblemEncoder()
+        t = enc.encode(truth)
+        coded = np.array([[[enc.encode(v) for v in votes]]], dtype=np.int32)
+        cell = eng.aggregate(coded, np.array([t], dtype=np.int32)).cells[0, 0]
+        want = pyoracle.cell_integers(votes, truth)
+        assert (cell["max_count"], cell["truth_count"], cell["n_modes"], cell["hit"]) == (
+            want["max_count"], want["truth_count"], want["n_modes"], want["hit"])
+
+
+def test_accuracy_canonical_float():
+    tie = np.zeros(1025, dtype=np.int64)
+    tie[1], tie[2], tie[4] = 17, 3, 2
+    assert scoring.accuracy_from_tie_classes(tie, 30) == (17 + 1.5 + 0.5) / 30
+    assert scoring.exact_accuracy_from_tie_classes(tie, 30) == Fraction(19, 30)
+    tie[3] = 2
+    assert abs(scoring.accuracy_from_tie_classes(tie, 30) - float(Fraction(19, 30) + Fraction(2, 90))) < 1e-15
+    # golden: 0.675 * 30 = 20.25
+    tie[:] = 0
+    tie[1], tie[4] = 20, 1
+    assert scoring.accuracy_from_tie_classes(tie, 30) == 0.675
+    v = scoring.avg_tokens_used(10904, 30)
+    assert isinstance(v, np.float64) and repr(float(v)) == "363.46666666666664"   # results_log_majority_vote.json:5
+
+
+def test_pass_at_k_matches_combinatorial_definition():
+    for n, c, k in [(16, 0, 4), (16, 3, 1), (16, 3, 4), (16, 16, 8), (100, 7, 64), (1024, 5, 1024), (8, 2, 8)]:
+        want = 1.0 - (math.comb(n - c, k) / math.comb(n, k) if n - c >= k else 0.0)
+        got = float(scoring.pass_at_k(n, np.array([c]), k)[0])
+        assert abs(got - want) < 1e-12, (n, c, k)
+    big = scoring.pass_at_k(2 ** 20, np.array([0, 1, 2 ** 19, 2 ** 20]), 1024)
+    assert big[0] == 0.0 and 0 < big[1] < 0.001 and big[2] == 1.0 and big[3] == 1.0
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+def test_numpy_generator_equals_c_generator(dist):
+    for (P, B, N, off) in [(5, 3, 257, 0), (3, 2, 64, 10 ** 6), (2, 1, 5, 9999)]:
+        a, t, tr = synth.fill(P, B, N, 0xC0FFEE, dist, off, want_tokens=True)
+        a2, t2, tr2 = coracle.synth_fill(P, B, N, 0xC0FFEE, dist, off, want_tokens=True)
+        assert np.array_equal(a, a2) and np.array_equal(t, t2) and np.array_equal(tr, tr2)
+        assert a.min() >= 0 and a.max() < 1000 and t.min() >= 100 and t.max() <= 12000
+    assert np.array_equal(synth.truth(7, 5, 3), coracle.synth_truth(7, 5, 3))
+
+
+def test_generator_distributions_have_the_intended_shape():
+    a, _, tr = coracle.synth_fill(8, 1, 1 << 14, 11, 1)
+    for p in range(8):
+        counts = np.bincount(a[p, 0], minlength=1000)
+        assert counts.argmax() == tr[p] and counts.max() > 0.08 * (1 << 14)
+    a, _, tr = coracle.synth_fill(8, 1, 4096, 11, 2)
+    assert all((a[p] == tr[p]).all() for p in range(8))
+    a, _, tr = coracle.synth_fill(8, 2, 4096, 11, 3)
+    out = coracle.aggregate(a, tr)
+    assert out["cells"]["n_modes"][::2, 0].tolist() == [2] * 4 and out["cells"]["n_modes"][1::2, 0].tolist() == [3] * 4
+    assert out["cells"]["hit"][:, 0].tolist() == [1, 1, 0, 0, 1, 1, 0, 0]
+
+
+def test_generator_is_shard_consistent():
+    whole, _, tr = coracle.synth_fill(10, 2, 33, 77, 1)
+    lo, hi = scv_dist.shard_bounds(10, 1, 3)
+    part, _, trp = coracle.synth_fill(hi - lo, 2, 33, 77, 1, p_offset=lo)
+    assert np.array_equal(whole[lo:hi], part) and np.array_equal(tr[lo:hi], trp)
+
+
+def test_shard_bounds_partition():
+    for P in (0, 1, 7, 30, 10000):
+        for world in (1, 2, 3, 8):
+            bounds = [scv_dist.shard_bounds(P, r, world) for r in range(world)]
+            assert bounds[0][0] == 0 and bounds[-1][1] == P
+            assert all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in bounds) - min(h - l for l, h in bounds) <= 1
+    assert scv_dist.shard_bounds(10000, 0, 8) == (0, 1250)
+
+
+def test_shard_then_sum_equals_unsharded():
+    """local counters + integer sum == unsharded, for any world size."""
+    eng = OracleEngine()
+    a, t, tr = coracle.synth_fill(23, 3, 64, 5, 3, want_tokens=True)
+    nv = np.array([64, 7, 1], dtype=np.int32)
+    whole = eng.aggregate(a, tr, tokens=t, n_valid=nv)
+    for world in (2, 3, 8):
+        tie = np.zeros_like(whole.tie_class_hits)
+        tok = np.zeros_like(whole.token_sum)
+        tcs = np.zeros_like(whole.truth_count_sum)
+        for r in range(world):
+            lo, hi = scv_dist.shard_bounds(23, r, world)
+            if hi > lo:
+                part = eng.aggregate(a[lo:hi], tr[lo:hi], tokens=t[lo:hi], n_valid=nv)
+                tie += part.tie_class_hits
+                tok += part.token_sum
+                tcs += part.truth_count_sum
+                assert_results_equal(part, type(whole)(hi - lo, 3, whole.cells[lo:hi], whole.cell_tokens[lo:hi],
+                                                       part.tie_class_hits, part.token_sum, part.truth_count_sum))
+        assert np.array_equal(tie, whole.tie_class_hits) and np.array_equal(tok, whole.token_sum)
+        assert np.array_equal(tcs, whole.truth_count_sum)
+
+
+def test_bootstrap_oracle_properties():
+    a, _, tr = coracle.synth_fill(50, 2, 32, 9, 3)
+    cells = coracle.aggregate(a, tr)["cells"]
+    rc, c1 = coracle.bootstrap(cells, 0, 20, 1234, 4)
+    assert rc == 0 and c1.shape == (20, 2, 4)
+    rc, c2 = coracle.bootstrap(cells, 5, 9, 1234, 4)
+    assert rc == 0 and np.array_equal(c1[5:9], c2)          # resample r depends only on (seed, r)
+    assert (c1.sum(axis=2) <= 50).all() and c1[:, :, 0].sum() == 0
+    rc, _ = coracle.bootstrap(cells, 0, 20, 1234, 3)          # class 3 exists -> M = 3 too small
+    assert rc != 0
+    acc, lo, hi = scoring.bootstrap_percentiles(c1, 50)
+    assert acc.shape == (20, 2) and (lo <= hi).all()
