@@ -1,0 +1,275 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs; against the committed golden fixtures; and, at BASELINE.json's full cell size,
+through size-independent properties.  Integer work => the bar is bit-exact everywhere.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+from o1_inference_scaling_laws_amd import _lib, o1_dropin, synth
+from o1_inference_scaling_laws_amd.engine import (AggregateResult, cells_from_torch, counters_size)
+from o1_inference_scaling_laws_amd.extract import build_vote_tensors
+from oracle import coracle
+from tests._adapters import (TEST_MODEL, TEST_PROMPT, OracleEngine, assert_results_equal, build_cache,
+                             make_dataset)
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle(answers, truth, tokens=None, n_valid=None):
+    return OracleEngine().aggregate(answers, truth, tokens=tokens, n_valid=n_valid)
+
+
+# ---- seeded inputs, HOST mode -----------------------------------------------------------------
+
+SHAPES = [  # (P, B, N): aligned, unaligned rows (N % 4 != 0), tiny, one vote, more cells than the grid
+    (30, 8, 4096), (7, 3, 1001), (5, 2, 3), (4, 1, 1), (2, 5, 2), (600, 2, 259), (3, 1, 70001), (1, 1, 1 << 20),
+]
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_host_mode_bit_exact_vs_oracle(hip_engine, dist, shape):
+    P, B, N = shape
+    a, t, tr = coracle.synth_fill(P, B, N, 1000 + dist, dist, want_tokens=True)
+    got = hip_engine.aggregate(a, tr, tokens=t)
+    assert_results_equal(got, oracle(a, tr, tokens=t))
+    got = hip_engine.aggregate(a, tr)            # votes-only kernel variant
+    assert_results_equal(got, oracle(a, tr), check_tokens=False)
+
+
+@pytest.mark.parametrize("n_valid", [[4096, 2048, 1024, 1, 0, 3, 4095, 17], [1, 1, 1, 1, 2, 4, 8, 16]])
+def test_ragged_prefix_budgets(hip_engine, n_valid):
+    """o1.py:274-276: budgets vote over prefixes of one pool; n_valid == 0 -> multimode([]) -> no hit."""
+    a, t, tr = coracle.synth_fill(30, 8, 4096, 7, 1, want_tokens=True)
+    nv = np.array(n_valid, dtype=np.int32)
+    got = hip_engine.aggregate(a, tr, tokens=t, n_valid=nv)
+    want = oracle(a, tr, tokens=t, n_valid=nv)
+    assert_results_equal(got, want)
+    if 0 in n_valid:
+        b = n_valid.index(0)
+        assert (got.cells["max_count"][:, b] == 0).all() and (got.cells["min_mode"][:, b] == -1).all()
+        assert (got.cells["hit"][:, b] == 0).all() and (got.cells["n_modes"][:, b] == 0).all()
+
+
+def test_spare_bins_and_truth_outside_histogram(hip_engine):
+    rng = np.random.default_rng(5)
+    a = rng.integers(990, 1024, size=(40, 2, 515), dtype=np.int32)
+    tr = rng.integers(-5, 1030, size=(40,), dtype=np.int32)
+    tr[:4] = [-1, 1024, 2 ** 31 - 1, -2 ** 31]
+    assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
+
+
+def test_all_bins_tied_gives_1024_modes(hip_engine):
+    a = np.tile(np.arange(1024, dtype=np.int32), 3).reshape(1, 1, 3072)
+    got = hip_engine.aggregate(a, np.array([1023], dtype=np.int32))
+    c = got.cells[0, 0]
+    assert (c["max_count"], c["n_modes"], c["min_mode"], c["hit"], c["truth_count"]) == (3, 1024, 0, 1, 3)
+    assert got.tie_class_hits[0, 1024] == 1
+
+
+def test_negative_tokens_and_int64_sums(hip_engine):
+    a = np.zeros((2, 1, 1 << 16), dtype=np.int32)
+    t = np.full((2, 1, 1 << 16), 2 ** 31 - 1, dtype=np.int32)
+    t[1] = -(2 ** 31)
+    got = hip_engine.aggregate(a, np.zeros(2, dtype=np.int32), tokens=t)
+    assert got.cell_tokens[0, 0] == (2 ** 31 - 1) * (1 << 16) and got.cell_tokens[1, 0] == -(2 ** 31) * (1 << 16)
+    assert got.token_sum[0] == got.cell_tokens.sum()
+
+
+def test_empty_shapes(hip_engine):
+    for shape in [(0, 3, 16), (4, 0, 16), (4, 2, 0)]:
+        P, B, N = shape
+        a = np.zeros(shape, dtype=np.int32)
+        got = hip_engine.aggregate(a, np.zeros(P, dtype=np.int32))
+        assert got.tie_class_hits.sum() == 0 and got.cells.shape == (P, B)
+        if N == 0 and P and B:
+            assert (got.cells["max_count"] == 0).all() and (got.cells["min_mode"] == -1).all()
+
+
+def test_domain_error_is_loud_and_clamp_flag_matches_oracle(hip_engine):
+    a = np.array([[[5, 5, 2000, -1, 7, 7, 7, 1, 2, 3]]], dtype=np.int32)
+    tr = np.array([5], dtype=np.int32)
+    with pytest.raises(_lib.DomainError):
+        hip_engine.aggregate(a, tr)
+    # the error word is cleared: a clean call afterwards succeeds
+    assert hip_engine.aggregate(np.minimum(np.abs(a), 999), tr).cells[0, 0]["max_count"] == 3
+    from o1_inference_scaling_laws_amd.engine import Engine
+    with Engine(clamp_to_invalid_bin=True) as eng:
+        got = eng.aggregate(a, tr)
+        want = coracle.aggregate(a, tr, clamp=True)
+        assert want["rc"] == 0
+        for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+            assert np.array_equal(got.cells[f], want["cells"][f])
+
+
+def test_argument_errors(hip_engine):
+    L, ctx = hip_engine._L, hip_engine._ctx
+    assert L.scv_aggregate_i32(ctx, None, None, None, None, 1, 1, 4, 0, None, None, None, None, None) == _lib.ERR_ARG
+    assert b"truth" in L.scv_last_error()
+    assert L.scv_aggregate_i32(ctx, None, None, None, None, -1, 1, 4, 0, None, None, None, None, None) == _lib.ERR_ARG
+    assert L.scv_set_tuning(ctx, 5, 0, 0, 0) == _lib.ERR_ARG
+
+
+@pytest.mark.parametrize("copies", [8, 16, 32])
+@pytest.mark.parametrize("threads", [256, 512, 1024])
+@pytest.mark.parametrize("unroll", [2, 4, 8])
+def test_every_kernel_variant_is_bit_exact(hip_engine, copies, threads, unroll):
+    a, t, tr = coracle.synth_fill(9, 3, 30001, 99, 1, want_tokens=True)
+    nv = np.array([30001, 12345, 2], dtype=np.int32)
+    want = oracle(a, tr, tokens=t, n_valid=nv)
+    try:
+        hip_engine.set_tuning(copies=copies, threads=threads, wg_per_cu=2, unroll=unroll)
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
+        assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), want, check_tokens=False)
+    finally:
+        hip_engine.set_tuning(copies=16, threads=512, wg_per_cu=2, unroll=4)
+
+
+# ---- golden fixtures generated from the unmodified reference ------------------------------------
+
+def test_golden_fixtures_through_the_gpu(hip_engine, golden, tmp_path):
+    from fractions import Fraction
+    cfg = o1_dropin.DropInConfig(model=TEST_MODEL, prompt=TEST_PROMPT, engine=hip_engine, helper_folder=str(tmp_path))
+    for case in golden["cases"]:
+        ds = make_dataset(case["truths"])
+        cache = build_cache(ds, case["samples"])
+        vt = build_vote_tensors(ds, cache, [(case["token_limit"], case["N"])], TEST_MODEL, TEST_PROMPT)
+        res = hip_engine.aggregate(vt.answers, vt.truth, tokens=vt.tokens, n_valid=vt.n_valid)
+        for p, (num, den, tok) in enumerate(case["per_problem"]):
+            cell = res.cells[p, 0]
+            assert (Fraction(1, int(cell["n_modes"])) if cell["hit"] else Fraction(0)) == Fraction(num, den)
+            assert int(res.cell_tokens[p, 0]) == tok
+        assert res.exact_accuracy(0) == Fraction(*case["accuracy_exact"])
+        acc, avg = o1_dropin.run_experiments(cfg, ds, cache, case["token_limit"], case["N"])
+        assert abs(acc - float(case["accuracy_live"])) < 1e-12 and repr(float(avg)) == case["avg_tokens_used"]
+    pipe = golden["pipeline"]
+    ds = make_dataset(pipe["truths"])
+    cache = build_cache(ds, pipe["samples"])
+    o1_dropin.run_majority_vote_inference_experiments(cfg, ds, cache)
+    o1_dropin.run_just_ask_nicely_experiments(cfg, ds, cache)
+    for name, want in pipe["results_logs"].items():
+        assert (tmp_path / name).read_text() == want, name
+
+
+# ---- DEVICE mode (torch tensors), device generator, BASELINE sizes ------------------------------
+
+def _device_run(hip_engine, P, B, N, seed, dist, with_tokens=False, n_valid=None, p_offset=0):
+    import torch
+    dev = torch.device("cuda:0")
+    ans = torch.empty((P, B, N), dtype=torch.int32, device=dev)
+    tok = torch.empty((P, B, N), dtype=torch.int32, device=dev) if with_tokens else None
+    tr = torch.empty((P,), dtype=torch.int32, device=dev)
+    hip_engine.synth_fill_device(ans, tok, tr, P=P, B=B, N=N, seed=seed, dist=dist, p_offset=p_offset)
+    nv = None if n_valid is None else torch.tensor(n_valid, dtype=torch.int32, device=dev)
+    counters, cells, ctok = hip_engine.aggregate_device(ans, tr, tokens=tok, n_valid=nv)
+    hip_engine.sync()
+    return ans, tok, tr, counters, cells, ctok
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+def test_device_generator_equals_cpu_mirror(hip_engine, dist):
+    P, B, N = 6, 3, 1037
+    ans, tok, tr, *_ = _device_run(hip_engine, P, B, N, 0xC0FFEE, dist, with_tokens=True, p_offset=12345)
+    a, t, trc = synth.fill(P, B, N, 0xC0FFEE, dist, p_offset=12345, want_tokens=True)
+    assert np.array_equal(ans.cpu().numpy(), a) and np.array_equal(tok.cpu().numpy(), t)
+    assert np.array_equal(tr.cpu().numpy(), trc)
+
+
+@pytest.mark.parametrize("dist", [0, 1, 3])
+def test_config_C2_full_size_bit_exact(hip_engine, dist):
+    """BASELINE config 2: P=30 x B=8 x N=2^17 synthetic int32, bit-exact vs the CPU loop."""
+    P, B, N = 30, 8, 1 << 17
+    ans, tok, tr, counters, cells, ctok = _device_run(hip_engine, P, B, N, 20240914, dist, with_tokens=True)
+    a, t, trc = coracle.synth_fill(P, B, N, 20240914, dist, want_tokens=True)
+    assert np.array_equal(ans.cpu().numpy(), a)
+    want = oracle(a, trc, tokens=t)
+    got = AggregateResult.from_counters(counters.cpu().numpy(), P, B, cells_from_torch(cells), ctok.cpu().numpy())
+    assert_results_equal(got, want)
+    assert got.accuracy(0) == want.accuracy(0) and got.avg_tokens_used(0) == want.avg_tokens_used(0)
+
+
+def test_config_C3_cell_size_properties(hip_engine):
+    """BASELINE config 3 cells (N = 2^20, B = 8) on a slab of problems that fits comfortably:
+    (1) sampled problems bit-exact vs the oracle on CPU-regenerated rows, (2) invariants of every
+    cell, (3) shard additivity, (4) duplication: a cell voted twice doubles counts, keeps modes."""
+    import torch
+    P, B, N, seed = 96, 8, 1 << 20, 31337
+    ans, _, tr, counters, cells, _ = _device_run(hip_engine, P, B, N, seed, 1, p_offset=5000)
+    c = cells_from_torch(cells)
+    cnt = counters.cpu().numpy()
+    # (1)
+    for p in (0, 37, 95):
+        a, _, trc = coracle.synth_fill(1, B, N, seed, 1, p_offset=5000 + p)
+        want = coracle.aggregate(a, trc)["cells"]
+        for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+            assert np.array_equal(c[f][p], want[f][0]), (p, f)
+    # (2)
+    assert (c["truth_count"] <= c["max_count"]).all() and (c["max_count"] <= N).all()
+    assert ((c["truth_count"] == c["max_count"]) == (c["hit"] == 1)).all()
+    assert (c["n_modes"] >= 1).all() and (c["min_mode"] >= 0).all() and (c["min_mode"] < 1000).all()
+    tie = cnt[: B * 1025].reshape(B, 1025)
+    assert np.array_equal(tie.sum(axis=1), c["hit"].sum(axis=0))
+    assert np.array_equal(cnt[B * 1025 + B:], c["truth_count"].astype(np.int64).sum(axis=0))
+    # (3)
+    acc = torch.zeros(counters_size(B), dtype=torch.int64, device="cuda:0")
+    for lo, hi in ((0, 11), (11, 64), (64, 96)):
+        hip_engine.aggregate_device(ans[lo:hi], tr[lo:hi], counters=acc, cells=False)
+    hip_engine.sync()
+    assert np.array_equal(acc.cpu().numpy(), cnt)
+    # (4)
+    dup = torch.cat([ans[:4], ans[:4]], dim=2).contiguous()
+    _, dcells, _ = hip_engine.aggregate_device(dup, tr[:4])
+    hip_engine.sync()
+    d = cells_from_torch(dcells)
+    assert np.array_equal(d["max_count"], 2 * c["max_count"][:4]) and np.array_equal(d["n_modes"], c["n_modes"][:4])
+    assert np.array_equal(d["min_mode"], c["min_mode"][:4]) and np.array_equal(d["truth_count"], 2 * c["truth_count"][:4])
+
+
+def test_permutation_invariance(hip_engine):
+    import torch
+    ans, _, tr, counters, cells, _ = _device_run(hip_engine, 12, 4, 50000, 77, 3)
+    perm = torch.randperm(50000, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1))
+    c2, cells2, _ = hip_engine.aggregate_device(ans[:, :, perm].contiguous(), tr)
+    hip_engine.sync()
+    assert torch.equal(cells, cells2) and torch.equal(counters, c2)
+
+
+def test_device_mode_domain_error_surfaces_at_sync(hip_engine):
+    import torch
+    ans = torch.full((2, 1, 64), 5, dtype=torch.int32, device="cuda:0")
+    ans[1, 0, 63] = 4000
+    hip_engine.aggregate_device(ans, torch.zeros(2, dtype=torch.int32, device="cuda:0"))
+    with pytest.raises(_lib.DomainError):
+        hip_engine.sync()
+    hip_engine.sync()     # cleared
+
+
+# ---- bootstrap ------------------------------------------------------------------------------------
+
+def test_bootstrap_bit_exact_vs_oracle(hip_engine):
+    a, _, tr = coracle.synth_fill(257, 4, 96, 9, 3)
+    cells = coracle.aggregate(a, tr)["cells"]
+    rc, want = coracle.bootstrap(cells, 3, 203, 0xB007, 4)
+    assert rc == 0
+    got = hip_engine.bootstrap(hip_engine.aggregate(a, tr).cells, 3, 203, 0xB007, 4)
+    assert np.array_equal(got, want)
+    with pytest.raises(_lib.ScvError):
+        hip_engine.bootstrap(cells, 0, 10, 0xB007, 3)   # class 3 present, M too small
+
+
+def test_bootstrap_device_fused_no_host_roundtrip(hip_engine):
+    ans, _, tr, counters, cells, _ = _device_run(hip_engine, 500, 2, 4096, 5, 3)
+    out = hip_engine.bootstrap_device(cells, 0, 100, 42, 4)
+    hip_engine.sync()
+    rc, want = coracle.bootstrap(cells_from_torch(cells), 0, 100, 42, 4)
+    assert rc == 0 and np.array_equal(out.cpu().numpy(), want)
+
+
+def test_kernel_timing_is_reported(hip_engine):
+    hip_engine.drain_kernel_ns()
+    a, _, tr = coracle.synth_fill(4, 2, 4096, 1, 0)
+    hip_engine.aggregate(a, tr)
+    total, n = hip_engine.drain_kernel_ns()
+    assert n == 1 and 0 < total < 10 ** 9
