@@ -80,7 +80,9 @@ typedef struct scv_ctx scv_ctx;   /* opaque: device, stream, scratch, timing eve
 int scv_create(scv_ctx** out, int device, uint32_t flags);
 int scv_destroy(scv_ctx* ctx);
 
-/* Borrow an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+/* A new ctx launches on a private non-blocking stream.  scv_set_stream BORROWS the caller's
+ * hipStream_t instead (e.g. torch.cuda.current_stream().cuda_stream); NULL is the device's default
+ * stream -- which is what torch hands out until the user opens a stream of their own. */
 int scv_set_stream(scv_ctx* ctx, void* hip_stream);
 /* Block until everything queued on the ctx stream has finished; reports SCV_ERR_DOMAIN if a
  * DEVICE-mode aggregation since the last sync saw an out-of-domain vote. */
@@ -94,6 +96,9 @@ int scv_sync(scv_ctx* ctx);
  *   unroll        16-byte loads in flight per lane in {1,2,4,8}
  */
 int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unroll);
+/* Launch-geometry options for measurement: "grid" (> 0: exact persistent grid, 0: derive from the
+ * CU count), "balance" (default 1: shrink the grid so all workgroups stream the same number of cells). */
+int scv_set_option(scv_ctx* ctx, const char* key, int64_t value);
 
 /*
  * The hot path.  Replaces, for all P problems and B budgets at once,

@@ -35,6 +35,10 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    # One HIP runtime per process.  Device pointers and stream handles cross this boundary from
+    # torch, so libscvote must bind to the libamdhip64 torch has loaded (same SONAME, resolved to the
+    # already-loaded copy); loading ours first would bring in a second runtime from /opt/rocm.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     p, i32, i64, u32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
     L.scv_create.argtypes = [C.POINTER(p), C.c_int, u32]
@@ -42,6 +46,7 @@ def load():
     L.scv_set_stream.argtypes = [p, p]
     L.scv_sync.argtypes = [p]
     L.scv_set_tuning.argtypes = [p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.scv_set_option.argtypes = [p, C.c_char_p, i64]
     L.scv_aggregate_i32.argtypes = [p, p, p, p, p, i64, i32, i64, C.c_int, p, p, p, p, p]
     L.scv_bootstrap.argtypes = [p, p, i64, i32, i32, i32, u64, i32, C.c_int, p]
     L.scv_synth_fill_i32.argtypes = [p, p, p, p, i64, i32, i64, i64, u64, C.c_int]
@@ -53,7 +58,7 @@ def load():
     L.scv_last_error.restype = C.c_char_p
     L.scv_version.argtypes = []
     L.scv_version.restype = C.c_char_p
-    for name in ("scv_create", "scv_destroy", "scv_set_stream", "scv_sync", "scv_set_tuning", "scv_aggregate_i32",
+    for name in ("scv_create", "scv_destroy", "scv_set_stream", "scv_sync", "scv_set_tuning", "scv_set_option", "scv_aggregate_i32",
                  "scv_bootstrap", "scv_synth_fill_i32", "scv_last_kernel_ns", "scv_drain_kernel_ns",
                  "scv_device_count", "scv_device_info"):
         getattr(L, name).restype = C.c_int

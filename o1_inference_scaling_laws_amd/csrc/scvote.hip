@@ -48,6 +48,8 @@ struct scv_ctx {
     int64_t hbm_bytes = 0;
     // tuning
     int copies = 16, threads = 512, wg_per_cu = 2, unroll = 4;
+    int grid_override = 0;   // > 0: exact persistent grid size
+    int balance = 1;         // shrink the grid so every workgroup streams the same number of cells
     // device scratch
     uint32_t* d_err = nullptr;
     bool err_dirty = false;
@@ -131,7 +133,16 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     if (wg_per_cu > by_waves) wg_per_cu = by_waves;
     if (wg_per_cu < 1) wg_per_cu = 1;
     int64_t grid = (int64_t)ctx->num_cus * wg_per_cu;
+    if (ctx->grid_override > 0) grid = ctx->grid_override;
     if (grid > ncells) grid = ncells;
+    if (ctx->balance && ctx->grid_override <= 0) {
+        // Cells cost the same (same n_valid pattern per problem), and a 4 MiB cell is several
+        // percent of a launch: a ragged last round (10000 cells over 512 workgroups = 19.5 rounds)
+        // leaves half the chip idle for a whole cell.  Use the smallest grid with the same number
+        // of rounds, so every workgroup streams exactly `rounds` (or rounds-1) cells.
+        const int64_t rounds = (ncells + grid - 1) / grid;
+        grid = (ncells + rounds - 1) / rounds;
+    }
 
     KernelFn fn = pick_kernel(copies, threads, ctx->unroll, tokens != nullptr);
     SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -226,6 +237,8 @@ int scv_create(scv_ctx** out, int device, uint32_t flags) {
     ctx->threads = env_int("SCV_THREADS", ctx->threads);
     ctx->wg_per_cu = env_int("SCV_WG_PER_CU", ctx->wg_per_cu);
     ctx->unroll = env_int("SCV_UNROLL", ctx->unroll);
+    ctx->grid_override = env_int("SCV_GRID", 0);
+    ctx->balance = env_int("SCV_BALANCE", 1);
     if (!valid_copies(ctx->copies) || !valid_threads(ctx->threads) || !valid_unroll(ctx->unroll) || ctx->wg_per_cu < 1) {
         int code = fail(SCV_ERR_ARG, "bad SCV_* tuning environment");
         scv_destroy(ctx);
@@ -252,12 +265,7 @@ int scv_set_stream(scv_ctx* ctx, void* hip_stream) {
     if (int rc = set_device(ctx)) return rc;
     SCV_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream) { SCV_HIP(hipStreamDestroy(ctx->stream)); ctx->own_stream = false; }
-    if (hip_stream) {
-        ctx->stream = (hipStream_t)hip_stream;
-    } else {
-        SCV_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    }
+    ctx->stream = (hipStream_t)hip_stream;  // borrowed; NULL is the device's default stream
     return SCV_OK;
 }
 
@@ -276,6 +284,14 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
     if (threads > 0) { if (!valid_threads(threads)) return fail(SCV_ERR_ARG, "threads must be 256, 512 or 1024"); ctx->threads = threads; }
     if (wg_per_cu > 0) ctx->wg_per_cu = wg_per_cu;
     if (unroll > 0) { if (!valid_unroll(unroll)) return fail(SCV_ERR_ARG, "unroll must be 2, 4 or 8"); ctx->unroll = unroll; }
+    return SCV_OK;
+}
+
+int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return fail(SCV_ERR_ARG, "NULL argument");
+    if (!strcmp(key, "grid")) { if (value < 0 || value > (1 << 20)) return fail(SCV_ERR_ARG, "grid out of range"); ctx->grid_override = (int)value; }
+    else if (!strcmp(key, "balance")) ctx->balance = value != 0;
+    else return fail(SCV_ERR_ARG, "unknown option '%s'", key);
     return SCV_OK;
 }
 

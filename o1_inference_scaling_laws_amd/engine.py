@@ -105,12 +105,15 @@ class Engine:
     def set_tuning(self, copies: int = 0, threads: int = 0, wg_per_cu: int = 0, unroll: int = 0):
         check(self._L.scv_set_tuning(self._ctx, copies, threads, wg_per_cu, unroll))
 
+    def set_option(self, key: str, value: int):
+        check(self._L.scv_set_option(self._ctx, key.encode(), int(value)))
+
     def use_torch_stream(self):
         """Launch on torch's current stream so engine work orders with torch / RCCL ops."""
         import torch
-        s = torch.cuda.current_stream().cuda_stream
+        s = int(torch.cuda.current_stream().cuda_stream)   # 0 = the default stream: borrowed as such
         if s != self._bound_stream:
-            check(self._L.scv_set_stream(self._ctx, C.c_void_p(s) if s else None))
+            check(self._L.scv_set_stream(self._ctx, C.c_void_p(s)))
             self._bound_stream = s
 
     def sync(self):

@@ -227,6 +227,27 @@ def test_config_C3_cell_size_properties(hip_engine):
     assert np.array_equal(d["min_mode"], c["min_mode"][:4]) and np.array_equal(d["truth_count"], 2 * c["truth_count"][:4])
 
 
+def test_device_mode_orders_with_torch_default_stream(hip_engine):
+    """Regression: torch's default stream handle is 0; the engine must BORROW it (not open a private
+    stream), so counters.zero_() / aggregate / .cpu() on torch's stream are ordered without syncs."""
+    import torch
+    ans, _, tr, counters, cells, _ = _device_run(hip_engine, 64, 4, 1 << 16, 3, 1)
+    want = counters.clone()
+    acc = torch.empty_like(counters)
+    for _ in range(6):
+        acc.zero_()
+        hip_engine.aggregate_device(ans, tr, counters=acc, cells=False)
+    assert torch.equal(acc.cpu(), want.cpu())          # 6x-accumulated counters would differ
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        acc.zero_()
+        hip_engine.aggregate_device(ans, tr, counters=acc, cells=False)
+        got = acc.cpu()
+    assert torch.equal(got, want.cpu())
+    hip_engine.use_torch_stream()
+    hip_engine.sync()
+
+
 def test_permutation_invariance(hip_engine):
     import torch
     ans, _, tr, counters, cells, _ = _device_run(hip_engine, 12, 4, 50000, 77, 3)

@@ -26,7 +26,10 @@ def main():
     ap.add_argument("--unroll", default="2,4,8")
     ap.add_argument("--dists", default="1,0,2")
     ap.add_argument("--tokens", action="store_true")
+    ap.add_argument("--balance", default="1", help="comma list of 0/1: balanced-grid option")
+    ap.add_argument("--grids", default="0", help="comma list of explicit grid sizes (0 = derive)")
     ap.add_argument("--out", default="gpurun_out/sweep.json")
+    ap.add_argument("--top", type=int, default=8)
     args = ap.parse_args()
     import torch
     from o1_inference_scaling_laws_amd.engine import Engine, counters_size
@@ -44,7 +47,9 @@ def main():
         lds = (1024 * c + 96) * 4
         if w > (160 * 1024) // lds or w > 2048 // t:
             continue                                     # would be clamped to an already-listed point
-        variants.append((c, t, w, u))
+        for bal in lst(args.balance):
+            for g in lst(args.grids):
+                variants.append((c, t, w, u, bal, g))
     results = []
     nbytes = P * B * N * 4 * (2 if args.tokens else 1)
     for d in lst(args.dists):
@@ -55,6 +60,8 @@ def main():
         for r in range(args.rounds + 1):
             for v in variants:
                 eng.set_tuning(*v[:2], v[2], v[3])
+                eng.set_option("balance", v[4])
+                eng.set_option("grid", v[5])
                 counters.zero_()
                 eng.aggregate_device(ans, tr, tokens=tok, counters=counters, cells=cells)
                 eng.sync()
@@ -67,12 +74,12 @@ def main():
                 assert h == ref, f"variant {v} disagrees on dist {d}: {h} vs {ref}"
         for v in variants:
             med, mn = statistics.median(times[v]), min(times[v])
-            results.append({"dist": d, "copies": v[0], "threads": v[1], "wg_per_cu": v[2], "unroll": v[3],
+            results.append({"dist": d, "copies": v[0], "threads": v[1], "wg_per_cu": v[2], "unroll": v[3], "balance": v[4], "grid": v[5],
                             "median_ms": med / 1e6, "min_ms": mn / 1e6, "GBps_median": nbytes / med, "GBps_best": nbytes / mn})
-        best = sorted((r for r in results if r["dist"] == d), key=lambda r: r["median_ms"])[:8]
+        best = sorted((r for r in results if r["dist"] == d), key=lambda r: r["median_ms"])[:args.top]
         print(f"dist {d}: top variants (copies, threads, wg/cu, unroll) -> GB/s median")
         for r in best:
-            print(f"  R={r['copies']:2d} T={r['threads']:4d} wg={r['wg_per_cu']} U={r['unroll']}  {r['GBps_median']:7.0f} GB/s  ({r['median_ms']:.3f} ms)")
+            print(f"  R={r['copies']:2d} T={r['threads']:4d} wg={r['wg_per_cu']} U={r['unroll']} bal={r['balance']} grid={r['grid']}  {r['GBps_median']:7.0f} GB/s  ({r['median_ms']:.3f} ms)")
         sys.stdout.flush()
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     with open(args.out, "w") as f:
