@@ -47,7 +47,9 @@ struct scv_ctx {
     int64_t clock_khz = 0;
     int64_t hbm_bytes = 0;
     // tuning
-    int copies = 16, threads = 512, wg_per_cu = 2, unroll = 4;
+    int copies = 16, threads = 1024, wg_per_cu = 1, unroll = 4;
+    int stagger_vecs = 0;    // rotate each workgroup's start inside its cell (16-byte vectors per workgroup index)
+    int plain_loads = 0;
     int grid_override = 0;   // > 0: exact persistent grid size
     int balance = 1;         // shrink the grid so every workgroup streams the same number of cells
     // device scratch
@@ -121,6 +123,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
+    a.stagger_vecs = ctx->stagger_vecs;
+    a.plain_loads = ctx->plain_loads;
 
     int copies = ctx->copies, threads = ctx->threads;
     size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords) * sizeof(uint32_t);
@@ -239,6 +243,8 @@ int scv_create(scv_ctx** out, int device, uint32_t flags) {
     ctx->unroll = env_int("SCV_UNROLL", ctx->unroll);
     ctx->grid_override = env_int("SCV_GRID", 0);
     ctx->balance = env_int("SCV_BALANCE", 1);
+    ctx->stagger_vecs = env_int("SCV_STAGGER_VECS", ctx->stagger_vecs);
+    ctx->plain_loads = env_int("SCV_PLAIN_LOADS", 0);
     if (!valid_copies(ctx->copies) || !valid_threads(ctx->threads) || !valid_unroll(ctx->unroll) || ctx->wg_per_cu < 1) {
         int code = fail(SCV_ERR_ARG, "bad SCV_* tuning environment");
         scv_destroy(ctx);
@@ -291,6 +297,8 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return fail(SCV_ERR_ARG, "NULL argument");
     if (!strcmp(key, "grid")) { if (value < 0 || value > (1 << 20)) return fail(SCV_ERR_ARG, "grid out of range"); ctx->grid_override = (int)value; }
     else if (!strcmp(key, "balance")) ctx->balance = value != 0;
+    else if (!strcmp(key, "stagger_vecs")) { if (value < 0 || value > (1 << 28)) return fail(SCV_ERR_ARG, "stagger out of range"); ctx->stagger_vecs = (int)value; }
+    else if (!strcmp(key, "plain_loads")) ctx->plain_loads = value != 0;
     else return fail(SCV_ERR_ARG, "unknown option '%s'", key);
     return SCV_OK;
 }

@@ -51,6 +51,8 @@ struct AggArgs {
     unsigned long long* token_sum;
     unsigned long long* truth_sum;
     uint32_t* err_flag;
+    int32_t stagger_vecs;   // > 0: workgroup w starts each cell rotated by (w * stagger_vecs) 16-byte vectors
+    int32_t plain_loads;    // != 0: ordinary loads instead of non-temporal ones
 };
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -95,6 +97,25 @@ __device__ __forceinline__ int4 stream_load(const int4* p) {
     // read-once stream: non-temporal so the line is not kept for a reuse that never comes
     const v4i32 v = __builtin_nontemporal_load(reinterpret_cast<const v4i32*>(p));
     return make_int4(v.x, v.y, v.z, v.w);
+}
+
+// Stream the 16-byte vectors [lo, hi) of one cell into the replicated LDS histogram:
+// U loads in flight per lane, each wave instruction covering 1 KiB contiguous.
+template <int RL2, int T, int U, bool NT>
+__device__ __forceinline__ void stream_votes(uint32_t* hist, uint32_t copy, const int4* v4, int64_t lo, int64_t hi,
+                                             int tid, uint32_t& bad) {
+    int64_t i = lo + tid;
+    for (; i + (int64_t)(U - 1) * T < hi; i += (int64_t)U * T) {
+        int4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = NT ? stream_load(v4 + i + (int64_t)u * T) : v4[i + (int64_t)u * T];
+#pragma unroll
+        for (int u = 0; u < U; ++u) vote4<RL2>(hist, copy, x[u], bad);
+    }
+    for (; i < hi; i += T) {
+        const int4 x = NT ? stream_load(v4 + i) : v4[i];
+        vote4<RL2>(hist, copy, x, bad);
+    }
 }
 
 // RL2 = log2(copies), T = threads per workgroup, U = 16-byte loads in flight per lane.
@@ -147,16 +168,17 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
         const int64_t nvec = (n - head) >> 2;
         int64_t i = tid;
         if (!TOK) {
-            for (; i + (int64_t)(U - 1) * T < nvec; i += (int64_t)U * T) {
-                int4 x[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) x[u] = stream_load(v4 + i + (int64_t)u * T);
-#pragma unroll
-                for (int u = 0; u < U; ++u) vote4<RL2>(hist, copy, x[u], bad);
-            }
-            for (; i < nvec; i += T) {
-                const int4 x = stream_load(v4 + i);
-                vote4<RL2>(hist, copy, x, bad);
+            // votes are order-independent, so a workgroup may start anywhere in its cell: rotating the
+            // start by workgroup index de-synchronises the 250+ concurrent streams (otherwise all of
+            // them sit at the same offset of their 4 MiB-aligned cells at the same time).
+            int64_t rot = 0;
+            if (a.stagger_vecs > 0 && nvec > 0) rot = ((int64_t)blockIdx.x * a.stagger_vecs) % nvec;
+            if (a.plain_loads) {
+                stream_votes<RL2, T, U, false>(hist, copy, v4, rot, nvec, tid, bad);
+                if (rot) stream_votes<RL2, T, U, false>(hist, copy, v4, 0, rot, tid, bad);
+            } else {
+                stream_votes<RL2, T, U, true>(hist, copy, v4, rot, nvec, tid, bad);
+                if (rot) stream_votes<RL2, T, U, true>(hist, copy, v4, 0, rot, tid, bad);
             }
         } else {
             // the token row has the same misalignment as the vote row only if both bases agree

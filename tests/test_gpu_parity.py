@@ -124,7 +124,21 @@ def test_every_kernel_variant_is_bit_exact(hip_engine, copies, threads, unroll):
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
         assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), want, check_tokens=False)
     finally:
-        hip_engine.set_tuning(copies=16, threads=512, wg_per_cu=2, unroll=4)
+        hip_engine.set_tuning(copies=16, threads=1024, wg_per_cu=1, unroll=4)
+
+
+@pytest.mark.parametrize("stagger,plain,balance,grid", [(4099, 0, 1, 0), (1 << 16, 1, 0, 0), (0, 1, 1, 7), (12345, 0, 0, 3)])
+def test_launch_geometry_options_are_bit_exact(hip_engine, stagger, plain, balance, grid):
+    a, _, tr = coracle.synth_fill(37, 3, 100003, 5, 1)
+    nv = np.array([100003, 4097, 5], dtype=np.int32)
+    want = oracle(a, tr, n_valid=nv)
+    try:
+        for k, v in (("stagger_vecs", stagger), ("plain_loads", plain), ("balance", balance), ("grid", grid)):
+            hip_engine.set_option(k, v)
+        assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), want, check_tokens=False)
+    finally:
+        for k, v in (("stagger_vecs", 0), ("plain_loads", 0), ("balance", 1), ("grid", 0)):
+            hip_engine.set_option(k, v)
 
 
 # ---- golden fixtures generated from the unmodified reference ------------------------------------

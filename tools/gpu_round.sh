@@ -9,7 +9,7 @@ echo "== torch-free load"; timeout 120 python -c "import ctypes; L=ctypes.CDLL('
 echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
 echo "== bench"; timeout 600 python bench.py 2> gpurun_out/bench.err | tee gpurun_out/bench.json; tail -3 gpurun_out/bench.err
-echo "== sweep full chunk"; timeout 900 python tools/sweep.py --problems 1250 --copies 16,32 --threads 512,1024 --wg 1,2 --unroll 4,8 --dists 1 --rounds 3 --balance 0,1 --top 40 --out gpurun_out/sweep_full.json 2>&1 | tee gpurun_out/sweep_full.log | tail -45
+echo "== probe"; timeout 300 ./tools/hbm_probe.bin 42 2>&1 | tee gpurun_out/hbm_probe.log | tail -8
 echo "== rocprof kernel-trace"; cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_trace.log 2>&1; tail -2 $R/gpurun_out/prof_trace.log
 echo "== rocprof pmc FETCH_SIZE"; timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_fetch.log 2>&1; tail -2 $R/gpurun_out/prof_fetch.log
 echo "== rocprof pmc WRITE_SIZE"; timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_write.log 2>&1; tail -2 $R/gpurun_out/prof_write.log

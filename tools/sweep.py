@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--tokens", action="store_true")
     ap.add_argument("--balance", default="1", help="comma list of 0/1: balanced-grid option")
     ap.add_argument("--grids", default="0", help="comma list of explicit grid sizes (0 = derive)")
+    ap.add_argument("--stagger", default="0", help="comma list of stagger_vecs values")
+    ap.add_argument("--plain", default="0", help="comma list of 0/1: plain instead of non-temporal loads")
     ap.add_argument("--out", default="gpurun_out/sweep.json")
     ap.add_argument("--top", type=int, default=8)
     args = ap.parse_args()
@@ -49,7 +51,9 @@ def main():
             continue                                     # would be clamped to an already-listed point
         for bal in lst(args.balance):
             for g in lst(args.grids):
-                variants.append((c, t, w, u, bal, g))
+                for sg in lst(args.stagger):
+                    for pl in lst(args.plain):
+                        variants.append((c, t, w, u, bal, g, sg, pl))
     results = []
     nbytes = P * B * N * 4 * (2 if args.tokens else 1)
     for d in lst(args.dists):
@@ -62,6 +66,8 @@ def main():
                 eng.set_tuning(*v[:2], v[2], v[3])
                 eng.set_option("balance", v[4])
                 eng.set_option("grid", v[5])
+                eng.set_option("stagger_vecs", v[6])
+                eng.set_option("plain_loads", v[7])
                 counters.zero_()
                 eng.aggregate_device(ans, tr, tokens=tok, counters=counters, cells=cells)
                 eng.sync()
@@ -74,12 +80,12 @@ def main():
                 assert h == ref, f"variant {v} disagrees on dist {d}: {h} vs {ref}"
         for v in variants:
             med, mn = statistics.median(times[v]), min(times[v])
-            results.append({"dist": d, "copies": v[0], "threads": v[1], "wg_per_cu": v[2], "unroll": v[3], "balance": v[4], "grid": v[5],
+            results.append({"dist": d, "copies": v[0], "threads": v[1], "wg_per_cu": v[2], "unroll": v[3], "balance": v[4], "grid": v[5], "stagger": v[6], "plain": v[7],
                             "median_ms": med / 1e6, "min_ms": mn / 1e6, "GBps_median": nbytes / med, "GBps_best": nbytes / mn})
         best = sorted((r for r in results if r["dist"] == d), key=lambda r: r["median_ms"])[:args.top]
         print(f"dist {d}: top variants (copies, threads, wg/cu, unroll) -> GB/s median")
         for r in best:
-            print(f"  R={r['copies']:2d} T={r['threads']:4d} wg={r['wg_per_cu']} U={r['unroll']} bal={r['balance']} grid={r['grid']}  {r['GBps_median']:7.0f} GB/s  ({r['median_ms']:.3f} ms)")
+            print(f"  R={r['copies']:2d} T={r['threads']:4d} wg={r['wg_per_cu']} U={r['unroll']} bal={r['balance']} grid={r['grid']} stag={r['stagger']} plain={r['plain']}  {r['GBps_median']:7.0f} GB/s  ({r['median_ms']:.3f} ms)")
         sys.stdout.flush()
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     with open(args.out, "w") as f:
