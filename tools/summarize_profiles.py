@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Copy the judged rocprofv3 evidence from gpurun_out/ (scratch) into profiles/ (tracked):
+kernel-trace --stats summary + per-kernel PMC averages with the gfx950 FETCH_SIZE x2 correction
+(/opt/skills/guides/MI355X_MICROARCH.md, HBM section).  Usage: summarize_profiles.py r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
+os.makedirs(P, exist_ok=True)
+
+
+def newest(pattern):
+    files = glob.glob(os.path.join(G, pattern))
+    return max(files, key=os.path.getmtime) if files else None
+
+
+lines = [f"# rocprofv3 summary {tag} (MI355X, `python bench.py --no-cpu-baseline`)", ""]
+ks = newest("prof_trace/*/*_kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(P, f"{tag}_kernel_stats.csv"))
+    lines += ["## kernel-trace --stats (8 timed + 2 warmup + 1 parity step)", "", "| kernel | calls | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
+    for r in csv.DictReader(open(ks)):
+        lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {float(r['MinNs'])/1e6:.3f} | {float(r['MaxNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |")
+    lines.append("")
+kt = newest("prof_trace/*/*_kernel_trace.csv")
+if kt:
+    for r in csv.DictReader(open(kt)):
+        if "scv_hist_argmax" in r["Kernel_Name"]:
+            lines += [f"Dispatch geometry of `scv_hist_argmax`: grid {r['Grid_Size_X']} threads / workgroup {r['Workgroup_Size_X']}"
+                      f" = {int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])} workgroups, LDS {r['LDS_Block_Size']} B, VGPR {r['VGPR_Count']}, SGPR {r['SGPR_Count']}, scratch {r['Scratch_Size']}.", ""]
+            break
+pmc = collections.defaultdict(list)
+for sub in ("prof_fetch", "prof_write", "prof_lds"):
+    f = newest(f"{sub}/*/*_counter_collection.csv")
+    if not f:
+        continue
+    for r in csv.DictReader(open(f)):
+        if "scv_hist_argmax" in r["Kernel_Name"]:
+            pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+if pmc:
+    avg = {k: sum(v) / len(v) for k, v in pmc.items()}
+    lines += ["## PMC (separate --pmc passes, per launch of scv_hist_argmax, averaged)", "", "| counter | value |", "|---|---|"]
+    for k, v in sorted(avg.items()):
+        lines.append(f"| {k} | {v:.6g} |")
+    lines.append("")
+    algo = 1250 * 8 * (1 << 20) * 4
+    if "FETCH_SIZE" in avg:
+        fetch = avg["FETCH_SIZE"] * 1024 * 2       # KiB units; gfx950 reports 1/2 for wide coalesced streams
+        lines.append(f"HBM read traffic per launch = FETCH_SIZE x 1024 B x 2 (gfx950 correction) = {fetch/1e9:.3f} GB "
+                     f"vs algorithmic {algo/1e9:.3f} GB -> ratio {fetch/algo:.4f} (no wasted re-reads).")
+    if "WRITE_SIZE" in avg:
+        lines.append(f"HBM write traffic per launch = WRITE_SIZE x 1024 B = {avg['WRITE_SIZE']*1024/1e6:.3f} MB (cell records + counters).")
+    if "SQ_LDS_IDX_ACTIVE" in avg and "SQ_LDS_BANK_CONFLICT" in avg:
+        lines.append(f"LDS: bank-conflict cycles / active cycles = {avg['SQ_LDS_BANK_CONFLICT']/avg['SQ_LDS_IDX_ACTIVE']:.3f}; "
+                     f"active cycles per 64-vote ds_add_u32 = {avg['SQ_LDS_IDX_ACTIVE']/(algo/4/64):.2f}.")
+    json.dump({"pmc_avg": avg, "hbm_traffic_bytes": (avg.get("FETCH_SIZE", 0) * 2048 + avg.get("WRITE_SIZE", 0) * 1024)},
+              open(os.path.join(P, f"{tag}_pmc.json"), "w"), indent=1)
+for name in ("bench.json", "hbm_probe.log", "sweep.log", "sweep_full.log", "sweep_stagger.log"):
+    src = os.path.join(G, name)
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
+open(os.path.join(P, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
