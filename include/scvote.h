@@ -96,8 +96,13 @@ int scv_sync(scv_ctx* ctx);
  *   unroll        16-byte loads in flight per lane in {1,2,4,8}
  */
 int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unroll);
-/* Launch-geometry options for measurement: "grid" (> 0: exact persistent grid, 0: derive from the
- * CU count), "balance" (default 1: shrink the grid so all workgroups stream the same number of cells). */
+/* Launch options (measurement / tests): "grid" (> 0: exact persistent grid, 0: derive from the CU
+ * count), "balance" (default 1: shrink the grid so all workgroups stream the same number of items),
+ * "path" (0 auto | 1 streaming whole cells | 2 streaming split-N + merge | 3 small-N wave-per-cell),
+ * "segs" (split-N segments per cell, 0 auto), "sorted" (default 1: budgets traversed in descending
+ * n_valid order), "small_n_max" (auto: N <= this uses the small-N kernel), "auto_geometry" (default 1),
+ * "fused_counters_max" (cells at or below: per-cell atomics inside the hot kernel; above: a separate
+ * reduction of the cell table), "stagger_vecs", "plain_loads". */
 int scv_set_option(scv_ctx* ctx, const char* key, int64_t value);
 
 /*

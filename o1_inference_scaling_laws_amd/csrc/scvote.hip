@@ -50,6 +50,17 @@ struct scv_ctx {
     int copies = 16, threads = 1024, wg_per_cu = 1, unroll = 4;
     int stagger_vecs = 0;    // rotate each workgroup's start inside its cell (16-byte vectors per workgroup index)
     int plain_loads = 0;
+    int path = 0;            // 0 auto | 1 streaming, whole cells | 2 streaming, split-N | 3 small-N (wave per cell)
+    int segs_override = 0;   // > 0: segments per cell for path 2
+    int sorted = 1;          // traverse budgets in descending n_valid order
+    int small_n_max = 2048;  // auto: N <= this -> wave-per-cell kernel
+    bool user_tuned = false; // set_tuning called: auto geometry off
+    // split-N scratch (grown on demand)
+    void* d_partial = nullptr;
+    size_t d_partial_bytes = 0;
+    void* d_cells = nullptr;  // cell table scratch for the reduce kernel when the caller wants no cells
+    size_t d_cells_bytes = 0;
+    int fused_counters_max = 4096;  // cells: at or below, per-cell atomics inside the hot kernel; above, scv_reduce_cells
     int grid_override = 0;   // > 0: exact persistent grid size
     int balance = 1;         // shrink the grid so every workgroup streams the same number of cells
     // device scratch
@@ -109,7 +120,28 @@ int set_device(scv_ctx* ctx) {
     return SCV_OK;
 }
 
-// Launch the hot-path kernel on device pointers.  Accumulates into the per-budget counters.
+int ensure_cells(scv_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->d_cells_bytes) return SCV_OK;
+    if (ctx->d_cells) { SCV_HIP(hipFree(ctx->d_cells)); ctx->d_cells = nullptr; ctx->d_cells_bytes = 0; }
+    SCV_HIP(hipMalloc(&ctx->d_cells, bytes));
+    ctx->d_cells_bytes = bytes;
+    return SCV_OK;
+}
+
+int ensure_partial(scv_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->d_partial_bytes) return SCV_OK;
+    if (ctx->d_partial) { SCV_HIP(hipFree(ctx->d_partial)); ctx->d_partial = nullptr; ctx->d_partial_bytes = 0; }
+    SCV_HIP(hipMalloc(&ctx->d_partial, bytes));
+    ctx->d_partial_bytes = bytes;
+    return SCV_OK;
+}
+
+// Launch the hot path on device pointers.  Accumulates into the per-budget counters.
+//
+// Three regimes behind one entry point (auto-selected from the shape; "path" option forces one):
+//   small-N   N <= small_n_max            one wave per cell, sparse clear            (scv_small_cells)
+//   split-N   fewer cells than CUs, big N  several workgroups per cell + merge kernel  (scv_hist_argmax + scv_merge_partials)
+//   stream    everything else              one persistent workgroup streams whole cells (scv_hist_argmax)
 int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
                      const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells,
                      int64_t* cell_tokens, int64_t* tie, int64_t* tok_sum, int64_t* truth_sum) {
@@ -117,7 +149,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     if (ncells == 0) return SCV_OK;
     scv::AggArgs a;
     a.answers = answers; a.tokens = tokens; a.n_valid = n_valid; a.truth = truth;
-    a.ncells = ncells; a.N = N; a.B = B;
+    a.ncells = ncells; a.N = N; a.B = B; a.P = P;
     a.cells = cells; a.cell_tokens = cell_tokens;
     a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
     a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
@@ -125,31 +157,43 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.err_flag = ctx->d_err;
     a.stagger_vecs = ctx->stagger_vecs;
     a.plain_loads = ctx->plain_loads;
+    a.sorted = ctx->sorted;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr;
+    const bool tok = tokens != nullptr;
 
-    int copies = ctx->copies, threads = ctx->threads;
-    size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords) * sizeof(uint32_t);
-    if ((int64_t)lds > ctx->lds_max) return fail(SCV_ERR_ARG, "LDS request %zu exceeds device limit %lld", lds, (long long)ctx->lds_max);
-    // a workgroup needs lds bytes; cap residency so the persistent grid is what actually runs
-    int wg_per_cu = ctx->wg_per_cu;
-    const int by_lds = (int)((160 * 1024) / lds);
-    const int by_waves = 2048 / threads;
-    if (wg_per_cu > by_lds) wg_per_cu = by_lds;
-    if (wg_per_cu > by_waves) wg_per_cu = by_waves;
-    if (wg_per_cu < 1) wg_per_cu = 1;
-    int64_t grid = (int64_t)ctx->num_cus * wg_per_cu;
-    if (ctx->grid_override > 0) grid = ctx->grid_override;
-    if (grid > ncells) grid = ncells;
-    if (ctx->balance && ctx->grid_override <= 0) {
-        // Cells cost the same (same n_valid pattern per problem), and a 4 MiB cell is several
-        // percent of a launch: a ragged last round (10000 cells over 512 workgroups = 19.5 rounds)
-        // leaves half the chip idle for a whole cell.  Use the smallest grid with the same number
-        // of rounds, so every workgroup streams exactly `rounds` (or rounds-1) cells.
-        const int64_t rounds = (ncells + grid - 1) / grid;
-        grid = (ncells + rounds - 1) / rounds;
+    // per-budget counters: fused per-cell atomics for few cells, a separate reduction of the cell
+    // table for many (same-address device atomics serialise at ~12 ns each)
+    const bool want_counters = tie || truth_sum || (tok && tok_sum);
+    const bool use_reduce = want_counters && ncells > ctx->fused_counters_max;
+    if (use_reduce) {
+        a.tie_hits = nullptr; a.token_sum = nullptr; a.truth_sum = nullptr;
+        if (!a.cells || (tok && tok_sum && !a.cell_tokens)) {
+            const size_t cb = (size_t)ncells * sizeof(scv_cell);
+            if (int rc = ensure_cells(ctx, cb + (size_t)ncells * sizeof(int64_t) + 256)) return rc;
+            if (!a.cells) a.cells = static_cast<scv_cell*>(ctx->d_cells);
+            if (tok && !a.cell_tokens) a.cell_tokens = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->d_cells) + ((cb + 255) / 256) * 256);
+        }
     }
+    auto finish = [&](EventPair* ev_) -> int {
+        if (use_reduce) {
+            int64_t chunks = (P + 2047) / 2048;
+            const int64_t cap = ((int64_t)ctx->num_cus * 8 + B - 1) / B;
+            if (chunks > cap) chunks = cap;
+            if (chunks < 1) chunks = 1;
+            auto* th = reinterpret_cast<unsigned long long*>(tie);
+            auto* ts = reinterpret_cast<unsigned long long*>(tok_sum);
+            auto* tc = reinterpret_cast<unsigned long long*>(truth_sum);
+            if (tok) hipLaunchKernelGGL((scv::scv_reduce_cells<true>), dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
+            else hipLaunchKernelGGL((scv::scv_reduce_cells<false>), dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
+            SCV_HIP(hipGetLastError());
+        }
+        if (ev_) SCV_HIP(hipEventRecord(ev_->b, ctx->stream));
+        ctx->err_dirty = true;
+        return SCV_OK;
+    };
 
-    KernelFn fn = pick_kernel(copies, threads, ctx->unroll, tokens != nullptr);
-    SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int path = ctx->path;
+    if (path == 0) path = (N <= ctx->small_n_max) ? 3 : 1;
 
     EventPair* ev = nullptr;
     if (ctx->flags & SCV_FLAG_TIMING) {
@@ -160,13 +204,78 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             ctx->events.push_back(np);
         }
         ev = &ctx->events[ctx->events_used++];
-        SCV_HIP(hipEventRecord(ev->a, ctx->stream));
     }
+
+    if (path == 3) {
+        // ---- small-N: 8 waves per workgroup, 32 KiB of private histograms, up to 4 workgroups per CU
+        constexpr int T = 512, NW = T / 64;
+        const size_t lds = ((size_t)NW * scv::kBins + scv::kMaxSortedB) * sizeof(uint32_t);
+        int64_t grid = (ncells + NW - 1) / NW;
+        const int64_t cap = (int64_t)ctx->num_cus * 4;
+        if (grid > cap) grid = cap;
+        if (ctx->grid_override > 0) grid = ctx->grid_override;
+        if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+        if (tok) hipLaunchKernelGGL((scv::scv_small_cells<T, true>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((scv::scv_small_cells<T, false>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
+        SCV_HIP(hipGetLastError());
+        return finish(ev);
+    }
+
+    // ---- streaming kernel geometry ----------------------------------------------------------------
+    int copies = ctx->copies, threads = ctx->threads, wg_per_cu = ctx->wg_per_cu, unroll = ctx->unroll;
+    if (!ctx->user_tuned && N < 32768) { copies = 8; threads = 256; wg_per_cu = 4; unroll = 4; }  // mid N: cheaper epilogue, 4 cells in flight per CU
+    const size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords + scv::kMaxSortedB) * sizeof(uint32_t);
+    if ((int64_t)lds > ctx->lds_max) return fail(SCV_ERR_ARG, "LDS request %zu exceeds device limit %lld", lds, (long long)ctx->lds_max);
+    const int by_lds = (int)((160 * 1024) / lds);
+    const int by_waves = 2048 / threads;
+    if (wg_per_cu > by_lds) wg_per_cu = by_lds;
+    if (wg_per_cu > by_waves) wg_per_cu = by_waves;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    const int64_t slots = (int64_t)ctx->num_cus * wg_per_cu;
+
+    // split-N when whole cells cannot fill the chip: S workgroups per cell, then one merge launch
+    int64_t S = 1;
+    if (path == 2 || (ctx->path == 0 && 2 * ncells <= slots && N * 4 >= (128 << 10))) {
+        S = ctx->segs_override > 0 ? ctx->segs_override : (2 * slots + ncells - 1) / ncells;
+        const int64_t by_size = (N * 4) / (64 << 10);       // keep segments >= 64 KiB
+        if (ctx->segs_override <= 0 && S > by_size) S = by_size;
+        if (S > 4096) S = 4096;
+        if (S < 1) S = 1;
+    }
+    if (S > 1) {
+        a.segs = (int32_t)S;
+        a.seg_len = ((N + S - 1) / S + 3) & ~(int64_t)3;     // multiple of 4 votes: segments start 16-byte aligned in aligned rows
+        a.sorted = 0;                                        // merge kernel indexes partials by cell
+        const size_t items = (size_t)ncells * (size_t)S;
+        const size_t hist_bytes = items * scv::kBins * sizeof(uint32_t);
+        if (int rc = ensure_partial(ctx, hist_bytes + items * sizeof(long long) + 256)) return rc;
+        a.partial = static_cast<uint32_t*>(ctx->d_partial);
+        a.partial_tok = reinterpret_cast<long long*>(static_cast<char*>(ctx->d_partial) + ((hist_bytes + 255) / 256) * 256);
+    }
+    const int64_t nitems = ncells * S;
+    int64_t grid = slots;
+    if (ctx->grid_override > 0) grid = ctx->grid_override;
+    if (grid > nitems) grid = nitems;
+    if (ctx->balance && ctx->grid_override <= 0) {
+        // A 4 MiB cell is several percent of a launch: a ragged last round (10000 cells over 256
+        // workgroups = 39.06 rounds) idles most of the chip for a whole cell.  Use the smallest grid
+        // with the same number of rounds, so every workgroup streams `rounds` (or rounds-1) items.
+        const int64_t rounds = (nitems + grid - 1) / grid;
+        grid = (nitems + rounds - 1) / rounds;
+    }
+
+    KernelFn fn = pick_kernel(copies, threads, unroll, tok);
+    SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)threads), lds, ctx->stream, a);
     SCV_HIP(hipGetLastError());
-    if (ev) SCV_HIP(hipEventRecord(ev->b, ctx->stream));
-    ctx->err_dirty = true;
-    return SCV_OK;
+    if (S > 1) {
+        int64_t mgrid = ncells < (int64_t)ctx->num_cus * 8 ? ncells : (int64_t)ctx->num_cus * 8;
+        if (tok) hipLaunchKernelGGL((scv::scv_merge_partials<true>), dim3((unsigned)mgrid), dim3(1024), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((scv::scv_merge_partials<false>), dim3((unsigned)mgrid), dim3(1024), 0, ctx->stream, a);
+        SCV_HIP(hipGetLastError());
+    }
+    return finish(ev);
 }
 
 // Read and clear the device error word (stream must be idle).
@@ -245,6 +354,10 @@ int scv_create(scv_ctx** out, int device, uint32_t flags) {
     ctx->balance = env_int("SCV_BALANCE", 1);
     ctx->stagger_vecs = env_int("SCV_STAGGER_VECS", ctx->stagger_vecs);
     ctx->plain_loads = env_int("SCV_PLAIN_LOADS", 0);
+    ctx->path = env_int("SCV_PATH", 0);
+    ctx->sorted = env_int("SCV_SORTED", 1);
+    ctx->small_n_max = env_int("SCV_SMALL_N_MAX", ctx->small_n_max);
+    if (getenv("SCV_COPIES") || getenv("SCV_THREADS") || getenv("SCV_WG_PER_CU") || getenv("SCV_UNROLL")) ctx->user_tuned = true;
     if (!valid_copies(ctx->copies) || !valid_threads(ctx->threads) || !valid_unroll(ctx->unroll) || ctx->wg_per_cu < 1) {
         int code = fail(SCV_ERR_ARG, "bad SCV_* tuning environment");
         scv_destroy(ctx);
@@ -260,6 +373,8 @@ int scv_destroy(scv_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+    if (ctx->d_cells) (void)hipFree(ctx->d_cells);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -290,6 +405,7 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
     if (threads > 0) { if (!valid_threads(threads)) return fail(SCV_ERR_ARG, "threads must be 256, 512 or 1024"); ctx->threads = threads; }
     if (wg_per_cu > 0) ctx->wg_per_cu = wg_per_cu;
     if (unroll > 0) { if (!valid_unroll(unroll)) return fail(SCV_ERR_ARG, "unroll must be 2, 4 or 8"); ctx->unroll = unroll; }
+    if (copies > 0 || threads > 0 || wg_per_cu > 0 || unroll > 0) ctx->user_tuned = true;   // explicit geometry wins over the mid-N auto choice
     return SCV_OK;
 }
 
@@ -299,6 +415,12 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "balance")) ctx->balance = value != 0;
     else if (!strcmp(key, "stagger_vecs")) { if (value < 0 || value > (1 << 28)) return fail(SCV_ERR_ARG, "stagger out of range"); ctx->stagger_vecs = (int)value; }
     else if (!strcmp(key, "plain_loads")) ctx->plain_loads = value != 0;
+    else if (!strcmp(key, "path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "path must be 0..3"); ctx->path = (int)value; }
+    else if (!strcmp(key, "segs")) { if (value < 0 || value > 4096) return fail(SCV_ERR_ARG, "segs out of range"); ctx->segs_override = (int)value; }
+    else if (!strcmp(key, "sorted")) ctx->sorted = value != 0;
+    else if (!strcmp(key, "small_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "small_n_max < 0"); ctx->small_n_max = (int)(value > (1 << 30) ? (1 << 30) : value); }
+    else if (!strcmp(key, "auto_geometry")) ctx->user_tuned = value == 0;
+    else if (!strcmp(key, "fused_counters_max")) { if (value < 0) return fail(SCV_ERR_ARG, "fused_counters_max < 0"); ctx->fused_counters_max = (int)(value > (1 << 30) ? (1 << 30) : value); }
     else return fail(SCV_ERR_ARG, "unknown option '%s'", key);
     return SCV_OK;
 }

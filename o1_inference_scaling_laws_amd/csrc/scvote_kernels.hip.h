@@ -53,6 +53,12 @@ struct AggArgs {
     uint32_t* err_flag;
     int32_t stagger_vecs;   // > 0: workgroup w starts each cell rotated by (w * stagger_vecs) 16-byte vectors
     int32_t plain_loads;    // != 0: ordinary loads instead of non-temporal ones
+    int64_t P;              // problems (for the budget-major traversal)
+    int32_t sorted;         // != 0: traverse budgets in descending n_valid order
+    int32_t segs;           // split-N: segments per cell (1 = whole cells)
+    int64_t seg_len;        // split-N: votes per segment
+    uint32_t* partial;      // split-N: [ncells * segs][1024] partial histograms
+    long long* partial_tok; // split-N: [ncells * segs] partial token sums
 };
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -118,42 +124,170 @@ __device__ __forceinline__ void stream_votes(uint32_t* hist, uint32_t copy, cons
     }
 }
 
+// ---- work-item traversal ---------------------------------------------------------------------
+//
+// A work item is a (cell, segment).  Cells are traversed budget-major in DESCENDING n_valid order
+// (`ord`, built in LDS by every workgroup from n_valid[B]): with ragged prefix budgets
+// (o1.py:274-276, n_valid = 1,1,...,2,4,8,...) a problem-major static stride would hand one
+// workgroup all the long budgets; sorted budget-major striding gives every workgroup the same mix
+// and puts the long cells first (LPT).  With equal n_valid it is just another order.
+
+constexpr int kMaxSortedB = 512;
+
+__device__ __forceinline__ int64_t valid_len(const AggArgs& a, int32_t b) {
+    if (!a.n_valid) return a.N;
+    const int64_t nv = a.n_valid[b];
+    return nv < 0 ? 0 : (nv > a.N ? a.N : nv);
+}
+
+// returns true when `ord` is in use (caller must __syncthreads() before reading it)
+__device__ __forceinline__ bool build_budget_order(const AggArgs& a, int32_t* ord, int tid, int nthreads) {
+    if (!a.sorted || !a.n_valid || a.B > kMaxSortedB) return false;
+    for (int b = tid; b < a.B; b += nthreads) {
+        const int64_t nb = valid_len(a, b);
+        int rank = 0;
+        for (int c = 0; c < a.B; ++c) {
+            const int64_t nc = valid_len(a, c);
+            rank += (nc > nb) || (nc == nb && c < b);
+        }
+        ord[rank] = b;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void item_to_cell(const AggArgs& a, bool use_ord, const int32_t* ord, int64_t ci,
+                                             int64_t& p, int32_t& b) {
+    if (use_ord) {
+        const int64_t bi = ci / a.P;
+        p = ci - bi * a.P;
+        b = ord[bi];
+    } else {
+        p = ci / a.B;
+        b = (int32_t)(ci - p * a.B);
+    }
+}
+
+// ---- cell epilogue shared by the streaming kernel and the split-N merge kernel ------------------
+//
+// statistics.multimode (statistics.py:599-601) + o1.py:204-213 on per-thread bin counts cnt[k]
+// (bin = tid + k*T).  Precondition: red[48] was zeroed by thread 0 before the last barrier.
+template <int T, bool TOK>
+__device__ __forceinline__ void finalize_cell(const AggArgs& a, uint32_t* red, const uint32_t (&cnt)[kBins / T],
+                                              long long tsum, int tid, int64_t cell, int32_t b, int32_t truth) {
+    constexpr int NB = kBins / T;
+    constexpr int NW = T / 64;
+    const int lane = tid & 63, wid = tid >> 6;
+    uint32_t lmax = 0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        lmax = cnt[k] > lmax ? cnt[k] : lmax;
+        if (tid + k * T == truth) red[48] = cnt[k];   // truth_count = histogram[truth] (pass@k's c)
+    }
+    const uint32_t wmax = wave_max_u32(lmax);
+    if (lane == 0) red[wid] = wmax;
+    if (TOK) {
+        const long long wt = wave_sum_i64(tsum);
+        if (lane == 0) {
+            red[64 + 2 * wid] = (uint32_t)((unsigned long long)wt & 0xffffffffull);
+            red[65 + 2 * wid] = (uint32_t)((unsigned long long)wt >> 32);
+        }
+    }
+    __syncthreads();  // B2: per-wave maxima visible (and, in the streaming kernel, the histogram is zero again)
+
+    uint32_t maxc = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const uint32_t m = red[w]; maxc = m > maxc ? m : maxc; }
+    uint32_t nm = 0, mm = 1024u;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const uint32_t bin = (uint32_t)(tid + k * T);
+        if (cnt[k] == maxc) { nm += 1; mm = bin < mm ? bin : mm; }
+    }
+    nm = wave_sum_u32(nm);
+    mm = wave_min_u32(mm);
+    if (lane == 0) { red[16 + wid] = nm; red[32 + wid] = mm; }
+    __syncthreads();  // B3
+
+    if (tid == 0) {
+        uint32_t n_modes = 0, min_mode = 1024u;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            n_modes += red[16 + w];
+            const uint32_t m = red[32 + w];
+            min_mode = m < min_mode ? m : min_mode;
+        }
+        const uint32_t tc = red[48];
+        long long tok = 0;
+        if (TOK) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                tok += (long long)(((unsigned long long)red[65 + 2 * w] << 32) | red[64 + 2 * w]);
+        }
+        // o1.py:204-213: hit = truth in modes; multimode([]) == [] -> no hit when max_count == 0
+        const bool any = maxc > 0;
+        const uint32_t hit = (any && tc == maxc) ? 1u : 0u;
+        if (!any) n_modes = 0;
+        if (a.cells) {
+            uint4 rec;
+            rec.x = maxc;
+            rec.y = tc;
+            rec.z = (n_modes & 0xffffu) | ((any ? (min_mode & 0xffffu) : 0xffffu) << 16);
+            rec.w = hit;
+            reinterpret_cast<uint4*>(a.cells)[cell] = rec;
+        }
+        if (a.cell_tokens) a.cell_tokens[cell] = tok;
+        // o1.py:238-240 as integers: tie-class counter, token sum, truth-count sum
+        if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
+        if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
+        if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
+    }
+}
+
+// ---- kernel 1: streaming histogram / argmax (large N) -------------------------------------------
 // RL2 = log2(copies), T = threads per workgroup, U = 16-byte loads in flight per lane.
 template <int RL2, int T, int U, bool TOK>
 __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
     constexpr int R = 1 << RL2;
     constexpr int NB = kBins / T;        // bins folded per thread in the epilogue
-    constexpr int NW = T / 64;           // waves per workgroup
     constexpr int CH = R / 4;            // 16-byte chunks per bin
     constexpr int BPR = 64 / R;          // bins per 256-byte LDS row
-    static_assert(NB >= 1 && NW <= 16, "workgroup shape");
+    static_assert(NB >= 1 && T / 64 <= 16, "workgroup shape");
 
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* hist = smem;
     uint32_t* red = smem + kBins * R;
+    int32_t* ord = reinterpret_cast<int32_t*>(red + kRedWords);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
     const uint32_t copy = (uint32_t)lane & (R - 1);
 
     {   // zero the replicated histogram once; afterwards the epilogue leaves it zeroed
         uint4* h4 = reinterpret_cast<uint4*>(hist);
         for (int i = tid; i < kBins * R / 4; i += T) h4[i] = make_uint4(0, 0, 0, 0);
     }
+    const bool use_ord = build_budget_order(a, ord, tid, T);
     __syncthreads();
 
+    const int32_t S = a.segs;
+    const int64_t nitems = a.ncells * S;
     uint32_t bad = 0;
-    for (int64_t cell = blockIdx.x; cell < a.ncells; cell += gridDim.x) {
-        const int64_t p = cell / a.B;
-        const int32_t b = (int32_t)(cell - p * a.B);
-        int64_t n = a.N;
-        if (a.n_valid) {
-            const int64_t nv = a.n_valid[b];
-            n = nv < 0 ? 0 : (nv > a.N ? a.N : nv);
+    for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int64_t ci = S > 1 ? item / S : item;
+        const int32_t seg = S > 1 ? (int32_t)(item - ci * S) : 0;
+        int64_t p; int32_t b;
+        item_to_cell(a, use_ord, ord, ci, p, b);
+        const int64_t cell = p * a.B + b;
+        int64_t n = valid_len(a, b);
+        int64_t lo = 0;
+        if (S > 1) {                      // split-N: this workgroup owns votes [lo, lo + n) of the cell
+            lo = (int64_t)seg * a.seg_len;
+            int64_t hi = lo + a.seg_len;
+            hi = hi > n ? n : hi;
+            n = hi > lo ? hi - lo : 0;
         }
-        const int32_t* row = a.answers + cell * a.N;
-        const int32_t* trow = TOK ? a.tokens + cell * a.N : nullptr;
+        const int32_t* row = a.answers + cell * a.N + lo;
+        const int32_t* trow = TOK ? a.tokens + cell * a.N + lo : nullptr;
         long long tsum = 0;
 
         // ---- o1.py:181-195: stream the votes ------------------------------------------------
@@ -168,9 +302,8 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
         const int64_t nvec = (n - head) >> 2;
         int64_t i = tid;
         if (!TOK) {
-            // votes are order-independent, so a workgroup may start anywhere in its cell: rotating the
-            // start by workgroup index de-synchronises the 250+ concurrent streams (otherwise all of
-            // them sit at the same offset of their 4 MiB-aligned cells at the same time).
+            // votes are order-independent, so a workgroup may start anywhere in its cell (measurement
+            // option "stagger_vecs"; measured null-to-negative on MI355X, default off).
             int64_t rot = 0;
             if (a.stagger_vecs > 0 && nvec > 0) rot = ((int64_t)blockIdx.x * a.stagger_vecs) % nvec;
             if (a.plain_loads) {
@@ -181,10 +314,8 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
                 if (rot) stream_votes<RL2, T, U, true>(hist, copy, v4, 0, rot, tid, bad);
             }
         } else {
-            // the token row has the same misalignment as the vote row only if both bases agree
-            // mod 16; they do for the [P,B,N] layouts the ABI accepts (both rows start at
-            // base + cell*N*4 and hipMalloc / torch bases are 256-byte aligned).  A token base
-            // that is not 16-byte congruent takes the scalar route.
+            // the token row is 16-byte congruent with the vote row for the [P,B,N] layouts the ABI
+            // accepts when both bases are; a token base that is not takes the scalar route.
             const bool tok_vec = (((uintptr_t)(trow + head)) & 15u) == 0;
             if (tok_vec) {
                 const int4* t4 = reinterpret_cast<const int4*>(trow + head);
@@ -225,12 +356,10 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
             }
         }
         if (tid == 0) red[48] = 0;
-        __syncthreads();  // B1: all votes of this cell are in LDS
+        __syncthreads();  // B1: all votes of this item are in LDS
 
-        // ---- statistics.multimode (statistics.py:599-601): fold copies, find max count -------
-        const int32_t truth = a.truth[p];
+        // ---- fold the R copies (and zero them for the next item) -------------------------------
         uint32_t cnt[NB];
-        uint32_t lmax = 0;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int bin = tid + k * T;
@@ -244,69 +373,201 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
                 h4[jj] = make_uint4(0, 0, 0, 0);
             }
             cnt[k] = s;
-            lmax = s > lmax ? s : lmax;
-            if (bin == truth) red[48] = s;  // truth_count = histogram[truth] (pass@k's c)
         }
-        const uint32_t wmax = wave_max_u32(lmax);
-        if (lane == 0) red[wid] = wmax;
-        if (TOK) {
-            const long long wt = wave_sum_i64(tsum);
-            if (lane == 0) {
-                red[64 + 2 * wid] = (uint32_t)((unsigned long long)wt & 0xffffffffull);
-                red[65 + 2 * wid] = (uint32_t)((unsigned long long)wt >> 32);
-            }
-        }
-        __syncthreads();  // B2: per-wave maxima visible; histogram is zero again
-
-        uint32_t maxc = 0;
+        if (S > 1) {
+            // split-N: publish the partial histogram; scv_merge_partials finishes the cell
+            uint32_t* out = a.partial + (item << 10);
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { const uint32_t m = red[w]; maxc = m > maxc ? m : maxc; }
-        uint32_t nm = 0, mm = 1024u;
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const uint32_t bin = (uint32_t)(tid + k * T);
-            if (cnt[k] == maxc) { nm += 1; mm = bin < mm ? bin : mm; }
-        }
-        nm = wave_sum_u32(nm);
-        mm = wave_min_u32(mm);
-        if (lane == 0) { red[16 + wid] = nm; red[32 + wid] = mm; }
-        __syncthreads();  // B3
-
-        if (tid == 0) {
-            uint32_t n_modes = 0, min_mode = 1024u;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                n_modes += red[16 + w];
-                const uint32_t m = red[32 + w];
-                min_mode = m < min_mode ? m : min_mode;
-            }
-            const uint32_t tc = red[48];
-            long long tok = 0;
+            for (int k = 0; k < NB; ++k) out[tid + k * T] = cnt[k];
             if (TOK) {
-#pragma unroll
-                for (int w = 0; w < NW; ++w)
-                    tok += (long long)(((unsigned long long)red[65 + 2 * w] << 32) | red[64 + 2 * w]);
+                const long long wt = wave_sum_i64(tsum);
+                if (lane == 0) {
+                    red[64 + 2 * (tid >> 6)] = (uint32_t)((unsigned long long)wt & 0xffffffffull);
+                    red[65 + 2 * (tid >> 6)] = (uint32_t)((unsigned long long)wt >> 32);
+                }
             }
-            // o1.py:204-213: hit = truth in modes; multimode([]) == [] -> no hit when max_count == 0
+            __syncthreads();  // histogram zero again; wave token sums visible
+            if (TOK && tid == 0) {
+                long long tok = 0;
+                for (int w = 0; w < T / 64; ++w)
+                    tok += (long long)(((unsigned long long)red[65 + 2 * w] << 32) | red[64 + 2 * w]);
+                a.partial_tok[item] = tok;
+            }
+        } else {
+            finalize_cell<T, TOK>(a, red, cnt, tsum, tid, cell, b, a.truth[p]);
+            // the next item's votes may start: the histogram was re-zeroed before B2, and `red` is
+            // next written after the next B1, which thread 0 only reaches after finalize_cell.
+        }
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+}
+
+// ---- kernel 1b: merge the partial histograms of split cells -------------------------------------
+// 1024 threads per cell: thread (g = tid >> 8, q = tid & 255) sums bins 4q..4q+3 over segments
+// s == g (mod 4) with 16-byte loads (4 independent streams, 64+ KiB in flight), LDS combines the four
+// groups, then the common epilogue runs with one bin per thread.
+template <bool TOK>
+__global__ __launch_bounds__(1024) void scv_merge_partials(const AggArgs a) {
+    constexpr int T = 1024;
+    __shared__ __attribute__((aligned(16))) uint32_t part[4 * kBins];
+    __shared__ uint32_t red[kRedWords];
+    const int tid = threadIdx.x, g = tid >> 8, q = tid & 255;
+    const int32_t S = a.segs;
+    for (int64_t cell = blockIdx.x; cell < a.ncells; cell += gridDim.x) {
+        const int64_t p = cell / a.B;
+        const int32_t b = (int32_t)(cell - p * a.B);
+        // the streaming kernel numbers split items cell-major (sorted traversal is off when segs > 1)
+        const uint4* in = reinterpret_cast<const uint4*>(a.partial + ((cell * S) << 10)) + q;
+        uint4 acc = make_uint4(0, 0, 0, 0);
+        int32_t s = g;
+        for (; s + 12 < S; s += 16) {
+            const uint4 x0 = in[(int64_t)s << 8], x1 = in[(int64_t)(s + 4) << 8];
+            const uint4 x2 = in[(int64_t)(s + 8) << 8], x3 = in[(int64_t)(s + 12) << 8];
+            acc.x += x0.x + x1.x + x2.x + x3.x; acc.y += x0.y + x1.y + x2.y + x3.y;
+            acc.z += x0.z + x1.z + x2.z + x3.z; acc.w += x0.w + x1.w + x2.w + x3.w;
+        }
+        for (; s < S; s += 4) {
+            const uint4 x = in[(int64_t)s << 8];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        reinterpret_cast<uint4*>(part + g * kBins)[q] = acc;
+        long long tsum = 0;
+        if (TOK) for (int32_t t = tid; t < S; t += T) tsum += a.partial_tok[cell * S + t];
+        if (tid == 0) red[48] = 0;
+        __syncthreads();
+        uint32_t cnt[1];
+        cnt[0] = part[tid] + part[kBins + tid] + part[2 * kBins + tid] + part[3 * kBins + tid];
+        finalize_cell<T, TOK>(a, red, cnt, tsum, tid, cell, b, a.truth[p]);
+        // `part` is rewritten only after the other threads pass finalize_cell's barriers
+    }
+}
+
+// ---- kernel 1d: per-budget reduction of the cell table (o1.py:236-245 as integers) ----------------
+// Used instead of per-cell global atomics when there are many cells: hundreds of thousands of
+// same-address device atomics serialise at ~12 ns each and would dominate small-N workloads.
+// grid = (chunks, B); each workgroup reduces a block of problems for one budget.
+template <bool TOK>
+__global__ __launch_bounds__(256) void scv_reduce_cells(const scv_cell* cells, const int64_t* cell_tokens, int64_t P,
+                                                        int32_t B, unsigned long long* tie_hits,
+                                                        unsigned long long* token_sum, unsigned long long* truth_sum) {
+    __shared__ uint32_t tie[SCV_TIE_CLASSES];
+    __shared__ unsigned long long acc[2];
+    const int tid = threadIdx.x;
+    const int32_t b = blockIdx.y;
+    for (int i = tid; i < SCV_TIE_CLASSES; i += 256) tie[i] = 0;
+    if (tid < 2) acc[tid] = 0;
+    __syncthreads();
+    const int64_t per = (P + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)blockIdx.x * per;
+    const int64_t p1 = p0 + per < P ? p0 + per : P;
+    const uint4* c4 = reinterpret_cast<const uint4*>(cells);
+    unsigned long long tcs = 0;
+    long long tks = 0;
+    for (int64_t p = p0 + tid; p < p1; p += 256) {
+        const uint4 c = c4[p * B + b];
+        if (c.w & 0xffu) atomicAdd(&tie[c.z & 0xffffu], 1u);
+        tcs += c.y;
+        if (TOK) tks += cell_tokens[p * B + b];
+    }
+    tcs = (unsigned long long)wave_sum_i64((long long)tcs);
+    if (TOK) tks = wave_sum_i64(tks);
+    if ((tid & 63) == 0) {
+        atomicAdd(&acc[0], tcs);
+        if (TOK) atomicAdd(&acc[1], (unsigned long long)tks);
+    }
+    __syncthreads();
+    if (tie_hits)
+        for (int i = tid; i < SCV_TIE_CLASSES; i += 256)
+            if (tie[i]) atomicAdd(&tie_hits[(int64_t)b * SCV_TIE_CLASSES + i], (unsigned long long)tie[i]);
+    if (tid == 0) {
+        if (truth_sum && acc[0]) atomicAdd(&truth_sum[b], acc[0]);
+        if (TOK && token_sum && acc[1]) atomicAdd(&token_sum[b], acc[1]);
+    }
+}
+
+// ---- kernel 1c: small-N cells, one wave per cell, sparse clear ------------------------------------
+//
+// For N up to a few thousand the 64 KiB fold-and-zero of kernel 1 dominates.  Here every wave owns a
+// private 1024-word histogram and touches ONLY the bins its cell votes for:
+//   pass 1  h[v] += 1 for every vote               (ds_add_u32)
+//   pass 2  c = h[v]; max over votes -> max_count   (every modal value is seen by its own voters)
+//   pass 3  #votes with h[v] == max_count, divided by max_count = number of DISTINCT modal values
+//           (statistics.multimode's len); min over those v = min_mode; truth_count = h[truth]
+//   pass 4  h[v] = 0 for every vote                 (sparse clear: O(N), not O(1024))
+// No workgroup barrier at all: LDS operations of one wave execute in order.  Passes 2-4 re-read the
+// cell (<= 8 KiB, L1/L2 resident), so HBM traffic stays 4 B per vote.
+template <int T, bool TOK>
+__global__ __launch_bounds__(T) void scv_small_cells(const AggArgs a) {
+    constexpr int NW = T / 64;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t* h = smem + wid * kBins;
+    int32_t* ord = reinterpret_cast<int32_t*>(smem + NW * kBins);
+    for (int i = lane; i < kBins; i += 64) h[i] = 0;
+    const bool use_ord = build_budget_order(a, ord, tid, T);
+    __syncthreads();
+
+    uint32_t bad = 0;
+    const int64_t wave0 = (int64_t)blockIdx.x * NW + wid, nwaves = (int64_t)gridDim.x * NW;
+    for (int64_t ci = wave0; ci < a.ncells; ci += nwaves) {
+        int64_t p; int32_t b;
+        item_to_cell(a, use_ord, ord, ci, p, b);
+        const int64_t cell = p * a.B + b;
+        const int64_t n = valid_len(a, b);
+        const int32_t* row = a.answers + cell * a.N;
+        const int32_t truth = a.truth[p];
+        long long tsum = 0;
+        for (int64_t i = lane; i < n; i += 64) {                  // pass 1 (o1.py:181-195)
+            const uint32_t v = (uint32_t)row[i];
+            bad |= v;
+            atomicAdd(&h[v < 1023u ? v : 1023u], 1u);
+            if (TOK) tsum += a.tokens[cell * a.N + i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t lmax = 0;
+        for (int64_t i = lane; i < n; i += 64) {                  // pass 2
+            const uint32_t v = (uint32_t)row[i];
+            const uint32_t c = h[v < 1023u ? v : 1023u];
+            lmax = c > lmax ? c : lmax;
+        }
+        const uint32_t maxc = wave_max_u32(lmax);
+        uint32_t votes_at_max = 0, mm = 1024u;
+        for (int64_t i = lane; i < n; i += 64) {                  // pass 3 (statistics.py:599-601)
+            const uint32_t v = (uint32_t)row[i];
+            const uint32_t bin = v < 1023u ? v : 1023u;
+            if (h[bin] == maxc) { votes_at_max += 1; mm = bin < mm ? bin : mm; }
+        }
+        votes_at_max = wave_sum_u32(votes_at_max);
+        mm = wave_min_u32(mm);
+        const uint32_t tc = (truth >= 0 && truth < kBins) ? h[truth] : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t i = lane; i < n; i += 64) {                  // pass 4: sparse clear
+            const uint32_t v = (uint32_t)row[i];
+            h[v < 1023u ? v : 1023u] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        long long tok = 0;
+        if (TOK) tok = wave_sum_i64(tsum);
+        if (lane == 0) {
             const bool any = maxc > 0;
-            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;
-            if (!any) { n_modes = 0; }
+            const uint32_t n_modes = any ? votes_at_max / maxc : 0u;
+            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;         // o1.py:206
             if (a.cells) {
                 uint4 rec;
                 rec.x = maxc;
                 rec.y = tc;
-                rec.z = (n_modes & 0xffffu) | ((any ? (min_mode & 0xffffu) : 0xffffu) << 16);
+                rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
                 rec.w = hit;
                 reinterpret_cast<uint4*>(a.cells)[cell] = rec;
             }
             if (a.cell_tokens) a.cell_tokens[cell] = tok;
-            // o1.py:238-240 as integers: tie-class counter, token sum, truth-count sum
             if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
             if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
             if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
         }
-        // the next cell's votes may start: the histogram was re-zeroed before B2, and `red` is
-        // next written after the next B1, which thread 0 only reaches after this block.
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
 }

@@ -120,11 +120,14 @@ def test_every_kernel_variant_is_bit_exact(hip_engine, copies, threads, unroll):
     nv = np.array([30001, 12345, 2], dtype=np.int32)
     want = oracle(a, tr, tokens=t, n_valid=nv)
     try:
+        hip_engine.set_option("path", 1)
         hip_engine.set_tuning(copies=copies, threads=threads, wg_per_cu=2, unroll=unroll)
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
         assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), want, check_tokens=False)
     finally:
         hip_engine.set_tuning(copies=16, threads=1024, wg_per_cu=1, unroll=4)
+        hip_engine.set_option("auto_geometry", 1)
+        hip_engine.set_option("path", 0)
 
 
 @pytest.mark.parametrize("stagger,plain,balance,grid", [(4099, 0, 1, 0), (1 << 16, 1, 0, 0), (0, 1, 1, 7), (12345, 0, 0, 3)])
@@ -139,6 +142,101 @@ def test_launch_geometry_options_are_bit_exact(hip_engine, stagger, plain, balan
     finally:
         for k, v in (("stagger_vecs", 0), ("plain_loads", 0), ("balance", 1), ("grid", 0)):
             hip_engine.set_option(k, v)
+
+
+# ---- every regime of the kernel family, forced ------------------------------------------------------
+
+def _with_options(eng, opts):
+    class _Ctx:
+        def __enter__(self_):
+            for k, v in opts.items():
+                eng.set_option(k, v)
+        def __exit__(self_, *exc):
+            for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
+                         ("small_n_max", 2048), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096)):
+                eng.set_option(k, v)
+    return _Ctx()
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [(50, 3, 1), (40, 2, 2), (33, 4, 3), (70, 8, 64), (20, 3, 100), (9, 2, 257),
+                                   (5, 11, 2048), (3, 2, 5001), (2000, 2, 17)])
+def test_small_n_wave_per_cell_path(hip_engine, dist, shape):
+    P, B, N = shape
+    a, t, tr = coracle.synth_fill(P, B, N, 300 + dist, dist, want_tokens=True)
+    nv = np.array([max(0, N - 3 * b) if b % 2 else N >> (b // 2) for b in range(B)], dtype=np.int32)
+    with _with_options(hip_engine, {"path": 3}):
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
+        assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+
+
+def test_small_n_path_spare_bins_ties_and_truth_edges(hip_engine):
+    rng = np.random.default_rng(11)
+    a = rng.integers(1000, 1024, size=(300, 3, 37), dtype=np.int32)
+    a[:100] = rng.integers(0, 4, size=(100, 3, 37), dtype=np.int32)         # heavy ties among few values
+    tr = rng.integers(-3, 1027, size=(300,), dtype=np.int32)
+    with _with_options(hip_engine, {"path": 3}):
+        assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
+        bad = a.copy()
+        bad[7, 1, 5] = 5000
+        with pytest.raises(_lib.DomainError):
+            hip_engine.aggregate(bad, tr)
+
+
+@pytest.mark.parametrize("segs", [2, 3, 7, 64])
+@pytest.mark.parametrize("shape,dist", [((3, 2, 70001), 1), ((1, 1, 1 << 20), 3), ((5, 3, 40000), 0), ((2, 2, 9), 2)])
+def test_split_n_path(hip_engine, segs, shape, dist):
+    P, B, N = shape
+    a, t, tr = coracle.synth_fill(P, B, N, 500 + segs, dist, want_tokens=True)
+    nv = np.array([N if b == 0 else max(1, N // (3 * b)) for b in range(B)], dtype=np.int32)
+    with _with_options(hip_engine, {"path": 2, "segs": segs}):
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+        assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
+
+
+@pytest.mark.parametrize("sorted_", [0, 1])
+def test_streaming_path_sorted_and_natural_traversal(hip_engine, sorted_):
+    a, t, tr = coracle.synth_fill(41, 11, 3000, 8, 1, want_tokens=True)
+    nv = np.array([1, 1, 1, 1, 1, 1, 1, 1, 2, 4, 3000], dtype=np.int32)      # the reference's ragged family, scaled
+    with _with_options(hip_engine, {"path": 1, "sorted": sorted_}):
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+    a = np.ascontiguousarray(np.broadcast_to(a[:1, :1, :600], (2, 600, 600)))    # B > 512: sorted order unavailable
+    tr2 = tr[:2]
+    nv2 = np.arange(600, dtype=np.int32)
+    with _with_options(hip_engine, {"path": 1, "sorted": sorted_}):
+        assert_results_equal(hip_engine.aggregate(a, tr2, n_valid=nv2), oracle(a, tr2, n_valid=nv2), check_tokens=False)
+    with _with_options(hip_engine, {"path": 3, "sorted": sorted_}):
+        assert_results_equal(hip_engine.aggregate(a, tr2, n_valid=nv2), oracle(a, tr2, n_valid=nv2), check_tokens=False)
+
+
+@pytest.mark.parametrize("fused_max", [0, 1 << 30])
+@pytest.mark.parametrize("path", [1, 2, 3])
+def test_counters_fused_and_reduced_agree(hip_engine, fused_max, path):
+    """Per-budget counters via per-cell atomics (few cells) and via scv_reduce_cells (many cells)."""
+    import torch
+    a, t, tr = coracle.synth_fill(700, 5, 300, 21, 3, want_tokens=True)
+    nv = np.array([300, 150, 7, 1, 0], dtype=np.int32)
+    want = oracle(a, tr, tokens=t, n_valid=nv)
+    with _with_options(hip_engine, {"path": path, "fused_counters_max": fused_max, "segs": 2}):
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
+        # DEVICE mode without a cell table from the caller: the library's own scratch feeds the reduction
+        dev = torch.device("cuda:0")
+        ta, tt, ttr = (torch.from_numpy(x).to(dev) for x in (a, t, tr))
+        counters, _, _ = hip_engine.aggregate_device(ta, ttr, tokens=tt, n_valid=torch.from_numpy(nv).to(dev), cells=False)
+        hip_engine.sync()
+        got = AggregateResult.from_counters(counters.cpu().numpy(), 700, 5)
+        assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum)
+        assert np.array_equal(got.truth_count_sum, want.truth_count_sum)
+
+
+def test_auto_dispatch_covers_all_regimes(hip_engine):
+    """auto: N <= 2048 -> wave-per-cell; few big cells -> split-N; otherwise whole-cell streaming
+    (with the mid-N geometry below N = 32768)."""
+    for (P, B, N) in [(500, 2, 128), (2, 1, 1 << 19), (700, 1, 8192), (300, 1, 40000)]:
+        a, t, tr = coracle.synth_fill(P, B, N, 77, 1, want_tokens=True)
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
 
 
 # ---- golden fixtures generated from the unmodified reference ------------------------------------

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Throughput of the hot path outside the headline regime: tokens stream, few-cells (C2), small N.
+Cold-cache discipline: cycles enough distinct buffers to exceed the 256 MiB Infinity Cache."""
+from __future__ import annotations
+
+import json
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run(eng, torch, P, B, N, tokens, dist=1, nbuf=None, rounds=6, n_valid=None):
+    from o1_inference_scaling_laws_amd.engine import counters_size
+    dev = torch.device("cuda:0")
+    per = P * B * N * 4 * (2 if tokens else 1)
+    if nbuf is None:
+        nbuf = max(1, min(8, int(600e6 // max(per, 1)) + 1))
+    bufs = []
+    for i in range(nbuf):
+        a = torch.empty((P, B, N), dtype=torch.int32, device=dev)
+        t = torch.empty((P, B, N), dtype=torch.int32, device=dev) if tokens else None
+        tr = torch.empty((P,), dtype=torch.int32, device=dev)
+        eng.synth_fill_device(a, t, tr, P=P, B=B, N=N, seed=11 + i, dist=dist)
+        bufs.append((a, t, tr))
+    nv = None if n_valid is None else torch.tensor(n_valid, dtype=torch.int32, device=dev)
+    counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
+    cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
+    eng.sync(); eng.drain_kernel_ns()
+    times = []
+    for r in range(rounds + 1):
+        for (a, t, tr) in bufs:
+            counters.zero_()
+            eng.aggregate_device(a, tr, tokens=t, n_valid=nv, counters=counters, cells=cells)
+            eng.sync()
+            ns, n = eng.drain_kernel_ns()
+            if r:
+                times.append(ns / n)
+    med = statistics.median(times)
+    votes = P * B * N if n_valid is None else P * sum(min(v, N) for v in n_valid)
+    return {"shape": [P, B, N], "tokens": tokens, "buffers": nbuf, "median_us": med / 1e3, "min_us": min(times) / 1e3,
+            "GBps": votes * 4 * (2 if tokens else 1) / med, "votes_per_s": votes / (med * 1e-9)}
+
+
+def main():
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine
+    eng = Engine(device=0, timing=True)
+    out = []
+    cases = [
+        ("headline slab", 256, 8, 1 << 20, False, None),
+        ("tokens stream", 128, 8, 1 << 20, True, None),
+        ("C2 30x8x2^17", 30, 8, 1 << 17, False, None),
+        ("C2 + tokens", 30, 8, 1 << 17, True, None),
+        ("P=30 B=1 N=2^20", 30, 1, 1 << 20, False, None),
+        ("P=1 B=1 N=2^24", 1, 1, 1 << 24, False, None),
+        ("ragged D4 N>>(7-b)", 256, 8, 1 << 20, False, [(1 << 20) >> (7 - b) for b in range(8)]),
+        ("mid N=4096 P=20000", 20000, 8, 4096, False, None),
+        ("small N=256 P=100000", 100000, 4, 256, False, None),
+        ("small N=64 P=200000", 200000, 4, 64, False, None),
+        ("reference family 30x11x8", 30, 11, 8, True, [1] * 8 + [2, 4, 8]),
+    ]
+    for name, P, B, N, tok, nv in cases:
+        r = run(eng, torch, P, B, N, tok, n_valid=nv)
+        r["name"] = name
+        out.append(r)
+        print(f"{name:28s} {str(r['shape']):22s} tok={int(tok)}  {r['median_us']:10.1f} us  {r['GBps']:8.1f} GB/s  {r['votes_per_s']:.3e} votes/s", flush=True)
+        torch.cuda.empty_cache()
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(out, open("gpurun_out/regimes.json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
