@@ -128,6 +128,22 @@ int scv_aggregate_i32(scv_ctx* ctx,
                       int64_t* truth_count_sum_out);
 
 /*
+ * Prefix budgets over ONE sample pool per problem.  The reference's budgets
+ * T >= 2^11 vote over prefixes of the same samples (o1.py:274-277 with the idx-keyed cache of
+ * o1.py:85-88).  pool / tokens are int32 [P, N]; cell (p, b) votes over pool[p, 0:n_valid[b]]
+ * (n_valid required, any order, B <= 512).  Outputs and conventions are exactly those of
+ * scv_aggregate_i32 called on the dense expansion answers[p, b, :] = pool[p, :], but the pool is
+ * streamed once: 4 * max_b n_valid[b] algorithmic bytes per problem instead of 4 * sum_b n_valid[b].
+ */
+int scv_aggregate_prefix_i32(scv_ctx* ctx,
+                             const int32_t* pool, const int32_t* tokens,
+                             const int32_t* n_valid, const int32_t* truth,
+                             int64_t P, int32_t B, int64_t N, int mem_kind,
+                             scv_cell* cells_out, int64_t* cell_tokens_out,
+                             int64_t* tie_class_hits_out, int64_t* token_sum_out,
+                             int64_t* truth_count_sum_out);
+
+/*
  * Problem-level bootstrap (new semantics, not in the reference).  For resample
  * r in [r_begin, r_end): draw P problem indices idx_j = mulhi32(hi32(mix64(seed + G*(r*P+j+1))), P)
  * and count, per budget, hits by tie class.  counts_out int64 [r_end-r_begin, B, M]; a drawn hit

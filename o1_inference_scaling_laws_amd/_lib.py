@@ -48,6 +48,7 @@ def load():
     L.scv_set_tuning.argtypes = [p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.scv_set_option.argtypes = [p, C.c_char_p, i64]
     L.scv_aggregate_i32.argtypes = [p, p, p, p, p, i64, i32, i64, C.c_int, p, p, p, p, p]
+    L.scv_aggregate_prefix_i32.argtypes = [p, p, p, p, p, i64, i32, i64, C.c_int, p, p, p, p, p]
     L.scv_bootstrap.argtypes = [p, p, i64, i32, i32, i32, u64, i32, C.c_int, p]
     L.scv_synth_fill_i32.argtypes = [p, p, p, p, i64, i32, i64, i64, u64, C.c_int]
     L.scv_last_kernel_ns.argtypes = [p, C.POINTER(u64)]
@@ -58,7 +59,7 @@ def load():
     L.scv_last_error.restype = C.c_char_p
     L.scv_version.argtypes = []
     L.scv_version.restype = C.c_char_p
-    for name in ("scv_create", "scv_destroy", "scv_set_stream", "scv_sync", "scv_set_tuning", "scv_set_option", "scv_aggregate_i32",
+    for name in ("scv_create", "scv_destroy", "scv_set_stream", "scv_sync", "scv_set_tuning", "scv_set_option", "scv_aggregate_i32", "scv_aggregate_prefix_i32",
                  "scv_bootstrap", "scv_synth_fill_i32", "scv_last_kernel_ns", "scv_drain_kernel_ns",
                  "scv_device_count", "scv_device_info"):
         getattr(L, name).restype = C.c_int

@@ -53,7 +53,7 @@ struct scv_ctx {
     int path = 0;            // 0 auto | 1 streaming, whole cells | 2 streaming, split-N | 3 small-N (wave per cell)
     int segs_override = 0;   // > 0: segments per cell for path 2
     int sorted = 1;          // traverse budgets in descending n_valid order
-    int small_n_max = 2048;  // auto: N <= this -> wave-per-cell kernel
+    int small_n_max = 512;   // auto: N <= this -> wave-per-cell kernel (crossover measured: profiles/r01_crossover_d*.log)
     bool user_tuned = false; // set_tuning called: auto geometry off
     // split-N scratch (grown on demand)
     void* d_partial = nullptr;
@@ -223,7 +223,13 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
 
     // ---- streaming kernel geometry ----------------------------------------------------------------
     int copies = ctx->copies, threads = ctx->threads, wg_per_cu = ctx->wg_per_cu, unroll = ctx->unroll;
-    if (!ctx->user_tuned && N < 32768) { copies = 8; threads = 256; wg_per_cu = 4; unroll = 4; }  // mid N: cheaper epilogue, 4 cells in flight per CU
+    if (!ctx->user_tuned) {
+        // measured crossover (tools/crossover.py): the per-cell fold costs 1024*R LDS words, so short
+        // cells want small R and several cells in flight per CU; long cells want one big workgroup.
+        if (N < 32768) { copies = 8; threads = 256; wg_per_cu = 4; unroll = 4; }
+        else if (N < 262144) { copies = 16; threads = 512; wg_per_cu = 2; unroll = 4; }
+        else { copies = 16; threads = 1024; wg_per_cu = 1; unroll = 4; }
+    }
     const size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords + scv::kMaxSortedB) * sizeof(uint32_t);
     if ((int64_t)lds > ctx->lds_max) return fail(SCV_ERR_ARG, "LDS request %zu exceeds device limit %lld", lds, (long long)ctx->lds_max);
     const int by_lds = (int)((160 * 1024) / lds);
@@ -276,6 +282,90 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         SCV_HIP(hipGetLastError());
     }
     return finish(ev);
+}
+
+// Prefix budgets over one pool [P, N]: one pass, snapshots at the boundaries (scv_prefix_hist /
+// scv_small_prefix).  Same outputs as launch_aggregate on the dense [P, B, N] expansion.
+int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, const int32_t* n_valid,
+                  const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells, int64_t* cell_tokens,
+                  int64_t* tie, int64_t* tok_sum, int64_t* truth_sum) {
+    const int64_t ncells = P * (int64_t)B;
+    if (ncells == 0) return SCV_OK;
+    scv::AggArgs a;
+    a.answers = pool; a.tokens = tokens; a.n_valid = n_valid; a.truth = truth;
+    a.ncells = ncells; a.N = N; a.B = B; a.P = P;
+    a.cells = cells; a.cell_tokens = cell_tokens;
+    a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
+    a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
+    a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
+    a.err_flag = ctx->d_err;
+    a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.sorted = 1;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr;
+    const bool tok = tokens != nullptr;
+    const bool want_counters = tie || truth_sum || (tok && tok_sum);
+    const bool use_reduce = want_counters && ncells > ctx->fused_counters_max;
+    if (use_reduce) {
+        a.tie_hits = nullptr; a.token_sum = nullptr; a.truth_sum = nullptr;
+        if (!a.cells || (tok && tok_sum && !a.cell_tokens)) {
+            const size_t cb = (size_t)ncells * sizeof(scv_cell);
+            if (int rc = ensure_cells(ctx, cb + (size_t)ncells * sizeof(int64_t) + 256)) return rc;
+            if (!a.cells) a.cells = static_cast<scv_cell*>(ctx->d_cells);
+            if (tok && !a.cell_tokens) a.cell_tokens = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->d_cells) + ((cb + 255) / 256) * 256);
+        }
+    }
+    EventPair* ev = nullptr;
+    if (ctx->flags & SCV_FLAG_TIMING) {
+        if (ctx->events_used == ctx->events.size()) {
+            EventPair np;
+            SCV_HIP(hipEventCreate(&np.a));
+            SCV_HIP(hipEventCreate(&np.b));
+            ctx->events.push_back(np);
+        }
+        ev = &ctx->events[ctx->events_used++];
+        SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+    }
+    int path = ctx->path;
+    if (path == 0 || path == 2) path = (N <= ctx->small_n_max) ? 3 : 1;
+    if (path == 3) {
+        constexpr int T = 512, NW = T / 64;
+        const size_t lds = ((size_t)NW * scv::kBins + scv::kMaxSortedB) * sizeof(uint32_t);
+        int64_t grid = (P + NW - 1) / NW;
+        const int64_t cap = (int64_t)ctx->num_cus * 4;
+        if (grid > cap) grid = cap;
+        if (tok) hipLaunchKernelGGL((scv::scv_small_prefix<T, true>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((scv::scv_small_prefix<T, false>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
+    } else {
+        int copies, threads, wg_per_cu;
+        if (N < 32768) { copies = 8; threads = 256; wg_per_cu = 4; }
+        else if (N < 262144) { copies = 16; threads = 512; wg_per_cu = 2; }
+        else { copies = 16; threads = 1024; wg_per_cu = 1; }
+        const size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords + scv::kMaxSortedB) * sizeof(uint32_t);
+        int64_t grid = (int64_t)ctx->num_cus * wg_per_cu;
+        if (grid > P) grid = P;
+        if (ctx->balance) { const int64_t rounds = (P + grid - 1) / grid; grid = (P + rounds - 1) / rounds; }
+        KernelFn fn;
+        if (threads == 256) fn = tok ? (KernelFn)scv::scv_prefix_hist<3, 256, 4, true> : (KernelFn)scv::scv_prefix_hist<3, 256, 4, false>;
+        else if (threads == 512) fn = tok ? (KernelFn)scv::scv_prefix_hist<4, 512, 4, true> : (KernelFn)scv::scv_prefix_hist<4, 512, 4, false>;
+        else fn = tok ? (KernelFn)scv::scv_prefix_hist<4, 1024, 4, true> : (KernelFn)scv::scv_prefix_hist<4, 1024, 4, false>;
+        SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)threads), lds, ctx->stream, a);
+    }
+    SCV_HIP(hipGetLastError());
+    if (use_reduce) {
+        int64_t chunks = (P + 2047) / 2048;
+        const int64_t cap = ((int64_t)ctx->num_cus * 8 + B - 1) / B;
+        if (chunks > cap) chunks = cap;
+        if (chunks < 1) chunks = 1;
+        auto* th = reinterpret_cast<unsigned long long*>(tie);
+        auto* ts = reinterpret_cast<unsigned long long*>(tok_sum);
+        auto* tc = reinterpret_cast<unsigned long long*>(truth_sum);
+        if (tok) hipLaunchKernelGGL((scv::scv_reduce_cells<true>), dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
+        else hipLaunchKernelGGL((scv::scv_reduce_cells<false>), dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
+        SCV_HIP(hipGetLastError());
+    }
+    if (ev) SCV_HIP(hipEventRecord(ev->b, ctx->stream));
+    ctx->err_dirty = true;
+    return SCV_OK;
 }
 
 // Read and clear the device error word (stream must be idle).
@@ -425,31 +515,39 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     return SCV_OK;
 }
 
-int scv_aggregate_i32(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
-                      const int32_t* truth, int64_t P, int32_t B, int64_t N, int mem_kind, scv_cell* cells_out,
-                      int64_t* cell_tokens_out, int64_t* tie_class_hits_out, int64_t* token_sum_out,
-                      int64_t* truth_count_sum_out) {
+}  // extern "C" (reopened below)
+
+namespace {
+
+// Shared body of scv_aggregate_i32 (dense: rows of B*N votes per problem) and
+// scv_aggregate_prefix_i32 (prefix: one row of N votes per problem).
+int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
+                     const int32_t* truth, int64_t P, int32_t B, int64_t N, int mem_kind, scv_cell* cells_out,
+                     int64_t* cell_tokens_out, int64_t* tie_class_hits_out, int64_t* token_sum_out,
+                     int64_t* truth_count_sum_out) {
     if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
     if (P < 0 || B < 0 || N < 0) return fail(SCV_ERR_ARG, "negative shape P=%lld B=%d N=%lld", (long long)P, B, (long long)N);
     if (N > 0x7fffffffll) return fail(SCV_ERR_ARG, "N=%lld exceeds 2^31-1 (cell counts are u32)", (long long)N);
     if (P > 0 && B > 0 && !truth) return fail(SCV_ERR_ARG, "truth is NULL");
     if (P > 0 && B > 0 && N > 0 && !answers) return fail(SCV_ERR_ARG, "answers is NULL");
+    if (prefix && B > 0 && !n_valid) return fail(SCV_ERR_ARG, "prefix mode needs n_valid");
+    if (prefix && B > scv::kMaxSortedB) return fail(SCV_ERR_ARG, "prefix mode supports at most %d budgets", scv::kMaxSortedB);
     if (mem_kind != SCV_MEM_HOST && mem_kind != SCV_MEM_DEVICE) return fail(SCV_ERR_ARG, "bad mem_kind %d", mem_kind);
     if (int rc = set_device(ctx)) return rc;
+    auto launch = prefix ? launch_prefix : launch_aggregate;
 
     if (mem_kind == SCV_MEM_DEVICE)
-        return launch_aggregate(ctx, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
-                                tie_class_hits_out, token_sum_out, truth_count_sum_out);
+        return launch(ctx, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
+                      tie_class_hits_out, token_sum_out, truth_count_sum_out);
 
     // ---- HOST: stage problem-chunks through HBM ------------------------------------------------
-    const size_t row_bytes = (size_t)B * (size_t)N * sizeof(int32_t);           // one problem
-    const size_t budget = (size_t)env_int("SCV_STAGE_MB", 2048) << 20;           // votes (+tokens) per chunk
+    const size_t row_bytes = (prefix ? (size_t)1 : (size_t)B) * (size_t)N * sizeof(int32_t);   // votes of one problem
+    const size_t budget = (size_t)env_int("SCV_STAGE_MB", 2048) << 20;                          // votes (+tokens) per chunk
     const size_t per_problem = row_bytes * (tokens ? 2 : 1);
     int64_t chunk = per_problem ? (int64_t)(budget / per_problem) : P;
     if (chunk < 1) chunk = 1;
     if (chunk > P) chunk = P;
     const size_t counters_bytes = ((size_t)B * SCV_TIE_CLASSES + 2 * (size_t)B) * sizeof(int64_t);
-    // layout of the staging block
     size_t off = 0;
     const size_t o_ans = off; off = align_up(off + (size_t)chunk * row_bytes, 256);
     const size_t o_tok = off; off = align_up(off + (tokens ? (size_t)chunk * row_bytes : 0), 256);
@@ -466,17 +564,18 @@ int scv_aggregate_i32(scv_ctx* ctx, const int32_t* answers, const int32_t* token
     hipStream_t s = ctx->stream;
     SCV_HIP(hipMemsetAsync(base + o_cnt, 0, counters_bytes > 0 ? counters_bytes : 1, s));
     if (n_valid && B > 0) SCV_HIP(hipMemcpyAsync(base + o_nv, n_valid, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    const size_t row_elems = row_bytes / sizeof(int32_t);
     for (int64_t p0 = 0; p0 < P; p0 += chunk) {
         const int64_t pc = (P - p0 < chunk) ? (P - p0) : chunk;
-        if (row_bytes) SCV_HIP(hipMemcpyAsync(base + o_ans, answers + (size_t)p0 * B * N, (size_t)pc * row_bytes, hipMemcpyHostToDevice, s));
-        if (tokens && row_bytes) SCV_HIP(hipMemcpyAsync(base + o_tok, tokens + (size_t)p0 * B * N, (size_t)pc * row_bytes, hipMemcpyHostToDevice, s));
+        if (row_bytes) SCV_HIP(hipMemcpyAsync(base + o_ans, answers + (size_t)p0 * row_elems, (size_t)pc * row_bytes, hipMemcpyHostToDevice, s));
+        if (tokens && row_bytes) SCV_HIP(hipMemcpyAsync(base + o_tok, tokens + (size_t)p0 * row_elems, (size_t)pc * row_bytes, hipMemcpyHostToDevice, s));
         SCV_HIP(hipMemcpyAsync(base + o_truth, truth + p0, (size_t)pc * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        if (int rc = launch_aggregate(ctx, reinterpret_cast<const int32_t*>(base + o_ans),
-                                      tokens ? reinterpret_cast<const int32_t*>(base + o_tok) : nullptr,
-                                      n_valid ? reinterpret_cast<const int32_t*>(base + o_nv) : nullptr,
-                                      reinterpret_cast<const int32_t*>(base + o_truth), pc, B, N,
-                                      reinterpret_cast<scv_cell*>(base + o_cells),
-                                      reinterpret_cast<int64_t*>(base + o_ctok), d_tie, d_tok, d_ts))
+        if (int rc = launch(ctx, reinterpret_cast<const int32_t*>(base + o_ans),
+                            tokens ? reinterpret_cast<const int32_t*>(base + o_tok) : nullptr,
+                            n_valid ? reinterpret_cast<const int32_t*>(base + o_nv) : nullptr,
+                            reinterpret_cast<const int32_t*>(base + o_truth), pc, B, N,
+                            reinterpret_cast<scv_cell*>(base + o_cells),
+                            reinterpret_cast<int64_t*>(base + o_ctok), d_tie, d_tok, d_ts))
             return rc;
         if (cells_out && B > 0) SCV_HIP(hipMemcpyAsync(cells_out + (size_t)p0 * B, base + o_cells, (size_t)pc * B * sizeof(scv_cell), hipMemcpyDeviceToHost, s));
         if (cell_tokens_out && B > 0) SCV_HIP(hipMemcpyAsync(cell_tokens_out + (size_t)p0 * B, base + o_ctok, (size_t)pc * B * sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -491,6 +590,26 @@ int scv_aggregate_i32(scv_ctx* ctx, const int32_t* answers, const int32_t* token
     uint32_t w = 0;
     if (int rc = fetch_err(ctx, &w)) return rc;
     return check_err_word(ctx, w);
+}
+
+}  // namespace
+
+extern "C" {
+
+int scv_aggregate_i32(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
+                      const int32_t* truth, int64_t P, int32_t B, int64_t N, int mem_kind, scv_cell* cells_out,
+                      int64_t* cell_tokens_out, int64_t* tie_class_hits_out, int64_t* token_sum_out,
+                      int64_t* truth_count_sum_out) {
+    return aggregate_common(ctx, false, answers, tokens, n_valid, truth, P, B, N, mem_kind, cells_out, cell_tokens_out,
+                            tie_class_hits_out, token_sum_out, truth_count_sum_out);
+}
+
+int scv_aggregate_prefix_i32(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, const int32_t* n_valid,
+                             const int32_t* truth, int64_t P, int32_t B, int64_t N, int mem_kind, scv_cell* cells_out,
+                             int64_t* cell_tokens_out, int64_t* tie_class_hits_out, int64_t* token_sum_out,
+                             int64_t* truth_count_sum_out) {
+    return aggregate_common(ctx, true, pool, tokens, n_valid, truth, P, B, N, mem_kind, cells_out, cell_tokens_out,
+                            tie_class_hits_out, token_sum_out, truth_count_sum_out);
 }
 
 int scv_bootstrap(scv_ctx* ctx, const scv_cell* cells, int64_t P, int32_t B, int32_t r_begin, int32_t r_end,

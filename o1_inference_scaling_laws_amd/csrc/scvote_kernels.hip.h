@@ -243,14 +243,103 @@ __device__ __forceinline__ void finalize_cell(const AggArgs& a, uint32_t* red, c
     }
 }
 
+// Stream one contiguous run of votes (a whole cell, a split-N segment, or the run between two
+// prefix boundaries) into the replicated histogram; accumulates the token sum when TOK.
+template <int RL2, int T, int U, bool TOK>
+__device__ __forceinline__ void stream_row(const AggArgs& a, uint32_t* hist, uint32_t copy, const int32_t* row,
+                                           const int32_t* trow, int64_t n, int tid, uint32_t& bad, long long& tsum) {
+    // head: scalars up to the first 16-byte boundary (rows are unaligned when N % 4 != 0)
+    int64_t head = (int64_t)(((16u - (uint32_t)((uintptr_t)row & 15u)) & 15u) >> 2);
+    if (head > n) head = n;
+    if (tid < head) {
+        vote<RL2>(hist, copy, (uint32_t)row[tid], bad);
+        if (TOK) tsum += trow[tid];
+    }
+    const int4* v4 = reinterpret_cast<const int4*>(row + head);
+    const int64_t nvec = (n - head) >> 2;
+    int64_t i = tid;
+    if (!TOK) {
+        // votes are order-independent, so a workgroup may start anywhere in its cell (measurement
+        // option "stagger_vecs"; measured null-to-negative on MI355X, default off).
+        int64_t rot = 0;
+        if (a.stagger_vecs > 0 && nvec > 0) rot = ((int64_t)blockIdx.x * a.stagger_vecs) % nvec;
+        if (a.plain_loads) {
+            stream_votes<RL2, T, U, false>(hist, copy, v4, rot, nvec, tid, bad);
+            if (rot) stream_votes<RL2, T, U, false>(hist, copy, v4, 0, rot, tid, bad);
+        } else {
+            stream_votes<RL2, T, U, true>(hist, copy, v4, rot, nvec, tid, bad);
+            if (rot) stream_votes<RL2, T, U, true>(hist, copy, v4, 0, rot, tid, bad);
+        }
+    } else {
+        // the token row is 16-byte congruent with the vote row for the layouts the ABI accepts when
+        // both bases are; a token base that is not takes the scalar route.
+        const bool tok_vec = (((uintptr_t)(trow + head)) & 15u) == 0;
+        if (tok_vec) {
+            const int4* t4 = reinterpret_cast<const int4*>(trow + head);
+            constexpr int UT = U > 1 ? U / 2 : 1;
+            for (; i + (int64_t)(UT - 1) * T < nvec; i += (int64_t)UT * T) {
+                int4 x[UT], y[UT];
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+                    x[u] = stream_load(v4 + i + (int64_t)u * T);
+                    y[u] = stream_load(t4 + i + (int64_t)u * T);
+                }
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+                    vote4<RL2>(hist, copy, x[u], bad);
+                    tsum += (long long)y[u].x + (long long)y[u].y + (long long)y[u].z + (long long)y[u].w;
+                }
+            }
+            for (; i < nvec; i += T) {
+                const int4 x = stream_load(v4 + i);
+                const int4 y = stream_load(t4 + i);
+                vote4<RL2>(hist, copy, x, bad);
+                tsum += (long long)y.x + (long long)y.y + (long long)y.z + (long long)y.w;
+            }
+        } else {
+            for (; i < nvec; i += T) {
+                const int4 x = stream_load(v4 + i);
+                vote4<RL2>(hist, copy, x, bad);
+                const int32_t* ts = trow + head + 4 * i;
+                tsum += (long long)ts[0] + (long long)ts[1] + (long long)ts[2] + (long long)ts[3];
+            }
+        }
+    }
+    {   // tail: the < 4 votes after the last full 16-byte vector
+        const int64_t t0 = head + (nvec << 2);
+        if (tid < n - t0) {
+            vote<RL2>(hist, copy, (uint32_t)row[t0 + tid], bad);
+            if (TOK) tsum += trow[t0 + tid];
+        }
+    }
+}
+
+// Fold the R copies of every bin owned by this thread (bin = tid + k*T); ZERO re-arms the histogram.
+template <int RL2, int T, bool ZERO>
+__device__ __forceinline__ void fold_copies(uint32_t* hist, int tid, uint32_t (&cnt)[kBins / T]) {
+    constexpr int R = 1 << RL2, CH = R / 4, BPR = 64 / R;
+#pragma unroll
+    for (int k = 0; k < kBins / T; ++k) {
+        const int bin = tid + k * T;
+        uint4* h4 = reinterpret_cast<uint4*>(hist + (bin << RL2));
+        uint32_t s = 0;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int jj = (j + bin / BPR) & (CH - 1);   // rotate: the 16-lane groups of a b128 read hit 16 distinct slots
+            const uint4 x = h4[jj];
+            s += x.x + x.y + x.z + x.w;
+            if (ZERO) h4[jj] = make_uint4(0, 0, 0, 0);
+        }
+        cnt[k] = s;
+    }
+}
+
 // ---- kernel 1: streaming histogram / argmax (large N) -------------------------------------------
 // RL2 = log2(copies), T = threads per workgroup, U = 16-byte loads in flight per lane.
 template <int RL2, int T, int U, bool TOK>
 __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
     constexpr int R = 1 << RL2;
     constexpr int NB = kBins / T;        // bins folded per thread in the epilogue
-    constexpr int CH = R / 4;            // 16-byte chunks per bin
-    constexpr int BPR = 64 / R;          // bins per 256-byte LDS row
     static_assert(NB >= 1 && T / 64 <= 16, "workgroup shape");
 
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -290,90 +379,12 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
         const int32_t* trow = TOK ? a.tokens + cell * a.N + lo : nullptr;
         long long tsum = 0;
 
-        // ---- o1.py:181-195: stream the votes ------------------------------------------------
-        // head: scalars up to the first 16-byte boundary (rows are unaligned when N % 4 != 0)
-        int64_t head = (int64_t)(((16u - (uint32_t)((uintptr_t)row & 15u)) & 15u) >> 2);
-        if (head > n) head = n;
-        if (tid < head) {
-            vote<RL2>(hist, copy, (uint32_t)row[tid], bad);
-            if (TOK) tsum += trow[tid];
-        }
-        const int4* v4 = reinterpret_cast<const int4*>(row + head);
-        const int64_t nvec = (n - head) >> 2;
-        int64_t i = tid;
-        if (!TOK) {
-            // votes are order-independent, so a workgroup may start anywhere in its cell (measurement
-            // option "stagger_vecs"; measured null-to-negative on MI355X, default off).
-            int64_t rot = 0;
-            if (a.stagger_vecs > 0 && nvec > 0) rot = ((int64_t)blockIdx.x * a.stagger_vecs) % nvec;
-            if (a.plain_loads) {
-                stream_votes<RL2, T, U, false>(hist, copy, v4, rot, nvec, tid, bad);
-                if (rot) stream_votes<RL2, T, U, false>(hist, copy, v4, 0, rot, tid, bad);
-            } else {
-                stream_votes<RL2, T, U, true>(hist, copy, v4, rot, nvec, tid, bad);
-                if (rot) stream_votes<RL2, T, U, true>(hist, copy, v4, 0, rot, tid, bad);
-            }
-        } else {
-            // the token row is 16-byte congruent with the vote row for the [P,B,N] layouts the ABI
-            // accepts when both bases are; a token base that is not takes the scalar route.
-            const bool tok_vec = (((uintptr_t)(trow + head)) & 15u) == 0;
-            if (tok_vec) {
-                const int4* t4 = reinterpret_cast<const int4*>(trow + head);
-                constexpr int UT = U > 1 ? U / 2 : 1;
-                for (; i + (int64_t)(UT - 1) * T < nvec; i += (int64_t)UT * T) {
-                    int4 x[UT], y[UT];
-#pragma unroll
-                    for (int u = 0; u < UT; ++u) {
-                        x[u] = stream_load(v4 + i + (int64_t)u * T);
-                        y[u] = stream_load(t4 + i + (int64_t)u * T);
-                    }
-#pragma unroll
-                    for (int u = 0; u < UT; ++u) {
-                        vote4<RL2>(hist, copy, x[u], bad);
-                        tsum += (long long)y[u].x + (long long)y[u].y + (long long)y[u].z + (long long)y[u].w;
-                    }
-                }
-                for (; i < nvec; i += T) {
-                    const int4 x = stream_load(v4 + i);
-                    const int4 y = stream_load(t4 + i);
-                    vote4<RL2>(hist, copy, x, bad);
-                    tsum += (long long)y.x + (long long)y.y + (long long)y.z + (long long)y.w;
-                }
-            } else {
-                for (; i < nvec; i += T) {
-                    const int4 x = stream_load(v4 + i);
-                    vote4<RL2>(hist, copy, x, bad);
-                    const int32_t* ts = trow + head + 4 * i;
-                    tsum += (long long)ts[0] + (long long)ts[1] + (long long)ts[2] + (long long)ts[3];
-                }
-            }
-        }
-        {   // tail: the < 4 votes after the last full 16-byte vector
-            const int64_t t0 = head + (nvec << 2);
-            if (tid < n - t0) {
-                vote<RL2>(hist, copy, (uint32_t)row[t0 + tid], bad);
-                if (TOK) tsum += trow[t0 + tid];
-            }
-        }
+        stream_row<RL2, T, U, TOK>(a, hist, copy, row, trow, n, tid, bad, tsum);   // o1.py:181-195
         if (tid == 0) red[48] = 0;
         __syncthreads();  // B1: all votes of this item are in LDS
 
-        // ---- fold the R copies (and zero them for the next item) -------------------------------
         uint32_t cnt[NB];
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int bin = tid + k * T;
-            uint4* h4 = reinterpret_cast<uint4*>(hist + (bin << RL2));
-            uint32_t s = 0;
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int jj = (j + bin / BPR) & (CH - 1);
-                const uint4 x = h4[jj];
-                s += x.x + x.y + x.z + x.w;
-                h4[jj] = make_uint4(0, 0, 0, 0);
-            }
-            cnt[k] = s;
-        }
+        fold_copies<RL2, T, true>(hist, tid, cnt);     // and zero them for the next item
         if (S > 1) {
             // split-N: publish the partial histogram; scv_merge_partials finishes the cell
             uint32_t* out = a.partial + (item << 10);
@@ -568,6 +579,137 @@ __global__ __launch_bounds__(T) void scv_small_cells(const AggArgs a) {
             if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
             if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
         }
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+}
+
+// ---- kernel 1e: prefix budgets over one sample pool ---------------------------
+//
+// The reference's budgets T >= 2^11 vote over PREFIXES of one pool of samples per problem
+// (o1.py:274-277: N = T // 2048 samples idx 0..N-1 of the same cache keys, o1.py:85-88).  Instead of a
+// dense [P, B, N] tensor that repeats the pool B times, stream pool[p, 0:max n_valid] ONCE and
+// snapshot the running histogram at every boundary (ascending n_valid): fold without zeroing ->
+// cell (p, b).  Algorithmic bytes: 4 * max_b n_valid[b] per problem instead of 4 * sum_b n_valid[b].
+// Here a.answers / a.tokens are [P, N] and a.ncells = P (work items are problems).
+template <int RL2, int T, int U, bool TOK>
+__global__ __launch_bounds__(T) void scv_prefix_hist(const AggArgs a) {
+    constexpr int R = 1 << RL2;
+    constexpr int NB = kBins / T;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* hist = smem;
+    uint32_t* red = smem + kBins * R;
+    int32_t* ord = reinterpret_cast<int32_t*>(red + kRedWords);   // budgets in DESCENDING n_valid order
+    const int tid = threadIdx.x;
+    const uint32_t copy = (uint32_t)(tid & 63) & (R - 1);
+    {
+        uint4* h4 = reinterpret_cast<uint4*>(hist);
+        for (int i = tid; i < kBins * R / 4; i += T) h4[i] = make_uint4(0, 0, 0, 0);
+    }
+    build_budget_order(a, ord, tid, T);   // host guarantees n_valid != NULL, B <= kMaxSortedB, sorted = 1
+    __syncthreads();
+
+    uint32_t bad = 0;
+    for (int64_t p = blockIdx.x; p < a.P; p += gridDim.x) {
+        const int32_t* row = a.answers + p * a.N;
+        const int32_t* trow = TOK ? a.tokens + p * a.N : nullptr;
+        const int32_t truth = a.truth[p];
+        long long tsum = 0;          // running token sum of this thread over the prefix so far
+        int64_t done = 0;
+        for (int32_t k = a.B - 1; k >= 0; --k) {               // ascending n_valid
+            const int32_t b = ord[k];
+            const int64_t n = valid_len(a, b);
+            if (n > done) {
+                stream_row<RL2, T, U, TOK>(a, hist, copy, row + done, TOK ? trow + done : nullptr, n - done, tid, bad, tsum);
+                done = n;
+            }
+            if (tid == 0) red[48] = 0;
+            __syncthreads();                                    // votes up to n are in LDS
+            uint32_t cnt[NB];
+            if (k == 0) fold_copies<RL2, T, true>(hist, tid, cnt);   // last (longest) budget: re-arm for the next problem
+            else fold_copies<RL2, T, false>(hist, tid, cnt);
+            finalize_cell<T, TOK>(a, red, cnt, tsum, tid, p * a.B + b, b, truth);
+            // finalize_cell's barriers order this snapshot's reads before the next run's votes
+        }
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+}
+
+// Small pools: one wave per problem; after each boundary the passes 2-3 of scv_small_cells run over
+// the whole prefix [0, n) (L1-resident), the sparse clear runs once at the end.
+template <int T, bool TOK>
+__global__ __launch_bounds__(T) void scv_small_prefix(const AggArgs a) {
+    constexpr int NW = T / 64;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t* h = smem + wid * kBins;
+    int32_t* ord = reinterpret_cast<int32_t*>(smem + NW * kBins);
+    for (int i = lane; i < kBins; i += 64) h[i] = 0;
+    build_budget_order(a, ord, tid, T);
+    __syncthreads();
+    uint32_t bad = 0;
+    const int64_t wave0 = (int64_t)blockIdx.x * NW + wid, nwaves = (int64_t)gridDim.x * NW;
+    for (int64_t p = wave0; p < a.P; p += nwaves) {
+        const int32_t* row = a.answers + p * a.N;
+        const int32_t truth = a.truth[p];
+        long long tsum = 0;
+        int64_t done = 0;
+        for (int32_t k = a.B - 1; k >= 0; --k) {
+            const int32_t b = ord[k];
+            const int64_t n = valid_len(a, b);
+            for (int64_t i = done + lane; i < n; i += 64) {
+                const uint32_t v = (uint32_t)row[i];
+                bad |= v;
+                atomicAdd(&h[v < 1023u ? v : 1023u], 1u);
+                if (TOK) tsum += a.tokens[p * a.N + i];
+            }
+            if (n > done) done = n;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t lmax = 0;
+            for (int64_t i = lane; i < n; i += 64) {
+                const uint32_t v = (uint32_t)row[i];
+                const uint32_t c = h[v < 1023u ? v : 1023u];
+                lmax = c > lmax ? c : lmax;
+            }
+            const uint32_t maxc = wave_max_u32(lmax);
+            uint32_t votes_at_max = 0, mm = 1024u;
+            for (int64_t i = lane; i < n; i += 64) {
+                const uint32_t v = (uint32_t)row[i];
+                const uint32_t bin = v < 1023u ? v : 1023u;
+                if (h[bin] == maxc) { votes_at_max += 1; mm = bin < mm ? bin : mm; }
+            }
+            votes_at_max = wave_sum_u32(votes_at_max);
+            mm = wave_min_u32(mm);
+            const uint32_t tc = (truth >= 0 && truth < kBins) ? h[truth] : 0u;
+            long long tok = 0;
+            if (TOK) tok = wave_sum_i64(tsum);
+            if (lane == 0) {
+                const int64_t cell = p * a.B + b;
+                const bool any = maxc > 0;
+                const uint32_t n_modes = any ? votes_at_max / maxc : 0u;
+                const uint32_t hit = (any && tc == maxc) ? 1u : 0u;
+                if (a.cells) {
+                    uint4 rec;
+                    rec.x = maxc;
+                    rec.y = tc;
+                    rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
+                    rec.w = hit;
+                    reinterpret_cast<uint4*>(a.cells)[cell] = rec;
+                }
+                if (a.cell_tokens) a.cell_tokens[cell] = tok;
+                if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
+                if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
+                if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int64_t i = lane; i < done; i += 64) {             // sparse clear, once per problem
+            const uint32_t v = (uint32_t)row[i];
+            h[v < 1023u ? v : 1023u] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
 }

@@ -154,6 +154,33 @@ class Engine:
                                         _np_ptr(cell_tokens), _np_ptr(tie), _np_ptr(tok), _np_ptr(tcs)))
         return AggregateResult(P, B, cells, cell_tokens, tie, tok, tcs)
 
+    def aggregate_prefix(self, pool, truth, n_valid, tokens=None, want_cells=True) -> AggregateResult:
+        """pool int32 [P,N] (numpy), n_valid int32 [B]: budget b votes over pool[p, :n_valid[b]].
+        One pass over the pool (scv_aggregate_prefix_i32); same result as ``aggregate`` on the dense
+        expansion.  Blocking."""
+        pool = np.ascontiguousarray(pool, dtype=np.int32)
+        if pool.ndim != 2:
+            raise ValueError("pool must be [P, N]")
+        P, N = pool.shape
+        truth = np.ascontiguousarray(truth, dtype=np.int32)
+        n_valid = np.ascontiguousarray(n_valid, dtype=np.int32)
+        if truth.shape != (P,) or n_valid.ndim != 1:
+            raise ValueError("truth must be [P] and n_valid [B]")
+        B = n_valid.shape[0]
+        if tokens is not None:
+            tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+            if tokens.shape != pool.shape:
+                raise ValueError("tokens must match pool")
+        cells = np.zeros((P, B), dtype=CELL_DTYPE) if want_cells else None
+        cell_tokens = np.zeros((P, B), dtype=np.int64) if (want_cells and tokens is not None) else None
+        tie = np.zeros((B, TIE_CLASSES), dtype=np.int64)
+        tok = np.zeros((B,), dtype=np.int64)
+        tcs = np.zeros((B,), dtype=np.int64)
+        check(self._L.scv_aggregate_prefix_i32(self._ctx, _np_ptr(pool), _np_ptr(tokens), _np_ptr(n_valid),
+                                               _np_ptr(truth), P, B, N, _lib.MEM_HOST, _np_ptr(cells),
+                                               _np_ptr(cell_tokens), _np_ptr(tie), _np_ptr(tok), _np_ptr(tcs)))
+        return AggregateResult(P, B, cells, cell_tokens, tie, tok, tcs)
+
     def bootstrap(self, cells: np.ndarray, r_begin: int, r_end: int, seed: int, M: int) -> np.ndarray:
         """cells CELL_DTYPE [P,B] -> int64 [r_end-r_begin, B, M].  Blocking.  See scv_bootstrap."""
         cells = np.ascontiguousarray(cells)
@@ -199,6 +226,36 @@ class Engine:
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
         check(self._L.scv_aggregate_i32(
             self._ctx, ptr(answers), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, _lib.MEM_DEVICE,
+            ptr(cells), ptr(cell_tokens),
+            C.c_void_p(base), C.c_void_p(base + 8 * B * TIE_CLASSES), C.c_void_p(base + 8 * (B * TIE_CLASSES + B))))
+        return counters, cells, cell_tokens
+
+    def aggregate_prefix_device(self, pool, truth, n_valid, tokens=None, counters=None, cells=None, cell_tokens=None):
+        """pool torch.int32 cuda [P,N], n_valid torch.int32 cuda [B].  Asynchronous; see aggregate_device."""
+        import torch
+        if not (pool.is_cuda and pool.dtype == torch.int32 and pool.is_contiguous() and pool.dim() == 2):
+            raise ValueError("pool must be a contiguous CUDA int32 tensor [P, N]")
+        P, N = pool.shape
+        B = int(n_valid.shape[0])
+        dev = pool.device
+        for name, t, shape in (("truth", truth, (P,)), ("tokens", tokens, (P, N)), ("n_valid", n_valid, (B,))):
+            if t is None:
+                continue
+            if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == shape and t.device == dev):
+                raise ValueError(f"{name} must be a contiguous CUDA int32 tensor {shape} on {dev}")
+        self.use_torch_stream()
+        if counters is None:
+            counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
+        if cells is None:
+            cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
+        elif cells is False:
+            cells = None
+        if cell_tokens is None and tokens is not None and cells is not None:
+            cell_tokens = torch.empty((P, B), dtype=torch.int64, device=dev)
+        base = counters.data_ptr()
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        check(self._L.scv_aggregate_prefix_i32(
+            self._ctx, ptr(pool), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, _lib.MEM_DEVICE,
             ptr(cells), ptr(cell_tokens),
             C.c_void_p(base), C.c_void_p(base + 8 * B * TIE_CLASSES), C.c_void_p(base + 8 * (B * TIE_CLASSES + B))))
         return counters, cells, cell_tokens

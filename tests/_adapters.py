@@ -27,6 +27,16 @@ class OracleEngine:
                                out["tie_class_hits"], out["token_sum"], out["truth_count_sum"])
 
 
+    def aggregate_prefix(self, pool, truth, n_valid, tokens=None, want_cells=True):
+        """Oracle for the prefix mode = the dense oracle on answers[p, b, :] = pool[p, :]."""
+        pool = np.asarray(pool, dtype=np.int32)
+        B = len(n_valid)
+        dense = np.ascontiguousarray(np.broadcast_to(pool[:, None, :], (pool.shape[0], B, pool.shape[1])))
+        dtok = None if tokens is None else np.ascontiguousarray(
+            np.broadcast_to(np.asarray(tokens, dtype=np.int32)[:, None, :], dense.shape))
+        return self.aggregate(dense, truth, tokens=dtok, n_valid=np.asarray(n_valid, dtype=np.int32), want_cells=want_cells)
+
+
 def make_dataset(truth_strings):
     return [{"problem": f"Problem {i}: compute f({i}).", "answer": s, "url": f"https://aops/2024_AIME_{i}"}
             for i, s in enumerate(truth_strings)]

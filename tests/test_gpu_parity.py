@@ -153,7 +153,7 @@ def _with_options(eng, opts):
                 eng.set_option(k, v)
         def __exit__(self_, *exc):
             for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
-                         ("small_n_max", 2048), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096)):
+                         ("small_n_max", 512), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096)):
                 eng.set_option(k, v)
     return _Ctx()
 
@@ -232,11 +232,63 @@ def test_counters_fused_and_reduced_agree(hip_engine, fused_max, path):
 
 
 def test_auto_dispatch_covers_all_regimes(hip_engine):
-    """auto: N <= 2048 -> wave-per-cell; few big cells -> split-N; otherwise whole-cell streaming
-    (with the mid-N geometry below N = 32768)."""
-    for (P, B, N) in [(500, 2, 128), (2, 1, 1 << 19), (700, 1, 8192), (300, 1, 40000)]:
+    """auto: N <= 512 -> wave-per-cell; few big cells -> split-N; otherwise whole-cell streaming
+    with the geometry picked from N (three bands)."""
+    for (P, B, N) in [(500, 2, 128), (2, 1, 1 << 19), (700, 1, 8192), (300, 1, 40000), (260, 1, 300000)]:
         a, t, tr = coracle.synth_fill(P, B, N, 77, 1, want_tokens=True)
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
+
+
+# ---- prefix budgets over one pool (SURVEY 8f rank 2) -------------------------------------------------
+
+PREFIX_CASES = [  # (P, N, n_valid, dist)
+    (30, 8, [1, 2, 4, 8], 1),                                   # the reference's 2048-pool: maj@1,2,4,8 (o1.py:276)
+    (300, 128, [1, 2, 4, 8, 16, 32, 64, 128], 1),               # shade_regions family (o1.py:267)
+    (40, 500, [500, 0, 7, 7, 499, 1, 250], 3),                  # unsorted, duplicates, empty
+    (25, 20001, [20001, 5, 10000, 4097, 4096, 4095, 1], 0),     # streaming path, unaligned boundaries
+    (300, 70000, [1 << 16, 70000, 1 << 10, 3], 1),
+    (3, 1 << 20, [1 << k for k in range(0, 21, 2)], 1),         # maj@4^k curve from one 2^20 pool
+    (7, 3000, [3000], 2),
+]
+
+
+@pytest.mark.parametrize("case", PREFIX_CASES, ids=lambda c: f"P{c[0]}_N{c[1]}_B{len(c[2])}")
+def test_prefix_mode_equals_dense_oracle(hip_engine, case):
+    P, N, nv, dist = case
+    a, t, tr = coracle.synth_fill(P, 1, N, 900 + N, dist, want_tokens=True)
+    pool, tpool = a[:, 0, :], t[:, 0, :]
+    nv = np.array(nv, dtype=np.int32)
+    want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
+    assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+    assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
+    with _with_options(hip_engine, {"fused_counters_max": 0}):
+        assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+    if N <= 4096:
+        with _with_options(hip_engine, {"path": 1}):       # force the streaming kernel on a small pool
+            assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+        with _with_options(hip_engine, {"path": 3}):
+            assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+
+
+def test_prefix_mode_device_and_errors(hip_engine):
+    import torch
+    dev = torch.device("cuda:0")
+    P, N = 64, 1 << 16
+    pool = torch.empty((P, 1, N), dtype=torch.int32, device=dev)
+    tr = torch.empty((P,), dtype=torch.int32, device=dev)
+    hip_engine.synth_fill_device(pool, None, tr, P=P, B=1, N=N, seed=3, dist=1)
+    nv = torch.tensor([N, N // 2, 100, 1], dtype=torch.int32, device=dev)
+    counters, cells, _ = hip_engine.aggregate_prefix_device(pool.view(P, N), tr, nv)
+    hip_engine.sync()
+    want = OracleEngine().aggregate_prefix(pool.view(P, N).cpu().numpy(), tr.cpu().numpy(), nv.cpu().numpy())
+    got = AggregateResult.from_counters(counters.cpu().numpy(), P, 4, cells_from_torch(cells))
+    assert_results_equal(got, want, check_tokens=False)
+    L, ctx = hip_engine._L, hip_engine._ctx
+    a = np.zeros((2, 8), dtype=np.int32)
+    z = np.zeros(2, dtype=np.int32)
+    vp = lambda x: x.ctypes.data_as(__import__("ctypes").c_void_p)   # noqa: E731
+    assert L.scv_aggregate_prefix_i32(ctx, vp(a), None, None, vp(z), 2, 3, 8, 0, None, None, None, None, None) == _lib.ERR_ARG
+    assert b"n_valid" in L.scv_last_error()
 
 
 # ---- golden fixtures generated from the unmodified reference ------------------------------------
