@@ -42,27 +42,45 @@ def avg_tokens_used(token_sum: int, num_problems: int) -> np.float64:
     return np.float64(int(token_sum)) / np.float64(num_problems)
 
 
+def _pass_at_k_running(n, c, ks):
+    """1 - prod_{i<k} (1 - c/(n-i)) for every k in ks (ascending), sharing one running log-sum.
+    k terms per value, no cancellation: relative error ~ k * 1e-16."""
+    c = np.asarray(c, dtype=np.int64)
+    n = np.broadcast_to(np.asarray(n, dtype=np.int64), c.shape)
+    nf, cf = n.astype(np.float64), c.astype(np.float64)
+    ks = sorted(int(k) for k in ks)
+    out, acc, i = {}, np.zeros(c.shape, dtype=np.float64), 0
+    for k in ks:
+        while i < k:
+            den = nf - i
+            ok = den > cf                                   # n - i > c: factor (n-c-i)/(n-i) is positive
+            acc = acc + np.log1p(np.where(ok, -cf / np.where(ok, den, 1.0), 0.0))
+            i += 1
+        val = 1.0 - np.exp(acc)
+        val = np.where((n - c) < k, 1.0, val)               # fewer than k wrong samples: certain hit
+        val = np.where(c == 0, 0.0, val)
+        out[k] = np.clip(val, 0.0, 1.0)
+    return out
+
+
 def pass_at_k(n, c, k: int):
-    """Unbiased pass@k (Chen et al. 2021): 1 - C(n-c, k) / C(n, k), vectorised over c.
+    """Unbiased pass@k (Chen et al. 2021): 1 - C(n-c, k) / C(n, k), vectorised over n and c.
 
     NEW semantics (the reference has no pass@k).  n = votes in the cell, c = truth_count
-    from the engine.  Product form, evaluated in float64: prod_{i=n-c+1..n} (1 - k/i).
+    from the engine (integer, bit-exact).  The float is evaluated by THIS one function for every path
+    (product form in log space, k terms).
     """
-    c = np.asarray(c, dtype=np.int64)
-    n_arr = np.broadcast_to(np.asarray(n, dtype=np.int64), c.shape)
-    out = np.ones(c.shape, dtype=np.float64)
-    flat_c, flat_n, flat_o = c.reshape(-1), n_arr.reshape(-1), out.reshape(-1)
-    for idx in range(flat_c.size):
-        ci, ni = int(flat_c[idx]), int(flat_n[idx])
-        if ni - ci < k:
-            flat_o[idx] = 1.0
-        elif ci == 0:
-            flat_o[idx] = 0.0
-        else:
-            # log-space for large c: sum log1p(-k/i)
-            i = np.arange(ni - ci + 1, ni + 1, dtype=np.float64)
-            flat_o[idx] = 1.0 - float(np.exp(np.sum(np.log1p(-k / i))))
-    return out
+    return _pass_at_k_running(n, c, [k])[int(k)]
+
+
+PASS_K_SWEEP = tuple(2 ** i for i in range(11))   # k = 1, 2, 4, ..., 1024 (BASELINE.json config 5)
+
+
+def pass_at_k_sweep(n_valid, truth_count, ks=PASS_K_SWEEP):
+    """truth_count [P, B] (from the cell table), n_valid [B] -> {k: mean-over-problems pass@k [B]}."""
+    tc = np.asarray(truth_count, dtype=np.int64)
+    n = np.asarray(n_valid, dtype=np.int64).reshape(1, -1)
+    return {k: v.mean(axis=0) for k, v in _pass_at_k_running(n, tc, ks).items()}
 
 
 def bootstrap_percentiles(counts, num_problems: int, lo=2.5, hi=97.5):

@@ -91,7 +91,10 @@ def test_pass_at_k_matches_combinatorial_definition():
         got = float(scoring.pass_at_k(n, np.array([c]), k)[0])
         assert abs(got - want) < 1e-12, (n, c, k)
     big = scoring.pass_at_k(2 ** 20, np.array([0, 1, 2 ** 19, 2 ** 20]), 1024)
-    assert big[0] == 0.0 and 0 < big[1] < 0.001 and big[2] == 1.0 and big[3] == 1.0
+    assert big[0] == 0.0 and abs(big[1] - 1024 / 2 ** 20) < 1e-13 and big[2] == 1.0 and big[3] == 1.0
+    sweep = scoring.pass_at_k_sweep([16, 8], np.array([[0, 8], [4, 2], [16, 0]]))
+    assert sorted(sweep) == [2 ** i for i in range(11)] and sweep[1].shape == (2,)
+    assert abs(sweep[1][0] - (0 + 4 / 16 + 1) / 3) < 1e-12 and abs(sweep[8][1] - (1 + 1 + 0) / 3) < 1e-12
 
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3])
