@@ -100,9 +100,11 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  * count), "balance" (default 1: shrink the grid so all workgroups stream the same number of items),
  * "path" (0 auto | 1 streaming whole cells | 2 streaming split-N + merge | 3 small-N wave-per-cell),
  * "segs" (split-N segments per cell, 0 auto), "sorted" (default 1: budgets traversed in descending
- * n_valid order), "small_n_max" (auto: N <= this uses the small-N kernel), "auto_geometry" (default 1),
+ * n_valid order), "small_n_max" (auto: N <= this uses the small-N kernel), "tiny_n_max" (<= 32: N <= this
+ * uses the register-only several-cells-per-wave kernel inside the small path), "auto_geometry" (default 1),
  * "fused_counters_max" (cells at or below: per-cell atomics inside the hot kernel; above: a separate
- * reduction of the cell table), "stagger_vecs", "plain_loads". */
+ * reduction of the cell table), "pin_host" (default 0; 1: HOST-mode calls hipHostRegister caller buffers
+ * of 32 MiB or more for the duration of the call -- measured no faster than pageable copies), "stagger_vecs", "plain_loads". */
 int scv_set_option(scv_ctx* ctx, const char* key, int64_t value);
 
 /*

@@ -53,6 +53,7 @@ struct scv_ctx {
     int path = 0;            // 0 auto | 1 streaming, whole cells | 2 streaming, split-N | 3 small-N (wave per cell)
     int segs_override = 0;   // > 0: segments per cell for path 2
     int sorted = 1;          // traverse budgets in descending n_valid order
+    int tiny_n_max = 32;     // auto/small path: N <= this -> register-only kernel, several cells per wave
     int small_n_max = 512;   // auto: N <= this -> wave-per-cell kernel (crossover measured: profiles/r01_crossover_d*.log)
     bool user_tuned = false; // set_tuning called: auto geometry off
     // split-N scratch (grown on demand)
@@ -60,6 +61,7 @@ struct scv_ctx {
     size_t d_partial_bytes = 0;
     void* d_cells = nullptr;  // cell table scratch for the reduce kernel when the caller wants no cells
     size_t d_cells_bytes = 0;
+    int pin_host = 0;         // HOST mode: hipHostRegister large caller buffers (measured: no gain over pageable copies, off)
     int fused_counters_max = 4096;  // cells: at or below, per-cell atomics inside the hot kernel; above, scv_reduce_cells
     int grid_override = 0;   // > 0: exact persistent grid size
     int balance = 1;         // shrink the grid so every workgroup streams the same number of cells
@@ -206,6 +208,25 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         ev = &ctx->events[ctx->events_used++];
     }
 
+    if (path == 3 && N <= ctx->tiny_n_max && N <= 32) {
+        // ---- tiny cells: 64/G cells per wave, registers only
+        const int G = N <= 8 ? 8 : (N <= 16 ? 16 : 32);
+        const int64_t cells_per_wg = (int64_t)(64 / G) * 4;
+        int64_t grid = (ncells + cells_per_wg - 1) / cells_per_wg;
+        const int64_t cap = (int64_t)ctx->num_cus * 8;
+        if (grid > cap) grid = cap;
+        if (ctx->grid_override > 0) grid = ctx->grid_override;
+        if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+#define SCV_TINY(GG)                                                                                          \
+        do {                                                                                                  \
+            if (tok) hipLaunchKernelGGL((scv::scv_tiny_cells<GG, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, a); \
+            else hipLaunchKernelGGL((scv::scv_tiny_cells<GG, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);    \
+        } while (0)
+        if (G == 8) SCV_TINY(8); else if (G == 16) SCV_TINY(16); else SCV_TINY(32);
+#undef SCV_TINY
+        SCV_HIP(hipGetLastError());
+        return finish(ev);
+    }
     if (path == 3) {
         // ---- small-N: 8 waves per workgroup, 32 KiB of private histograms, up to 4 workgroups per CU
         constexpr int T = 512, NW = T / 64;
@@ -229,6 +250,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         if (N < 32768) { copies = 8; threads = 256; wg_per_cu = 4; unroll = 4; }
         else if (N < 262144) { copies = 16; threads = 512; wg_per_cu = 2; unroll = 4; }
         else { copies = 16; threads = 1024; wg_per_cu = 1; unroll = 4; }
+        // fewer cells than CUs: one cell per CU whatever the band, so give each the widest workgroup
+        if (ncells <= ctx->num_cus && N >= 4096) { copies = 16; threads = 1024; wg_per_cu = 1; unroll = 4; }
     }
     const size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords + scv::kMaxSortedB) * sizeof(uint32_t);
     if ((int64_t)lds > ctx->lds_max) return fail(SCV_ERR_ARG, "LDS request %zu exceeds device limit %lld", lds, (long long)ctx->lds_max);
@@ -508,8 +531,10 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "path must be 0..3"); ctx->path = (int)value; }
     else if (!strcmp(key, "segs")) { if (value < 0 || value > 4096) return fail(SCV_ERR_ARG, "segs out of range"); ctx->segs_override = (int)value; }
     else if (!strcmp(key, "sorted")) ctx->sorted = value != 0;
+    else if (!strcmp(key, "tiny_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "tiny_n_max < 0"); ctx->tiny_n_max = (int)(value > 32 ? 32 : value); }
     else if (!strcmp(key, "small_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "small_n_max < 0"); ctx->small_n_max = (int)(value > (1 << 30) ? (1 << 30) : value); }
     else if (!strcmp(key, "auto_geometry")) ctx->user_tuned = value == 0;
+    else if (!strcmp(key, "pin_host")) ctx->pin_host = value != 0;
     else if (!strcmp(key, "fused_counters_max")) { if (value < 0) return fail(SCV_ERR_ARG, "fused_counters_max < 0"); ctx->fused_counters_max = (int)(value > (1 << 30) ? (1 << 30) : value); }
     else return fail(SCV_ERR_ARG, "unknown option '%s'", key);
     return SCV_OK;
@@ -542,6 +567,21 @@ int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const in
 
     // ---- HOST: stage problem-chunks through HBM ------------------------------------------------
     const size_t row_bytes = (prefix ? (size_t)1 : (size_t)B) * (size_t)N * sizeof(int32_t);   // votes of one problem
+    // Pageable host memory is copied through the runtime's bounce buffers at a fraction of the link
+    // rate; pinning the caller's pages in place makes every chunk one DMA.  Best effort: a buffer that
+    // cannot be registered (already registered, not page-able) is simply copied the slow way.
+    struct Pin {
+        const void* p = nullptr;
+        ~Pin() { if (p) (void)hipHostUnregister(const_cast<void*>(p)); }
+        void pin(const void* q, size_t bytes) {
+            if (q && bytes >= ((size_t)32 << 20) && hipHostRegister(const_cast<void*>(q), bytes, hipHostRegisterDefault) == hipSuccess) p = q;
+            else (void)hipGetLastError();
+        }
+    } pin_a, pin_t;
+    if (ctx->pin_host) {
+        pin_a.pin(answers, (size_t)P * row_bytes);
+        pin_t.pin(tokens, (size_t)P * row_bytes);
+    }
     const size_t budget = (size_t)env_int("SCV_STAGE_MB", 2048) << 20;                          // votes (+tokens) per chunk
     const size_t per_problem = row_bytes * (tokens ? 2 : 1);
     int64_t chunk = per_problem ? (int64_t)(budget / per_problem) : P;

@@ -583,6 +583,103 @@ __global__ __launch_bounds__(T) void scv_small_cells(const AggArgs a) {
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
 }
 
+// ---- kernel 1f: tiny cells (N <= 32), several cells per wave, registers only --------------------
+//
+// The reference's own budgets are N = 1, 1, ..., 2, 4, 8 (o1.py:276; up to 128 with shade_regions).
+// A cell of N <= G votes occupies G = 8 / 16 / 32 adjacent lanes, one vote per lane, so a wave holds
+// 64/G cells.  count_i = #{j : v_j == v_i} by rotating the votes through the lane group (G-1
+// ds_bpermute + compare); then the same identities as scv_small_cells: max_count = max_i count_i,
+// len(multimode) = #{i : count_i == max_count} / max_count, min_mode = min v_i over those.
+// No histogram, no LDS memory, no barrier.  Cells are taken in natural (memory) order so a wave reads
+// and writes contiguous bytes; (p, b) advance incrementally (no per-cell division).
+template <int G>
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) { const uint32_t w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) { const uint32_t w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ uint32_t group_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ long long group_sum_i64(long long v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int G, bool TOK>
+__global__ __launch_bounds__(256) void scv_tiny_cells(const AggArgs a) {
+    constexpr int CPW = 64 / G;                       // cells per wave
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / G, l = lane % G, base = lane - l;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t cell = wave * CPW + sub;
+    int64_t p = cell / a.B;
+    int32_t b = (int32_t)(cell - p * a.B);
+    const int64_t step = nwaves * CPW;
+    const int64_t dp = step / a.B;
+    const int32_t db = (int32_t)(step - dp * a.B);
+    uint32_t bad = 0;
+    for (; cell - sub < a.ncells; cell += step) {      // wave-uniform trip count (shuffles need all lanes)
+        const bool live = cell < a.ncells;
+        const int64_t n = live ? valid_len(a, b) : 0;
+        const bool active = l < n;
+        uint32_t bin = 0xffffffffu;                    // inactive lanes never match anything
+        long long tok = 0;
+        if (active) {
+            const uint32_t v = (uint32_t)a.answers[cell * a.N + l];
+            bad |= v;
+            bin = v < 1023u ? v : 1023u;
+            if (TOK) tok = a.tokens[cell * a.N + l];
+        }
+        uint32_t cnt = active ? 1u : 0u;
+#pragma unroll
+        for (int r = 1; r < G; ++r) {
+            const uint32_t other = (uint32_t)__shfl((int)bin, base + ((l + r) & (G - 1)), 64);
+            cnt += (active && other == bin) ? 1u : 0u;
+        }
+        const uint32_t maxc = group_max_u32<G>(cnt);
+        const bool at_max = active && cnt == maxc;
+        const uint32_t votes_at_max = group_sum_u32<G>(at_max ? 1u : 0u);
+        const uint32_t mm = group_min_u32<G>(at_max ? bin : 1024u);
+        const int32_t truth = live ? a.truth[p] : -1;
+        const uint32_t tc = group_sum_u32<G>((active && (int32_t)bin == truth) ? 1u : 0u);
+        if (TOK) tok = group_sum_i64<G>(tok);
+        if (l == 0 && live) {
+            const bool any = maxc > 0;
+            const uint32_t n_modes = any ? votes_at_max / maxc : 0u;
+            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;               // o1.py:206
+            if (a.cells) {
+                uint4 rec;
+                rec.x = maxc;
+                rec.y = tc;
+                rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
+                rec.w = hit;
+                reinterpret_cast<uint4*>(a.cells)[cell] = rec;
+            }
+            if (a.cell_tokens) a.cell_tokens[cell] = tok;
+            if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
+            if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
+            if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
+        }
+        p += dp;
+        b += db;
+        if (b >= a.B) { b -= a.B; p += 1; }
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+}
+
 // ---- kernel 1e: prefix budgets over one sample pool ---------------------------
 //
 // The reference's budgets T >= 2^11 vote over PREFIXES of one pool of samples per problem

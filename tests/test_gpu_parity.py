@@ -153,7 +153,7 @@ def _with_options(eng, opts):
                 eng.set_option(k, v)
         def __exit__(self_, *exc):
             for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
-                         ("small_n_max", 512), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096)):
+                         ("small_n_max", 512), ("tiny_n_max", 32), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096)):
                 eng.set_option(k, v)
     return _Ctx()
 
@@ -169,6 +169,43 @@ def test_small_n_wave_per_cell_path(hip_engine, dist, shape):
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
         assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (50, 3, 1), (41, 11, 8), (333, 5, 7), (64, 8, 9), (100, 3, 16), (77, 2, 17),
+                                   (30, 7, 32), (5000, 3, 4), (3, 1, 0)])
+def test_tiny_cells_register_path(hip_engine, dist, shape):
+    """N <= 32: several cells per wave (G = 8/16/32 lanes per cell), the reference's own budget sizes."""
+    P, B, N = shape
+    if N == 0:
+        a, t, tr = np.zeros((P, B, 0), np.int32), np.zeros((P, B, 0), np.int32), np.zeros(P, np.int32)
+    else:
+        a, t, tr = coracle.synth_fill(P, B, N, 40 + dist, dist, want_tokens=True)
+        a = a % (3 + dist * 300)                                   # few distinct values -> many ties
+    nv = np.array([(N >> (b % 4)) if b % 3 else N for b in range(B)], dtype=np.int32)
+    for opts in ({"path": 3}, {"path": 0}, {"path": 3, "tiny_n_max": 0}, {"path": 3, "fused_counters_max": 0}):
+        with _with_options(hip_engine, opts):
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+            assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
+
+
+def test_tiny_cells_reference_family_and_domain(hip_engine, golden):
+    """The reference's real shape: [30, 11, 8] with n_valid = 1 x8, 2, 4, 8 goes through the tiny path."""
+    pipe = golden["pipeline"]
+    ds = make_dataset(pipe["truths"])
+    cache = build_cache(ds, pipe["samples"])
+    budgets = [(k, n) for _, k, n in o1_dropin.majority_vote_budgets(False)]
+    vt = build_vote_tensors(ds, cache, budgets, TEST_MODEL, TEST_PROMPT)
+    assert vt.answers.shape == (30, 11, 8)
+    want = oracle(vt.answers, vt.truth, tokens=vt.tokens, n_valid=vt.n_valid)
+    assert_results_equal(hip_engine.aggregate(vt.answers, vt.truth, tokens=vt.tokens, n_valid=vt.n_valid), want)
+    bad = vt.answers.copy()
+    bad[3, 10, 7] = 1 << 20
+    with pytest.raises(_lib.DomainError):
+        hip_engine.aggregate(bad, vt.truth, n_valid=vt.n_valid)
+    bad[3, 10, 7] = 0
+    bad[3, 0, 5] = -7                       # beyond n_valid[0] == 1: never read, not an error
+    hip_engine.aggregate(bad, vt.truth, n_valid=vt.n_valid)
 
 
 def test_small_n_path_spare_bins_ties_and_truth_edges(hip_engine):
