@@ -53,6 +53,7 @@ struct scv_ctx {
     int path = 0;            // 0 auto | 1 streaming, whole cells | 2 streaming, split-N | 3 small-N (wave per cell)
     int segs_override = 0;   // > 0: segments per cell for path 2
     int sorted = 1;          // traverse budgets in descending n_valid order
+    int small_reg = 1;       // small path: 1 = register-resident variant for N <= 128 (measured +10 %), 2 = also for N <= 512 (measured slower)
     int tiny_n_max = 32;     // auto/small path: N <= this -> register-only kernel, several cells per wave
     int small_n_max = 512;   // auto: N <= this -> wave-per-cell kernel (crossover measured: profiles/r01_crossover_d*.log)
     bool user_tuned = false; // set_tuning called: auto geometry off
@@ -236,7 +237,13 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         if (grid > cap) grid = cap;
         if (ctx->grid_override > 0) grid = ctx->grid_override;
         if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
-        if (tok) hipLaunchKernelGGL((scv::scv_small_cells<T, true>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
+        if (N <= 128 && ctx->small_reg) {
+            if (tok) hipLaunchKernelGGL((scv::scv_small_cells_reg<T, 2, true>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
+            else hipLaunchKernelGGL((scv::scv_small_cells_reg<T, 2, false>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
+        } else if (N <= 512 && ctx->small_reg > 1) {
+            if (tok) hipLaunchKernelGGL((scv::scv_small_cells_reg<T, 8, true>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
+            else hipLaunchKernelGGL((scv::scv_small_cells_reg<T, 8, false>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
+        } else if (tok) hipLaunchKernelGGL((scv::scv_small_cells<T, true>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
         else hipLaunchKernelGGL((scv::scv_small_cells<T, false>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
         SCV_HIP(hipGetLastError());
         return finish(ev);
@@ -531,8 +538,9 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "path must be 0..3"); ctx->path = (int)value; }
     else if (!strcmp(key, "segs")) { if (value < 0 || value > 4096) return fail(SCV_ERR_ARG, "segs out of range"); ctx->segs_override = (int)value; }
     else if (!strcmp(key, "sorted")) ctx->sorted = value != 0;
+    else if (!strcmp(key, "small_reg")) ctx->small_reg = (int)(value < 0 ? 0 : (value > 2 ? 2 : value));
     else if (!strcmp(key, "tiny_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "tiny_n_max < 0"); ctx->tiny_n_max = (int)(value > 32 ? 32 : value); }
-    else if (!strcmp(key, "small_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "small_n_max < 0"); ctx->small_n_max = (int)(value > (1 << 30) ? (1 << 30) : value); }
+    else if (!strcmp(key, "small_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "small_n_max < 0"); ctx->small_n_max = (int)(value > 32768 ? 32768 : value); }
     else if (!strcmp(key, "auto_geometry")) ctx->user_tuned = value == 0;
     else if (!strcmp(key, "pin_host")) ctx->pin_host = value != 0;
     else if (!strcmp(key, "fused_counters_max")) { if (value < 0) return fail(SCV_ERR_ARG, "fused_counters_max < 0"); ctx->fused_counters_max = (int)(value > (1 << 30) ? (1 << 30) : value); }

@@ -61,25 +61,48 @@ struct AggArgs {
     long long* partial_tok; // split-N: [ncells * segs] partial token sums
 };
 
+// 64-lane reductions on the VALU (DPP), not through the LDS crossbar: __shfl_xor lowers to
+// ds_bpermute_b32, which has LDS latency and queues behind the histogram atomics.  gfx9 scan idiom:
+// row_shr 1/2/4/8 inside each 16-lane row, row_bcast15 / row_bcast31 across rows, total in lane 63.
+#define SCV_DPP(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), (rmask), 0xf, false)
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { uint32_t w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
-    return v;
+    uint32_t t;
+    t = (uint32_t)SCV_DPP(0, v, 0x111, 0xf); v = t > v ? t : v;   // row_shr:1
+    t = (uint32_t)SCV_DPP(0, v, 0x112, 0xf); v = t > v ? t : v;   // row_shr:2
+    t = (uint32_t)SCV_DPP(0, v, 0x114, 0xf); v = t > v ? t : v;   // row_shr:4
+    t = (uint32_t)SCV_DPP(0, v, 0x118, 0xf); v = t > v ? t : v;   // row_shr:8
+    t = (uint32_t)SCV_DPP(0, v, 0x142, 0xa); v = t > v ? t : v;   // row_bcast:15 -> rows 1, 3
+    t = (uint32_t)SCV_DPP(0, v, 0x143, 0xc); v = t > v ? t : v;   // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { uint32_t w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
-    return v;
+    uint32_t t;
+    t = (uint32_t)SCV_DPP(-1, v, 0x111, 0xf); v = t < v ? t : v;
+    t = (uint32_t)SCV_DPP(-1, v, 0x112, 0xf); v = t < v ? t : v;
+    t = (uint32_t)SCV_DPP(-1, v, 0x114, 0xf); v = t < v ? t : v;
+    t = (uint32_t)SCV_DPP(-1, v, 0x118, 0xf); v = t < v ? t : v;
+    t = (uint32_t)SCV_DPP(-1, v, 0x142, 0xa); v = t < v ? t : v;
+    t = (uint32_t)SCV_DPP(-1, v, 0x143, 0xc); v = t < v ? t : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += (uint32_t)SCV_DPP(0, v, 0x111, 0xf);
+    v += (uint32_t)SCV_DPP(0, v, 0x112, 0xf);
+    v += (uint32_t)SCV_DPP(0, v, 0x114, 0xf);
+    v += (uint32_t)SCV_DPP(0, v, 0x118, 0xf);
+    v += (uint32_t)SCV_DPP(0, v, 0x142, 0xa);
+    v += (uint32_t)SCV_DPP(0, v, 0x143, 0xc);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// 64-bit sum as three 32-bit lane sums of 22/21/21-bit limbs (each limb sum < 64 * 2^22 = 2^28): exact
+// for any int64 inputs modulo 2^64, no carries across lanes needed.
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    const unsigned long long u = (unsigned long long)v;
+    const unsigned long long s0 = wave_sum_u32((uint32_t)(u & 0x3fffffu));
+    const unsigned long long s1 = wave_sum_u32((uint32_t)((u >> 22) & 0x1fffffu));
+    const unsigned long long s2 = wave_sum_u32((uint32_t)((u >> 43) & 0x1fffffu));
+    return (long long)(s0 + (s1 << 22) + (s2 << 43));
 }
 
 template <int RL2>
@@ -583,6 +606,105 @@ __global__ __launch_bounds__(T) void scv_small_cells(const AggArgs a) {
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
 }
 
+// Register-resident variant for N <= 64*KV: every lane keeps its KV votes (and the counts it reads
+// back) in registers, so the cell is read from memory once and the LDS sees exactly N atomics, N reads
+// and N clears; the next cell's votes are prefetched while the current one is being counted.
+template <int T, int KV, bool TOK>
+__global__ __launch_bounds__(T) void scv_small_cells_reg(const AggArgs a) {
+    constexpr int NW = T / 64;
+    constexpr uint32_t kNone = 0xffffffffu;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t* h = smem + wid * kBins;
+    int32_t* ord = reinterpret_cast<int32_t*>(smem + NW * kBins);
+    for (int i = lane; i < kBins; i += 64) h[i] = 0;
+    const bool use_ord = build_budget_order(a, ord, tid, T);
+    __syncthreads();
+
+    uint32_t bad = 0;
+    const int64_t wave0 = (int64_t)blockIdx.x * NW + wid, nwaves = (int64_t)gridDim.x * NW;
+
+    auto load_cell = [&](int64_t ci, uint32_t (&bins)[KV], long long& tsum, int64_t& cell, int32_t& b, int64_t& p) {
+        item_to_cell(a, use_ord, ord, ci, p, b);
+        cell = p * a.B + b;
+        const int64_t n = valid_len(a, b);
+        const int32_t* row = a.answers + cell * a.N;
+        tsum = 0;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const int64_t i = lane + 64 * k;
+            bins[k] = kNone;
+            if (i < n) {
+                const uint32_t v = (uint32_t)row[i];
+                bad |= v;
+                bins[k] = v < 1023u ? v : 1023u;
+                if (TOK) tsum += a.tokens[cell * a.N + i];
+            }
+        }
+    };
+
+    uint32_t cur[KV], nxt[KV];
+    long long tsum = 0, ntsum = 0;
+    int64_t cell = 0, ncell = 0, p = 0, np_ = 0;
+    int32_t b = 0, nb = 0;
+    int64_t ci = wave0;
+    if (ci < a.ncells) load_cell(ci, cur, tsum, cell, b, p);
+    for (; ci < a.ncells; ci += nwaves) {
+        const bool more = ci + nwaves < a.ncells;
+        if (more) load_cell(ci + nwaves, nxt, ntsum, ncell, nb, np_);     // prefetch: in flight during the passes below
+#pragma unroll
+        for (int k = 0; k < KV; ++k) if (cur[k] != kNone) atomicAdd(&h[cur[k]], 1u);        // pass 1
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t c[KV], lmax = 0;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {                                                       // pass 2
+            c[k] = cur[k] != kNone ? h[cur[k]] : 0u;
+            lmax = c[k] > lmax ? c[k] : lmax;
+        }
+        const int32_t truth = a.truth[p];
+        const uint32_t tc = (truth >= 0 && truth < kBins) ? h[truth] : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < KV; ++k) if (cur[k] != kNone) h[cur[k]] = 0;                     // pass 4: sparse clear
+        const uint32_t maxc = wave_max_u32(lmax);
+        uint32_t votes_at_max = 0, mm = 1024u;
+#pragma unroll
+        for (int k = 0; k < KV; ++k)                                                         // pass 3, from registers
+            if (cur[k] != kNone && c[k] == maxc) { votes_at_max += 1; mm = cur[k] < mm ? cur[k] : mm; }
+        votes_at_max = wave_sum_u32(votes_at_max);
+        mm = wave_min_u32(mm);
+        long long tok = 0;
+        if (TOK) tok = wave_sum_i64(tsum);
+        if (lane == 0) {
+            const bool any = maxc > 0;
+            const uint32_t n_modes = any ? votes_at_max / maxc : 0u;
+            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;                               // o1.py:206
+            if (a.cells) {
+                uint4 rec;
+                rec.x = maxc;
+                rec.y = tc;
+                rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
+                rec.w = hit;
+                reinterpret_cast<uint4*>(a.cells)[cell] = rec;
+            }
+            if (a.cell_tokens) a.cell_tokens[cell] = tok;
+            if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
+            if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
+            if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < KV; ++k) cur[k] = nxt[k];
+            tsum = ntsum; cell = ncell; b = nb; p = np_;
+        }
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+}
+
 // ---- kernel 1f: tiny cells (N <= 32), several cells per wave, registers only --------------------
 //
 // The reference's own budgets are N = 1, 1, ..., 2, 4, 8 (o1.py:276; up to 128 with shade_regions).
@@ -592,36 +714,73 @@ __global__ __launch_bounds__(T) void scv_small_cells(const AggArgs a) {
 // len(multimode) = #{i : count_i == max_count} / max_count, min_mode = min v_i over those.
 // No histogram, no LDS memory, no barrier.  Cells are taken in natural (memory) order so a wave reads
 // and writes contiguous bytes; (p, b) advance incrementally (no per-cell division).
-template <int G>
-__device__ __forceinline__ uint32_t group_max_u32(uint32_t v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) { const uint32_t w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
-    return v;
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
+// lane i <- lane i ^ 16 inside each 32-lane half (LDS crossbar, no LDS memory): swizzle bit mode, and 0x1f, xor 0x10
+__device__ __forceinline__ uint32_t swap_rows(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); }
+
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kQuadXor3 = 0x1B;   // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
+constexpr int kHalfMirror = 0x141, kRowMirror = 0x140;                // lane i -> 7-i / 15-i inside its 8 / 16 lanes
+
+// all-reduce inside aligned groups of G lanes: xor-butterfly on DPP (quads, half rows, rows)
+#define SCV_GROUP_ALLREDUCE(NAME, OP)                                                              \
+    template <int G>                                                                               \
+    __device__ __forceinline__ uint32_t NAME(uint32_t v) {                                         \
+        uint32_t t;                                                                                \
+        t = dpp_mov<kQuadXor1>(v); v = OP(v, t);                                                   \
+        t = dpp_mov<kQuadXor2>(v); v = OP(v, t);                                                   \
+        t = dpp_mov<kHalfMirror>(v); v = OP(v, t);                                                 \
+        if (G >= 16) { t = dpp_mov<kRowMirror>(v); v = OP(v, t); }                                 \
+        if (G >= 32) { t = swap_rows(v); v = OP(v, t); }                                           \
+        return v;                                                                                  \
+    }
+#define SCV_OP_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define SCV_OP_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define SCV_OP_ADD(a, b) ((a) + (b))
+SCV_GROUP_ALLREDUCE(group_max_u32, SCV_OP_MAX)
+SCV_GROUP_ALLREDUCE(group_min_u32, SCV_OP_MIN)
+SCV_GROUP_ALLREDUCE(group_sum_u32, SCV_OP_ADD)
+
 template <int G>
-__device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) { const uint32_t w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
-    return v;
+__device__ __forceinline__ long long group_sum_i64(long long v) {    // limbs as in wave_sum_i64
+    const unsigned long long u = (unsigned long long)v;
+    const unsigned long long s0 = group_sum_u32<G>((uint32_t)(u & 0x3fffffu));
+    const unsigned long long s1 = group_sum_u32<G>((uint32_t)((u >> 22) & 0x1fffffu));
+    const unsigned long long s2 = group_sum_u32<G>((uint32_t)((u >> 43) & 0x1fffffu));
+    return (long long)(s0 + (s1 << 22) + (s2 << 43));
 }
-template <int G>
-__device__ __forceinline__ uint32_t group_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+
+// #{ other lanes of my row whose value equals mine }, rotating the row with row_ror:1..15
+template <int R>
+__device__ __forceinline__ uint32_t count_row_matches(uint32_t mine, uint32_t theirs) {
+    if constexpr (R == 0) return 0;
+    else return (dpp_mov<0x120 + R>(theirs) == mine ? 1u : 0u) + count_row_matches<R - 1>(mine, theirs);
 }
+
+// count_i = #{ j in my G-lane cell : bin_j == bin_i } (inactive lanes carry 0xffffffff and get 0)
 template <int G>
-__device__ __forceinline__ long long group_sum_i64(long long v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+__device__ __forceinline__ uint32_t count_equal_in_group(uint32_t bin, bool active) {
+    uint32_t cnt;
+    if constexpr (G == 8) {
+        const uint32_t m = dpp_mov<kHalfMirror>(bin);                       // i ^ 7
+        cnt = 1u + (dpp_mov<kQuadXor1>(bin) == bin) + (dpp_mov<kQuadXor2>(bin) == bin) + (dpp_mov<kQuadXor3>(bin) == bin)
+                 + (m == bin) + (dpp_mov<kQuadXor1>(m) == bin) + (dpp_mov<kQuadXor2>(m) == bin) + (dpp_mov<kQuadXor3>(m) == bin);
+    } else if constexpr (G == 16) {
+        cnt = 1u + count_row_matches<15>(bin, bin);
+    } else {
+        const uint32_t other = swap_rows(bin);                               // the cell's second 16-lane row
+        cnt = 1u + count_row_matches<15>(bin, bin) + (other == bin ? 1u : 0u) + count_row_matches<15>(bin, other);
+    }
+    return active ? cnt : 0u;
 }
 
 template <int G, bool TOK>
 __global__ __launch_bounds__(256) void scv_tiny_cells(const AggArgs a) {
     constexpr int CPW = 64 / G;                       // cells per wave
     const int lane = threadIdx.x & 63;
-    const int sub = lane / G, l = lane % G, base = lane - l;
+    const int sub = lane / G, l = lane % G;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int64_t cell = wave * CPW + sub;
@@ -643,12 +802,7 @@ __global__ __launch_bounds__(256) void scv_tiny_cells(const AggArgs a) {
             bin = v < 1023u ? v : 1023u;
             if (TOK) tok = a.tokens[cell * a.N + l];
         }
-        uint32_t cnt = active ? 1u : 0u;
-#pragma unroll
-        for (int r = 1; r < G; ++r) {
-            const uint32_t other = (uint32_t)__shfl((int)bin, base + ((l + r) & (G - 1)), 64);
-            cnt += (active && other == bin) ? 1u : 0u;
-        }
+        const uint32_t cnt = count_equal_in_group<G>(bin, active);
         const uint32_t maxc = group_max_u32<G>(cnt);
         const bool at_max = active && cnt == maxc;
         const uint32_t votes_at_max = group_sum_u32<G>(at_max ? 1u : 0u);

@@ -153,22 +153,23 @@ def _with_options(eng, opts):
                 eng.set_option(k, v)
         def __exit__(self_, *exc):
             for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
-                         ("small_n_max", 512), ("tiny_n_max", 32), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096)):
+                         ("small_n_max", 512), ("tiny_n_max", 32), ("small_reg", 1), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096)):
                 eng.set_option(k, v)
     return _Ctx()
 
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3])
-@pytest.mark.parametrize("shape", [(50, 3, 1), (40, 2, 2), (33, 4, 3), (70, 8, 64), (20, 3, 100), (9, 2, 257),
-                                   (5, 11, 2048), (3, 2, 5001), (2000, 2, 17)])
+@pytest.mark.parametrize("shape", [(50, 3, 1), (40, 2, 2), (33, 4, 3), (70, 8, 64), (20, 3, 100), (900, 2, 128), (9, 2, 257),
+                                   (300, 3, 512), (5, 11, 2048), (3, 2, 5001), (2000, 2, 17), (4000, 1, 33)])
 def test_small_n_wave_per_cell_path(hip_engine, dist, shape):
     P, B, N = shape
     a, t, tr = coracle.synth_fill(P, B, N, 300 + dist, dist, want_tokens=True)
     nv = np.array([max(0, N - 3 * b) if b % 2 else N >> (b // 2) for b in range(B)], dtype=np.int32)
-    with _with_options(hip_engine, {"path": 3}):
-        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
-        assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
-        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+    for opts in ({"path": 3}, {"path": 3, "small_reg": 0, "tiny_n_max": 0}, {"path": 3, "small_reg": 2, "tiny_n_max": 0}):
+        with _with_options(hip_engine, opts):
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
+            assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
 
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3])
