@@ -40,3 +40,21 @@ def all_gather_cells(cells_local, P: int, group=None):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([parts[r][: sizes[r]] for r in range(world)], dim=0)
+
+
+def aggregate_sharded(engine, answers_local, truth_local, num_problems: int, tokens_local=None, n_valid=None,
+                      group=None, want_cells=True):
+    """One sharded evaluation: this rank's contiguous block of problems goes through
+    ``engine.aggregate_device`` (any object with that method: the HIP engine in production), the packed
+    int64 counters are summed over the ranks with ONE all-reduce, and the reference's floats are taken
+    over the GLOBAL number of problems.  Returns an ``AggregateResult`` whose counters are global and
+    whose cell table is this rank's block."""
+    from .engine import AggregateResult, cells_from_torch
+    P_local, B = int(answers_local.shape[0]), int(answers_local.shape[1])
+    counters, cells, cell_tokens = engine.aggregate_device(
+        answers_local, truth_local, tokens=tokens_local, n_valid=n_valid, cells=None if want_cells else False)
+    all_reduce_counters(counters, group)
+    host_cells = cells_from_torch(cells) if cells is not None else None
+    host_ctok = cell_tokens.cpu().numpy() if cell_tokens is not None else None
+    return AggregateResult.from_counters(counters.cpu().numpy(), P_local, B, host_cells, host_ctok,
+                                         num_problems=num_problems)

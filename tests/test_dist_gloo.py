@@ -47,6 +47,51 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+class _CpuDeviceEngine:
+    """Test double with the engine's DEVICE-mode signature, computing on CPU tensors via the oracle."""
+
+    def aggregate_device(self, answers, truth, tokens=None, n_valid=None, counters=None, cells=None, cell_tokens=None):
+        out = coracle.aggregate(answers.numpy(), truth.numpy(), tokens=None if tokens is None else tokens.numpy(),
+                                n_valid=None if n_valid is None else n_valid.numpy())
+        cnt = torch.from_numpy(_pack(out).copy())
+        c = torch.from_numpy(out["cells"].view(np.uint8).reshape(answers.shape[0], answers.shape[1], 16).copy())
+        return cnt, (None if cells is False else c), (torch.from_numpy(out["cell_tokens"]) if tokens is not None else None)
+
+
+def _worker_api(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = scv_dist.shard_bounds(P, rank, world)
+        a, t, tr = coracle.synth_fill(hi - lo, B, N, SEED, 1, p_offset=lo, want_tokens=True)
+        res = scv_dist.aggregate_sharded(_CpuDeviceEngine(), torch.from_numpy(a), torch.from_numpy(tr), P,
+                                         tokens_local=torch.from_numpy(t))
+        assert res.cells.shape == (hi - lo, B)
+        if rank == 1:
+            q.put(([res.accuracy(b) for b in range(B)], [float(res.avg_tokens_used(b)) for b in range(B)]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_aggregate_sharded_api_three_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_api, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    acc, avg = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a, t, tr = coracle.synth_fill(P, B, N, SEED, 1, want_tokens=True)
+    whole = AggregateResult.from_counters(_pack(coracle.aggregate(a, tr, tokens=t)), P, B)
+    assert acc == [whole.accuracy(b) for b in range(B)]
+    assert avg == [float(whole.avg_tokens_used(b)) for b in range(B)]
+
+
 def test_two_rank_all_reduce_equals_unsharded():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
