@@ -82,7 +82,9 @@ int scv_destroy(scv_ctx* ctx);
 
 /* A new ctx launches on a private non-blocking stream.  scv_set_stream BORROWS the caller's
  * hipStream_t instead (e.g. torch.cuda.current_stream().cuda_stream); NULL is the device's default
- * stream -- which is what torch hands out until the user opens a stream of their own. */
+ * stream -- which is what torch hands out until the user opens a stream of their own.  Does not
+ * synchronise (legal while the new stream is being captured into a hipGraph): every DEVICE-mode
+ * entry point only enqueues work, so aggregation + bootstrap can be captured once and replayed. */
 int scv_set_stream(scv_ctx* ctx, void* hip_stream);
 /* Block until everything queued on the ctx stream has finished; reports SCV_ERR_DOMAIN if a
  * DEVICE-mode aggregation since the last sync saw an out-of-domain vote. */

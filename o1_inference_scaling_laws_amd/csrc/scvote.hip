@@ -504,8 +504,14 @@ int scv_destroy(scv_ctx* ctx) {
 int scv_set_stream(scv_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
     if (int rc = set_device(ctx)) return rc;
-    SCV_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->own_stream) { SCV_HIP(hipStreamDestroy(ctx->stream)); ctx->own_stream = false; }
+    // No synchronisation here (same contract as any set-stream call: ordering between the old and the
+    // new stream is the caller's): a sync would be illegal while the new stream is being captured
+    // into a hipGraph.  Only the ctx's own private stream is drained before it is destroyed.
+    if (ctx->own_stream) {
+        SCV_HIP(hipStreamSynchronize(ctx->stream));
+        SCV_HIP(hipStreamDestroy(ctx->stream));
+        ctx->own_stream = false;
+    }
     ctx->stream = (hipStream_t)hip_stream;  // borrowed; NULL is the device's default stream
     return SCV_OK;
 }

@@ -450,6 +450,63 @@ def test_device_mode_orders_with_torch_default_stream(hip_engine):
     hip_engine.sync()
 
 
+def test_maximum_cell_size_counts_do_not_overflow(hip_engine):
+    """One cell of N = 2^31 - 1 votes (the ABI's maximum): degenerate data puts every vote in one bin,
+    so max_count = truth_count = 2147483647 must survive the u32 counters, the 16 LDS copies and the
+    split-N partial histograms (1 cell -> 512 segments)."""
+    import torch
+    N = 2 ** 31 - 1
+    ans, _, tr, counters, cells, _ = _device_run(hip_engine, 1, 1, N, 12, 2)
+    c = cells_from_torch(cells)[0, 0]
+    assert (int(c["max_count"]), int(c["truth_count"]), int(c["n_modes"]), int(c["hit"])) == (N, N, 1, 1)
+    assert int(c["min_mode"]) == int(tr.cpu()[0])
+    with _with_options(hip_engine, {"path": 1}):                      # same cell, one workgroup, no split
+        _, cells1, _ = hip_engine.aggregate_device(ans, tr)
+        hip_engine.sync()
+    assert torch.equal(cells1, cells)
+    del ans
+    torch.cuda.empty_cache()
+
+
+def test_hot_path_is_hipgraph_capturable():
+    """memset + hot-path kernel(s) + bootstrap captured into ONE hipGraph and replayed on new data:
+    DEVICE-mode entry points only enqueue work (no sync, no allocation after warm-up)."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine
+    dev = torch.device("cuda:0")
+    with Engine(device=0) as eng:                       # no SCV_FLAG_TIMING: event records stay out of the graph
+        P, B, N = 64, 4, 1 << 14
+        ans = torch.empty((P, B, N), dtype=torch.int32, device=dev)
+        tr = torch.empty((P,), dtype=torch.int32, device=dev)
+        counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
+        cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
+        boot = torch.empty((16, B, 4), dtype=torch.int64, device=dev)
+        eng.synth_fill_device(ans, None, tr, P=P, B=B, N=N, seed=1, dist=3)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):                   # warm-up on the capture stream (sizes scratch, sets attributes)
+            counters.zero_()
+            eng.aggregate_device(ans, tr, counters=counters, cells=cells)
+            eng.bootstrap_device(cells, 0, 16, 7, 4, out=boot)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            counters.zero_()
+            eng.aggregate_device(ans, tr, counters=counters, cells=cells)
+            eng.bootstrap_device(cells, 0, 16, 7, 4, out=boot)
+        for seed in (2, 3):
+            eng.use_torch_stream()
+            eng.synth_fill_device(ans, None, tr, P=P, B=B, N=N, seed=seed, dist=3)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            a, _, trc = coracle.synth_fill(P, B, N, seed, 3)
+            want = oracle(a, trc)
+            got = AggregateResult.from_counters(counters.cpu().numpy(), P, B, cells_from_torch(cells))
+            assert_results_equal(got, want, check_tokens=False)
+            rc, wb = coracle.bootstrap(want.cells, 0, 16, 7, 4)
+            assert rc == 0 and np.array_equal(boot.cpu().numpy(), wb)
+
+
 def test_permutation_invariance(hip_engine):
     import torch
     ans, _, tr, counters, cells, _ = _device_run(hip_engine, 12, 4, 50000, 77, 3)
