@@ -123,6 +123,14 @@ int set_device(scv_ctx* ctx) {
     return SCV_OK;
 }
 
+// Per-cell device atomics land on ~B addresses and serialise at ~12 ns each: ncells/B * 12 ns in all.
+// The kernel itself needs ncells * 4N bytes / 7 TB/s.  Atomics are hidden when 4N*B >> 84 KB, so
+// only short cells in large numbers go through the separate reduction of the cell table.
+bool reduce_counters_separately(const scv_ctx* ctx, int64_t ncells, int32_t B, int64_t N) {
+    if (ctx->fused_counters_max == 0) return true;                       // forced (tests)
+    return ncells > ctx->fused_counters_max && N * (int64_t)B < 65536;
+}
+
 int ensure_cells(scv_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->d_cells_bytes) return SCV_OK;
     if (ctx->d_cells) { SCV_HIP(hipFree(ctx->d_cells)); ctx->d_cells = nullptr; ctx->d_cells_bytes = 0; }
@@ -167,7 +175,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     // per-budget counters: fused per-cell atomics for few cells, a separate reduction of the cell
     // table for many (same-address device atomics serialise at ~12 ns each)
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
-    const bool use_reduce = want_counters && ncells > ctx->fused_counters_max;
+    const bool use_reduce = want_counters && reduce_counters_separately(ctx, ncells, B, N);
     if (use_reduce) {
         a.tie_hits = nullptr; a.token_sum = nullptr; a.truth_sum = nullptr;
         if (!a.cells || (tok && tok_sum && !a.cell_tokens)) {
@@ -333,7 +341,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
-    const bool use_reduce = want_counters && ncells > ctx->fused_counters_max;
+    const bool use_reduce = want_counters && reduce_counters_separately(ctx, ncells, B, N);
     if (use_reduce) {
         a.tie_hits = nullptr; a.token_sum = nullptr; a.truth_sum = nullptr;
         if (!a.cells || (tok && tok_sum && !a.cell_tokens)) {
