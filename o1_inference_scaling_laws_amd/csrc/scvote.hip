@@ -84,7 +84,7 @@ int env_int(const char* name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
-bool valid_copies(int c) { return c == 8 || c == 16 || c == 32; }
+bool valid_copies(int c) { return c == 4 || c == 8 || c == 16 || c == 32; }
 bool valid_threads(int t) { return t == 256 || t == 512 || t == 1024; }
 bool valid_unroll(int u) { return u == 2 || u == 4 || u == 8; }
 
@@ -112,6 +112,7 @@ KernelFn pick_t(int t, int u, bool tok) {
 }
 KernelFn pick_kernel(int copies, int t, int u, bool tok) {
     switch (copies) {
+    case 4: return pick_t<2>(t, u, tok);
     case 8: return pick_t<3>(t, u, tok);
     case 32: return pick_t<5>(t, u, tok);
     default: return pick_t<4>(t, u, tok);
@@ -123,12 +124,13 @@ int set_device(scv_ctx* ctx) {
     return SCV_OK;
 }
 
-// Per-cell device atomics land on ~B addresses and serialise at ~12 ns each: ncells/B * 12 ns in all.
-// The kernel itself needs ncells * 4N bytes / 7 TB/s.  Atomics are hidden when 4N*B >> 84 KB, so
-// only short cells in large numbers go through the separate reduction of the cell table.
+// Per-cell device atomics land on ~B addresses and serialise at the memory side.  Measured
+// (profiles/r01_crossover_r4_d1.log): 65536 cells of 64 KiB with fused atomics run at 4.1 TB/s, with
+// the separate reduction at 6.6 TB/s -- the serialised tail is NOT hidden behind the stream.  Keep the
+// counters fused in the one launch only for few cells, or when a problem row is >= 4 MiB (the headline).
 bool reduce_counters_separately(const scv_ctx* ctx, int64_t ncells, int32_t B, int64_t N) {
     if (ctx->fused_counters_max == 0) return true;                       // forced (tests)
-    return ncells > ctx->fused_counters_max && N * (int64_t)B < 65536;
+    return ncells > ctx->fused_counters_max && N * (int64_t)B < (1 << 20);
 }
 
 int ensure_cells(scv_ctx* ctx, size_t bytes) {
@@ -262,7 +264,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     if (!ctx->user_tuned) {
         // measured crossover (tools/crossover.py): the per-cell fold costs 1024*R LDS words, so short
         // cells want small R and several cells in flight per CU; long cells want one big workgroup.
-        if (N < 32768) { copies = 8; threads = 256; wg_per_cu = 4; unroll = 4; }
+        if (N < 4096) { copies = 4; threads = 256; wg_per_cu = 6; unroll = 4; }     // latency-bound: most cells in flight
+        else if (N < 32768) { copies = 8; threads = 256; wg_per_cu = 4; unroll = 4; }
         else if (N < 262144) { copies = 16; threads = 512; wg_per_cu = 2; unroll = 4; }
         else { copies = 16; threads = 1024; wg_per_cu = 1; unroll = 4; }
         // fewer cells than CUs: one cell per CU whatever the band, so give each the widest workgroup
@@ -535,7 +538,7 @@ int scv_sync(scv_ctx* ctx) {
 
 int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unroll) {
     if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
-    if (copies > 0) { if (!valid_copies(copies)) return fail(SCV_ERR_ARG, "copies must be 8, 16 or 32"); ctx->copies = copies; }
+    if (copies > 0) { if (!valid_copies(copies)) return fail(SCV_ERR_ARG, "copies must be 4, 8, 16 or 32"); ctx->copies = copies; }
     if (threads > 0) { if (!valid_threads(threads)) return fail(SCV_ERR_ARG, "threads must be 256, 512 or 1024"); ctx->threads = threads; }
     if (wg_per_cu > 0) ctx->wg_per_cu = wg_per_cu;
     if (unroll > 0) { if (!valid_unroll(unroll)) return fail(SCV_ERR_ARG, "unroll must be 2, 4 or 8"); ctx->unroll = unroll; }

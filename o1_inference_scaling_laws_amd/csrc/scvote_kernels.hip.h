@@ -18,7 +18,8 @@
 //    32-lane groups over 32 banks; with this layout the bank is (bin*R + lane) % 32, so for R = 32
 //    every lane of a group owns its bank (conflict-free for ANY data, including all-equal votes);
 //    for R = 16 at most 2 lanes share a bank (free: the 4-cycle issue already covers 2 array
-//    cycles), R = 8 -> <= 4-way.  Throughput is therefore independent of the answer distribution:
+//    cycles), R = 8 -> <= 4-way, R = 4 -> <= 8-way (still above the HBM rate; used for short cells,
+//    where LDS footprint -> workgroups per CU -> cells in flight is what matters).  Throughput is therefore independent of the answer distribution:
 //    peaked / degenerate inputs (the realistic case: 40-70 % of votes on one bin) cost the same as
 //    uniform ones.  This is what a 64-wide wavefront + 160 KiB LDS buys; it is not a warp-shaped
 //    design.

@@ -109,10 +109,10 @@ def test_argument_errors(hip_engine):
     assert L.scv_aggregate_i32(ctx, None, None, None, None, 1, 1, 4, 0, None, None, None, None, None) == _lib.ERR_ARG
     assert b"truth" in L.scv_last_error()
     assert L.scv_aggregate_i32(ctx, None, None, None, None, -1, 1, 4, 0, None, None, None, None, None) == _lib.ERR_ARG
-    assert L.scv_set_tuning(ctx, 5, 0, 0, 0) == _lib.ERR_ARG
+    assert L.scv_set_tuning(ctx, 5, 0, 0, 0) == _lib.ERR_ARG and L.scv_set_tuning(ctx, 2, 0, 0, 0) == _lib.ERR_ARG
 
 
-@pytest.mark.parametrize("copies", [8, 16, 32])
+@pytest.mark.parametrize("copies", [4, 8, 16, 32])
 @pytest.mark.parametrize("threads", [256, 512, 1024])
 @pytest.mark.parametrize("unroll", [2, 4, 8])
 def test_every_kernel_variant_is_bit_exact(hip_engine, copies, threads, unroll):

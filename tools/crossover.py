@@ -15,10 +15,10 @@ def main():
     B = 4
     dist = int(os.environ.get("DIST", "1"))
     variants = [("small", {"path": 3}, None)]
-    for (c, t, w, u) in [(8, 256, 4, 4), (8, 256, 4, 2), (8, 512, 2, 4), (16, 512, 2, 4), (16, 1024, 1, 4), (32, 1024, 1, 4)]:
+    for (c, t, w, u) in [(4, 256, 8, 4), (4, 256, 8, 2), (4, 256, 6, 4), (8, 256, 4, 4), (8, 256, 4, 2), (8, 512, 2, 4), (16, 512, 2, 4), (16, 1024, 1, 4)]:
         variants.append((f"stream R{c} T{t} wg{w} U{u}", {"path": 1}, (c, t, w, u)))
     out = []
-    for N in [8, 16, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 524288]:
+    for N in [int(x) for x in os.environ.get("NS", "8,16,64,256,1024,2048,4096,8192,16384,32768,65536,131072,524288").split(",")]:
         P = max(1, total // (N * B))
         a = torch.empty((P, B, N), dtype=torch.int32, device=dev)
         tr = torch.empty((P,), dtype=torch.int32, device=dev)
