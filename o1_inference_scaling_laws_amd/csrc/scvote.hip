@@ -79,6 +79,23 @@ struct scv_ctx {
 
 namespace {
 
+constexpr size_t kMaxTimedLaunches = 8192;   // timing ring: undrained records beyond this are dropped
+
+// Next hipEvent pair of the timing ring (NULL without SCV_FLAG_TIMING).
+int next_event_pair(scv_ctx* ctx, EventPair** out) {
+    *out = nullptr;
+    if (!(ctx->flags & SCV_FLAG_TIMING)) return SCV_OK;
+    if (ctx->events_used >= kMaxTimedLaunches) ctx->events_used = 0;
+    if (ctx->events_used == ctx->events.size()) {
+        EventPair np;
+        SCV_HIP(hipEventCreate(&np.a));
+        SCV_HIP(hipEventCreate(&np.b));
+        ctx->events.push_back(np);
+    }
+    *out = &ctx->events[ctx->events_used++];
+    return SCV_OK;
+}
+
 int env_int(const char* name, int dflt) {
     const char* s = getenv(name);
     return (s && *s) ? atoi(s) : dflt;
@@ -151,10 +168,12 @@ int ensure_partial(scv_ctx* ctx, size_t bytes) {
 
 // Launch the hot path on device pointers.  Accumulates into the per-budget counters.
 //
-// Three regimes behind one entry point (auto-selected from the shape; "path" option forces one):
-//   small-N   N <= small_n_max            one wave per cell, sparse clear            (scv_small_cells)
-//   split-N   fewer cells than CUs, big N  several workgroups per cell + merge kernel  (scv_hist_argmax + scv_merge_partials)
+// Regimes behind one entry point (auto-selected from the shape; the "path" option forces one):
+//   tiny      N <= 32                      64/G cells per wave, registers only          (scv_tiny_cells)
+//   small-N   N <= small_n_max            one wave per cell, sparse clear              (scv_small_cells[_reg])
+//   split-N   cells <= CUs/2, big N        several workgroups per cell + merge kernel   (scv_hist_argmax + scv_merge_partials)
 //   stream    everything else              one persistent workgroup streams whole cells (scv_hist_argmax)
+// plus scv_reduce_cells behind any of them when the per-budget counters are not fused.
 int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
                      const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells,
                      int64_t* cell_tokens, int64_t* tie, int64_t* tok_sum, int64_t* truth_sum) {
@@ -209,15 +228,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     if (path == 0) path = (N <= ctx->small_n_max) ? 3 : 1;
 
     EventPair* ev = nullptr;
-    if (ctx->flags & SCV_FLAG_TIMING) {
-        if (ctx->events_used == ctx->events.size()) {
-            EventPair np;
-            SCV_HIP(hipEventCreate(&np.a));
-            SCV_HIP(hipEventCreate(&np.b));
-            ctx->events.push_back(np);
-        }
-        ev = &ctx->events[ctx->events_used++];
-    }
+    if (int rc = next_event_pair(ctx, &ev)) return rc;
 
     if (path == 3 && N <= ctx->tiny_n_max && N <= 32) {
         // ---- tiny cells: 64/G cells per wave, registers only
@@ -355,16 +366,8 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
         }
     }
     EventPair* ev = nullptr;
-    if (ctx->flags & SCV_FLAG_TIMING) {
-        if (ctx->events_used == ctx->events.size()) {
-            EventPair np;
-            SCV_HIP(hipEventCreate(&np.a));
-            SCV_HIP(hipEventCreate(&np.b));
-            ctx->events.push_back(np);
-        }
-        ev = &ctx->events[ctx->events_used++];
-        SCV_HIP(hipEventRecord(ev->a, ctx->stream));
-    }
+    if (int rc = next_event_pair(ctx, &ev)) return rc;
+    if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
     int path = ctx->path;
     if (path == 0 || path == 2) path = (N <= ctx->small_n_max) ? 3 : 1;
     if (path == 3) {

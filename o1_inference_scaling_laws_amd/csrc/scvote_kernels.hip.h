@@ -1,11 +1,16 @@
 // scvote_kernels.hip.h -- gfx950 (CDNA4 / MI355X) device code of the self-consistency engine.
 //
-// Kernel 1  scv_hist_argmax   THE hot path.  Replaces, per (problem, budget) cell,
-//           /root/reference/o1.py:181-195 (collect N votes, sum tokens), o1.py:202
-//           (statistics.multimode) and o1.py:204-213 (tie-aware score), and accumulates the integer
-//           part of the per-budget reduction o1.py:229-245.
-// Kernel 2  scv_bootstrap_k   problem-level bootstrap over the per-cell table.
-// Kernel 0  scv_synth_fill_k  closed-form synthetic generator (spec: include/scvote.h).
+// scv_hist_argmax     THE hot path: one persistent workgroup streams whole cells (or split-N segments).
+//                     Replaces, per (problem, budget) cell, /root/reference/o1.py:181-195 (collect N
+//                     votes, sum tokens), o1.py:202 (statistics.multimode) and o1.py:204-213 (tie-aware
+//                     score), and accumulates the integer part of the per-budget reduction o1.py:229-245.
+// scv_merge_partials  finishes cells that were split over several workgroups.
+// scv_small_cells[_reg], scv_tiny_cells   the same arithmetic for short cells (one wave per cell /
+//                     several cells per wave) -- the reference's own N = 1..128.
+// scv_prefix_hist, scv_small_prefix       budgets that are prefixes of one sample pool, one pass.
+// scv_reduce_cells    per-budget integer counters from the cell table when cells are short and many.
+// scv_bootstrap_k     problem-level bootstrap over the per-cell table.
+// scv_synth_fill_k    closed-form synthetic generator (spec: include/scvote.h).
 //
 // Design (DESIGN.md has the numbers):
 //  * Pure integer/indexing work, HBM-bound: 4 algorithmic bytes per vote, nothing written per vote.
