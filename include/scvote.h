@@ -106,7 +106,8 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  * uses the register-only several-cells-per-wave kernel inside the small path), "auto_geometry" (default 1),
  * "fused_counters_max" (cells at or below: per-cell atomics inside the hot kernel; above: a separate
  * reduction of the cell table), "pin_host" (default 0; 1: HOST-mode calls hipHostRegister caller buffers
- * of 32 MiB or more for the duration of the call -- measured no faster than pageable copies), "stagger_vecs", "plain_loads". */
+ * of 32 MiB or more for the duration of the call -- measured no faster than pageable copies), "prefetch"
+ * (default 1: cross-item prefetch in the streaming kernel), "stagger_vecs", "plain_loads". */
 int scv_set_option(scv_ctx* ctx, const char* key, int64_t value);
 
 /*

@@ -50,6 +50,7 @@ struct scv_ctx {
     int copies = 16, threads = 1024, wg_per_cu = 1, unroll = 4;
     int stagger_vecs = 0;    // rotate each workgroup's start inside its cell (16-byte vectors per workgroup index)
     int plain_loads = 0;
+    int prefetch = 1;        // streaming kernel: first tile of the next item is loaded before the current epilogue
     int path = 0;            // 0 auto | 1 streaming, whole cells | 2 streaming, split-N | 3 small-N (wave per cell)
     int segs_override = 0;   // > 0: segments per cell for path 2
     int sorted = 1;          // traverse budgets in descending n_valid order
@@ -189,6 +190,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.err_flag = ctx->d_err;
     a.stagger_vecs = ctx->stagger_vecs;
     a.plain_loads = ctx->plain_loads;
+    a.prefetch = ctx->prefetch;
     a.sorted = ctx->sorted;
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr;
     const bool tok = tokens != nullptr;
@@ -275,7 +277,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     if (!ctx->user_tuned) {
         // measured crossover (tools/crossover.py): the per-cell fold costs 1024*R LDS words, so short
         // cells want small R and several cells in flight per CU; long cells want one big workgroup.
-        if (N < 4096) { copies = 4; threads = 256; wg_per_cu = 6; unroll = 4; }     // latency-bound: most cells in flight
+        if (N < 4096) { copies = 4; threads = 256; wg_per_cu = 8; unroll = 2; }     // latency-bound: most cells in flight
         else if (N < 32768) { copies = 8; threads = 256; wg_per_cu = 4; unroll = 4; }
         else if (N < 262144) { copies = 16; threads = 512; wg_per_cu = 2; unroll = 4; }
         else { copies = 16; threads = 1024; wg_per_cu = 1; unroll = 4; }
@@ -351,7 +353,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
-    a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.sorted = 1;
+    a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.prefetch = 0; a.sorted = 1;
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
@@ -555,6 +557,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "balance")) ctx->balance = value != 0;
     else if (!strcmp(key, "stagger_vecs")) { if (value < 0 || value > (1 << 28)) return fail(SCV_ERR_ARG, "stagger out of range"); ctx->stagger_vecs = (int)value; }
     else if (!strcmp(key, "plain_loads")) ctx->plain_loads = value != 0;
+    else if (!strcmp(key, "prefetch")) ctx->prefetch = value != 0;
     else if (!strcmp(key, "path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "path must be 0..3"); ctx->path = (int)value; }
     else if (!strcmp(key, "segs")) { if (value < 0 || value > 4096) return fail(SCV_ERR_ARG, "segs out of range"); ctx->segs_override = (int)value; }
     else if (!strcmp(key, "sorted")) ctx->sorted = value != 0;

@@ -59,6 +59,7 @@ struct AggArgs {
     uint32_t* err_flag;
     int32_t stagger_vecs;   // > 0: workgroup w starts each cell rotated by (w * stagger_vecs) 16-byte vectors
     int32_t plain_loads;    // != 0: ordinary loads instead of non-temporal ones
+    int32_t prefetch;       // != 0: load the first tile of the next item before the current item's epilogue
     int64_t P;              // problems (for the budget-major traversal)
     int32_t sorted;         // != 0: traverse budgets in descending n_valid order
     int32_t segs;           // split-N: segments per cell (1 = whole cells)
@@ -363,6 +364,37 @@ __device__ __forceinline__ void fold_copies(uint32_t* hist, int tid, uint32_t (&
     }
 }
 
+// One work item of the streaming kernel, resolved to pointers: (cell, segment) -> votes [row, row + n).
+struct StreamItem {
+    const int32_t* row;
+    const int4* v4;       // first 16-byte aligned vector of the run
+    int64_t n, head, nvec, cell, p;
+    int32_t b;
+};
+
+__device__ __forceinline__ void describe_item(const AggArgs& a, bool use_ord, const int32_t* ord, int64_t item,
+                                              StreamItem& it, int64_t& lo) {
+    const int32_t S = a.segs;
+    const int64_t ci = S > 1 ? item / S : item;
+    const int32_t seg = S > 1 ? (int32_t)(item - ci * S) : 0;
+    item_to_cell(a, use_ord, ord, ci, it.p, it.b);
+    it.cell = it.p * a.B + it.b;
+    int64_t n = valid_len(a, it.b);
+    lo = 0;
+    if (S > 1) {                      // split-N: this workgroup owns votes [lo, lo + n) of the cell
+        lo = (int64_t)seg * a.seg_len;
+        int64_t hi = lo + a.seg_len;
+        hi = hi > n ? n : hi;
+        n = hi > lo ? hi - lo : 0;
+    }
+    it.n = n;
+    it.row = a.answers + it.cell * a.N + lo;
+    int64_t head = (int64_t)(((16u - (uint32_t)((uintptr_t)it.row & 15u)) & 15u) >> 2);
+    it.head = head > n ? n : head;
+    it.v4 = reinterpret_cast<const int4*>(it.row + it.head);
+    it.nvec = (n - it.head) >> 2;
+}
+
 // ---- kernel 1: streaming histogram / argmax (large N) -------------------------------------------
 // RL2 = log2(copies), T = threads per workgroup, U = 16-byte loads in flight per lane.
 template <int RL2, int T, int U, bool TOK>
@@ -390,25 +422,53 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
     const int32_t S = a.segs;
     const int64_t nitems = a.ncells * S;
     uint32_t bad = 0;
-    for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const int64_t ci = S > 1 ? item / S : item;
-        const int32_t seg = S > 1 ? (int32_t)(item - ci * S) : 0;
-        int64_t p; int32_t b;
-        item_to_cell(a, use_ord, ord, ci, p, b);
-        const int64_t cell = p * a.B + b;
-        int64_t n = valid_len(a, b);
-        int64_t lo = 0;
-        if (S > 1) {                      // split-N: this workgroup owns votes [lo, lo + n) of the cell
-            lo = (int64_t)seg * a.seg_len;
-            int64_t hi = lo + a.seg_len;
-            hi = hi > n ? n : hi;
-            n = hi > lo ? hi - lo : 0;
+    // Cross-item prefetch (votes-only variant): the first U*T vectors of the NEXT item are loaded into
+    // registers before the current item's epilogue (B1 / fold / reductions), so a short cell's load
+    // latency overlaps the previous cell's epilogue instead of following it.
+    const bool pf = !TOK && a.prefetch && a.stagger_vecs == 0 && !a.plain_loads;
+    int4 pre[U];
+    StreamItem cur;
+    int64_t cur_lo = 0;
+    if ((int64_t)blockIdx.x < nitems) {
+        describe_item(a, use_ord, ord, blockIdx.x, cur, cur_lo);
+        if (pf) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t idx = tid + (int64_t)u * T;
+                pre[u] = idx < cur.nvec ? stream_load(cur.v4 + idx) : make_int4(0, 0, 0, 0);
+            }
         }
-        const int32_t* row = a.answers + cell * a.N + lo;
-        const int32_t* trow = TOK ? a.tokens + cell * a.N + lo : nullptr;
+    }
+    for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int64_t cell = cur.cell, p = cur.p;
+        const int32_t b = cur.b;
         long long tsum = 0;
-
-        stream_row<RL2, T, U, TOK>(a, hist, copy, row, trow, n, tid, bad, tsum);   // o1.py:181-195
+        if (pf) {
+            // o1.py:181-195 with the first tile already in registers
+            if (tid < cur.head) vote<RL2>(hist, copy, (uint32_t)cur.row[tid], bad);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (tid + (int64_t)u * T < cur.nvec) vote4<RL2>(hist, copy, pre[u], bad);
+            if (cur.nvec > (int64_t)U * T) stream_votes<RL2, T, U, true>(hist, copy, cur.v4, (int64_t)U * T, cur.nvec, tid, bad);
+            const int64_t t0 = cur.head + (cur.nvec << 2);
+            if (tid < cur.n - t0) vote<RL2>(hist, copy, (uint32_t)cur.row[t0 + tid], bad);
+        } else {
+            const int32_t* trow = TOK ? a.tokens + cell * a.N + cur_lo : nullptr;
+            stream_row<RL2, T, U, TOK>(a, hist, copy, cur.row, trow, cur.n, tid, bad, tsum);   // o1.py:181-195
+        }
+        const bool more = item + gridDim.x < nitems;
+        StreamItem nxt = cur;
+        int64_t nxt_lo = 0;
+        if (more) {
+            describe_item(a, use_ord, ord, item + gridDim.x, nxt, nxt_lo);
+            if (pf) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t idx = tid + (int64_t)u * T;
+                    pre[u] = idx < nxt.nvec ? stream_load(nxt.v4 + idx) : make_int4(0, 0, 0, 0);
+                }
+            }
+        }
         if (tid == 0) red[48] = 0;
         __syncthreads();  // B1: all votes of this item are in LDS
 
@@ -438,6 +498,8 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
             // the next item's votes may start: the histogram was re-zeroed before B2, and `red` is
             // next written after the next B1, which thread 0 only reaches after finalize_cell.
         }
+        cur = nxt;
+        cur_lo = nxt_lo;
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
 }

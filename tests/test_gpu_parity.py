@@ -234,6 +234,20 @@ def test_split_n_path(hip_engine, segs, shape, dist):
         assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
 
 
+@pytest.mark.parametrize("prefetch", [0, 1])
+@pytest.mark.parametrize("shape", [(700, 3, 1000), (300, 2, 4099), (90, 5, 16385), (600, 1, 513), (40, 2, 70001)])
+def test_streaming_path_with_and_without_cross_item_prefetch(hip_engine, prefetch, shape):
+    P, B, N = shape
+    a, t, tr = coracle.synth_fill(P, B, N, 77 + N, 1, want_tokens=True)
+    nv = np.array([N if b % 2 == 0 else max(0, N // 3 - b) for b in range(B)], dtype=np.int32)
+    with _with_options(hip_engine, {"path": 1, "prefetch": prefetch}):
+        assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
+        assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+    with _with_options(hip_engine, {"path": 2, "segs": 5, "prefetch": prefetch}):
+        assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
+
+
 @pytest.mark.parametrize("sorted_", [0, 1])
 def test_streaming_path_sorted_and_natural_traversal(hip_engine, sorted_):
     a, t, tr = coracle.synth_fill(41, 11, 3000, 8, 1, want_tokens=True)
