@@ -78,6 +78,24 @@ def test_negative_tokens_and_int64_sums(hip_engine):
     assert got.token_sum[0] == got.cell_tokens.sum()
 
 
+def test_host_mode_streams_problem_chunks(hip_engine, monkeypatch):
+    """SCV_MEM_HOST stages problem-chunks through one HBM block (C3 is 335 GB: it never fits at once).
+    Force many small chunks and check cells, per-cell tokens and the accumulated counters."""
+    import ctypes
+    monkeypatch.setenv("SCV_STAGE_MB", "1")                    # 1 MiB of votes(+tokens) per chunk
+    a, t, tr = coracle.synth_fill(97, 3, 4099, 31, 3, want_tokens=True)     # 4.8 MB of votes -> ~10 chunks
+    nv = np.array([4099, 2048, 1], dtype=np.int32)
+    want = oracle(a, tr, tokens=t, n_valid=nv)
+    assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
+    pool, tpool = a[:, 0, :], t[:, 0, :]
+    assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool),
+                         OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool))
+    ns = ctypes.c_uint64()
+    assert hip_engine._L.scv_last_kernel_ns(hip_engine._ctx, ctypes.byref(ns)) == 0 and ns.value > 0
+    total, n = hip_engine.drain_kernel_ns()
+    assert n >= 10 and total > 0
+
+
 def test_empty_shapes(hip_engine):
     for shape in [(0, 3, 16), (4, 0, 16), (4, 2, 0)]:
         P, B, N = shape
