@@ -67,6 +67,34 @@ def main():
         out.append(r)
         print(f"{name:28s} {str(r['shape']):22s} tok={int(tok)}  {r['median_us']:10.1f} us  {r['GBps']:8.1f} GB/s  {r['votes_per_s']:.3e} votes/s", flush=True)
         torch.cuda.empty_cache()
+    # prefix budgets over one pool: one pass vs the dense expansion (reported separately: different bytes)
+    from o1_inference_scaling_laws_amd.engine import counters_size
+    import statistics as st
+    dev = torch.device("cuda:0")
+    for (P, N, nv) in [(2048, 1 << 20, [(1 << 20) >> (7 - b) for b in range(8)]), (2048, 1 << 20, [((b + 1) << 20) // 8 for b in range(8)])]:
+        pool = torch.empty((P, 1, N), dtype=torch.int32, device=dev)
+        tr = torch.empty((P,), dtype=torch.int32, device=dev)
+        eng.synth_fill_device(pool, None, tr, P=P, B=1, N=N, seed=4, dist=1)
+        nvt = torch.tensor(nv, dtype=torch.int32, device=dev)
+        counters = torch.zeros(counters_size(len(nv)), dtype=torch.int64, device=dev)
+        cells = torch.empty((P, len(nv), 16), dtype=torch.uint8, device=dev)
+        eng.sync(); eng.drain_kernel_ns()
+        ts = []
+        for r in range(6):
+            counters.zero_()
+            eng.aggregate_prefix_device(pool.view(P, N), tr, nvt, counters=counters, cells=cells)
+            eng.sync()
+            ns, n = eng.drain_kernel_ns()
+            if r:
+                ts.append(ns / n)
+        med = st.median(ts)
+        votes = P * sum(nv)
+        r = {"name": f"prefix one-pass n_valid={'pow2' if nv[-1] >= 2 * nv[-2] else 'linear'}", "shape": [P, len(nv), N], "median_us": med / 1e3,
+             "GBps": P * max(nv) * 4 / med, "votes_per_s": votes / (med * 1e-9), "dense_equivalent_GBps": votes * 4 / med}
+        out.append(r)
+        print(f"{r['name']:28s} {str(r['shape']):22s}        {r['median_us']:10.1f} us  {r['GBps']:8.1f} GB/s of pool bytes  {r['votes_per_s']:.3e} votes/s (dense-equivalent {r['dense_equivalent_GBps']:.0f} GB/s)", flush=True)
+        del pool
+        torch.cuda.empty_cache()
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(out, open("gpurun_out/regimes.json", "w"), indent=1)
 
