@@ -548,6 +548,30 @@ def test_permutation_invariance(hip_engine):
     assert torch.equal(cells, cells2) and torch.equal(counters, c2)
 
 
+@pytest.mark.parametrize("off_a,off_t", [(1, 1), (1, 2), (3, 0), (0, 3)])
+@pytest.mark.parametrize("shape", [(37, 3, 4099), (9, 2, 40000), (400, 2, 100), (500, 3, 7)])
+def test_device_pointers_not_16_byte_aligned(hip_engine, off_a, off_t, shape):
+    """Views into larger device buffers: vote and token bases misaligned (differently) w.r.t. 16 bytes."""
+    import torch
+    P, B, N = shape
+    a, t, tr = coracle.synth_fill(P, B, N, 17, 1, want_tokens=True)
+    dev = torch.device("cuda:0")
+    flat_a = torch.zeros(P * B * N + 8, dtype=torch.int32, device=dev)
+    flat_t = torch.zeros(P * B * N + 8, dtype=torch.int32, device=dev)
+    va = flat_a[off_a: off_a + P * B * N].view(P, B, N)
+    vt = flat_t[off_t: off_t + P * B * N].view(P, B, N)
+    va.copy_(torch.from_numpy(a))
+    vt.copy_(torch.from_numpy(t))
+    assert va.data_ptr() % 16 == (4 * off_a) % 16 and va.is_contiguous()
+    want = oracle(a, tr, tokens=t)
+    for path in (0, 1, 3):
+        with _with_options(hip_engine, {"path": path}):
+            counters, cells, ctok = hip_engine.aggregate_device(va, torch.from_numpy(tr).to(dev), tokens=vt)
+            hip_engine.sync()
+            got = AggregateResult.from_counters(counters.cpu().numpy(), P, B, cells_from_torch(cells), ctok.cpu().numpy())
+            assert_results_equal(got, want)
+
+
 def test_device_mode_domain_error_surfaces_at_sync(hip_engine):
     import torch
     ans = torch.full((2, 1, 64), 5, dtype=torch.int32, device="cuda:0")
