@@ -58,3 +58,40 @@ def aggregate_sharded(engine, answers_local, truth_local, num_problems: int, tok
     host_ctok = cell_tokens.cpu().numpy() if cell_tokens is not None else None
     return AggregateResult.from_counters(counters.cpu().numpy(), P_local, B, host_cells, host_ctok,
                                          num_problems=num_problems)
+
+
+class CounterPipeline:
+    """Rotating packed-counter buffers so the (latency-bound, 65.7 KB) all-reduce of evaluation i runs on
+    RCCL's own stream while the kernel of evaluation i+1 streams its chunk: ``acquire(i)`` waits for the
+    buffer's previous all-reduce and zeroes it, ``publish(i)`` starts the asynchronous all-reduce,
+    ``drain()`` waits for everything outstanding.  With one rank it degenerates to plain buffers."""
+
+    def __init__(self, buffers, group=None):
+        self.buffers = list(buffers)
+        self.pending = [None] * len(self.buffers)
+        self.group = group
+
+    def _distributed(self):
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def acquire(self, i: int):
+        k = i % len(self.buffers)
+        if self.pending[k] is not None:
+            self.pending[k].wait()
+            self.pending[k] = None
+        self.buffers[k].zero_()
+        return self.buffers[k]
+
+    def publish(self, i: int):
+        import torch.distributed as dist
+        k = i % len(self.buffers)
+        if self._distributed():
+            self.pending[k] = dist.all_reduce(self.buffers[k], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return self.buffers[k]
+
+    def drain(self):
+        for k, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[k] = None

@@ -92,6 +92,51 @@ def test_aggregate_sharded_api_three_ranks():
     assert avg == [float(whole.avg_tokens_used(b)) for b in range(B)]
 
 
+def _worker_pipeline(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pipe = scv_dist.CounterPipeline([torch.zeros(counters_size(B), dtype=torch.int64) for _ in range(2)])
+        results = []
+        for i in range(5):                                    # 5 evaluations over 2 rotating buffers
+            buf = pipe.acquire(i)
+            lo, hi = scv_dist.shard_bounds(P, rank, world)
+            a, t, tr = coracle.synth_fill(hi - lo, B, N, SEED + i, 1, p_offset=lo, want_tokens=True)
+            buf += torch.from_numpy(_pack(coracle.aggregate(a, tr, tokens=t)))
+            pipe.publish(i)
+            if i >= 1:                                        # read evaluation i-1 only after its reduce finished
+                pipe.pending[(i - 1) % 2] and pipe.pending[(i - 1) % 2].wait()
+                results.append(pipe.buffers[(i - 1) % 2].clone())
+        pipe.drain()
+        results.append(pipe.buffers[4 % 2].clone())
+        if rank == 0:
+            q.put([r.numpy() for r in results])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_counter_pipeline_overlapped_all_reduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipeline, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(results) == 5
+    for i, got in enumerate(results):
+        a, t, tr = coracle.synth_fill(P, B, N, SEED + i, 1, want_tokens=True)
+        assert np.array_equal(got, _pack(coracle.aggregate(a, tr, tokens=t))), i
+    single = scv_dist.CounterPipeline([torch.zeros(4, dtype=torch.int64)])
+    single.acquire(0).add_(3)
+    assert single.publish(0).tolist() == [3, 3, 3, 3] and single.acquire(1).tolist() == [0, 0, 0, 0]
+
+
 def test_two_rank_all_reduce_equals_unsharded():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
