@@ -27,6 +27,8 @@ def test_header_declares_the_boundary():
 
 
 def test_library_is_built_in_tree_and_exports_every_declared_symbol():
+    if not os.path.exists(_build.LIB_PATH):            # fresh checkout: the .so is git-ignored; hipcc cross-compiles gfx950 here
+        _build.build()
     assert os.path.exists(_build.LIB_PATH), "run __graft_entry__.build() first"
     assert os.path.commonpath([REPO, _build.LIB_PATH]) == REPO
     L = ctypes.CDLL(_build.LIB_PATH)
