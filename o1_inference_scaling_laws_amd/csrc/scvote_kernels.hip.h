@@ -846,58 +846,75 @@ __device__ __forceinline__ uint32_t count_equal_in_group(uint32_t bin, bool acti
 
 template <int G, bool TOK>
 __global__ __launch_bounds__(256) void scv_tiny_cells(const AggArgs a) {
-    constexpr int CPW = 64 / G;                       // cells per wave
+    constexpr int CPW = 64 / G;                       // cells per wave per slice
+    constexpr int K = 4;                              // independent slices in flight per wave: a wave's single
+                                                      // 256-byte load cannot cover HBM latency (Little's law)
     const int lane = threadIdx.x & 63;
     const int sub = lane / G, l = lane % G;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t step = nwaves * CPW;                // cells between consecutive slices of this wave
     int64_t cell = wave * CPW + sub;
     int64_t p = cell / a.B;
     int32_t b = (int32_t)(cell - p * a.B);
-    const int64_t step = nwaves * CPW;
     const int64_t dp = step / a.B;
     const int32_t db = (int32_t)(step - dp * a.B);
     uint32_t bad = 0;
-    for (; cell - sub < a.ncells; cell += step) {      // wave-uniform trip count (shuffles need all lanes)
-        const bool live = cell < a.ncells;
-        const int64_t n = live ? valid_len(a, b) : 0;
-        const bool active = l < n;
-        uint32_t bin = 0xffffffffu;                    // inactive lanes never match anything
-        long long tok = 0;
-        if (active) {
-            const uint32_t v = (uint32_t)a.answers[cell * a.N + l];
-            bad |= v;
-            bin = v < 1023u ? v : 1023u;
-            if (TOK) tok = a.tokens[cell * a.N + l];
-        }
-        const uint32_t cnt = count_equal_in_group<G>(bin, active);
-        const uint32_t maxc = group_max_u32<G>(cnt);
-        const bool at_max = active && cnt == maxc;
-        const uint32_t votes_at_max = group_sum_u32<G>(at_max ? 1u : 0u);
-        const uint32_t mm = group_min_u32<G>(at_max ? bin : 1024u);
-        const int32_t truth = live ? a.truth[p] : -1;
-        const uint32_t tc = group_sum_u32<G>((active && (int32_t)bin == truth) ? 1u : 0u);
-        if (TOK) tok = group_sum_i64<G>(tok);
-        if (l == 0 && live) {
-            const bool any = maxc > 0;
-            const uint32_t n_modes = any ? votes_at_max / maxc : 0u;
-            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;               // o1.py:206
-            if (a.cells) {
-                uint4 rec;
-                rec.x = maxc;
-                rec.y = tc;
-                rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
-                rec.w = hit;
-                reinterpret_cast<uint4*>(a.cells)[cell] = rec;
+    for (; cell - sub < a.ncells; ) {                  // wave-uniform trip count (DPP needs all lanes)
+        // ---- issue the loads of K slices first -------------------------------------------------
+        int64_t cells_k[K], p_k[K];
+        int32_t b_k[K], truth_k[K];
+        uint32_t bin_k[K];
+        long long tok_k[K];
+        bool active_k[K], live_k[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            cells_k[k] = cell; p_k[k] = p; b_k[k] = b;
+            live_k[k] = cell < a.ncells;
+            const int64_t n = live_k[k] ? valid_len(a, b) : 0;
+            active_k[k] = l < n;
+            bin_k[k] = 0xffffffffu;                    // inactive lanes never match anything
+            tok_k[k] = 0;
+            truth_k[k] = live_k[k] ? a.truth[p] : -1;
+            if (active_k[k]) {
+                bin_k[k] = (uint32_t)a.answers[cell * a.N + l];
+                if (TOK) tok_k[k] = a.tokens[cell * a.N + l];
             }
-            if (a.cell_tokens) a.cell_tokens[cell] = tok;
-            if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
-            if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
-            if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
+            cell += step; p += dp; b += db;
+            if (b >= a.B) { b -= a.B; p += 1; }
         }
-        p += dp;
-        b += db;
-        if (b >= a.B) { b -= a.B; p += 1; }
+        // ---- then count, slice by slice (registers only) ---------------------------------------
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool active = active_k[k];
+            uint32_t bin = bin_k[k];
+            if (active) { bad |= bin; bin = bin < 1023u ? bin : 1023u; }
+            const uint32_t cnt = count_equal_in_group<G>(bin, active);
+            const uint32_t maxc = group_max_u32<G>(cnt);
+            const bool at_max = active && cnt == maxc;
+            const uint32_t votes_at_max = group_sum_u32<G>(at_max ? 1u : 0u);
+            const uint32_t mm = group_min_u32<G>(at_max ? bin : 1024u);
+            const uint32_t tc = group_sum_u32<G>((active && (int32_t)bin == truth_k[k]) ? 1u : 0u);
+            long long tok = 0;
+            if (TOK) tok = group_sum_i64<G>(tok_k[k]);
+            if (l == 0 && live_k[k]) {
+                const bool any = maxc > 0;
+                const uint32_t n_modes = any ? votes_at_max / maxc : 0u;
+                const uint32_t hit = (any && tc == maxc) ? 1u : 0u;               // o1.py:206
+                if (a.cells) {
+                    uint4 rec;
+                    rec.x = maxc;
+                    rec.y = tc;
+                    rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
+                    rec.w = hit;
+                    reinterpret_cast<uint4*>(a.cells)[cells_k[k]] = rec;
+                }
+                if (a.cell_tokens) a.cell_tokens[cells_k[k]] = tok;
+                if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b_k[k] * SCV_TIE_CLASSES + n_modes], 1ull);
+                if (TOK && a.token_sum) atomicAdd(&a.token_sum[b_k[k]], (unsigned long long)tok);
+                if (a.truth_sum) atomicAdd(&a.truth_sum[b_k[k]], (unsigned long long)tc);
+            }
+        }
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
 }
