@@ -217,8 +217,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             auto* th = reinterpret_cast<unsigned long long*>(tie);
             auto* ts = reinterpret_cast<unsigned long long*>(tok_sum);
             auto* tc = reinterpret_cast<unsigned long long*>(truth_sum);
-            if (tok) hipLaunchKernelGGL((scv::scv_reduce_cells<true>), dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
-            else hipLaunchKernelGGL((scv::scv_reduce_cells<false>), dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
+            if (tok) hipLaunchKernelGGL((scv::scv_reduce_cells<true>), dim3((unsigned)chunks, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
+            else hipLaunchKernelGGL((scv::scv_reduce_cells<false>), dim3((unsigned)chunks, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
             SCV_HIP(hipGetLastError());
         }
         if (ev_) SCV_HIP(hipEventRecord(ev_->b, ctx->stream));
@@ -405,8 +405,8 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
         auto* th = reinterpret_cast<unsigned long long*>(tie);
         auto* ts = reinterpret_cast<unsigned long long*>(tok_sum);
         auto* tc = reinterpret_cast<unsigned long long*>(truth_sum);
-        if (tok) hipLaunchKernelGGL((scv::scv_reduce_cells<true>), dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
-        else hipLaunchKernelGGL((scv::scv_reduce_cells<false>), dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
+        if (tok) hipLaunchKernelGGL((scv::scv_reduce_cells<true>), dim3((unsigned)chunks, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
+        else hipLaunchKernelGGL((scv::scv_reduce_cells<false>), dim3((unsigned)chunks, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
         SCV_HIP(hipGetLastError());
     }
     if (ev) SCV_HIP(hipEventRecord(ev->b, ctx->stream));

@@ -555,35 +555,37 @@ __global__ __launch_bounds__(256) void scv_reduce_cells(const scv_cell* cells, c
     __shared__ uint32_t tie[SCV_TIE_CLASSES];
     __shared__ unsigned long long acc[2];
     const int tid = threadIdx.x;
-    const int32_t b = blockIdx.y;
-    for (int i = tid; i < SCV_TIE_CLASSES; i += 256) tie[i] = 0;
-    if (tid < 2) acc[tid] = 0;
-    __syncthreads();
     const int64_t per = (P + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per;
     const int64_t p1 = p0 + per < P ? p0 + per : P;
     const uint4* c4 = reinterpret_cast<const uint4*>(cells);
-    unsigned long long tcs = 0;
-    long long tks = 0;
-    for (int64_t p = p0 + tid; p < p1; p += 256) {
-        const uint4 c = c4[p * B + b];
-        if (c.w & 0xffu) atomicAdd(&tie[c.z & 0xffffu], 1u);
-        tcs += c.y;
-        if (TOK) tks += cell_tokens[p * B + b];
-    }
-    tcs = (unsigned long long)wave_sum_i64((long long)tcs);
-    if (TOK) tks = wave_sum_i64(tks);
-    if ((tid & 63) == 0) {
-        atomicAdd(&acc[0], tcs);
-        if (TOK) atomicAdd(&acc[1], (unsigned long long)tks);
-    }
-    __syncthreads();
-    if (tie_hits)
-        for (int i = tid; i < SCV_TIE_CLASSES; i += 256)
-            if (tie[i]) atomicAdd(&tie_hits[(int64_t)b * SCV_TIE_CLASSES + i], (unsigned long long)tie[i]);
-    if (tid == 0) {
-        if (truth_sum && acc[0]) atomicAdd(&truth_sum[b], acc[0]);
-        if (TOK && token_sum && acc[1]) atomicAdd(&token_sum[b], acc[1]);
+    for (int32_t b = blockIdx.y; b < B; b += gridDim.y) {          // gridDim.y is capped at 65535
+        for (int i = tid; i < SCV_TIE_CLASSES; i += 256) tie[i] = 0;
+        if (tid < 2) acc[tid] = 0;
+        __syncthreads();
+        unsigned long long tcs = 0;
+        long long tks = 0;
+        for (int64_t p = p0 + tid; p < p1; p += 256) {
+            const uint4 c = c4[p * B + b];
+            if (c.w & 0xffu) atomicAdd(&tie[c.z & 0xffffu], 1u);
+            tcs += c.y;
+            if (TOK) tks += cell_tokens[p * B + b];
+        }
+        tcs = (unsigned long long)wave_sum_i64((long long)tcs);
+        if (TOK) tks = wave_sum_i64(tks);
+        if ((tid & 63) == 0) {
+            atomicAdd(&acc[0], tcs);
+            if (TOK) atomicAdd(&acc[1], (unsigned long long)tks);
+        }
+        __syncthreads();
+        if (tie_hits)
+            for (int i = tid; i < SCV_TIE_CLASSES; i += 256)
+                if (tie[i]) atomicAdd(&tie_hits[(int64_t)b * SCV_TIE_CLASSES + i], (unsigned long long)tie[i]);
+        if (tid == 0) {
+            if (truth_sum && acc[0]) atomicAdd(&truth_sum[b], acc[0]);
+            if (TOK && token_sum && acc[1]) atomicAdd(&token_sum[b], acc[1]);
+        }
+        __syncthreads();                                            // before the next budget re-zeroes tie / acc
     }
 }
 

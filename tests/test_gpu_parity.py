@@ -301,6 +301,17 @@ def test_counters_fused_and_reduced_agree(hip_engine, fused_max, path):
         assert np.array_equal(got.truth_count_sum, want.truth_count_sum)
 
 
+def test_many_budgets_beyond_grid_y_limit(hip_engine):
+    """B = 70000 budgets (> 65535 = gridDim.y limit of the counter reduction; > 512 = sorted traversal off)."""
+    rng = np.random.default_rng(3)
+    P, B, N = 2, 70000, 3
+    a = rng.integers(0, 5, size=(P, B, N), dtype=np.int32)
+    tr = np.array([1, 4], dtype=np.int32)
+    nv = rng.integers(0, N + 1, size=(B,), dtype=np.int32)
+    want = oracle(a, tr, n_valid=nv)
+    assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), want, check_tokens=False)
+
+
 def test_auto_dispatch_covers_all_regimes(hip_engine):
     """auto: N <= 512 -> wave-per-cell; few big cells -> split-N; otherwise whole-cell streaming
     with the geometry picked from N (three bands)."""
