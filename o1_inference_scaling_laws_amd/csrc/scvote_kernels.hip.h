@@ -197,6 +197,25 @@ __device__ __forceinline__ void item_to_cell(const AggArgs& a, bool use_ord, con
     }
 }
 
+// Walks the traversal index ci -> (p, b) for a fixed stride without a 64-bit division per cell
+// (item_to_cell costs ~130 instructions): one division at construction, then add-and-carry.
+struct CellWalker {
+    int64_t major, minor;     // natural: (p, b) = (major, minor), minor < B;  sorted: (bi, p) = (major, minor), minor < P
+    int64_t dmajor, dminor, modulus;
+    __device__ __forceinline__ CellWalker(const AggArgs& a, bool use_ord, int64_t ci0, int64_t stride) {
+        modulus = use_ord ? a.P : (int64_t)a.B;
+        major = ci0 / modulus; minor = ci0 - major * modulus;
+        dmajor = stride / modulus; dminor = stride - dmajor * modulus;
+    }
+    __device__ __forceinline__ void advance() {
+        major += dmajor; minor += dminor;
+        if (minor >= modulus) { minor -= modulus; major += 1; }
+    }
+    __device__ __forceinline__ void get(bool use_ord, const int32_t* ord, int64_t& p, int32_t& b) const {
+        if (use_ord) { p = minor; b = ord[major]; } else { p = major; b = (int32_t)minor; }
+    }
+};
+
 // ---- cell epilogue shared by the streaming kernel and the split-N merge kernel ------------------
 //
 // statistics.multimode (statistics.py:599-601) + o1.py:204-213 on per-thread bin counts cnt[k]
@@ -589,6 +608,13 @@ __global__ __launch_bounds__(256) void scv_reduce_cells(const scv_cell* cells, c
     }
 }
 
+// votes_at_max is an exact multiple of maxc (every modal value is voted maxc times) and the quotient is
+// <= 1024, so a float reciprocal multiply rounded to nearest is exact -- ~4 instructions instead of the
+// ~25 of an emulated 32-bit integer division (these kernels are instruction-issue bound).
+__device__ __forceinline__ uint32_t exact_quotient(uint32_t votes_at_max, uint32_t maxc) {
+    return (uint32_t)((float)votes_at_max * __builtin_amdgcn_rcpf((float)maxc) + 0.5f);
+}
+
 // ---- kernel 1c: small-N cells, one wave per cell, sparse clear ------------------------------------
 //
 // For N up to a few thousand the 64 KiB fold-and-zero of kernel 1 dominates.  Here every wave owns a
@@ -613,9 +639,11 @@ __global__ __launch_bounds__(T) void scv_small_cells(const AggArgs a) {
 
     uint32_t bad = 0;
     const int64_t wave0 = (int64_t)blockIdx.x * NW + wid, nwaves = (int64_t)gridDim.x * NW;
+    CellWalker walk(a, use_ord, wave0, nwaves);
     for (int64_t ci = wave0; ci < a.ncells; ci += nwaves) {
         int64_t p; int32_t b;
-        item_to_cell(a, use_ord, ord, ci, p, b);
+        walk.get(use_ord, ord, p, b);
+        walk.advance();
         const int64_t cell = p * a.B + b;
         const int64_t n = valid_len(a, b);
         const int32_t* row = a.answers + cell * a.N;
@@ -627,8 +655,7 @@ __global__ __launch_bounds__(T) void scv_small_cells(const AggArgs a) {
             atomicAdd(&h[v < 1023u ? v : 1023u], 1u);
             if (TOK) tsum += a.tokens[cell * a.N + i];
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order: only pin the compiler's order
         uint32_t lmax = 0;
         for (int64_t i = lane; i < n; i += 64) {                  // pass 2
             const uint32_t v = (uint32_t)row[i];
@@ -645,19 +672,17 @@ __global__ __launch_bounds__(T) void scv_small_cells(const AggArgs a) {
         votes_at_max = wave_sum_u32(votes_at_max);
         mm = wave_min_u32(mm);
         const uint32_t tc = (truth >= 0 && truth < kBins) ? h[truth] : 0u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order: only pin the compiler's order
         for (int64_t i = lane; i < n; i += 64) {                  // pass 4: sparse clear
             const uint32_t v = (uint32_t)row[i];
             h[v < 1023u ? v : 1023u] = 0;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order: only pin the compiler's order
         long long tok = 0;
         if (TOK) tok = wave_sum_i64(tsum);
         if (lane == 0) {
             const bool any = maxc > 0;
-            const uint32_t n_modes = any ? votes_at_max / maxc : 0u;
+            const uint32_t n_modes = any ? exact_quotient(votes_at_max, maxc) : 0u;
             const uint32_t hit = (any && tc == maxc) ? 1u : 0u;         // o1.py:206
             if (a.cells) {
                 uint4 rec;
@@ -678,11 +703,10 @@ __global__ __launch_bounds__(T) void scv_small_cells(const AggArgs a) {
 
 // Register-resident variant for N <= 64*KV: every lane keeps its KV votes (and the counts it reads
 // back) in registers, so the cell is read from memory once and the LDS sees exactly N atomics, N reads
-// and N clears; the next cell's votes are prefetched while the current one is being counted.
+// and N clears; K cells are loaded per batch so enough bytes are in flight to cover memory latency.
 template <int T, int KV, bool TOK>
 __global__ __launch_bounds__(T) void scv_small_cells_reg(const AggArgs a) {
     constexpr int NW = T / 64;
-    constexpr uint32_t kNone = 0xffffffffu;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     uint32_t* h = smem + wid * kBins;
@@ -691,85 +715,107 @@ __global__ __launch_bounds__(T) void scv_small_cells_reg(const AggArgs a) {
     const bool use_ord = build_budget_order(a, ord, tid, T);
     __syncthreads();
 
+    struct Cell {                 // everything the passes need, loaded (not yet used) by the prefetch
+        uint32_t raw[KV];         // this lane's votes, unclamped
+        int32_t tokv[KV];
+        uint32_t mask;            // bit k: vote k exists (lane + 64k < n)
+        int32_t truth, b;
+        int64_t cell;
+    };
     uint32_t bad = 0;
     const int64_t wave0 = (int64_t)blockIdx.x * NW + wid, nwaves = (int64_t)gridDim.x * NW;
+    CellWalker walk(a, use_ord, wave0, nwaves);
 
-    auto load_cell = [&](int64_t ci, uint32_t (&bins)[KV], long long& tsum, int64_t& cell, int32_t& b, int64_t& p) {
-        item_to_cell(a, use_ord, ord, ci, p, b);
-        cell = p * a.B + b;
-        const int64_t n = valid_len(a, b);
-        const int32_t* row = a.answers + cell * a.N;
-        tsum = 0;
+    auto prefetch = [&](Cell& c) {          // issues loads only: nothing here waits on memory
+        int64_t p;
+        walk.get(use_ord, ord, p, c.b);
+        walk.advance();
+        c.cell = p * a.B + c.b;
+        const int64_t n = valid_len(a, c.b);
+        const int32_t* row = a.answers + c.cell * a.N;
+        c.truth = a.truth[p];
+        c.mask = 0;
 #pragma unroll
         for (int k = 0; k < KV; ++k) {
             const int64_t i = lane + 64 * k;
-            bins[k] = kNone;
+            c.raw[k] = 0; c.tokv[k] = 0;
             if (i < n) {
-                const uint32_t v = (uint32_t)row[i];
-                bad |= v;
-                bins[k] = v < 1023u ? v : 1023u;
-                if (TOK) tsum += a.tokens[cell * a.N + i];
+                c.mask |= 1u << k;
+                c.raw[k] = (uint32_t)row[i];
+                if (TOK) c.tokv[k] = a.tokens[c.cell * a.N + i];
             }
         }
     };
 
-    uint32_t cur[KV], nxt[KV];
-    long long tsum = 0, ntsum = 0;
-    int64_t cell = 0, ncell = 0, p = 0, np_ = 0;
-    int32_t b = 0, nb = 0;
-    int64_t ci = wave0;
-    if (ci < a.ncells) load_cell(ci, cur, tsum, cell, b, p);
-    for (; ci < a.ncells; ci += nwaves) {
-        const bool more = ci + nwaves < a.ncells;
-        if (more) load_cell(ci + nwaves, nxt, ntsum, ncell, nb, np_);     // prefetch: in flight during the passes below
+    // K cells per batch: a wave's single cell (<= 512 B) in flight cannot cover HBM latency (32 waves x
+    // 256 B = 8 KB per CU ~ 1 TB/s by Little's law); K cells are loaded back to back, then counted one
+    // after the other through the same wave-private histogram.
+    constexpr int K = KV <= 2 ? 4 : 2;
+    Cell batch[K];
+    for (int64_t ci = wave0; ci < a.ncells; ci += nwaves * K) {
 #pragma unroll
-        for (int k = 0; k < KV; ++k) if (cur[k] != kNone) atomicAdd(&h[cur[k]], 1u);        // pass 1
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        uint32_t c[KV], lmax = 0;
+        for (int j = 0; j < K; ++j)
+            if (ci + j * nwaves < a.ncells) prefetch(batch[j]);
 #pragma unroll
-        for (int k = 0; k < KV; ++k) {                                                       // pass 2
-            c[k] = cur[k] != kNone ? h[cur[k]] : 0u;
-            lmax = c[k] > lmax ? c[k] : lmax;
-        }
-        const int32_t truth = a.truth[p];
-        const uint32_t tc = (truth >= 0 && truth < kBins) ? h[truth] : 0u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < K; ++j) {
+            if (ci + j * nwaves >= a.ncells) break;
+            const Cell& cur = batch[j];
+            uint32_t bin[KV];
+            long long tsum = 0;
 #pragma unroll
-        for (int k = 0; k < KV; ++k) if (cur[k] != kNone) h[cur[k]] = 0;                     // pass 4: sparse clear
-        const uint32_t maxc = wave_max_u32(lmax);
-        uint32_t votes_at_max = 0, mm = 1024u;
-#pragma unroll
-        for (int k = 0; k < KV; ++k)                                                         // pass 3, from registers
-            if (cur[k] != kNone && c[k] == maxc) { votes_at_max += 1; mm = cur[k] < mm ? cur[k] : mm; }
-        votes_at_max = wave_sum_u32(votes_at_max);
-        mm = wave_min_u32(mm);
-        long long tok = 0;
-        if (TOK) tok = wave_sum_i64(tsum);
-        if (lane == 0) {
-            const bool any = maxc > 0;
-            const uint32_t n_modes = any ? votes_at_max / maxc : 0u;
-            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;                               // o1.py:206
-            if (a.cells) {
-                uint4 rec;
-                rec.x = maxc;
-                rec.y = tc;
-                rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
-                rec.w = hit;
-                reinterpret_cast<uint4*>(a.cells)[cell] = rec;
+            for (int k = 0; k < KV; ++k) {
+                const bool on = (cur.mask >> k) & 1u;
+                bin[k] = cur.raw[k] < 1023u ? cur.raw[k] : 1023u;
+                if (on) { bad |= cur.raw[k]; if (TOK) tsum += cur.tokv[k]; }
             }
-            if (a.cell_tokens) a.cell_tokens[cell] = tok;
-            if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
-            if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
-            if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (more) {
+            // LDS operations of one wave execute in order, so the passes need no fence -- and must not
+            // have one: a fence would wait (vmcnt) for loads still in flight.  wave_barrier() only pins
+            // the compiler's order.
 #pragma unroll
-            for (int k = 0; k < KV; ++k) cur[k] = nxt[k];
-            tsum = ntsum; cell = ncell; b = nb; p = np_;
+            for (int k = 0; k < KV; ++k) if ((cur.mask >> k) & 1u) atomicAdd(&h[bin[k]], 1u);   // pass 1
+            __builtin_amdgcn_wave_barrier();
+            uint32_t c[KV];
+#pragma unroll
+            for (int k = 0; k < KV; ++k) c[k] = ((cur.mask >> k) & 1u) ? h[bin[k]] : 0u;        // pass 2
+            const uint32_t tc = (cur.truth >= 0 && cur.truth < kBins) ? h[cur.truth] : 0u;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < KV; ++k) if ((cur.mask >> k) & 1u) h[bin[k]] = 0;               // pass 4: sparse clear
+            __builtin_amdgcn_wave_barrier();
+            // one max over (count << 10 | 1023 - bin): max_count and the smallest modal bin together
+            uint32_t lkey = 0;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const uint32_t key = ((cur.mask >> k) & 1u) ? ((c[k] << 10) | (1023u - bin[k])) : 0u;
+                lkey = key > lkey ? key : lkey;
+            }
+            const uint32_t wkey = wave_max_u32(lkey);
+            const uint32_t maxc = wkey >> 10;
+            const uint32_t mm = 1023u - (wkey & 1023u);
+            uint32_t votes_at_max = 0;
+#pragma unroll
+            for (int k = 0; k < KV; ++k)                                                         // pass 3, from registers
+                votes_at_max += (((cur.mask >> k) & 1u) && c[k] == maxc) ? 1u : 0u;
+            votes_at_max = wave_sum_u32(votes_at_max);
+            long long tok = 0;
+            if (TOK) tok = wave_sum_i64(tsum);
+            if (lane == 0) {
+                const bool any = maxc > 0;
+                const uint32_t n_modes = any ? exact_quotient(votes_at_max, maxc) : 0u;
+                const uint32_t hit = (any && tc == maxc) ? 1u : 0u;                               // o1.py:206
+                if (a.cells) {
+                    uint4 rec;
+                    rec.x = maxc;
+                    rec.y = tc;
+                    rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
+                    rec.w = hit;
+                    reinterpret_cast<uint4*>(a.cells)[cur.cell] = rec;
+                }
+                if (a.cell_tokens) a.cell_tokens[cur.cell] = tok;
+                if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)cur.b * SCV_TIE_CLASSES + n_modes], 1ull);
+                if (TOK && a.token_sum) atomicAdd(&a.token_sum[cur.b], (unsigned long long)tok);
+                if (a.truth_sum) atomicAdd(&a.truth_sum[cur.b], (unsigned long long)tc);
+            }
         }
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
@@ -892,16 +938,19 @@ __global__ __launch_bounds__(256) void scv_tiny_cells(const AggArgs a) {
             uint32_t bin = bin_k[k];
             if (active) { bad |= bin; bin = bin < 1023u ? bin : 1023u; }
             const uint32_t cnt = count_equal_in_group<G>(bin, active);
-            const uint32_t maxc = group_max_u32<G>(cnt);
+            // one max over (count << 10 | 1023 - bin): the winner carries max_count AND the smallest modal bin
+            const uint32_t key = group_max_u32<G>(active ? ((cnt << 10) | (1023u - bin)) : 0u);
+            const uint32_t maxc = key >> 10;
+            const uint32_t mm = 1023u - (key & 1023u);
+            // one sum over (votes at max | votes for truth << 16): both are <= 32
             const bool at_max = active && cnt == maxc;
-            const uint32_t votes_at_max = group_sum_u32<G>(at_max ? 1u : 0u);
-            const uint32_t mm = group_min_u32<G>(at_max ? bin : 1024u);
-            const uint32_t tc = group_sum_u32<G>((active && (int32_t)bin == truth_k[k]) ? 1u : 0u);
+            const uint32_t sums = group_sum_u32<G>((at_max ? 1u : 0u) | ((active && (int32_t)bin == truth_k[k]) ? 0x10000u : 0u));
+            const uint32_t votes_at_max = sums & 0xffffu, tc = sums >> 16;
             long long tok = 0;
             if (TOK) tok = group_sum_i64<G>(tok_k[k]);
             if (l == 0 && live_k[k]) {
                 const bool any = maxc > 0;
-                const uint32_t n_modes = any ? votes_at_max / maxc : 0u;
+                const uint32_t n_modes = any ? exact_quotient(votes_at_max, maxc) : 0u;
                 const uint32_t hit = (any && tc == maxc) ? 1u : 0u;               // o1.py:206
                 if (a.cells) {
                     uint4 rec;
@@ -1001,7 +1050,6 @@ __global__ __launch_bounds__(T) void scv_small_prefix(const AggArgs a) {
                 if (TOK) tsum += a.tokens[p * a.N + i];
             }
             if (n > done) done = n;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             uint32_t lmax = 0;
             for (int64_t i = lane; i < n; i += 64) {
@@ -1024,7 +1072,7 @@ __global__ __launch_bounds__(T) void scv_small_prefix(const AggArgs a) {
             if (lane == 0) {
                 const int64_t cell = p * a.B + b;
                 const bool any = maxc > 0;
-                const uint32_t n_modes = any ? votes_at_max / maxc : 0u;
+                const uint32_t n_modes = any ? exact_quotient(votes_at_max, maxc) : 0u;
                 const uint32_t hit = (any && tc == maxc) ? 1u : 0u;
                 if (a.cells) {
                     uint4 rec;
@@ -1039,14 +1087,12 @@ __global__ __launch_bounds__(T) void scv_small_prefix(const AggArgs a) {
                 if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
                 if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
         for (int64_t i = lane; i < done; i += 64) {             // sparse clear, once per problem
             const uint32_t v = (uint32_t)row[i];
             h[v < 1023u ? v : 1023u] = 0;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
