@@ -21,6 +21,9 @@ import os
 import sys
 import time
 
+# the host driver only supports dmabuf IPC: RCCL across processes needs this (set before torch loads)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
