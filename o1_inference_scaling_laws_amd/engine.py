@@ -278,6 +278,71 @@ class Engine:
         return out
 
 
+class MultiDeviceEngine:
+    """Single-process use of several GPUs, for a reference-style script (o1.py is one process): problems
+    are sharded by contiguous block (dist.shard_bounds), each block goes through its own ``Engine`` on
+    its own device from its own thread (the ctypes calls release the GIL; every GPU has its own PCIe
+    link, so HOST-mode ingest scales with the device count), and the integer counters are summed on the
+    host -- the same algebra as the RCCL all-reduce of the one-process-per-GPU path, bit-exact.
+
+    ``devices``: list of HIP device indices (default: all visible).  The same index may appear twice
+    (two contexts on one GPU), which is how the 1-GPU test box exercises this class.
+    """
+
+    def __init__(self, devices=None, **engine_kwargs):
+        if devices is None:
+            n = _lib.load().scv_device_count()
+            if n <= 0:
+                raise _lib.ScvError(_lib.ERR_NO_DEVICE, "no HIP device visible")
+            devices = list(range(n))
+        self.engines = [Engine(device=d, **engine_kwargs) for d in devices]
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _run(self, fn_name, rows, truth, per_shard_kwargs, shared_kwargs):
+        from concurrent.futures import ThreadPoolExecutor
+        from .dist import shard_bounds
+        P, G = rows.shape[0], len(self.engines)
+        bounds = [shard_bounds(P, g, G) for g in range(G)]
+
+        def work(g):
+            lo, hi = bounds[g]
+            if hi == lo:
+                return None
+            kw = {k: (None if v is None else v[lo:hi]) for k, v in per_shard_kwargs.items()}
+            return getattr(self.engines[g], fn_name)(rows[lo:hi], truth[lo:hi], **kw, **shared_kwargs)
+
+        with ThreadPoolExecutor(max_workers=G) as pool:
+            parts = [r for r in pool.map(work, range(G)) if r is not None]
+        if not parts:
+            return getattr(self.engines[0], fn_name)(rows, truth, **per_shard_kwargs, **shared_kwargs)
+        cat = lambda xs: None if any(x is None for x in xs) else np.concatenate(xs, axis=0)  # noqa: E731
+        return AggregateResult(
+            P, parts[0].B, cat([r.cells for r in parts]), cat([r.cell_tokens for r in parts]),
+            sum(r.tie_class_hits for r in parts), sum(r.token_sum for r in parts),
+            sum(r.truth_count_sum for r in parts))
+
+    def aggregate(self, answers, truth, tokens=None, n_valid=None, want_cells=True) -> AggregateResult:
+        answers = np.ascontiguousarray(answers, dtype=np.int32)
+        truth = np.ascontiguousarray(truth, dtype=np.int32)
+        tokens = None if tokens is None else np.ascontiguousarray(tokens, dtype=np.int32)
+        return self._run("aggregate", answers, truth, {"tokens": tokens}, {"n_valid": n_valid, "want_cells": want_cells})
+
+    def aggregate_prefix(self, pool, truth, n_valid, tokens=None, want_cells=True) -> AggregateResult:
+        pool = np.ascontiguousarray(pool, dtype=np.int32)
+        truth = np.ascontiguousarray(truth, dtype=np.int32)
+        tokens = None if tokens is None else np.ascontiguousarray(tokens, dtype=np.int32)
+        return self._run("aggregate_prefix", pool, truth, {"tokens": tokens}, {"n_valid": n_valid, "want_cells": want_cells})
+
+
 def cells_from_torch(cells_u8) -> np.ndarray:
     """uint8 cuda/cpu [P,B,16] -> CELL_DTYPE [P,B] on the host."""
     arr = cells_u8.detach().cpu().numpy()

@@ -614,6 +614,29 @@ def test_bootstrap_device_fused_no_host_roundtrip(hip_engine):
     assert rc == 0 and np.array_equal(out.cpu().numpy(), want)
 
 
+def test_multi_device_engine_single_process(golden, tmp_path):
+    """Single-process sharding over several contexts (here: three contexts on cuda:0): per-shard engines
+    in threads, counters summed on the host == one engine; also as the drop-in's engine."""
+    from o1_inference_scaling_laws_amd.engine import MultiDeviceEngine
+    a, t, tr = coracle.synth_fill(101, 3, 5003, 9, 3, want_tokens=True)
+    nv = np.array([5003, 77, 1], dtype=np.int32)
+    want = oracle(a, tr, tokens=t, n_valid=nv)
+    with MultiDeviceEngine(devices=[0, 0, 0]) as multi:
+        assert_results_equal(multi.aggregate(a, tr, tokens=t, n_valid=nv), want)
+        assert_results_equal(multi.aggregate(a[:2], tr[:2], n_valid=nv), oracle(a[:2], tr[:2], n_valid=nv), check_tokens=False)
+        pool, tpool = a[:, 0, :], t[:, 0, :]
+        assert_results_equal(multi.aggregate_prefix(pool, tr, nv, tokens=tpool),
+                             OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool))
+        cfg = o1_dropin.DropInConfig(model=TEST_MODEL, prompt=TEST_PROMPT, engine=multi, helper_folder=str(tmp_path))
+        pipe = golden["pipeline"]
+        ds = make_dataset(pipe["truths"])
+        o1_dropin.run_majority_vote_inference_experiments(cfg, ds, build_cache(ds, pipe["samples"]))
+        assert (tmp_path / "results_log_majority_vote.json").read_text() == pipe["results_logs"]["results_log_majority_vote.json"]
+    with MultiDeviceEngine() as every:                       # default: all visible devices
+        assert len(every.engines) >= 1
+        assert_results_equal(every.aggregate(a, tr, tokens=t, n_valid=nv), want)
+
+
 def test_kernel_timing_is_reported(hip_engine):
     hip_engine.drain_kernel_ns()
     a, _, tr = coracle.synth_fill(4, 2, 4096, 1, 0)
