@@ -38,6 +38,8 @@ def lib():
         p = C.c_void_p
         L.scvo_aggregate_i32.argtypes = [p, p, p, p, C.c_int64, C.c_int32, C.c_int64, C.c_int, p, p, p, p, p]
         L.scvo_aggregate_i32.restype = C.c_int
+        L.scvo_aggregate_i32_mt.argtypes = [p, p, p, p, C.c_int64, C.c_int32, C.c_int64, C.c_int, C.c_int, p, p, p, p, p]
+        L.scvo_aggregate_i32_mt.restype = C.c_int
         L.scvo_synth_fill_i32.argtypes = [p, p, p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_uint64, C.c_int]
         L.scvo_synth_fill_i32.restype = C.c_int
         L.scvo_bootstrap.argtypes = [p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, p]
@@ -69,6 +71,26 @@ def aggregate(answers, truth, tokens=None, n_valid=None, clamp=False):
     tcs = np.zeros((B,), dtype=np.int64)
     rc = lib().scvo_aggregate_i32(_ptr(answers), _ptr(tokens), _ptr(n_valid), _ptr(truth), P, B, N,
                                   int(bool(clamp)), _ptr(cells), _ptr(cell_tokens), _ptr(tie), _ptr(tok), _ptr(tcs))
+    return {"rc": rc, "cells": cells, "cell_tokens": cell_tokens, "tie_class_hits": tie,
+            "token_sum": tok, "truth_count_sum": tcs}
+
+
+def aggregate_mt(answers, truth, threads, tokens=None, n_valid=None, clamp=False):
+    """aggregate() with the problems spread over `threads` OpenMP threads (bench.py all-cores baseline)."""
+    answers = np.ascontiguousarray(answers, dtype=np.int32)
+    P, B, N = answers.shape
+    truth = np.ascontiguousarray(truth, dtype=np.int32)
+    if tokens is not None:
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+    if n_valid is not None:
+        n_valid = np.ascontiguousarray(n_valid, dtype=np.int32)
+    cells = np.zeros((P, B), dtype=CELL_DTYPE)
+    cell_tokens = np.zeros((P, B), dtype=np.int64)
+    tie = np.zeros((B, TIE_CLASSES), dtype=np.int64)
+    tok = np.zeros((B,), dtype=np.int64)
+    tcs = np.zeros((B,), dtype=np.int64)
+    rc = lib().scvo_aggregate_i32_mt(_ptr(answers), _ptr(tokens), _ptr(n_valid), _ptr(truth), P, B, N, int(bool(clamp)),
+                                     int(threads), _ptr(cells), _ptr(cell_tokens), _ptr(tie), _ptr(tok), _ptr(tcs))
     return {"rc": rc, "cells": cells, "cell_tokens": cell_tokens, "tie_class_hits": tie,
             "token_sum": tok, "truth_count_sum": tcs}
 

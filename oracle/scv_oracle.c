@@ -167,6 +167,39 @@ int scvo_aggregate_i32(const int32_t* answers, const int32_t* tokens,
     return (bad && !clamp) ? -2002 : 0;
 }
 
+/* Same computation with the problems spread over OpenMP threads (cells are independent, o1.py:234
+ * already farms problems out to independent threads); used only for bench.py's all-cores baseline.
+ * Per-budget outputs are reduced at the end, in problem order, so the result equals the 1-thread one. */
+int scvo_aggregate_i32_mt(const int32_t* answers, const int32_t* tokens,
+                          const int32_t* n_valid, const int32_t* truth,
+                          int64_t P, int32_t B, int64_t N, int clamp, int threads,
+                          scvo_cell* cells_out, int64_t* cell_tokens_out,
+                          int64_t* tie_class_hits_out, int64_t* token_sum_out,
+                          int64_t* truth_count_sum_out) {
+    if (P < 0 || B < 0 || N < 0 || !cells_out || !cell_tokens_out) return -2001;
+    int bad = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1) reduction(| : bad)
+#endif
+    for (int64_t p = 0; p < P; ++p) {
+        const int rc = scvo_aggregate_i32(answers + p * B * N, tokens ? tokens + p * B * N : NULL, n_valid, truth + p, 1, B, N,
+                                          clamp, cells_out + p * B, cell_tokens_out + p * B, NULL, NULL, NULL);
+        if (rc == -2002) bad |= 1;          /* out-of-domain vote seen (cells still hold the clamped result) */
+        else if (rc != 0) bad |= 2;
+    }
+    if (tie_class_hits_out) memset(tie_class_hits_out, 0, sizeof(int64_t) * (size_t)B * SCVO_TIE_CLASSES);
+    if (token_sum_out) memset(token_sum_out, 0, sizeof(int64_t) * (size_t)B);
+    if (truth_count_sum_out) memset(truth_count_sum_out, 0, sizeof(int64_t) * (size_t)B);
+    for (int64_t p = 0; p < P; ++p)
+        for (int32_t b = 0; b < B; ++b) {
+            const scvo_cell* c = &cells_out[p * B + b];
+            if (tie_class_hits_out && c->hit) tie_class_hits_out[(int64_t)b * SCVO_TIE_CLASSES + c->n_modes] += 1;
+            if (token_sum_out) token_sum_out[b] += cell_tokens_out[p * B + b];
+            if (truth_count_sum_out) truth_count_sum_out[b] += c->truth_count;
+        }
+    return (bad & 2) ? -2001 : ((bad & 1) ? -2002 : 0);
+}
+
 /* ---- problem-level bootstrap (spec in include/scvote.h, scv_bootstrap) ---------------------- */
 
 int scvo_bootstrap(const scvo_cell* cells, int64_t P, int32_t B,
