@@ -293,12 +293,17 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     if (wg_per_cu < 1) wg_per_cu = 1;
     const int64_t slots = (int64_t)ctx->num_cus * wg_per_cu;
 
-    // split-N when whole cells cannot fill the chip: S workgroups per cell, then one merge launch
+    // split-N when whole cells cannot fill the chip: S workgroups per cell, then one merge launch.
+    // Measured (tools/segs_sweep.py): best is ONE round of items (at most one per workgroup slot) with
+    // segments of at least 512 KiB -- more, smaller segments only add fold/publish/merge work.
     int64_t S = 1;
-    if (path == 2 || (ctx->path == 0 && 2 * ncells <= slots && N * 4 >= (128 << 10))) {
-        S = ctx->segs_override > 0 ? ctx->segs_override : (2 * slots + ncells - 1) / ncells;
-        const int64_t by_size = (N * 4) / (64 << 10);       // keep segments >= 64 KiB
-        if (ctx->segs_override <= 0 && S > by_size) S = by_size;
+    if (path == 2 || (ctx->path == 0 && 2 * ncells <= slots && N * 4 >= (1 << 20))) {
+        if (ctx->segs_override > 0) S = ctx->segs_override;
+        else {
+            S = slots / ncells;
+            const int64_t by_size = (N * 4) / (512 << 10);
+            if (S > by_size) S = by_size;
+        }
         if (S > 4096) S = 4096;
         if (S < 1) S = 1;
     }
