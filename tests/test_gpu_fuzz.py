@@ -1,0 +1,100 @@
+"""Randomised parity: 500 seeded (shape, distribution, n_valid, tokens, mode, launch options) draws, every
+one compared bit for bit with the CPU oracle through the C ABI.  Complements the hand-picked cases."""
+import numpy as np
+import pytest
+
+from o1_inference_scaling_laws_amd import _lib
+from oracle import coracle
+from tests._adapters import OracleEngine, assert_results_equal
+
+pytestmark = pytest.mark.gpu
+
+DEFAULTS = (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1), ("small_n_max", 512),
+            ("tiny_n_max", 32), ("small_reg", 1), ("prefetch", 1), ("stagger_vecs", 0), ("plain_loads", 0),
+            ("fused_counters_max", 4096))
+
+
+def _draw(rng):
+    regime = rng.choice(["tiny", "small", "mid", "large", "few_big"], p=[0.25, 0.25, 0.25, 0.15, 0.10])
+    if regime == "tiny":
+        P, B, N = int(rng.integers(1, 400)), int(rng.integers(1, 12)), int(rng.integers(0, 33))
+    elif regime == "small":
+        P, B, N = int(rng.integers(1, 120)), int(rng.integers(1, 6)), int(rng.integers(33, 700))
+    elif regime == "mid":
+        P, B, N = int(rng.integers(1, 40)), int(rng.integers(1, 5)), int(rng.integers(700, 9000))
+    elif regime == "large":
+        P, B, N = int(rng.integers(1, 12)), int(rng.integers(1, 4)), int(rng.integers(9000, 80000))
+    else:
+        P, B, N = int(rng.integers(1, 4)), int(rng.integers(1, 3)), int(rng.integers(200000, 600000))
+    dist = int(rng.integers(0, 4))
+    narrow = int(rng.choice([0, 0, 3, 40]))                      # fold values into few bins -> heavy ties
+    tokens = bool(rng.integers(0, 2))
+    nv_kind = rng.choice(["none", "random", "prefix", "zeros"], p=[0.35, 0.35, 0.2, 0.1])
+    if nv_kind == "none":
+        nv = None
+    elif nv_kind == "random":
+        nv = rng.integers(0, N + 1, size=B)
+    elif nv_kind == "prefix":
+        nv = np.array([max(0, N >> (B - 1 - b)) for b in range(B)])
+    else:
+        nv = np.where(rng.integers(0, 2, size=B) == 1, N, 0)
+    opts = {}
+    if rng.random() < 0.6:
+        opts["path"] = int(rng.integers(0, 4))
+        if opts["path"] == 2:
+            opts["segs"] = int(rng.choice([0, 2, 3, 5, 16]))
+    if rng.random() < 0.3:
+        opts["sorted"] = int(rng.integers(0, 2))
+    if rng.random() < 0.3:
+        opts["fused_counters_max"] = int(rng.choice([0, 1, 4096]))
+    if rng.random() < 0.25:
+        opts["prefetch"] = 0
+    if rng.random() < 0.2:
+        opts["balance"] = 0
+    if rng.random() < 0.2:
+        opts["grid"] = int(rng.integers(1, 40))
+    if rng.random() < 0.2:
+        opts["tiny_n_max"] = 0
+    if rng.random() < 0.2:
+        opts["small_reg"] = int(rng.integers(0, 3))
+    tuning = None
+    if rng.random() < 0.3:
+        tuning = (int(rng.choice([4, 8, 16, 32])), int(rng.choice([256, 512, 1024])), int(rng.integers(1, 5)),
+                  int(rng.choice([2, 4, 8])))
+    prefix = bool(rng.random() < 0.25) and nv is not None
+    return P, B, N, dist, narrow, tokens, nv, opts, tuning, prefix
+
+
+@pytest.mark.parametrize("seed", range(500))
+def test_random_configuration_is_bit_exact(hip_engine, seed):
+    rng = np.random.default_rng(10_000 + seed)
+    P, B, N, dist, narrow, tokens, nv, opts, tuning, prefix = _draw(rng)
+    if N == 0:
+        a = np.zeros((P, B, 0), np.int32); t = np.zeros((P, B, 0), np.int32); tr = np.zeros(P, np.int32)
+    else:
+        a, t, tr = coracle.synth_fill(P, B, N, seed, dist, want_tokens=True)
+        if narrow:
+            a = a % narrow
+            tr = (tr % narrow).astype(np.int32)
+    nv = None if nv is None else np.asarray(nv, dtype=np.int32)
+    tk = t if tokens else None
+    try:
+        for k, v in opts.items():
+            hip_engine.set_option(k, v)
+        if tuning:
+            hip_engine.set_tuning(*tuning)
+        if prefix:
+            pool, tpool = a[:, 0, :], (None if tk is None else tk[:, 0, :])
+            got = hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool)
+            want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
+        else:
+            got = hip_engine.aggregate(a, tr, tokens=tk, n_valid=nv)
+            want = OracleEngine().aggregate(a, tr, tokens=tk, n_valid=nv)
+        assert_results_equal(got, want, check_tokens=tokens)
+    except _lib.ScvError as e:                                   # only argument errors we provoked on purpose
+        raise AssertionError(f"seed {seed}: {e} for P={P} B={B} N={N} opts={opts} tuning={tuning} prefix={prefix}")
+    finally:
+        for k, v in DEFAULTS:
+            hip_engine.set_option(k, v)
+        hip_engine.set_tuning(copies=16, threads=1024, wg_per_cu=1, unroll=4)
+        hip_engine.set_option("auto_geometry", 1)
