@@ -1,5 +1,7 @@
 """Randomised parity: 500 seeded (shape, distribution, n_valid, tokens, mode, launch options) draws, every
 one compared bit for bit with the CPU oracle through the C ABI.  Complements the hand-picked cases."""
+import os
+
 import numpy as np
 import pytest
 
@@ -65,7 +67,7 @@ def _draw(rng):
     return P, B, N, dist, narrow, tokens, nv, opts, tuning, prefix
 
 
-@pytest.mark.parametrize("seed", range(500))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SCV_FUZZ_FIRST", "0")), int(os.environ.get("SCV_FUZZ_FIRST", "0")) + int(os.environ.get("SCV_FUZZ_SEEDS", "500"))))
 def test_random_configuration_is_bit_exact(hip_engine, seed):
     rng = np.random.default_rng(10_000 + seed)
     P, B, N, dist, narrow, tokens, nv, opts, tuning, prefix = _draw(rng)
