@@ -91,11 +91,13 @@ int scv_set_stream(scv_ctx* ctx, void* hip_stream);
 int scv_sync(scv_ctx* ctx);
 
 /*
- * Kernel tuning knobs (for A/B measurement; 0 / negative = keep current):
+ * Streaming-kernel geometry (for A/B measurement; 0 / negative = keep current).  By default the
+ * library picks the geometry from the shape (measured bands); any explicit value here
+ * switches that off until scv_set_option(ctx, "auto_geometry", 1).
  *   copies        LDS sub-histogram replication R in {4,8,16,32}
  *   threads       workgroup size in {256,512,1024}
- *   wg_per_cu     persistent workgroups per CU
- *   unroll        16-byte loads in flight per lane in {1,2,4,8}
+ *   wg_per_cu     persistent workgroups per CU (clamped by LDS and wave capacity)
+ *   unroll        16-byte loads in flight per lane in {2,4,8}
  */
 int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unroll);
 /* Launch options (measurement / tests): "grid" (> 0: exact persistent grid, 0: derive from the CU
@@ -104,8 +106,8 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  * "segs" (split-N segments per cell, 0 auto), "sorted" (default 1: budgets traversed in descending
  * n_valid order), "small_n_max" (auto: N <= this uses the small-N kernel), "tiny_n_max" (<= 32: N <= this
  * uses the register-only several-cells-per-wave kernel inside the small path), "auto_geometry" (default 1),
- * "fused_counters_max" (cells at or below: per-cell atomics inside the hot kernel; above: a separate
- * reduction of the cell table), "pin_host" (default 0; 1: HOST-mode calls hipHostRegister caller buffers
+ * "fused_counters_max" (cells at or below, or problem rows >= 4 MiB: per-cell atomics inside the hot
+ * kernel; otherwise a separate reduction of the cell table; 0 forces the reduction), "small_reg", "pin_host" (default 0; 1: HOST-mode calls hipHostRegister caller buffers
  * of 32 MiB or more for the duration of the call -- measured no faster than pageable copies), "prefetch"
  * (default 1: cross-item prefetch in the streaming kernel), "stagger_vecs", "plain_loads". */
 int scv_set_option(scv_ctx* ctx, const char* key, int64_t value);
