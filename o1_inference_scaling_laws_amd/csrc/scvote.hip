@@ -137,10 +137,25 @@ KernelFn pick_kernel(int copies, int t, int u, bool tok) {
     }
 }
 
-int set_device(scv_ctx* ctx) {
-    SCV_HIP(hipSetDevice(ctx->device));
-    return SCV_OK;
-}
+// Every entry point runs on the ctx device and leaves the caller's current HIP device as it found it
+// (a process driving several GPUs from one thread -- MultiDeviceEngine -- must not have torch's
+// current device moved under it).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    int enter(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+        if (prev != device) {
+            SCV_HIP(hipSetDevice(device));
+            switched = true;
+        }
+        return SCV_OK;
+    }
+    ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+};
+#define SCV_ENTER(ctx)                                                                             \
+    DeviceGuard guard_;                                                                            \
+    if (int rc_ = guard_.enter((ctx)->device)) return rc_
 
 // Per-cell device atomics land on ~B addresses and serialise at the memory side.  Measured
 // (profiles/r01_crossover_r4_d1.log): 65536 cells of 64 KiB with fused atomics run at 4.1 TB/s, with
@@ -217,7 +232,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             auto* th = reinterpret_cast<unsigned long long*>(tie);
             auto* ts = reinterpret_cast<unsigned long long*>(tok_sum);
             auto* tc = reinterpret_cast<unsigned long long*>(truth_sum);
-            if (tok) hipLaunchKernelGGL((scv::scv_reduce_cells<true>), dim3((unsigned)chunks, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
+            // token reads only when token_sum is wanted: cell_tokens scratch exists exactly then
+            if (tok && tok_sum) hipLaunchKernelGGL((scv::scv_reduce_cells<true>), dim3((unsigned)chunks, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
             else hipLaunchKernelGGL((scv::scv_reduce_cells<false>), dim3((unsigned)chunks, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
             SCV_HIP(hipGetLastError());
         }
@@ -410,7 +426,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
         auto* th = reinterpret_cast<unsigned long long*>(tie);
         auto* ts = reinterpret_cast<unsigned long long*>(tok_sum);
         auto* tc = reinterpret_cast<unsigned long long*>(truth_sum);
-        if (tok) hipLaunchKernelGGL((scv::scv_reduce_cells<true>), dim3((unsigned)chunks, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
+        if (tok && tok_sum) hipLaunchKernelGGL((scv::scv_reduce_cells<true>), dim3((unsigned)chunks, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
         else hipLaunchKernelGGL((scv::scv_reduce_cells<false>), dim3((unsigned)chunks, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
         SCV_HIP(hipGetLastError());
     }
@@ -420,9 +436,9 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
 }
 
 // Read and clear the device error word (stream must be idle).
-int fetch_err(scv_ctx* ctx, uint32_t* out) {
+int fetch_err(scv_ctx* ctx, uint32_t* out, bool force = false) {
     *out = 0;
-    if (!ctx->err_dirty) return SCV_OK;
+    if (!ctx->err_dirty && !force) return SCV_OK;
     SCV_HIP(hipMemcpyAsync(out, ctx->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SCV_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
     SCV_HIP(hipStreamSynchronize(ctx->stream));
@@ -471,7 +487,8 @@ int scv_create(scv_ctx** out, int device, uint32_t flags) {
     if (!ctx) return fail(SCV_ERR_ALLOC, "out of host memory");
     ctx->device = device;
     ctx->flags = flags;
-    hipError_t e = hipSetDevice(device);
+    DeviceGuard guard_;                       // restores the caller's current device on every return path
+    hipError_t e = guard_.enter(device) == SCV_OK ? hipSuccess : hipErrorInvalidDevice;
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -510,7 +527,8 @@ int scv_create(scv_ctx** out, int device, uint32_t flags) {
 
 int scv_destroy(scv_ctx* ctx) {
     if (!ctx) return SCV_OK;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard_;
+    (void)guard_.enter(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
@@ -524,7 +542,7 @@ int scv_destroy(scv_ctx* ctx) {
 
 int scv_set_stream(scv_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
-    if (int rc = set_device(ctx)) return rc;
+    SCV_ENTER(ctx);
     // No synchronisation here (same contract as any set-stream call: ordering between the old and the
     // new stream is the caller's): a sync would be illegal while the new stream is being captured
     // into a hipGraph.  Only the ctx's own private stream is drained before it is destroyed.
@@ -539,10 +557,12 @@ int scv_set_stream(scv_ctx* ctx, void* hip_stream) {
 
 int scv_sync(scv_ctx* ctx) {
     if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
-    if (int rc = set_device(ctx)) return rc;
+    SCV_ENTER(ctx);
     SCV_HIP(hipStreamSynchronize(ctx->stream));
     uint32_t w = 0;
-    if (int rc = fetch_err(ctx, &w)) return rc;
+    // always read the word (4 bytes): a hot path captured into a hipGraph is replayed without passing
+    // through launch_aggregate, so the host-side dirty flag says nothing about replays
+    if (int rc = fetch_err(ctx, &w, true)) return rc;
     return check_err_word(ctx, w);
 }
 
@@ -594,7 +614,7 @@ int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const in
     if (prefix && B > 0 && !n_valid) return fail(SCV_ERR_ARG, "prefix mode needs n_valid");
     if (prefix && B > scv::kMaxSortedB) return fail(SCV_ERR_ARG, "prefix mode supports at most %d budgets", scv::kMaxSortedB);
     if (mem_kind != SCV_MEM_HOST && mem_kind != SCV_MEM_DEVICE) return fail(SCV_ERR_ARG, "bad mem_kind %d", mem_kind);
-    if (int rc = set_device(ctx)) return rc;
+    SCV_ENTER(ctx);
     auto launch = prefix ? launch_prefix : launch_aggregate;
 
     if (mem_kind == SCV_MEM_DEVICE)
@@ -697,7 +717,7 @@ int scv_bootstrap(scv_ctx* ctx, const scv_cell* cells, int64_t P, int32_t B, int
     const size_t lds = (size_t)B * M * sizeof(uint32_t);
     if (lds > 64 * 1024) return fail(SCV_ERR_ARG, "bootstrap: B*M=%lld counters exceed 64 KiB of LDS", (long long)B * M);
     if (mem_kind != SCV_MEM_HOST && mem_kind != SCV_MEM_DEVICE) return fail(SCV_ERR_ARG, "bad mem_kind %d", mem_kind);
-    if (int rc = set_device(ctx)) return rc;
+    SCV_ENTER(ctx);
     const int32_t R = r_end - r_begin;
     if (R == 0) return SCV_OK;
     hipStream_t s = ctx->stream;
@@ -731,7 +751,7 @@ int scv_synth_fill_i32(scv_ctx* ctx, int32_t* answers, int32_t* tokens, int32_t*
     if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
     if (P < 0 || B < 0 || N < 0 || p_offset < 0) return fail(SCV_ERR_ARG, "synth_fill: negative shape");
     if (dist < SCV_DIST_UNIFORM || dist > SCV_DIST_TIE) return fail(SCV_ERR_ARG, "synth_fill: unknown dist %d", dist);
-    if (int rc = set_device(ctx)) return rc;
+    SCV_ENTER(ctx);
     if (P == 0) return SCV_OK;
     int64_t grid = P * (int64_t)B;
     if (B == 0) grid = (P + 255) / 256;
@@ -748,7 +768,7 @@ int scv_last_kernel_ns(scv_ctx* ctx, uint64_t* ns_out) {
     if (!ctx || !ns_out) return fail(SCV_ERR_ARG, "NULL argument");
     if (!(ctx->flags & SCV_FLAG_TIMING) || ctx->events_used == 0)
         return fail(SCV_ERR_NOT_TIMED, "no timed launch (create the ctx with SCV_FLAG_TIMING)");
-    if (int rc = set_device(ctx)) return rc;
+    SCV_ENTER(ctx);
     EventPair& ev = ctx->events[ctx->events_used - 1];
     SCV_HIP(hipEventSynchronize(ev.b));
     float ms = 0.f;
@@ -760,7 +780,7 @@ int scv_last_kernel_ns(scv_ctx* ctx, uint64_t* ns_out) {
 int scv_drain_kernel_ns(scv_ctx* ctx, uint64_t* total_ns_out, uint64_t* launches_out) {
     if (!ctx || !total_ns_out || !launches_out) return fail(SCV_ERR_ARG, "NULL argument");
     if (!(ctx->flags & SCV_FLAG_TIMING)) return fail(SCV_ERR_NOT_TIMED, "ctx was created without SCV_FLAG_TIMING");
-    if (int rc = set_device(ctx)) return rc;
+    SCV_ENTER(ctx);
     double total = 0;
     for (size_t i = 0; i < ctx->events_used; ++i) {
         SCV_HIP(hipEventSynchronize(ctx->events[i].b));

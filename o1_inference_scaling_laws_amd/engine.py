@@ -76,7 +76,11 @@ class Engine:
         self._L = _lib.load()            # raises ImportError when csrc/libscvote.so is missing
         self._ctx = C.c_void_p()
         flags = (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_CLAMP if clamp_to_invalid_bin else 0)
-        check(self._L.scv_create(C.byref(self._ctx), -1 if device is None else int(device), flags))
+        if device is None:
+            import torch
+            device = torch.cuda.current_device() if torch.cuda.is_available() else -1
+        self.device = int(device)
+        check(self._L.scv_create(C.byref(self._ctx), self.device, flags))
         info = (C.c_int64 * 4)()
         check(self._L.scv_device_info(self._ctx, C.byref(info)))
         self.num_cus, self.lds_bytes, self.clock_khz, self.hbm_bytes = (int(x) for x in info)
@@ -108,10 +112,15 @@ class Engine:
     def set_option(self, key: str, value: int):
         check(self._L.scv_set_option(self._ctx, key.encode(), int(value)))
 
+    def _check_device(self, tensor, name="tensor"):
+        if self.device >= 0 and tensor.device.index != self.device:
+            raise ValueError(f"{name} lives on {tensor.device} but this engine is bound to cuda:{self.device}")
+
     def use_torch_stream(self):
-        """Launch on torch's current stream so engine work orders with torch / RCCL ops."""
+        """Launch on torch's current stream OF THE ENGINE'S DEVICE so engine work orders with torch / RCCL ops."""
         import torch
-        s = int(torch.cuda.current_stream().cuda_stream)   # 0 = the default stream: borrowed as such
+        dev = self.device if self.device >= 0 else None
+        s = int(torch.cuda.current_stream(dev).cuda_stream)   # 0 = the default stream: borrowed as such
         if s != self._bound_stream:
             check(self._L.scv_set_stream(self._ctx, C.c_void_p(s)))
             self._bound_stream = s
@@ -203,6 +212,7 @@ class Engine:
             raise ValueError("answers must be a contiguous CUDA int32 tensor [P, B, N]")
         P, B, N = answers.shape
         dev = answers.device
+        self._check_device(answers, "answers")
         for name, t, shape in (("truth", truth, (P,)), ("tokens", tokens, (P, B, N)), ("n_valid", n_valid, (B,))):
             if t is None:
                 continue
@@ -238,6 +248,7 @@ class Engine:
         P, N = pool.shape
         B = int(n_valid.shape[0])
         dev = pool.device
+        self._check_device(pool, "pool")
         for name, t, shape in (("truth", truth, (P,)), ("tokens", tokens, (P, N)), ("n_valid", n_valid, (B,))):
             if t is None:
                 continue
@@ -270,6 +281,7 @@ class Engine:
         """cells uint8 cuda [P,B,16] -> int64 cuda [r_end-r_begin, B, M] (asynchronous)."""
         import torch
         P, B = cells.shape[0], cells.shape[1]
+        self._check_device(cells, "cells")
         self.use_torch_stream()
         if out is None:
             out = torch.empty((r_end - r_begin, B, M), dtype=torch.int64, device=cells.device)

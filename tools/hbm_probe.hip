@@ -1,16 +1,32 @@
 // hbm_probe.hip -- measurement utility (not product code): attainable HBM READ bandwidth on gfx950
 // for the access-pattern class of scv_hist_argmax (every workgroup streams whole contiguous 4 MiB
 // cells with 16-byte loads), so roofline.frac can also be quoted against a measured read ceiling
-// instead of the 8 TB/s datasheet number.  Usage: hbm_probe.bin [GB=40]
+// instead of the 8 TB/s datasheet number -- and the known-bytes kernel on which the gfx950
+// FETCH_SIZE half-count is calibrated (MI355X_MICROARCH.md, HBM section).
+//
+//   hbm_probe.bin [cells=10000]          sweep of read variants over cells x 4 MiB (10000 = the bench chunk)
+//   hbm_probe.bin [cells] --calib        3 launches of ONE variant (read_cells_pipe<4>, grid 250 x 1024) and nothing
+//                                        else: run under `rocprofv3 --pmc FETCH_SIZE` to get FETCH_SIZE per launch
+//                                        for exactly cells * 4 MiB of algorithmic reads
+//
+// Variants:
+//   cells      the round-1 probe: per cell, U loads then U consumes; no load is in flight while a wave consumes
+//   pipe       register double buffering: the U loads of step i+1 are issued BEFORE step i is consumed, across
+//              cell boundaries too (what the vote kernel's cross-cell prefetch + 16 de-synchronised waves achieve)
+//   stride     plain grid-stride loop over the whole buffer (no cell structure)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ v4i ld(const v4i* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 
 template <int U, bool NT>
 __global__ void read_cells(const v4i* __restrict__ src, long cell_vecs, long ncells, int* sink) {
@@ -20,10 +36,43 @@ __global__ void read_cells(const v4i* __restrict__ src, long cell_vecs, long nce
         for (long i = threadIdx.x; i + (long)(U - 1) * blockDim.x < cell_vecs; i += (long)U * blockDim.x) {
             v4i x[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = NT ? __builtin_nontemporal_load(p + i + (long)u * blockDim.x) : p[i + (long)u * blockDim.x];
+            for (int u = 0; u < U; ++u) x[u] = ld<NT>(p + i + (long)u * blockDim.x);
 #pragma unroll
             for (int u = 0; u < U; ++u) acc ^= x[u].x ^ x[u].y ^ x[u].z ^ x[u].w;
         }
+    }
+    if (acc == 0x12345678) *sink = acc;
+}
+
+// The workgroup's cells form one logical stream of steps (U*T vectors each); step s+1 is loaded before
+// step s is consumed, so every lane always has U..2U loads in flight.
+template <int U, bool NT>
+__global__ void read_cells_pipe(const v4i* __restrict__ src, long cell_vecs, long ncells, int* sink) {
+    int acc = 0;
+    const long T = blockDim.x;
+    const long steps_per_cell = cell_vecs / (U * T);           // host guarantees divisibility
+    const long my_cells = blockIdx.x < ncells ? (ncells - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const long nsteps = my_cells * steps_per_cell;
+    auto addr = [&](long s) {
+        const long c = s / steps_per_cell, k = s - c * steps_per_cell;
+        return src + (blockIdx.x + c * gridDim.x) * cell_vecs + k * U * T + threadIdx.x;
+    };
+    v4i cur[U], nxt[U];
+    if (nsteps > 0) {
+        const v4i* p = addr(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = ld<NT>(p + (long)u * T);
+    }
+    for (long s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) {
+            const v4i* p = addr(s + 1);
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = ld<NT>(p + (long)u * T);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= cur[u].x ^ cur[u].y ^ cur[u].z ^ cur[u].w;
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
     if (acc == 0x12345678) *sink = acc;
 }
@@ -35,7 +84,7 @@ __global__ void read_gridstride(const v4i* __restrict__ src, long nvec, int* sin
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i + (U - 1) * stride < nvec; i += U * stride) {
         v4i x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+        for (int u = 0; u < U; ++u) x[u] = ld<NT>(src + i + u * stride);
 #pragma unroll
         for (int u = 0; u < U; ++u) acc ^= x[u].x ^ x[u].y ^ x[u].z ^ x[u].w;
     }
@@ -44,7 +93,13 @@ __global__ void read_gridstride(const v4i* __restrict__ src, long nvec, int* sin
 
 __global__ void fill(v4i* dst, long nvec) {
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) { v4i v = {(int)i, 1, 2, 3}; dst[i] = v; }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        // pseudo-random words: a constant pattern would flatter the memory system's power budget
+        unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull;
+        z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+        v4i v = {(int)z, (int)(z >> 32), (int)(z * 3), (int)(z >> 17)};
+        dst[i] = v;
+    }
 }
 
 template <typename F>
@@ -61,16 +116,29 @@ double time_ms(F f, int reps = 5) {
 }
 
 int main(int argc, char** argv) {
-    const double gb = argc > 1 ? atof(argv[1]) : 40.0;
+    long ncells = 10000;
+    bool calib = false;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--calib")) calib = true;
+        else ncells = atol(argv[i]);
+    }
     const long cell_bytes = 4l << 20;
-    const long ncells = (long)(gb * 1e9 / cell_bytes);
     const long bytes = ncells * cell_bytes, nvec = bytes / 16, cell_vecs = cell_bytes / 16;
     v4i* buf; int* sink;
     CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&sink, 4));
     fill<<<4096, 256>>>(buf, nvec); CK(hipDeviceSynchronize());
-    printf("buffer %.2f GB = %ld cells of 4 MiB\n", bytes / 1e9, ncells);
+    printf("buffer %.3f GB = %ld cells of 4 MiB (algorithmic read bytes per launch: %ld)\n", bytes / 1e9, ncells, bytes);
+    if (calib) {
+        for (int r = 0; r < 3; ++r) {
+            read_cells_pipe<4, true><<<250, 1024>>>(buf, cell_vecs, ncells, sink);
+            CK(hipDeviceSynchronize());
+        }
+        printf("calib: 3 launches of read_cells_pipe<4,nt> grid 250 x 1024, %ld bytes each\n", bytes);
+        return 0;
+    }
     struct Cfg { int grid, threads; };
-    const Cfg cfgs[] = {{256, 1024}, {250, 1024}, {512, 512}, {500, 512}, {256, 512}, {1024, 256}, {2048, 256}};
+    const Cfg cfgs[] = {{250, 1024}, {256, 1024}, {500, 512}, {512, 512}, {1000, 256}, {2000, 256}};
+    double best = 0;
     for (const Cfg& c : cfgs) {
         double a = time_ms([&] { read_cells<4, true><<<c.grid, c.threads>>>(buf, cell_vecs, ncells, sink); });
         double b = time_ms([&] { read_cells<4, false><<<c.grid, c.threads>>>(buf, cell_vecs, ncells, sink); });
@@ -78,12 +146,24 @@ int main(int argc, char** argv) {
         double e = time_ms([&] { read_cells<2, true><<<c.grid, c.threads>>>(buf, cell_vecs, ncells, sink); });
         printf("cells   grid %4d x %4d : U4 nt %6.0f | U4 plain %6.0f | U8 nt %6.0f | U2 nt %6.0f GB/s\n", c.grid, c.threads,
                bytes / a / 1e6, bytes / b / 1e6, bytes / d / 1e6, bytes / e / 1e6);
+        best = std::max({best, bytes / a / 1e6, bytes / d / 1e6, bytes / e / 1e6});
     }
-    const Cfg gs[] = {{256, 1024}, {512, 512}, {2048, 256}, {4096, 256}, {8192, 256}};
+    for (const Cfg& c : cfgs) {
+        double a = time_ms([&] { read_cells_pipe<4, true><<<c.grid, c.threads>>>(buf, cell_vecs, ncells, sink); });
+        double b = time_ms([&] { read_cells_pipe<4, false><<<c.grid, c.threads>>>(buf, cell_vecs, ncells, sink); });
+        double d = time_ms([&] { read_cells_pipe<2, true><<<c.grid, c.threads>>>(buf, cell_vecs, ncells, sink); });
+        double e = time_ms([&] { read_cells_pipe<8, true><<<c.grid, c.threads>>>(buf, cell_vecs, ncells, sink); });
+        printf("pipe    grid %4d x %4d : U4 nt %6.0f | U4 plain %6.0f | U2 nt %6.0f | U8 nt %6.0f GB/s\n", c.grid, c.threads,
+               bytes / a / 1e6, bytes / b / 1e6, bytes / d / 1e6, bytes / e / 1e6);
+        best = std::max({best, bytes / a / 1e6, bytes / d / 1e6, bytes / e / 1e6});
+    }
+    const Cfg gs[] = {{256, 1024}, {512, 512}, {2048, 256}, {8192, 256}};
     for (const Cfg& c : gs) {
         double a = time_ms([&] { read_gridstride<4, true><<<c.grid, c.threads>>>(buf, nvec, sink); });
         double b = time_ms([&] { read_gridstride<4, false><<<c.grid, c.threads>>>(buf, nvec, sink); });
         printf("stride  grid %4d x %4d : U4 nt %6.0f | U4 plain %6.0f GB/s\n", c.grid, c.threads, bytes / a / 1e6, bytes / b / 1e6);
+        best = std::max(best, bytes / a / 1e6);
     }
+    printf("READ_CEILING_GBPS %.0f\n", best);
     return 0;
 }
