@@ -9,8 +9,13 @@ extraction (network call) -- becomes a vote for answer 0 with 0 tokens (o1.py:19
 Value domain: the engine histograms bins 0..1023.  AIME answers 0..999 map to themselves; any other
 value the cache holds (negative, >= 1000, non-integral) is an ordinary candidate for
 statistics.multimode, so it is dictionary-encoded per problem into the spare
-bins 1000..1023.  More than 24 distinct such values in one problem raises DomainOverflow (there is
-no CPU fallback).
+bins 1000..1023.  A problem with more than 24 distinct such values is re-encoded DENSELY instead:
+multimode and the score (o1.py:202-210) depend only on the equality classes of the votes and on
+which class the truth is in, so ALL distinct values of that problem (truth included) are mapped
+injectively, in first-seen order, onto bins 0..k-1 -- exact while the problem has at most 1024
+distinct values (always, for the reference's N <= 128).  Only beyond that DomainOverflow is raised
+(there is no CPU fallback).  For a densely re-encoded problem the cell's ``min_mode`` is a code, not
+an answer; ``VoteTensors.code_tables[p]`` decodes it.
 
 O1_MODEL and PROMPT are parameters: they are part of the key (o1.py:86) and are read from the
 reference module at install time (o1_dropin.install), never copied into this repository.
@@ -25,8 +30,12 @@ SPARE_BASE, SPARE_COUNT = 1000, 24
 FAILED_VOTE = (0, 0)  # o1.py:192
 
 
+NUM_BINS = 1024
+
+
 class DomainOverflow(ValueError):
-    """A problem has more than 24 distinct out-of-domain answers."""
+    """The encoder at hand is full: > 24 distinct out-of-domain answers for ``ProblemEncoder`` (the
+    extractor then switches the problem to ``DenseEncoder``), > 1024 distinct answers for ``DenseEncoder``."""
 
 
 def generation_key(model: str, prompt: str, problem: str, token_limit: int, idx: int) -> str:
@@ -88,12 +97,34 @@ class ProblemEncoder:
         return code
 
 
+class DenseEncoder:
+    """Per-problem dictionary over ALL values: the i-th distinct value seen -> bin i (injective, so the
+    equality classes -- all that statistics.multimode and ``truth in modes`` look at -- are preserved)."""
+
+    def __init__(self):
+        self._codes = {}
+
+    def encode(self, v) -> int:
+        v = _canonical(v)
+        code = self._codes.get(v)
+        if code is None:
+            if len(self._codes) >= NUM_BINS:
+                raise DomainOverflow(f"more than {NUM_BINS} distinct answers in one problem")
+            code = len(self._codes)
+            self._codes[v] = code
+        return code
+
+    def table(self):
+        return list(self._codes)
+
+
 @dataclass
 class VoteTensors:
     answers: np.ndarray   # int32 [P, B, Nmax]
     tokens: np.ndarray    # int32 [P, B, Nmax]
     n_valid: np.ndarray   # int32 [B]
     truth: np.ndarray     # int32 [P]
+    code_tables: dict = None   # p -> [value of bin 0, value of bin 1, ...] for densely re-encoded problems
 
 
 def build_vote_tensors(dataset, cache: dict, budgets, model: str, prompt: str) -> VoteTensors:
@@ -108,18 +139,31 @@ def build_vote_tensors(dataset, cache: dict, budgets, model: str, prompt: str) -
     tokens = np.zeros((P, B, max(nmax, 1)), dtype=np.int32)
     n_valid = np.array([n for _, n in budgets], dtype=np.int32).reshape(B)
     truth = np.zeros((P,), dtype=np.int32)
+    code_tables = {}
     for p, example in enumerate(dataset):
-        enc = ProblemEncoder()
-        truth[p] = enc.encode(int(example["answer"]))          # o1.py:206
-        memo = {}
-        for b, (key_limit, n) in enumerate(budgets):
+        raw = {}                                                # (key_limit, idx) -> (answer, tokens), first-seen order
+        for key_limit, n in budgets:
             for idx in range(n):
                 k = (key_limit, idx)
-                if k not in memo:
+                if k not in raw:
                     ans, tok = resolve_vote(cache, model, prompt, example["problem"], key_limit, idx)
                     tok = int(tok)
                     if not -2 ** 31 <= tok < 2 ** 31:
                         raise ValueError(f"token count {tok} does not fit int32")
-                    memo[k] = (enc.encode(ans), tok)
-                answers[p, b, idx], tokens[p, b, idx] = memo[k]
-    return VoteTensors(answers, tokens, n_valid, truth)
+                    raw[k] = (ans, tok)
+        true_answer = int(example["answer"])                    # o1.py:206
+        try:
+            enc = ProblemEncoder()
+            truth_code = enc.encode(true_answer)
+            codes = {k: enc.encode(ans) for k, (ans, _tok) in raw.items()}
+        except DomainOverflow:                                  # > 24 distinct out-of-domain values: dense re-encoding
+            enc = DenseEncoder()
+            truth_code = enc.encode(true_answer)
+            codes = {k: enc.encode(ans) for k, (ans, _tok) in raw.items()}
+            code_tables[p] = enc.table()
+        truth[p] = truth_code
+        for b, (key_limit, n) in enumerate(budgets):
+            for idx in range(n):
+                k = (key_limit, idx)
+                answers[p, b, idx], tokens[p, b, idx] = codes[k], raw[k][1]
+    return VoteTensors(answers, tokens, n_valid, truth, code_tables)

@@ -92,16 +92,40 @@ def run_experiments(cfg: DropInConfig, dataset, cache: dict, token_limit: int, N
 
 
 def _run_family(cfg: DropInConfig, dataset, cache, budgets):
-    """All budgets of a family in ONE engine call: answers [P, B, Nmax] + n_valid[B]."""
-    res = _aggregate(cfg, dataset, cache, [(key_limit, n) for _, key_limit, n in budgets])
+    """All budgets of a family in at most two engine calls.
+
+    Budgets that share a key token limit vote over PREFIXES of one sample pool (o1.py:274-277 with the
+    idx-keyed cache of o1.py:85-88: T = 2^11, 2^12, 2^13, ... are samples 0..N-1 of the 2048-token
+    pool): they go through the engine's prefix mode as ONE pool [P, Nmax] + n_valid -- the pool is
+    streamed once instead of being expanded B times.  The remaining budgets (one
+    sample each, distinct key limits) go as one dense [P, B', 1] call.  An engine without
+    ``aggregate_prefix`` gets everything as one dense [P, B, Nmax] call."""
+    eng = cfg.get_engine()
+    by_key = {}
+    for i, (_token_limit, key_limit, _n) in enumerate(budgets):
+        by_key.setdefault(key_limit, []).append(i)
+    pooled = {k: idx for k, idx in by_key.items() if len(idx) > 1 and hasattr(eng, "aggregate_prefix")}
+    dense = [i for k, idx in by_key.items() if k not in pooled for i in idx]
+    floats = [None] * len(budgets)
+    if dense:
+        res = _aggregate(cfg, dataset, cache, [(budgets[i][1], budgets[i][2]) for i in dense])
+        for j, i in enumerate(dense):
+            floats[i] = (res.accuracy(j), res.avg_tokens_used(j))
+    for key_limit, idx in pooled.items():
+        ns = [budgets[i][2] for i in idx]
+        vt = build_vote_tensors(dataset, cache, [(key_limit, max(ns))], cfg.model, cfg.prompt)
+        res = eng.aggregate_prefix(vt.answers[:, 0, :], vt.truth, np.asarray(ns, dtype=np.int32),
+                                   tokens=vt.tokens[:, 0, :])
+        for j, i in enumerate(idx):
+            floats[i] = (res.accuracy(j), res.avg_tokens_used(j))
     if cfg.save_cache is not None:
         cfg.save_cache(cache, cfg.cache_filename)
     results = []
-    for b, (token_limit, _key_limit, _n) in enumerate(budgets):
+    for i, (token_limit, _key_limit, _n) in enumerate(budgets):
         results.append({                                          # o1.py:278-283 / :303-307
             "token_limit": token_limit,
-            "accuracy": res.accuracy(b),
-            "avg_tokens_used": res.avg_tokens_used(b),
+            "accuracy": floats[i][0],
+            "avg_tokens_used": floats[i][1],
         })
     return results
 
@@ -174,4 +198,3 @@ __all__ = [
     "run_majority_vote_inference_experiments", "run_just_ask_nicely_experiments",
     "majority_vote_budgets", "just_ask_nicely_budgets", "default_engine",
 ]
-_ = np  # numpy types appear in the returned records (np.float64, like the reference's np.mean)

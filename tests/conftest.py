@@ -15,8 +15,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden():
     import json
+    from tests.golden import gen
     with open(os.path.join(REPO, "tests", "golden", "golden_o1.json")) as f:
-        return json.load(f)
+        g = json.load(f)
+    for case in g["cases"]:
+        gen.materialise(case)          # generator-backed cases: samples are rebuilt, not stored
+    return g
 
 
 @pytest.fixture(scope="session")

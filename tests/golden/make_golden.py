@@ -168,6 +168,27 @@ def direct_cases():
     return cases
 
 
+def generated_cases():
+    """Cases whose samples come from a closed-form generator (tests/golden/gen.py): the fixture stores the
+    generator parameters + what the reference returned, not the samples.  These reach the kernels the
+    small cases cannot: N in the thousands (register-resident and streaming kernels), rows that are not
+    16-byte aligned (N % 4 != 0), and problems with more than 24 distinct out-of-domain answers."""
+    from tests.golden import gen
+    specs = [
+        ("many_out_of_domain_40", {"kind": "many_out_of_domain", "seed": 5, "P": 12, "N": 64, "distinct": 40}),
+        ("many_out_of_domain_100", {"kind": "many_out_of_domain", "seed": 6, "P": 8, "N": 128, "distinct": 100}),
+        ("large_n_3000", {"kind": "large_n", "seed": 9, "P": 6, "N": 3000}),
+        ("large_n_4501", {"kind": "large_n", "seed": 10, "P": 6, "N": 4501}),
+        ("large_n_17001", {"kind": "large_n", "seed": 11, "P": 6, "N": 17001}),
+    ]
+    cases = []
+    for name, g in specs:
+        params = {k: v for k, v in g.items() if k != "kind"}
+        truths, samples = gen.GENERATORS[g["kind"]](**params)
+        cases.append({"name": name, "gen": g, "truths": truths, "samples": samples, "token_limit": 2048, "N": g["N"]})
+    return cases
+
+
 def main():
     consts = rh.reference_constants()
     truths, samples = pipeline_case(7)
@@ -182,7 +203,7 @@ def main():
                 logs[name] = f.read()
         out["pipeline"] = {"truths": [str(t) for t in truths], "samples": samples, "results_logs": logs}
 
-        for case in direct_cases():
+        for case in direct_cases() + generated_cases():
             ds = rh.make_dataset(case["truths"])
             cache = rh.build_cache(consts, ds, case["samples"])
             T, N = case["token_limit"], case["N"]
@@ -199,6 +220,8 @@ def main():
             case["accuracy_exact"] = [exact.numerator, exact.denominator]
             case["accuracy_live"] = repr(float(acc))
             case["avg_tokens_used"] = repr(float(avg))
+            if "gen" in case:
+                del case["samples"]                 # re-materialised from case["gen"] by tests/conftest.py
             out["cases"].append(case)
     path = os.path.join(HERE, "golden_o1.json")
     with open(path, "w") as f:

@@ -10,7 +10,7 @@ import pytest
 from o1_inference_scaling_laws_amd import dist as scv_dist
 from o1_inference_scaling_laws_amd import extract, o1_dropin, scoring, synth
 from oracle import coracle, pyoracle
-from tests._adapters import TEST_MODEL, TEST_PROMPT, OracleEngine, assert_results_equal
+from tests._adapters import TEST_MODEL, TEST_PROMPT, OracleEngine, assert_results_equal, build_cache, make_dataset
 
 
 def test_bucketing_matches_reference_restatement():
@@ -51,6 +51,35 @@ def test_domain_encoding_and_overflow():
         enc.encode(5000 + i)
     with pytest.raises(extract.DomainOverflow):
         enc.encode(99999)
+
+
+def test_more_than_24_out_of_domain_values_are_reencoded_densely_not_rejected():
+    """the reference accepts any int (o1.py:140); multimode only sees equality classes,
+    so a problem whose spare-bin dictionary would overflow is mapped injectively onto bins 0..k-1."""
+    import statistics
+    rng = random.Random(11)
+    eng = OracleEngine()
+    for trial in range(20):
+        N = rng.choice([40, 64, 128])
+        pool = [rng.choice([-1, 1]) * rng.randrange(1000, 10 ** 9) for _ in range(rng.randint(25, 60))]
+        truth = rng.randrange(1000)
+        votes = [rng.choice(pool + [truth, truth, 5, 7]) for _ in range(N)]
+        ds = make_dataset([str(truth)])
+        cache = build_cache(ds, [(0, 2048, i, v, 10 + i) for i, v in enumerate(votes)])
+        vt = extract.build_vote_tensors(ds, cache, [(2048, N)], TEST_MODEL, TEST_PROMPT)
+        if len({v for v in votes if not 0 <= v < 1000}) > 24:
+            assert 0 in vt.code_tables and vt.answers.max() < 1024 and vt.truth[0] == 0
+            assert [vt.code_tables[0][c] for c in vt.answers[0, 0]] == votes
+        res = eng.aggregate(vt.answers, vt.truth, tokens=vt.tokens, n_valid=vt.n_valid)
+        modes = statistics.multimode(votes)
+        assert int(res.cells["n_modes"][0, 0]) == len(modes)
+        assert bool(res.cells["hit"][0, 0]) == (truth in modes)
+        assert int(res.cells["truth_count"][0, 0]) == votes.count(truth)
+    # beyond 1024 distinct values in one problem there is no exact 1024-bin encoding: loud error
+    ds = make_dataset(["1"])
+    cache = build_cache(ds, [(0, 2048, i, 5000 + i, 1) for i in range(1100)])
+    with pytest.raises(extract.DomainOverflow):
+        extract.build_vote_tensors(ds, cache, [(2048, 1100)], TEST_MODEL, TEST_PROMPT)
 
 
 def test_encoded_cells_agree_with_multimode_on_arbitrary_ints():
@@ -172,3 +201,42 @@ def test_bootstrap_oracle_properties():
     assert rc != 0
     acc, lo, hi = scoring.bootstrap_percentiles(c1, 50)
     assert acc.shape == (20, 2) and (lo <= hi).all()
+
+
+def test_family_driver_sends_shared_pool_budgets_through_prefix_mode(tmp_path):
+    """o1.py:274-277: T >= 2^11 are prefixes of the 2048-token pool -> ONE prefix call [P, Nmax] + n_valid;
+    the single-sample budgets -> one dense call; records equal the all-dense path."""
+    calls = []
+
+    class Spy(OracleEngine):
+        def aggregate(self, answers, truth, **kw):
+            calls.append(("dense", np.asarray(answers).shape, None))
+            return super().aggregate(answers, truth, **kw)
+
+        def aggregate_prefix(self, pool, truth, n_valid, **kw):
+            calls.append(("prefix", np.asarray(pool).shape, [int(v) for v in n_valid]))
+            return super().aggregate_prefix(pool, truth, n_valid, **kw)
+
+    class DenseOnly:
+        def aggregate(self, *a, **k):
+            return OracleEngine().aggregate(*a, **k)
+
+    rng = random.Random(4)
+    truths = [rng.randrange(1000) for _ in range(9)]
+    ds = make_dataset([str(t) for t in truths])
+    samples = []
+    for p in range(9):
+        for T in [2 ** i for i in range(4, 11)]:
+            samples.append((p, T, 0, rng.choice([truths[p], 3, 4]), rng.randrange(100, 999)))
+        for idx in range(128):
+            samples.append((p, 2048, idx, rng.choice([truths[p], truths[p], 3, 4, 2000]), rng.randrange(100, 9999)))
+    cache = build_cache(ds, samples)
+    for shade, want_nv in ((False, [1, 2, 4, 8]), (True, [1, 2, 4, 8, 16, 32, 64, 128])):
+        calls.clear()
+        cfg = o1_dropin.DropInConfig(model=TEST_MODEL, prompt=TEST_PROMPT, engine=Spy(), helper_folder=str(tmp_path))
+        got = o1_dropin._run_family(cfg, ds, cache, o1_dropin.majority_vote_budgets(shade))
+        assert sorted(c[0] for c in calls) == ["dense", "prefix"]
+        assert [c for c in calls if c[0] == "prefix"][0][1:] == ((9, want_nv[-1]), want_nv)
+        assert [c for c in calls if c[0] == "dense"][0][1] == (9, 7, 1)
+        cfg2 = o1_dropin.DropInConfig(model=TEST_MODEL, prompt=TEST_PROMPT, engine=DenseOnly(), helper_folder=str(tmp_path))
+        assert got == o1_dropin._run_family(cfg2, ds, cache, o1_dropin.majority_vote_budgets(shade))

@@ -12,6 +12,18 @@ from oracle import ref_harness as rh
 pytestmark = pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present")
 
 
+PNGS = ("accuracy_vs_tokens_no_shade_regions.png", "token_limit_vs_actual.png", "just_ask_nicely_tokens.png")
+
+
+def _image_hash(path):
+    """sha256 over (shape, decoded RGBA pixels): independent of PNG metadata chunks."""
+    import hashlib
+    import matplotlib.image as mpimg
+    import numpy as np
+    img = np.ascontiguousarray(mpimg.imread(path))
+    return hashlib.sha256(repr(img.shape).encode() + img.tobytes()).hexdigest()
+
+
 def _pipeline_inputs(seed=99):
     rng = random.Random(seed)
     truths = [rng.randrange(1000) for _ in range(30)]
@@ -38,6 +50,11 @@ def test_installed_dropin_reproduces_reference_logs(batched, oracle_engine):
                 for n in ("results_log_majority_vote.json", "results_log_just_ask_nicely.json")}
         for n in want:
             os.remove(os.path.join(workdir, "helpers", n))
+        # the PNGs the reference's own plot_* functions rendered from ITS records
+        # (plot_helpers.py:41-43, 56-57, 79-88; Agg backend, the reference's fixed figsize / dpi)
+        want_png = {n: _image_hash(os.path.join(workdir, "graphs", n)) for n in PNGS}
+        for n in PNGS:
+            os.remove(os.path.join(workdir, "graphs", n))
         import contextlib, io
         o1_dropin.install(o1, engine=oracle_engine, batched=batched)
         with contextlib.redirect_stdout(io.StringIO()):
@@ -45,7 +62,8 @@ def test_installed_dropin_reproduces_reference_logs(batched, oracle_engine):
             o1.run_just_ask_nicely_experiments(ds, cache)
         for n, text in want.items():
             assert open(os.path.join(workdir, "helpers", n)).read() == text, n
-        assert os.path.exists(os.path.join(workdir, "graphs", "accuracy_vs_tokens_no_shade_regions.png"))
+        for n, h in want_png.items():
+            assert _image_hash(os.path.join(workdir, "graphs", n)) == h, f"{n}: rendered pixels differ"
 
 
 def test_shade_regions_and_full_range_records_match(oracle_engine):
