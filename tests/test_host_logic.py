@@ -215,7 +215,7 @@ def test_family_driver_sends_shared_pool_budgets_through_prefix_mode(tmp_path):
 
         def aggregate_prefix(self, pool, truth, n_valid, **kw):
             calls.append(("prefix", np.asarray(pool).shape, [int(v) for v in n_valid]))
-            return super().aggregate_prefix(pool, truth, n_valid, **kw)
+            return OracleEngine().aggregate_prefix(pool, truth, n_valid, **kw)   # (the oracle's own prefix = its dense path)
 
     class DenseOnly:
         def aggregate(self, *a, **k):
