@@ -56,7 +56,11 @@ struct scv_ctx {
     int sorted = 1;          // traverse budgets in descending n_valid order
     int small_reg = 1;       // small path: 1 = register-resident variant for N <= 128 (measured +10 %), 2 = also for N <= 512 (measured slower)
     int tiny_n_max = 32;     // auto/small path: N <= this -> register-only kernel, several cells per wave
-    int small_n_max = 512;   // auto: N <= this -> wave-per-cell kernel (crossover measured: profiles/r01_crossover_d*.log)
+    int small_n_max = 512;   // auto (reg path off): N <= this -> wave-per-cell kernel (crossover measured: profiles/r01_crossover_d*.log)
+    int reg_km = 1;          // reg path: batches in flight per wave = km x 4 KiB
+    int reg_shape = 0;       // reg path: force a kernel shape (A/B runs), see launch_aggregate
+    int reg_dense4 = 0;      // reg path, 512 < N <= 1024: 1 = dense bin scan instead of the sparse read-back (A/B option)
+    int reg_n_max = 4096;    // auto: 32 < N <= this -> register-resident cells kernel (scv_reg_cells); 0 = off (round-1 dispatch)
     bool user_tuned = false; // set_tuning called: auto geometry off
     // split-N scratch (grown on demand)
     void* d_partial = nullptr;
@@ -128,6 +132,35 @@ KernelFn pick_t(int t, int u, bool tok) {
     default: return pick_u<RL2, 512>(u, tok);
     }
 }
+template <int G, int V, int K, bool DENSE>
+KernelFn pick_reg_gv(bool tok, bool vec) {
+    if (tok) return vec ? (KernelFn)scv::scv_reg_cells<G, V, K, true, true, DENSE> : (KernelFn)scv::scv_reg_cells<G, V, K, true, false, DENSE>;
+    return vec ? (KernelFn)scv::scv_reg_cells<G, V, K, false, true, DENSE> : (KernelFn)scv::scv_reg_cells<G, V, K, false, false, DENSE>;
+}
+// lanes per cell g, 16-byte vectors per lane v (capacity 4*g*v votes); short cells run K = 4 / v batches per
+// iteration (4 KiB of votes in flight per wave behind the batch being counted -- measured: 8 KiB is slower, the
+// waves wait on LDS, not on memory).
+template <int KM>
+KernelFn pick_reg_km(int g, int v, bool tok, bool vec) {
+    if (g == 16) return v == 1 ? pick_reg_gv<16, 1, 4 * KM, false>(tok, vec) : (v == 2 ? pick_reg_gv<16, 2, 2 * KM, false>(tok, vec) : pick_reg_gv<16, 4, KM, false>(tok, vec));
+    if (g == 32) return v == 1 ? pick_reg_gv<32, 1, 4 * KM, false>(tok, vec) : (v == 2 ? pick_reg_gv<32, 2, 2 * KM, false>(tok, vec) : pick_reg_gv<32, 4, KM, false>(tok, vec));
+    return v == 1 ? pick_reg_gv<64, 1, 4 * KM, false>(tok, vec) : (v == 2 ? pick_reg_gv<64, 2, 2 * KM, false>(tok, vec) : pick_reg_gv<64, 4, KM, false>(tok, vec));
+}
+KernelFn pick_reg_kernel(int g, int v, bool tok, bool vec, bool dense4, int km) {
+    if (g == 64 && v == 4 && dense4) return pick_reg_gv<64, 4, 1, true>(tok, vec);
+    return km == 4 ? pick_reg_km<4>(g, v, tok, vec) : (km == 2 ? pick_reg_km<2>(g, v, tok, vec) : pick_reg_km<1>(g, v, tok, vec));
+}
+// long cells: V vectors per lane per part, H parts per cell (capacity 256 * V * H votes), dense bin scan
+template <int V, int H>
+KernelFn pick_dense_vh(bool tok, bool vec) {
+    if (tok) return vec ? (KernelFn)scv::scv_reg_dense<V, H, true, true> : (KernelFn)scv::scv_reg_dense<V, H, true, false>;
+    return vec ? (KernelFn)scv::scv_reg_dense<V, H, false, true> : (KernelFn)scv::scv_reg_dense<V, H, false, false>;
+}
+KernelFn pick_dense_kernel(int v, int h, bool tok, bool vec) {
+    if (v == 4) return h == 1 ? pick_dense_vh<4, 1>(tok, vec) : (h == 2 ? pick_dense_vh<4, 2>(tok, vec) : pick_dense_vh<4, 4>(tok, vec));
+    return h == 1 ? pick_dense_vh<8, 1>(tok, vec) : pick_dense_vh<8, 2>(tok, vec);
+}
+
 KernelFn pick_kernel(int copies, int t, int u, bool tok) {
     switch (copies) {
     case 4: return pick_t<2>(t, u, tok);
@@ -207,7 +240,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.plain_loads = ctx->plain_loads;
     a.prefetch = ctx->prefetch;
     a.sorted = ctx->sorted;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0;
     const bool tok = tokens != nullptr;
 
     // per-budget counters: fused per-cell atomics for few cells, a separate reduction of the cell
@@ -243,10 +276,62 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     };
 
     int path = ctx->path;
-    if (path == 0) path = (N <= ctx->small_n_max) ? 3 : 1;
+    if (path == 0) {
+        if (N > ctx->tiny_n_max && N <= ctx->reg_n_max) path = 4;
+        else path = (N <= ctx->small_n_max) ? 3 : 1;
+    }
+    if (path == 4 && (N > 4096 || N < 1)) path = (N <= ctx->small_n_max) ? 3 : 1;   // forced reg path outside its range
 
     EventPair* ev = nullptr;
     if (int rc = next_event_pair(ctx, &ev)) return rc;
+
+    if (path == 4) {
+        // ---- register-resident cells: single-wave workgroups, 16 KiB of LDS each, 8 per CU
+        const bool vec = (N % 4 == 0) && (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0);
+        // shape of the kernel from N; the "reg_shape" option forces one for A/B runs:
+        // g*100 + v (sparse: g lanes per cell, v vectors per lane) or 1000 + v*10 + h (dense: h parts of v vectors)
+        int g = 0, v = 0, h = 0;
+        if (N <= 64) { g = 16; v = 1; }
+        else if (N <= 128) { g = 16; v = 2; }
+        else if (N <= 256) { g = 16; v = 4; }
+        else if (N <= 512) { g = 32; v = 4; }
+        else if (N <= 1024) { g = 64; v = 4; }
+        else if (N <= 2048) { v = 8; h = 1; }
+        else { v = 8; h = 2; }
+        if (ctx->reg_shape >= 1000) {
+            const int fv = (ctx->reg_shape - 1000) / 10, fh = ctx->reg_shape % 10;
+            if ((fv == 4 && (fh == 1 || fh == 2 || fh == 4) || fv == 8 && (fh == 1 || fh == 2)) && (int64_t)256 * fv * fh >= N) { g = 0; v = fv; h = fh; }
+        } else if (ctx->reg_shape > 0) {
+            const int fg = ctx->reg_shape / 100, fv = ctx->reg_shape % 100;
+            if ((fg == 16 || fg == 32 || fg == 64) && (fv == 1 || fv == 2 || fv == 4) && (int64_t)4 * fg * fv >= N) { g = fg; v = fv; h = 0; }
+        }
+        const int64_t cpw = h ? 1 : 64 / g;
+        const int64_t nbatches = (ncells + cpw - 1) / cpw;
+        constexpr int WPG = scv::kRegWavesPerWG;
+        a.wave_lds_words = (int32_t)(scv::kRegWaveWords + (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0));
+        const size_t lds = (size_t)WPG * a.wave_lds_words * sizeof(uint32_t);
+        KernelFn fn = h ? pick_dense_kernel(v, h, tok, vec) : pick_reg_kernel(g, v, tok, vec, ctx->reg_dense4 != 0, ctx->reg_km);
+        SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // The grid is persistent, so it must not exceed what is resident at once (a surplus workgroup would start
+        // only when another one has finished ALL its batches: measured 2x).  Ask the runtime.
+        int per_cu = 0;
+        SCV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), WPG * 64, lds));
+        if (per_cu < 1) per_cu = 1;
+        int64_t grid = (int64_t)ctx->num_cus * per_cu;                     // workgroups of WPG independent waves
+        if (ctx->grid_override > 0) grid = ctx->grid_override;
+        const int64_t wgs_needed = (nbatches + WPG - 1) / WPG;
+        if (grid >= wgs_needed) grid = wgs_needed;
+        else {
+            // a wave strides over the batches by grid * WPG: keep the stride coprime with B so that every wave
+            // visits every budget (ragged n_valid would otherwise give some waves only the long budgets)
+            auto gcd = [](int64_t x, int64_t y) { while (y) { const int64_t t = x % y; x = y; y = t; } return x; };
+            while (grid > 1 && gcd(grid * WPG, B) != 1 && gcd(grid, B) != 1) --grid;
+        }
+        if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+        hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(WPG * 64), lds, ctx->stream, a);
+        SCV_HIP(hipGetLastError());
+        return finish(ev);
+    }
 
     if (path == 3 && N <= ctx->tiny_n_max && N <= 32) {
         // ---- tiny cells: 64/G cells per wave, registers only
@@ -375,7 +460,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
     a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.prefetch = 0; a.sorted = 1;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
     const bool use_reduce = want_counters && reduce_counters_separately(ctx, ncells, B, N);
@@ -583,7 +668,11 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "stagger_vecs")) { if (value < 0 || value > (1 << 28)) return fail(SCV_ERR_ARG, "stagger out of range"); ctx->stagger_vecs = (int)value; }
     else if (!strcmp(key, "plain_loads")) ctx->plain_loads = value != 0;
     else if (!strcmp(key, "prefetch")) ctx->prefetch = value != 0;
-    else if (!strcmp(key, "path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "path must be 0..3"); ctx->path = (int)value; }
+    else if (!strcmp(key, "path")) { if (value < 0 || value > 4) return fail(SCV_ERR_ARG, "path must be 0..4"); ctx->path = (int)value; }
+    else if (!strcmp(key, "reg_dense4")) ctx->reg_dense4 = value != 0;
+    else if (!strcmp(key, "reg_km")) { if (value != 1 && value != 2 && value != 4) return fail(SCV_ERR_ARG, "reg_km must be 1, 2 or 4"); ctx->reg_km = (int)value; }
+    else if (!strcmp(key, "reg_shape")) { if (value < 0 || value > 9999) return fail(SCV_ERR_ARG, "reg_shape out of range"); ctx->reg_shape = (int)value; }
+    else if (!strcmp(key, "reg_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "reg_n_max < 0"); ctx->reg_n_max = (int)(value > 4096 ? 4096 : value); }
     else if (!strcmp(key, "segs")) { if (value < 0 || value > 4096) return fail(SCV_ERR_ARG, "segs out of range"); ctx->segs_override = (int)value; }
     else if (!strcmp(key, "sorted")) ctx->sorted = value != 0;
     else if (!strcmp(key, "small_reg")) ctx->small_reg = (int)(value < 0 ? 0 : (value > 2 ? 2 : value));

@@ -36,6 +36,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/scvote.h"
 
 namespace scv {
@@ -64,6 +66,7 @@ struct AggArgs {
     int32_t sorted;         // != 0: traverse budgets in descending n_valid order
     int32_t segs;           // split-N: segments per cell (1 = whole cells)
     int64_t seg_len;        // split-N: votes per segment
+    int32_t wave_lds_words; // register-resident kernels: LDS words per wave (histograms + n_valid cache)
     uint32_t* partial;      // split-N: [ncells * segs][1024] partial histograms
     long long* partial_tok; // split-N: [ncells * segs] partial token sums
 };
@@ -966,6 +969,591 @@ __global__ __launch_bounds__(256) void scv_tiny_cells(const AggArgs a) {
                 if (a.truth_sum) atomicAdd(&a.truth_sum[b_k[k]], (unsigned long long)tc);
             }
         }
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+}
+
+// ---- kernel 1g: register-resident cells (32 < N <= 4096), no barrier, no fold ---------------------
+//
+// PMC of the round-1 kernels in this range (profiles/r02_regimes_pmc_baseline.md): the wave-per-cell
+// kernels spend 37-76 % of their wave cycles parked on memory (every pass re-reads the cell, one cell
+// in flight per wave) and ~100 VALU + 40 SALU instructions of fixed work per cell; the streaming kernel
+// pays a 1024*R-word fold, three workgroup barriers and ~9000 SALU instructions per wave at N = 1-4 K.
+//
+// Here a cell lives in REGISTERS: it occupies G = 16 / 32 / 64 adjacent lanes (C = 64/G cells per wave)
+// and every lane holds V 16-byte vectors of it (capacity 4*G*V votes); the vectors of the NEXT batch of
+// cells are loaded into a second register set before the current batch is counted, so a wave always
+// has a whole batch (up to 16 KiB) in flight and never waits on memory with nothing to do.  Workgroups
+// are single waves: no barrier exists in the kernel.  Every cell slot of the wave owns a private
+// histogram in LDS, 1024 bins x R copies with R = G/16 (16 KiB per wave whatever G; a vote goes to copy
+// lane % R, so all-equal votes are at most 16-way same-address -- above the HBM rate, see DESIGN), and
+// only the bins a cell votes for are ever touched (sparse read-back, sparse clear):
+//   pass 1  h[bin][copy] += 1                                (ds_add_u32; inactive votes go to a trash word)
+//   pass 2  key = (sum over copies of h[bin]) << 10 | (1023 - bin), in place of the vote; running max
+//           -> one group reduction gives max_count AND the smallest modal bin
+//   pass 3  #keys >= max_count << 10, divided by max_count = len(statistics.multimode); h[truth]
+//   pass 4  h[bin][copy] = 0 for every vote
+// LDS operations of one wave execute in order, so the passes need no waits between them.  The
+// histogram is indexed by 1023 - bin so that the key's low bits are the histogram index.
+
+template <int G>
+__device__ __forceinline__ uint32_t cellgroup_max(uint32_t v) {
+    uint32_t t;
+    t = dpp_mov<kQuadXor1>(v); v = v > t ? v : t;
+    t = dpp_mov<kQuadXor2>(v); v = v > t ? v : t;
+    t = dpp_mov<kHalfMirror>(v); v = v > t ? v : t;
+    t = dpp_mov<kRowMirror>(v); v = v > t ? v : t;
+    if (G >= 32) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); v = r[0] > r[1] ? r[0] : r[1]; }
+    if (G >= 64) { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); v = r[0] > r[1] ? r[0] : r[1]; }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ uint32_t cellgroup_sum(uint32_t v) {
+    v += dpp_mov<kQuadXor1>(v);
+    v += dpp_mov<kQuadXor2>(v);
+    v += dpp_mov<kHalfMirror>(v);
+    v += dpp_mov<kRowMirror>(v);
+    if (G >= 32) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); v = r[0] + r[1]; }
+    if (G >= 64) { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); v = r[0] + r[1]; }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ long long cellgroup_sum_i64(long long v) {    // limbs as in wave_sum_i64
+    const unsigned long long u = (unsigned long long)v;
+    const unsigned long long s0 = cellgroup_sum<G>((uint32_t)(u & 0x3fffffu));
+    const unsigned long long s1 = cellgroup_sum<G>((uint32_t)((u >> 22) & 0x1fffffu));
+    const unsigned long long s2 = cellgroup_sum<G>((uint32_t)((u >> 43) & 0x1fffffu));
+    return (long long)(s0 + (s1 << 22) + (s2 << 43));
+}
+
+// key = count << kKeyShift | LDS byte address: 4 waves x 16.4 KB of LDS per workgroup need 17 address bits; counts are <= 4096 (13 bits)
+constexpr int kKeyShift = 17;
+constexpr uint32_t kKeyMask = (1u << kKeyShift) - 1u;
+constexpr int kRegCellBins = 1025;                   // 1024 bins + one trash bin that absorbs the votes of inactive lanes
+constexpr int kRegHistWords = 4 * kRegCellBins;      // per wave: C cells x 1025 bins x R copies, C * R = 4
+constexpr int kRegWaveWords = kRegHistWords + 64;    // + one word per lane: the "wide truth bin" (see below)
+constexpr int kRegWavesPerWG = 4;                    // independent waves per workgroup (one per SIMD)
+
+// Per-vote state is ONE register holding the LDS byte address A of the vote's bin (all copies):
+//   A = cellbase + ((1023 - bin) << S), S = log2(4 R)   -> ds_add at A | copy*4, ds_read_b{32,64,128} at A,
+//   key = count << 17 | A                                 -> ds_write at (key & 0x7fff) | copy*4
+// so a full cell costs ~13 instructions per vote: or (domain) . min . mad . or . ds_add | ds_read . 2 add .
+// lshl_or . max | cmp . addc | and_or . ds_write.  A is < 16400 + base < 2^15, counts are <= 4096 < 2^13.
+// LDS is addressed through address_space(3) pointers built from integers, so constant parts of an address
+// land in the instruction's offset field instead of a VALU add.
+//
+// Votes for the cell's TRUTH value do not go to the histogram: each lane counts them in a word of its own (the
+// "wide truth bin", 64 words per wave).  truth_count is needed anyway (pass@k's c, and the hit test), and the
+// truth is the one value known per cell before looking at the data that is usually the hot one -- in the
+// peaked distributions (and in the reference's real data whenever the majority is right) 40-70 % of a cell's
+// votes are the truth, i.e. up to 16 lanes of one ds_add on the same copy of the same bin, serialised.
+// Measured before this: peaked 2.6 / 3.3 / 4.3 / 5.5 TB/s at N = 256 / 1024 / 2048 / 4096 against 3.9 / 3.9 /
+// 5.5 / 6.4 uniform.  The histogram then holds every value but the truth (whose bin stays 0) and the
+// epilogue merges the two: max_count = max(hist max, truth_count), the truth joins the modes on a tie.
+//
+// DENSE (G = 64, long cells): after pass 1 the votes are dead; every lane scans its 16 bins (x = lane + 64 j:
+// consecutive lanes read consecutive 16-byte slots, conflict-free ds_read_b128 with immediate offsets), so the
+// per-vote cost is pass 1 alone (~5 instructions) and the rest is a fixed ~110 instructions per cell --
+// cheaper than the sparse read-back from ~24 votes per lane up; len(multimode) is then a count of BINS.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t scv_v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t scv_v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) scv_v2u lds_v2u;
+typedef __attribute__((address_space(3))) scv_v4u lds_v4u;
+
+template <int R>
+__device__ __forceinline__ uint32_t lds_count(uint32_t A) {
+    if (R == 4) { const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)A); return q.x + q.y + q.z + q.w; }
+    if (R == 2) { const scv_v2u q = *reinterpret_cast<lds_v2u*>((uintptr_t)A); return q.x + q.y; }
+    return *reinterpret_cast<lds_u32*>((uintptr_t)A);
+}
+__device__ __forceinline__ void lds_add1(uint32_t addr) {
+    __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>((uintptr_t)addr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// KB - (vm << S) in one VALU instruction (the compiler prefers shift + subtract)
+template <int S>
+__device__ __forceinline__ uint32_t bin_address(uint32_t KB, uint32_t vm) {
+    uint32_t A;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(A) : "v"(vm), "n"(-(1 << S)), "v"(KB));
+    return A;
+}
+
+// G lanes per cell, V 16-byte vectors per lane, K batches of C cells per loop iteration (short cells: more
+// bytes in flight per wave), TOK tokens stream, VEC rows are 16-byte aligned (N % 4 == 0 and aligned bases:
+// dwordx4 loads); !VEC takes dword loads with a lane-contiguous element order.
+template <int G, int V, int K, bool TOK, bool VEC, bool DENSE>
+__global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_cells(const AggArgs a) {
+    static_assert(!DENSE || G == 64, "the dense scan owns a whole wave per cell");
+    constexpr int C = 64 / G;                 // cells per wave per batch
+    constexpr int R = G / 16;                 // histogram copies per cell
+    constexpr int S = R == 4 ? 4 : (R == 2 ? 3 : 2);   // log2(bytes per bin)
+    constexpr int E = 4 * V;                  // votes per lane per batch
+    constexpr uint32_t CAP = 4u * G * V;      // votes per cell slot
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_wg[];
+    // The waves of a workgroup are independent (no barrier anywhere); they are grouped only so that the hardware
+    // spreads them evenly over the 4 SIMDs: single-wave workgroups were measured to pile up (3+3+1+1), leaving
+    // the kernel bound by its most crowded SIMD at ~75 % average residency.
+    const int lane = threadIdx.x & 63;
+    uint32_t* smem = smem_wg + (threadIdx.x >> 6) * a.wave_lds_words;
+    const uint32_t base = (uint32_t)(uintptr_t)(lds_u32*)smem;   // LDS byte offset of this wave's region
+    const int sub = lane / G, l = lane % G;
+    {
+        uint4* h4 = reinterpret_cast<uint4*>(smem);
+        for (int i = lane; i < kRegWaveWords / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
+    }
+    const uint32_t cellbase = base + (uint32_t)sub * (uint32_t)(kRegCellBins * R * 4);   // bytes
+    const uint32_t KB = cellbase + (1023u << S);        // address of bin 0 (histogram index 1023)
+    const uint32_t ATR = cellbase + (1024u << S);       // trash bin
+    const uint32_t copy4 = ((uint32_t)l & (R - 1)) * 4u;
+    const uint32_t TW = base + (uint32_t)kRegHistWords * 4u + (uint32_t)lane * 4u;   // this lane's word of the wide truth bin
+    // n_valid[B] cached behind the histograms (host sizes the region; B > kMaxSortedB reads it from memory):
+    // a global load here would put a dependent memory round trip in front of every batch's loads
+    uint32_t* nv_lds = smem + kRegWaveWords;
+    const bool nv_cached = a.n_valid && a.B <= kMaxSortedB;
+    if (nv_cached)
+        for (int i = lane; i < a.B; i += 64) nv_lds[i] = (uint32_t)valid_len(a, i);
+    __builtin_amdgcn_wave_barrier();
+
+    struct Batch {
+        uint32_t v[E];        // votes (loaded) -> bin address A (pass 1) -> key (pass 2)
+        int64_t cell;
+        int32_t b, truth;
+        uint32_t n;           // valid votes of this lane's cell (0 when the slot is past the last cell)
+    };
+    const int64_t nwaves = (int64_t)gridDim.x * kRegWavesPerWG;
+    const int64_t wave = (int64_t)blockIdx.x * kRegWavesPerWG + (threadIdx.x >> 6);
+    const int64_t stride = nwaves * C;                               // cells between consecutive batches of this wave
+    int64_t ncell = wave * C + sub;                                  // walker state of the NEXT batch to load
+    int64_t np = ncell / a.B;
+    int32_t nb = (int32_t)(ncell - np * a.B);
+    const int64_t dp = stride / a.B;
+    const int32_t db = (int32_t)(stride - dp * a.B);
+
+    auto element = [&](int k, int j) -> uint32_t {                  // index of vote (k, j) of this lane inside its cell
+        return VEC ? (uint32_t)((k * G + l) * 4 + j) : (uint32_t)((k * 4 + j) * G + l);
+    };
+    // Loads are UNCONDITIONAL (a vote past the valid prefix re-reads element 0 of the row; a slot past the last
+    // cell reads cell 0): the number of loads per batch is then a compile-time constant, so the compiler can
+    // wait for the current batch with s_waitcnt vmcnt(<loads of the next batch>) instead of vmcnt(0) --
+    // with predicated loads it cannot, and the prefetch would be drained before every batch.
+    auto load = [&](Batch& t) {                                     // issues loads only
+        t.cell = ncell; t.b = nb;
+        const bool live = ncell < a.ncells;
+        const int32_t bb = live ? nb : 0;
+        t.n = live ? (nv_cached ? nv_lds[bb] : (uint32_t)valid_len(a, bb)) : 0u;
+        t.truth = a.truth[live ? np : 0];
+        const int32_t* row = a.answers + (live ? ncell : 0) * a.N;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            if (VEC) {
+                const uint32_t vi = element(k, 0) < t.n ? (uint32_t)(k * G + l) : 0u;
+                const int4 x = stream_load(reinterpret_cast<const int4*>(row) + vi);
+                t.v[4 * k] = (uint32_t)x.x; t.v[4 * k + 1] = (uint32_t)x.y; t.v[4 * k + 2] = (uint32_t)x.z; t.v[4 * k + 3] = (uint32_t)x.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t e = element(k, j);
+                    t.v[4 * k + j] = (uint32_t)__builtin_nontemporal_load(row + (e < t.n ? e : 0u));
+                }
+            }
+        }
+        ncell += stride; np += dp; nb += db;
+        if (nb >= a.B) { nb -= a.B; np += 1; }
+    };
+
+    uint32_t bad = 0;
+    // pass 1 (o1.py:181-195): h[bin][copy] += 1; inactive votes feed the trash bin.  FULL: every lane's cell has
+    // exactly CAP valid votes (wave-uniform), so no vote needs an activity predicate.
+    auto vote_pass = [&](Batch& c, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        // activity of vote i as a MASK, not a predicate (64 live SGPR pairs would spill): element(i) < n  <=>
+        // const_i < nl with the lane term moved to the right-hand side; m = all ones when active
+        const int32_t nl = (int32_t)c.n - (VEC ? 4 * l : l);
+        // address of the truth's bin; a vote is a truth vote iff its bin address equals it (inactive slots carry ATR)
+        const uint32_t AT = (c.truth >= 0 && c.truth < kBins) ? KB - ((uint32_t)c.truth << S) : 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const uint32_t v = c.v[i];
+            const uint32_t vm = v < 1023u ? v : 1023u;
+            uint32_t A = bin_address<S>(KB, vm);
+            if (FULL) bad |= v;
+            else {
+                const int32_t ci = VEC ? (i >> 2) * G * 4 + (i & 3) : i * G;
+                const uint32_t m = (uint32_t)((ci - nl) >> 31);
+                bad |= v & m;                                       // an inactive slot holds a re-read of element 0
+                A = (A & m) | (ATR & ~m);
+            }
+            if (!DENSE) c.v[i] = A;                                 // a truth vote keeps its bin address: that bin reads 0 later
+            // a vote for the truth goes to this lane's own word instead of the (shared, contended) histogram bin
+            lds_add1(A == AT ? TW : (A | copy4));
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // passes 2-4, sparse: read back the counts of the bins this lane voted for
+    auto sparse_passes = [&](Batch& c, auto full_tag, uint32_t& gkey, uint32_t& at_max, uint32_t& tc) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        uint32_t lmax = 0;
+        constexpr int CH = E > 16 ? 8 : E;                          // bound the registers held by reads in flight
+#pragma unroll
+        for (int i0 = 0; i0 < E; i0 += CH) {
+            // all CH reads are issued before the first count is consumed (left alone, the scheduler keeps only
+            // two ds_reads in flight and the pass becomes a chain of LDS latencies: measured 48 % wave-wait)
+            uint32_t cn[CH];
+#pragma unroll
+            for (int i = i0; i < i0 + CH; ++i) cn[i - i0] = lds_count<R>(c.v[i]);
+            __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, CH, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2 /* VALU */, CH * 6, 0);
+#pragma unroll
+            for (int i = i0; i < i0 + CH; ++i) {
+                const uint32_t A = c.v[i];
+                uint32_t key = (cn[i - i0] << kKeyShift) | A;
+                if (!FULL) {                                            // A < ATR for every real bin: inactive -> key = ATR
+                    const uint32_t m = (uint32_t)((int32_t)(A - ATR) >> 31);   // (count 0, below every real key; pass 4
+                    key = (key & m) | (ATR & ~m);                       //  then clears the trash word, never another region)
+                }
+                c.v[i] = key;
+                lmax = key > lmax ? key : lmax;
+            }
+        }
+        gkey = cellgroup_max<G>(lmax);                              // every lane of the cell gets it
+        const uint32_t thr = gkey & ~kKeyMask;                       // max_count << kKeyShift
+        // pass 3 (statistics.py:599-601): votes at max -> number of distinct modes; h[truth]
+        at_max = 0;
+#pragma unroll
+        for (int i = 0; i < E; ++i) at_max += c.v[i] >= thr ? 1u : 0u;   // inactive keys have count 0: they only count when max_count == 0
+        tc = *reinterpret_cast<lds_u32*>((uintptr_t)TW);            // this lane's truth votes (summed over the cell below)
+        __builtin_amdgcn_wave_barrier();
+        // pass 4: sparse clear (an inactive vote's key addresses the trash bin)
+#pragma unroll
+        for (int i = 0; i < E; ++i) *reinterpret_cast<lds_u32*>((uintptr_t)((c.v[i] & kKeyMask) | copy4)) = 0u;
+        *reinterpret_cast<lds_u32*>((uintptr_t)TW) = 0u;
+        __builtin_amdgcn_wave_barrier();
+    };
+    // passes 2-4, dense (G = 64): lane scans histogram indices x = lane + 64 j
+    auto dense_passes = [&](Batch& c, uint32_t& gkey, uint32_t& at_max, uint32_t& tc) {
+        const uint32_t A0 = base + (uint32_t)lane * 16u;
+        uint32_t key[16];
+        uint32_t lmax = 0;
+#pragma unroll
+        for (int j0 = 0; j0 < 16; j0 += 8) {                        // 8 b128 reads (32 registers) in flight at a time
+#pragma unroll
+            for (int j = j0; j < j0 + 8; ++j) key[j] = lds_count<4>(A0 + 1024u * j);
+            __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2 /* VALU */, 8 * 5, 0);
+#pragma unroll
+            for (int j = j0; j < j0 + 8; ++j) {
+                key[j] = (key[j] << kKeyShift) | (A0 + 1024u * j);
+                lmax = key[j] > lmax ? key[j] : lmax;
+            }
+        }
+        tc = *reinterpret_cast<lds_u32*>((uintptr_t)TW);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) *reinterpret_cast<lds_v4u*>((uintptr_t)(A0 + 1024u * j)) = scv_v4u{0u, 0u, 0u, 0u};
+        *reinterpret_cast<lds_u32*>((uintptr_t)(ATR | copy4)) = 0u;        // keep the trash bin from wrapping
+        *reinterpret_cast<lds_u32*>((uintptr_t)TW) = 0u;
+        __builtin_amdgcn_wave_barrier();
+        gkey = cellgroup_max<64>(lmax);
+        const uint32_t thr = gkey & ~kKeyMask;
+        at_max = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) at_max += key[j] >= thr ? 1u : 0u;    // BINS at max (all 1024 when the cell is empty)
+    };
+
+    auto finish_cell = [&](const Batch& c, uint32_t gkey, uint32_t at_max, uint32_t tc_lane, long long tsum) {
+        const uint32_t hmax = gkey >> kKeyShift;                            // max count over every value but the truth
+        // (at_max, truth votes) summed over the cell in one reduction: both are <= 4096
+        const uint32_t sums = cellgroup_sum<G>(at_max | (tc_lane << 16));
+        const uint32_t sum_at_max = sums & 0xffffu, tc = sums >> 16;
+        long long tok = 0;
+        if (TOK) tok = cellgroup_sum_i64<G>(tsum);
+        if (l == 0 && c.cell < a.ncells) {
+            // merge (statistics.multimode over histogram values + the truth value): o1.py:202-206
+            const uint32_t maxc = tc > hmax ? tc : hmax;
+            const bool any = maxc > 0;
+            const uint32_t h_modes = hmax > 0 ? (DENSE ? sum_at_max : exact_quotient(sum_at_max, hmax)) : 0u;
+            const uint32_t h_min = 1023u - (((gkey & kKeyMask) - cellbase) >> S);
+            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;             // o1.py:206
+            const uint32_t n_modes = any ? (tc > hmax ? 1u : h_modes + hit) : 0u;
+            const uint32_t tv = (uint32_t)c.truth;                          // hit implies 0 <= truth < 1024
+            const uint32_t mm = tc > hmax ? tv : (hit && tv < h_min ? tv : h_min);
+            if (a.cells) {
+                uint4 rec;
+                rec.x = maxc;
+                rec.y = tc;
+                rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
+                rec.w = hit;
+                reinterpret_cast<uint4*>(a.cells)[c.cell] = rec;
+            }
+            if (a.cell_tokens) a.cell_tokens[c.cell] = tok;
+            if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)c.b * SCV_TIE_CLASSES + n_modes], 1ull);
+            if (TOK && a.token_sum) atomicAdd(&a.token_sum[c.b], (unsigned long long)tok);
+            if (a.truth_sum) atomicAdd(&a.truth_sum[c.b], (unsigned long long)tc);
+        }
+    };
+
+    // one loop step: count the batches in `cur` while the batches of `nxt` are in flight
+    auto step = [&](Batch (&cur)[K], Batch (&nxt)[K], bool more) {
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) load(nxt[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            Batch& c = cur[j];
+            const uint32_t n = c.n;
+            // tokens of the current batch: issued now, consumed after the LDS passes (only the sum is needed)
+            long long tsum = 0;
+            if (TOK) {
+                const int32_t* trow = a.tokens + (c.cell < a.ncells ? c.cell : 0) * a.N;
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    if (VEC) {
+                        const uint32_t vi = element(k, 0) < n ? (uint32_t)(k * G + l) : 0u;
+                        const int4 y = stream_load(reinterpret_cast<const int4*>(trow) + vi);
+                        tsum += (element(k, 0) < n ? (long long)y.x : 0) + (element(k, 1) < n ? (long long)y.y : 0)
+                              + (element(k, 2) < n ? (long long)y.z : 0) + (element(k, 3) < n ? (long long)y.w : 0);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint32_t e = element(k, q);
+                            const int32_t y = __builtin_nontemporal_load(trow + (e < n ? e : 0u));
+                            tsum += e < n ? (long long)y : 0;
+                        }
+                    }
+                }
+            }
+            uint32_t gkey, at_max, tc;
+            if (__all(n == CAP)) {
+                vote_pass(c, std::true_type{});
+                if (DENSE) dense_passes(c, gkey, at_max, tc); else sparse_passes(c, std::true_type{}, gkey, at_max, tc);
+            } else {
+                vote_pass(c, std::false_type{});
+                if (DENSE) dense_passes(c, gkey, at_max, tc); else sparse_passes(c, std::false_type{}, gkey, at_max, tc);
+            }
+            finish_cell(c, gkey, at_max, tc, tsum);
+        }
+    };
+
+    Batch bufa[K], bufb[K];
+    const int64_t nbatches = (a.ncells + C - 1) / C;
+    const int64_t istride = nwaves * K;
+    // iteration `it` of this wave covers batches it + j * nwaves, j < K (slots past the end count nothing);
+    // two buffers ping-pong so that no register copies are needed
+#pragma unroll
+    for (int j = 0; j < K; ++j) load(bufa[j]);
+    for (int64_t it = wave; it < nbatches; it += 2 * istride) {
+        step(bufa, bufb, it + istride < nbatches);
+        if (it + istride >= nbatches) break;
+        step(bufb, bufa, it + 2 * istride < nbatches);
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+}
+
+// ---- kernel 1h: register-streamed long cells (1024 < N <= 4096 and up), dense scan ----------------
+//
+// Same building blocks as scv_reg_cells with G = 64 (one wave per cell, R = 4 copies, no barrier), but a cell
+// is streamed in H parts of V vectors per lane: part s+1 is in flight while part s is voted, and since the
+// dense scan never looks at the votes again only 2 x 4V registers hold votes whatever the cell length
+// (N = 4096: 64 registers instead of 128 -> 2+ waves per SIMD instead of 1).  After the last part every lane
+// scans its 16 bins (ds_read_b128 at immediate offsets), zeroes them, and the wave reduces.
+template <int V, int H, bool TOK, bool VEC>
+__global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_dense(const AggArgs a) {
+    constexpr int S = 4;                      // 16 bytes per bin (4 copies)
+    constexpr int E = 4 * V;                  // votes per lane per part
+    constexpr uint32_t PART = 256u * V;       // votes per part
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_wg[];
+    const int lane = threadIdx.x & 63;
+    uint32_t* smem = smem_wg + (threadIdx.x >> 6) * a.wave_lds_words;   // independent waves, grouped for SIMD balance
+    const uint32_t base = (uint32_t)(uintptr_t)(lds_u32*)smem;
+    {
+        uint4* h4 = reinterpret_cast<uint4*>(smem);
+        for (int i = lane; i < kRegWaveWords / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
+    }
+    const uint32_t KB = base + (1023u << S);
+    const uint32_t ATR = base + (1024u << S);
+    const uint32_t copy4 = ((uint32_t)lane & 3u) * 4u;
+    const uint32_t A0 = base + (uint32_t)lane * 16u;
+    const uint32_t TW = base + (uint32_t)kRegHistWords * 4u + (uint32_t)lane * 4u;   // this lane's word of the wide truth bin
+    uint32_t* nv_lds = smem + kRegWaveWords;
+    const bool nv_cached = a.n_valid && a.B <= kMaxSortedB;
+    if (nv_cached)
+        for (int i = lane; i < a.B; i += 64) nv_lds[i] = (uint32_t)valid_len(a, i);
+    __builtin_amdgcn_wave_barrier();
+
+    struct Part {
+        uint32_t v[E];
+        int32_t tk[TOK ? E : 1];
+        uint32_t nrel;        // valid votes of the cell minus the votes before this part (may be <= 0 as int)
+    };
+    const int64_t nwaves = (int64_t)gridDim.x * kRegWavesPerWG;
+    const int64_t wave = (int64_t)blockIdx.x * kRegWavesPerWG + (threadIdx.x >> 6);
+    int64_t ncell = wave;                     // cell whose parts are being loaded
+    int64_t np = ncell / a.B;
+    int32_t nb = (int32_t)(ncell - np * a.B);
+    const int64_t dp = nwaves / a.B;
+    const int32_t db = (int32_t)(nwaves - dp * a.B);
+    uint32_t ln = 0;                          // valid_len of the cell being loaded
+    int lpart = 0;
+    auto begin_cell_load = [&]() {
+        const bool live = ncell < a.ncells;
+        const int32_t bb = live ? nb : 0;
+        ln = live ? (nv_cached ? nv_lds[bb] : (uint32_t)valid_len(a, bb)) : 0u;
+    };
+    auto element = [&](int k, int j) -> uint32_t {                  // index inside the part
+        return VEC ? (uint32_t)((k * 64 + lane) * 4 + j) : (uint32_t)((k * 4 + j) * 64 + lane);
+    };
+    // unconditional loads (constant count per part -> counted vmcnt waits), clamped to element 0 of the row
+    auto load_part = [&](Part& t) {
+        const bool live = ncell < a.ncells;
+        const int64_t rowoff = (live ? ncell : 0) * a.N + (int64_t)lpart * PART;
+        const int32_t nrel = (int32_t)ln - (int32_t)(lpart * PART);
+        t.nrel = (uint32_t)nrel;
+        const int32_t* row = a.answers + rowoff;
+        const int32_t* trow = TOK ? a.tokens + rowoff : nullptr;
+        const int64_t back = (int64_t)lpart * PART;                  // clamp target: element 0 of the row
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            if (VEC) {
+                const bool in = (int32_t)element(k, 0) < nrel;
+                const int4* src = in ? reinterpret_cast<const int4*>(row) + (k * 64 + lane) : reinterpret_cast<const int4*>(row - back);
+                const int4 x = stream_load(src);
+                t.v[4 * k] = (uint32_t)x.x; t.v[4 * k + 1] = (uint32_t)x.y; t.v[4 * k + 2] = (uint32_t)x.z; t.v[4 * k + 3] = (uint32_t)x.w;
+                if (TOK) {
+                    const int4* ts = in ? reinterpret_cast<const int4*>(trow) + (k * 64 + lane) : reinterpret_cast<const int4*>(trow - back);
+                    const int4 y = stream_load(ts);
+                    t.tk[4 * k] = y.x; t.tk[4 * k + 1] = y.y; t.tk[4 * k + 2] = y.z; t.tk[4 * k + 3] = y.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int32_t e = (int32_t)element(k, j);
+                    const int64_t off = e < nrel ? (int64_t)e : -back;
+                    t.v[4 * k + j] = (uint32_t)__builtin_nontemporal_load(row + off);
+                    if (TOK) t.tk[4 * k + j] = __builtin_nontemporal_load(trow + off);
+                }
+            }
+        }
+        if (++lpart == H) {
+            lpart = 0;
+            ncell += nwaves; np += dp; nb += db;
+            if (nb >= a.B) { nb -= a.B; np += 1; }
+            begin_cell_load();
+        }
+    };
+
+    uint32_t bad = 0;
+    long long tsum = 0;
+    auto vote_part = [&](const Part& c, uint32_t AT) {                 // AT: address of the truth's bin (or no address)
+        const int32_t nl = (int32_t)c.nrel - (VEC ? 4 * lane : lane);
+        if (__all((int32_t)c.nrel >= (int32_t)PART)) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const uint32_t v = c.v[i];
+                bad |= v;
+                const uint32_t A = bin_address<S>(KB, v < 1023u ? v : 1023u);
+                lds_add1(A == AT ? TW : (A | copy4));                           // truth votes: this lane's own word
+                if (TOK) tsum += c.tk[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const uint32_t v = c.v[i];
+                const int32_t ci = VEC ? (i >> 2) * 256 + (i & 3) : i * 64;
+                const uint32_t m = (uint32_t)((ci - nl) >> 31);                 // all ones when the vote is valid
+                bad |= v & m;
+                uint32_t A = bin_address<S>(KB, v < 1023u ? v : 1023u);
+                A = (A & m) | (ATR & ~m);
+                lds_add1(A == AT ? TW : (A | copy4));
+                if (TOK) tsum += (long long)(c.tk[i] & (int32_t)m);
+            }
+        }
+    };
+    auto finish_cell = [&](int64_t cell, int32_t b, int32_t truth) {
+        __builtin_amdgcn_wave_barrier();
+        uint32_t key[16];
+        uint32_t lmax = 0;
+#pragma unroll
+        for (int j0 = 0; j0 < 16; j0 += 8) {                        // 8 b128 reads (32 registers) in flight at a time
+#pragma unroll
+            for (int j = j0; j < j0 + 8; ++j) key[j] = lds_count<4>(A0 + 1024u * j);
+            __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2 /* VALU */, 8 * 5, 0);
+#pragma unroll
+            for (int j = j0; j < j0 + 8; ++j) {
+                key[j] = (key[j] << kKeyShift) | (A0 + 1024u * j);
+                lmax = key[j] > lmax ? key[j] : lmax;
+            }
+        }
+        const uint32_t tc_lane = *reinterpret_cast<lds_u32*>((uintptr_t)TW);   // this lane's truth votes
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) *reinterpret_cast<lds_v4u*>((uintptr_t)(A0 + 1024u * j)) = scv_v4u{0u, 0u, 0u, 0u};
+        *reinterpret_cast<lds_u32*>((uintptr_t)(ATR | copy4)) = 0u;        // keep the trash bin from wrapping
+        *reinterpret_cast<lds_u32*>((uintptr_t)TW) = 0u;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t gkey = cellgroup_max<64>(lmax);
+        const uint32_t thr = gkey & ~kKeyMask;
+        uint32_t at_max = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) at_max += key[j] >= thr ? 1u : 0u;    // BINS at max (<= 16 per lane)
+        const uint32_t bins_at_max = cellgroup_sum<64>(at_max);
+        const uint32_t tc = cellgroup_sum<64>(tc_lane);
+        long long tok = 0;
+        if (TOK) tok = cellgroup_sum_i64<64>(tsum);
+        tsum = 0;
+        if (lane == 0) {
+            // merge (statistics.multimode over histogram values + the truth value): o1.py:202-206
+            const uint32_t hmax = gkey >> kKeyShift;
+            const uint32_t maxc = tc > hmax ? tc : hmax;
+            const bool any = maxc > 0;
+            const uint32_t h_min = 1023u - (((gkey & kKeyMask) - base) >> S);
+            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;             // o1.py:206
+            const uint32_t n_modes = any ? (tc > hmax ? 1u : (hmax > 0 ? bins_at_max : 0u) + hit) : 0u;
+            const uint32_t tv = (uint32_t)truth;                            // hit implies 0 <= truth < 1024
+            const uint32_t mm = tc > hmax ? tv : (hit && tv < h_min ? tv : h_min);
+            if (a.cells) {
+                uint4 rec;
+                rec.x = maxc;
+                rec.y = tc;
+                rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
+                rec.w = hit;
+                reinterpret_cast<uint4*>(a.cells)[cell] = rec;
+            }
+            if (a.cell_tokens) a.cell_tokens[cell] = tok;
+            if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
+            if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
+            if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
+        }
+    };
+
+    // stream of parts: part q of this wave belongs to its cell number q / H; two buffers ping-pong
+    const int64_t my_cells = wave < a.ncells ? (a.ncells - wave + nwaves - 1) / nwaves : 0;
+    const int64_t nparts = my_cells * H;
+    int64_t ccell = wave;                     // cell being counted
+    int64_t cp = np;
+    int32_t cb = nb;
+    int cpart = 0;
+    int32_t ctruth = my_cells > 0 ? a.truth[cp] : 0;
+    auto count_part = [&](const Part& c) {
+        vote_part(c, (ctruth >= 0 && ctruth < kBins) ? KB - ((uint32_t)ctruth << S) : 0xffffffffu);
+        if (++cpart == H) {
+            cpart = 0;
+            finish_cell(ccell, cb, ctruth);
+            ccell += nwaves; cp += dp; cb += db;
+            if (cb >= a.B) { cb -= a.B; cp += 1; }
+            if (ccell < a.ncells) ctruth = a.truth[cp];
+        }
+    };
+    Part pa, pb;
+    begin_cell_load();
+    if (nparts > 0) load_part(pa);
+    for (int64_t q = 0; q < nparts; q += 2) {
+        if (q + 1 < nparts) load_part(pb);
+        count_part(pa);
+        if (q + 1 >= nparts) break;
+        if (q + 2 < nparts) load_part(pa);
+        count_part(pb);
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
 }

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1), ("small_n_max", 512),
             ("tiny_n_max", 32), ("small_reg", 1), ("prefetch", 1), ("stagger_vecs", 0), ("plain_loads", 0),
-            ("fused_counters_max", 4096))
+            ("fused_counters_max", 4096), ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0))
 
 
 def _draw(rng):
@@ -42,7 +42,7 @@ def _draw(rng):
         nv = np.where(rng.integers(0, 2, size=B) == 1, N, 0)
     opts = {}
     if rng.random() < 0.6:
-        opts["path"] = int(rng.integers(0, 4))
+        opts["path"] = int(rng.integers(0, 5))
         if opts["path"] == 2:
             opts["segs"] = int(rng.choice([0, 2, 3, 5, 16]))
     if rng.random() < 0.3:
@@ -59,6 +59,11 @@ def _draw(rng):
         opts["tiny_n_max"] = 0
     if rng.random() < 0.2:
         opts["small_reg"] = int(rng.integers(0, 3))
+    if rng.random() < 0.25:
+        opts["reg_n_max"] = int(rng.choice([0, 600]))            # round-1 dispatch below / above the register-resident range
+    if rng.random() < 0.4:                                       # forced register-kernel shape (ignored when its capacity is < N)
+        opts["reg_shape"] = int(rng.choice([1601, 1602, 1604, 3201, 3202, 3204, 6401, 6402, 6404, 1041, 1042, 1044, 1081, 1082]))
+        opts["reg_dense4"] = int(rng.integers(0, 2))
     tuning = None
     if rng.random() < 0.3:
         tuning = (int(rng.choice([4, 8, 16, 32])), int(rng.choice([256, 512, 1024])), int(rng.integers(1, 5)),

@@ -171,9 +171,53 @@ def _with_options(eng, opts):
                 eng.set_option(k, v)
         def __exit__(self_, *exc):
             for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
-                         ("small_n_max", 512), ("tiny_n_max", 32), ("small_reg", 1), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096)):
+                         ("small_n_max", 512), ("tiny_n_max", 32), ("small_reg", 1), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096),
+                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0)):
                 eng.set_option(k, v)
     return _Ctx()
+
+
+REG_SHAPES = [(700, 3, 33), (1200, 2, 64), (500, 4, 65), (301, 3, 100), (900, 2, 128), (333, 2, 129), (257, 4, 256), (200, 3, 257),
+              (150, 2, 500), (300, 3, 512), (90, 2, 513), (70, 3, 1000), (200, 2, 1024), (41, 2, 1025), (33, 3, 2047),
+              (100, 2, 2048), (20, 2, 2049), (19, 3, 3000), (17, 2, 4095), (60, 2, 4096)]
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", REG_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_register_resident_cells_path(hip_engine, dist, shape):
+    """scv_reg_cells: every (lanes per cell, vectors per lane, batches per iteration) variant, 16-byte aligned
+    rows and not (N % 4), tokens, ragged n_valid, all-equal votes (dist 2), small forced grids (many
+    iterations per wave) and the reduce-kernel / fused-counter branches."""
+    P, B, N = shape
+    a, t, tr = coracle.synth_fill(P, B, N, 900 + dist, dist, want_tokens=True)
+    nv = np.array([max(0, N - 3 * b) if b % 2 else N >> (b // 2) for b in range(B)], dtype=np.int32)
+    # every kernel shape whose capacity covers N: sparse g*100+v (4*g*v votes), dense 1000+10*v+h (256*v*h votes)
+    shapes = [g * 100 + v for g in (16, 32, 64) for v in (1, 2, 4) if 4 * g * v >= N]
+    shapes += [1000 + 10 * v + h for v, h in ((4, 1), (4, 2), (4, 4), (8, 1), (8, 2)) if 256 * v * h >= N]
+    pick = [shapes[(P + dist + i * 3) % len(shapes)] for i in range(3)]
+    for opts in ({"path": 4}, {"path": 4, "grid": 7, "fused_counters_max": 0, "reg_shape": pick[0]},
+                 {"path": 4, "grid": 64, "fused_counters_max": 1 << 30, "reg_shape": pick[1]}, {"path": 4, "reg_shape": pick[2], "reg_dense4": 1}):
+        with _with_options(hip_engine, opts):
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
+            assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+
+
+def test_register_resident_cells_spare_bins_ties_and_domain(hip_engine):
+    """bins 1000..1023 as modes, truth outside the histogram, 1024-way ties inside one cell, out-of-domain votes."""
+    rng = np.random.default_rng(12)
+    for N in (40, 200, 1024, 4096):
+        a = rng.integers(990, 1024, size=(50, 2, N), dtype=np.int32)
+        tr = rng.integers(-5, 1030, size=(50,), dtype=np.int32)
+        with _with_options(hip_engine, {"path": 4}):
+            assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
+    a = np.tile(np.arange(1024, dtype=np.int32), 4).reshape(1, 1, 4096).repeat(3, axis=0)
+    with _with_options(hip_engine, {"path": 4}):
+        got = hip_engine.aggregate(a, np.array([5, 1023, 2000], dtype=np.int32))
+        assert list(got.cells["n_modes"][:, 0]) == [1024] * 3 and list(got.cells["hit"][:, 0]) == [1, 1, 0]
+        bad = a.copy(); bad[1, 0, 77] = 1024
+        with pytest.raises(_lib.DomainError):
+            hip_engine.aggregate(bad, np.zeros(3, dtype=np.int32))
 
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3])

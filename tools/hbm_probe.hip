@@ -117,9 +117,10 @@ double time_ms(F f, int reps = 5) {
 
 int main(int argc, char** argv) {
     long ncells = 10000;
-    bool calib = false;
+    bool calib = false, shortcells = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--calib")) calib = true;
+        else if (!strcmp(argv[i], "--short")) shortcells = true;
         else ncells = atol(argv[i]);
     }
     const long cell_bytes = 4l << 20;
@@ -137,6 +138,23 @@ int main(int argc, char** argv) {
         return 0;
     }
     struct Cfg { int grid, threads; };
+    if (shortcells) {
+        // what a wave-per-batch kernel can pull: every wave streams 4 KiB (U = 4) or 8 KiB (U = 8) steps of its own,
+        // one step in flight behind the one being consumed; G waves per CU as 64- or 256-thread workgroups
+        const long cv = 256;                              // 4 KiB "cells"
+        const long nc = bytes / (cv * 16);
+        for (int wpc : {4, 8, 9, 12, 16, 24, 32}) {
+            for (int threads : {64, 256}) {
+                const int grid = 256 * wpc * 64 / threads;
+                double a4 = time_ms([&] { read_cells_pipe<4, true><<<grid, threads>>>(buf, cv * (threads / 64), nc / (threads / 64), sink); });
+                double a8 = time_ms([&] { read_cells_pipe<8, true><<<grid, threads>>>(buf, 2 * cv * (threads / 64), nc / (2 * threads / 64), sink); });
+                double a2 = time_ms([&] { read_cells_pipe<2, true><<<grid, threads>>>(buf, cv / 2 * (threads / 64), 2 * nc / (threads / 64), sink); });
+                printf("short   %2d waves/CU as %3d-thread WGs : 2 KiB/step %6.0f | 4 KiB/step %6.0f | 8 KiB/step %6.0f GB/s\n", wpc, threads,
+                       bytes / a2 / 1e6, bytes / a4 / 1e6, bytes / a8 / 1e6);
+            }
+        }
+        return 0;
+    }
     const Cfg cfgs[] = {{250, 1024}, {256, 1024}, {500, 512}, {512, 512}, {1000, 256}, {2000, 256}};
     double best = 0;
     for (const Cfg& c : cfgs) {

@@ -56,13 +56,26 @@ def main():
         ("P=30 B=1 N=2^20", 30, 1, 1 << 20, False, None),
         ("P=1 B=1 N=2^24", 1, 1, 1 << 24, False, None),
         ("ragged D4 N>>(7-b)", 256, 8, 1 << 20, False, [(1 << 20) >> (7 - b) for b in range(8)]),
+        ("mid N=16384 P=8000", 8000, 4, 16384, False, None),
+        ("mid N=8192 P=16000", 16000, 4, 8192, False, None),
         ("mid N=4096 P=20000", 20000, 8, 4096, False, None),
+        ("mid N=4096 + tokens", 20000, 4, 4096, True, None),
+        ("mid N=2048 P=40000", 40000, 4, 2048, False, None),
+        ("mid N=1024 P=50000", 50000, 4, 1024, False, None),
+        ("mid N=1024 D2 degenerate", 50000, 4, 1024, False, None, 2),
+        ("mid N=1000 (rows not 16-B aligned: N=1001)", 50000, 4, 1001, False, None),
+        ("small N=512 P=100000", 100000, 4, 512, False, None),
         ("small N=256 P=100000", 100000, 4, 256, False, None),
+        ("small N=256 + tokens", 100000, 4, 256, True, None),
+        ("small N=128 P=200000", 200000, 4, 128, False, None),
         ("small N=64 P=200000", 200000, 4, 64, False, None),
+        ("tiny N=16 P=400000", 400000, 4, 16, False, None),
+        ("tiny N=8 P=400000", 400000, 4, 8, False, None),
         ("reference family 30x11x8", 30, 11, 8, True, [1] * 8 + [2, 4, 8]),
     ]
-    for name, P, B, N, tok, nv in cases:
-        r = run(eng, torch, P, B, N, tok, n_valid=nv)
+    for case in cases:
+        name, P, B, N, tok, nv = case[:6]
+        r = run(eng, torch, P, B, N, tok, n_valid=nv, dist=case[6] if len(case) > 6 else 1)
         r["name"] = name
         out.append(r)
         print(f"{name:28s} {str(r['shape']):22s} tok={int(tok)}  {r['median_us']:10.1f} us  {r['GBps']:8.1f} GB/s  {r['votes_per_s']:.3e} votes/s", flush=True)
