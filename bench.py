@@ -4,13 +4,18 @@
 Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1 under torch.distributed.run)
 prints ONE JSON line on rank 0.
 
-Workload = BASELINE.json config C3, "synthetic int32 answers P=10k x B=8 x N=2^20" (335.5 GB, does
+Default workload = BASELINE.json config C3, "synthetic int32 answers P=10k x B=8 x N=2^20" (335.5 GB, does
 not fit 288 GB of HBM), streamed in problem-chunks: a STEP is one pass of the hot path over one
 chunk of 1250 problems x 8 budgets x 2^20 samples (41.9 GB = the per-GPU shard of config C4), so
 --steps 8 at N=1 is the whole of C3 and --gpus 8 --steps 1 is C4.  Weak scaling: every rank streams
 its own 1250-problem chunk per step (problems sharded by contiguous block, global problem index
 feeds the generator), followed by ONE RCCL all-reduce of the packed int64 per-budget counters
 (65.7 KB) -- the only exchange step of the path.
+
+Other workloads (never the driver's default): --workload c2 (BASELINE config 2, P=30 x B=8 x N=2^17, >= 5
+distinct tensors cycled so the 256 MiB Infinity Cache cannot serve reruns) and --workload c5 (BASELINE config
+5: P=10k x N=2^20 sharded by problem -- strong scaling -- vote + counters all-reduce + cell all-gather +
+1000-resample bootstrap, pass@k sweep on the host; o1_inference_scaling_laws_amd/passk.py).
 
 Inputs are generated ON DEVICE (closed-form integer generator, include/scvote.h) and are resident
 in HBM before the timed region; `--resident` distinct chunks are cycled (each is 41.9 GB >> the
@@ -19,12 +24,19 @@ the headline; --dist 0/2/3 select uniform/degenerate/tie.
 
 The timed region is bracketed by barrier + torch.cuda.synchronize() on both sides; the kernel's own
 duration is taken from hipEvents recorded by the library on the launch stream (scv_drain_kernel_ns).
+
+cpu_baseline (rank 0, N=1): the reference's own arithmetic -- statistics.multimode + o1.py:204-213 scoring on
+Python int lists (oracle/pybaseline.py, run as a subprocess) -- on one host core and on a process pool over the
+host cores, on a bounded sample of the same workload; the C restatement (oracle/scv_oracle.c) is a secondary
+field.  The same leg is the checker: GPU cells of a timed chunk vs the C oracle (>= 256 problems x 8 budgets x
+2^20 votes) and vs the Python reference arithmetic.  It is the ONLY place bench.py touches oracle/.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,8 +48,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-HBM_COPY_CEILING_GBS = 6290.0  # measured float4 copy on the same chip (same guide)
 BYTES_PER_VOTE = 4             # one int32 read per sample-vote, nothing written per vote
+DISTS = {0: "D0 uniform", 1: "D1 peaked", 2: "D2 degenerate", 3: "D3 tie"}
 
 
 def parse():
@@ -45,18 +57,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["c3", "c2"], default="c3",
-                    help="c3 (default, the metric's configuration): 1250-problem chunks of P=10k x B=8 x N=2^20; "
-                         "c2: BASELINE config 2, P=30 x B=8 x N=2^17 (125.8 MB), >= 5 distinct tensors cycled so the "
-                         "256 MiB Infinity Cache cannot serve reruns")
-    ap.add_argument("--problems-per-step", type=int, default=1250)
+    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3")
+    ap.add_argument("--problems-per-step", type=int, default=1250, help="c3/c2: problems per rank per step")
+    ap.add_argument("--problems", type=int, default=10000, help="c5: total problems (sharded over the ranks)")
+    ap.add_argument("--resamples", type=int, default=1000, help="c5: bootstrap resamples (split over the ranks)")
     ap.add_argument("--budgets", type=int, default=8)
     ap.add_argument("--samples", type=int, default=1 << 20)
     ap.add_argument("--dist", type=int, default=1, help="0 uniform, 1 peaked (headline), 2 degenerate, 3 tie")
     ap.add_argument("--resident", type=int, default=2, help="distinct chunks kept in HBM and cycled")
     ap.add_argument("--tokens", action="store_true", help="also stream the tokens tensor (8 B/vote)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=5.0, help="single-core Python reference arithmetic")
+    ap.add_argument("--parity-problems", type=int, default=256, help="problems of the last timed chunk checked vs the C oracle")
     ap.add_argument("--copies", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--wg-per-cu", type=int, default=0)
@@ -68,58 +80,121 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--share-device", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 (1-GPU box, with --backend gloo) to exercise the multi-process path")
+    ap.add_argument("--dump", default=None, help="rank 0 writes the last step's integer outputs (.npz) for bit-exact comparisons")
     return ap.parse_args()
 
 
-def cpu_baseline(seconds: float, B: int, N: int, seed: int, dist: int, gpu_cells=None, p_offset: int = 0):
-    """The cpu_baseline leg -- the ONLY place bench.py touches oracle/ (test infrastructure).
+# ---- the cpu_baseline leg: the only code here that touches oracle/ (test infrastructure) -------------------
 
-    Times the oracle (C restatement of o1.py:181-247; kind "port") on ONE host core, on a bounded sample
-    of the same workload: the first 16 problems x B x N of chunk 0, regenerated by the same closed-form
-    generator, passed repeatedly until ~`seconds` of CPU work; and, as the checker, compares the GPU's
-    cell table for those 16 problems with the oracle's bit for bit.  Also times the reference's own
-    arithmetic (statistics.multimode + scoring, oracle/pyoracle.py) on one cell for context."""
+def check_cells_vs_c_oracle(gpu_cells, P_check, B, N, seed, dist, p_offset, tokens=None):
+    """GPU cell table rows [0, P_check) of a chunk vs oracle/scv_oracle.c on the regenerated inputs, in slabs of
+    32 problems (1 GiB at N = 2^20) spread over the host cores.  Exits on the first differing field."""
     import numpy as np
-    from oracle import coracle, pyoracle
-    P = 16 if gpu_cells is None else min(16, gpu_cells.shape[0])
-    a, _, tr = coracle.synth_fill(P, B, N, seed, dist, p_offset=p_offset)
-    parity = None
-    if gpu_cells is not None:
-        want = coracle.aggregate(a, tr)["cells"]
+    from oracle import coracle
+    threads = min(os.cpu_count() or 1, 64)
+    done = 0
+    while done < P_check:
+        n = min(32, P_check - done)
+        a, _, tr = coracle.synth_fill(n, B, N, seed, dist, p_offset=p_offset + done)
+        want = coracle.aggregate_mt(a, tr, threads)
+        assert want["rc"] == 0
         for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
-            if not np.array_equal(gpu_cells[f][:P], want[f]):
-                sys.exit(f"PARITY FAILURE field {f}: GPU cell table differs from the CPU oracle")
-        parity = f"bit-exact vs the CPU oracle on the first {P} problems of chunk 0 ({P * B} cells x {N} votes)"
-    coracle.aggregate(a[:1], tr[:1])
-    votes, t0 = 0, time.perf_counter()
-    while True:
-        out = coracle.aggregate(a, tr)
-        assert out["rc"] == 0
-        votes += a.size
-        dt = time.perf_counter() - t0
-        if dt >= seconds:
-            break
-    row = a[0, 0, : min(N, 1 << 18)].tolist()
-    t1 = time.perf_counter()
-    pyoracle.process_votes(row, [0] * len(row), int(tr[0]))
-    py_rate = len(row) / (time.perf_counter() - t1)
-    # context: the same port with the problems spread over every host core (OpenMP), a few passes
+            if not np.array_equal(gpu_cells[f][done:done + n], want["cells"][f]):
+                sys.exit(f"PARITY FAILURE field {f}: GPU cell table differs from the CPU oracle (problems {p_offset + done}..)")
+        done += n
+    return done
+
+
+def cpu_baseline(args, B, N, gpu_first_cells, first_off, gpu_last_cells, last_off, last_is_timed):
+    import numpy as np
+    from oracle import coracle
     cores = os.cpu_count() or 1
+    # (1) the checker: wide comparison of a TIMED chunk with the C oracle + the first 16 problems of the sanity pass
+    t0 = time.perf_counter()
+    n16 = check_cells_vs_c_oracle(gpu_first_cells, min(16, gpu_first_cells.shape[0]), B, N, args.seed, args.dist, first_off)
+    nwide = check_cells_vs_c_oracle(gpu_last_cells, min(args.parity_problems, gpu_last_cells.shape[0]), B, N, args.seed, args.dist, last_off)
+    t_check = time.perf_counter() - t0
+    # (2) the reference's arithmetic (Python, statistics.multimode) on one core and on a process pool
+    procs = min(cores, 64)
+    cmd = [sys.executable, "-m", "oracle.pybaseline", "--B", str(B), "--N", str(N), "--seed", str(args.seed), "--dist", str(args.dist),
+           "--p-offset", str(last_off), "--seconds", str(args.cpu_baseline_seconds), "--procs", str(procs)]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, timeout=600)
+    if out.returncode != 0:
+        sys.exit("python baseline failed: " + out.stderr[-2000:])
+    py = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    # ... and its results against the GPU cells: score = hit / n_modes (o1.py:206-210) for every problem it scored
+    checked_py = 0
+    for p_str, scores in py["scores"].items():
+        row = int(p_str) - last_off
+        if not 0 <= row < gpu_last_cells.shape[0]:
+            continue
+        for b, s in enumerate(scores):
+            c = gpu_last_cells[row, b]
+            want = (1.0 / int(c["n_modes"])) if c["hit"] else 0.0
+            if float(s) != want:
+                sys.exit(f"PARITY FAILURE vs statistics.multimode: problem {p_str} budget {b}: python {s} gpu {want}")
+        checked_py += 1
+    # (3) secondary: the C port, one core and OpenMP over problems
+    P1 = 4
+    a, _, tr = coracle.synth_fill(P1, B, N, args.seed, args.dist, p_offset=last_off)
+    coracle.aggregate(a[:1], tr[:1])
+    votes, t1 = 0, time.perf_counter()
+    while True:
+        assert coracle.aggregate(a, tr)["rc"] == 0
+        votes += a.size
+        dt = time.perf_counter() - t1
+        if dt >= min(3.0, args.cpu_baseline_seconds):
+            break
     threads = min(cores, 64)
-    Pm = 4 * threads
-    am, _, trm = coracle.synth_fill(Pm, B, N, seed, dist, p_offset=p_offset)
+    Pm = 2 * threads
+    am, _, trm = coracle.synth_fill(Pm, B, N, args.seed, args.dist, p_offset=last_off)
     coracle.aggregate_mt(am, trm, threads)
     t2, passes = time.perf_counter(), 0
-    while passes < 3 or time.perf_counter() - t2 < min(3.0, seconds / 4):
+    while passes < 2 or time.perf_counter() - t2 < 1.5:
         assert coracle.aggregate_mt(am, trm, threads)["rc"] == 0
         passes += 1
     mt_rate = passes * am.size / (time.perf_counter() - t2)
-    return {"parity": parity, "value": votes / dt, "unit": "sample-votes/s", "cores": 1, "kind": "port",
-            "all_cores": {"value": mt_rate, "threads": threads, "host_cores": cores,
-                          "sample": f"{Pm} problems x {B} x {N}, {passes} passes, OpenMP over problems"},
-            "sample": f"{P} problems x {B} budgets x {N} samples (same generator, dist {dist}), "
-                      f"{votes // a.size} passes, {dt:.1f} s of oracle/scv_oracle.c on 1 of {os.cpu_count()} host cores",
-            "python_multimode_votes_per_s": py_rate}
+    parity = (f"bit-exact: {nwide} problems x {B} budgets x {N} votes of {'the last TIMED' if last_is_timed else 'a'} chunk + {n16} of the "
+              f"sanity pass vs oracle/scv_oracle.c ({t_check:.1f} s); {checked_py} problems x {B} cells also vs statistics.multimode "
+              f"(score = hit / n_modes, o1.py:202-210)")
+    ps, pa = py["single"], py.get("all_cores")
+    base = {
+        "value": ps["votes_per_s"], "unit": "sample-votes/s", "cores": 1, "kind": "port",
+        "what": "the reference's arithmetic: statistics.multimode(answers) + o1.py:204-213 scoring on Python int lists "
+                "(oracle/pyoracle.py, line-by-line restatement of o1.py:181-213; the unmodified reference cannot travel to the GPU box)",
+        "sample": f"{ps['problems']} problems x {B} budgets x {N} samples of the workload's generator (dist {args.dist}), "
+                  f"{ps['timed_s']:.1f} s on 1 of {cores} host cores",
+        "all_cores": None if pa is None else {
+            "value": pa["votes_per_s"], "processes": pa["procs"], "host_cores": cores,
+            "sample": f"{pa['problems']} problems x {B} x {N}, one problem per process (multiprocessing), wall {pa['wall_s']:.2f} s"},
+        "c_port": {"value": votes / dt, "cores": 1, "what": "oracle/scv_oracle.c (C restatement, the bit-exactness comparator)",
+                   "sample": f"{P1} problems x {B} x {N}, {votes // a.size} passes, {dt:.1f} s",
+                   "all_cores": {"value": mt_rate, "threads": threads, "sample": f"{Pm} problems x {B} x {N}, {passes} passes, OpenMP over problems"}},
+    }
+    return parity, base
+
+
+# ---- helpers -------------------------------------------------------------------------------------------------
+
+def committed_evidence():
+    """Numbers measured in SEPARATE profiled runs of this command and committed under profiles/ (labelled as such
+    in the JSON line): HBM bytes per launch from the PMC counters, and the pure-read ceiling of the probe."""
+    import glob
+    ev = {"traffic": None, "traffic_source": None, "read_ceiling_gbs": None, "read_ceiling_source": None}
+    pmcs = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")))
+    if pmcs:
+        with open(pmcs[-1]) as f:
+            ev["traffic"] = json.load(f).get("hbm_traffic_bytes")
+        ev["traffic_source"] = (os.path.relpath(pmcs[-1], REPO) + ": separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py`; "
+                                "FETCH_SIZE x2 (gfx950), factor calibrated on a known-bytes read kernel: profiles/r02_fetch_size_calibration.json")
+    probes = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_probe.log")))
+    for path in reversed(probes):
+        for line in open(path):
+            if line.startswith("READ_CEILING_GBPS"):
+                ev["read_ceiling_gbs"] = float(line.split()[1])
+                ev["read_ceiling_source"] = os.path.relpath(path, REPO) + " (tools/hbm_probe.hip: best pure-read kernel over the same 41.9 GB, another box of the pool)"
+                return ev
+    return ev
 
 
 def main():
@@ -136,24 +211,38 @@ def main():
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    ndev = torch.cuda.device_count()
+    # preflight for N > 1: one GPU per rank, or say loudly why not (the 1-GPU test box shares cuda:0 on purpose)
+    if world > 1 and not args.share_device and ndev < world:
+        sys.exit(f"bench.py --gpus {world}: only {ndev} HIP device(s) visible; one rank per GPU is required "
+                 f"(--share-device exists for the 1-GPU test box only)")
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            rccl_ranks = dist.get_world_size()
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    from o1_inference_scaling_laws_amd import passk
+    from o1_inference_scaling_laws_amd.dist import CounterPipeline, shard_bounds
     from o1_inference_scaling_laws_amd.engine import AggregateResult, Engine, cells_from_torch, counters_size
 
+    c5 = args.workload == "c5"
     if args.workload == "c2":
         args.problems_per_step, args.budgets, args.samples = 30, 8, 1 << 17
         args.resident = max(args.resident, 5)
+    if c5:
+        args.budgets = 1
+        lo, hi = shard_bounds(args.problems, rank, world)
+        args.problems_per_step, args.resident = hi - lo, 1
     Pc, B, N = args.problems_per_step, args.budgets, args.samples
-    use_graph = bool(args.graph) and world == 1
+    use_graph = bool(args.graph) and world == 1 and not c5
     eng = Engine(device=local_rank, timing=not use_graph)     # hipEvent records cannot live inside a captured graph
     eng.set_tuning(args.copies, args.threads, args.wg_per_cu, args.unroll)
 
@@ -167,21 +256,28 @@ def main():
         sys.exit(f"one chunk ({chunk_bytes / 1e9:.1f} GB) does not fit in free HBM ({free_b / 1e9:.1f} GB)")
     slots = []
     for s in range(R):
-        p_off = (s * world + rank) * Pc          # global problem index of this rank's block in chunk s
+        # global problem index of this rank's block: chunk s of a weak-scaling run, or the rank's shard of C5
+        p_off = shard_bounds(args.problems, rank, world)[0] if c5 else (s * world + rank) * Pc
         ans = torch.empty((Pc, B, N), dtype=torch.int32, device=dev)
         tok = torch.empty((Pc, B, N), dtype=torch.int32, device=dev) if args.tokens else None
         tr = torch.empty((Pc,), dtype=torch.int32, device=dev)
         eng.synth_fill_device(ans, tok, tr, P=Pc, B=B, N=N, seed=args.seed, dist=args.dist, p_offset=p_off)
         slots.append((ans, tok, tr, p_off))
     # two counter buffers: the all-reduce of step i (RCCL's own stream) overlaps the kernel of step i+1
-    from o1_inference_scaling_laws_amd.dist import CounterPipeline
     pipe = CounterPipeline([torch.zeros(counters_size(B), dtype=torch.int64, device=dev) for _ in range(2)])
     cells = torch.empty((Pc, B, 16), dtype=torch.uint8, device=dev)
     ctok = torch.empty((Pc, B), dtype=torch.int64, device=dev) if args.tokens else None
     eng.sync()
 
+    c5_state = {"M": None, "last": None, "boot_seed": args.seed ^ 0xB007}
+
     def step(i):
         ans, tok, tr, _ = slots[i % R]
+        if c5:
+            out = passk.evaluate_device(eng, ans, tr, args.problems, args.resamples, c5_state["boot_seed"], M=c5_state["M"],
+                                        tokens_local=tok, counters=pipe.buffers[i % 2], cells_local=cells)
+            c5_state["M"], c5_state["last"] = out.M, out      # the class bound is found once (host sync), then reused
+            return out.counters
         counters = pipe.acquire(i)           # waits for this buffer's previous all-reduce, zeroes it
         eng.aggregate_device(ans, tr, tokens=tok, counters=counters, cells=cells, cell_tokens=ctok)
         return pipe.publish(i)               # async all-reduce (no-op with one rank)
@@ -201,7 +297,6 @@ def main():
                 step(i)
             graphs[i] = g
         eng.use_torch_stream()
-        eager_step = step
 
         def step(i):                                      # noqa: F811 - replay instead of launching
             graphs[i % period].replay()
@@ -218,6 +313,7 @@ def main():
     step(0)
     fence()
     first_cells = cells_from_torch(cells) if rank == 0 else None
+    first_off = slots[0][3]
     if rank == 0:
         c = first_cells
         ok = ((c["truth_count"] <= c["max_count"]).all() and (c["max_count"] <= N).all()
@@ -252,51 +348,53 @@ def main():
         kern_avg_ns = float(kmax.item())
     else:
         kern_avg_ns = kern_ns / max(launches, 1)
+    # the cell table now holds the LAST TIMED step's chunk (c5: this rank's shard)
+    last_slot = slots[(args.warmup + args.steps - 1) % R] if args.steps > 0 else slots[0]
+    last_cells = cells_from_torch(cells) if rank == 0 else None
 
     votes_per_step_per_gpu = Pc * B * N
-    total_votes = votes_per_step_per_gpu * world * args.steps
+    total_votes = (args.problems * B * N if c5 else votes_per_step_per_gpu * world) * args.steps
     value = total_votes / elapsed
     bytes_per_launch = votes_per_step_per_gpu * BYTES_PER_VOTE * (2 if args.tokens else 1)
     achieved = bytes_per_launch / (kern_avg_ns * 1e-9) / 1e9
+    ev = committed_evidence() if (Pc, B, N, args.tokens, args.workload) == (1250, 8, 1 << 20, False, "c3") else {}
 
-    # HBM bytes per launch from the PMC counters: collected in SEPARATE rocprofv3 --pmc passes of this same
-    # command (tools/gpu_round.sh), FETCH_SIZE doubled per the gfx950 correction, summarised by
-    # tools/summarize_profiles.py into profiles/rNN_pmc.json.  Only valid for the default workload.
-    traffic, traffic_src = None, None
-    if (Pc, B, N, args.tokens) == (1250, 8, 1 << 20, False):
-        import glob
-        pmcs = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")))
-        if pmcs:
-            with open(pmcs[-1]) as f:
-                traffic = json.load(f).get("hbm_traffic_bytes")
-            traffic_src = os.path.relpath(pmcs[-1], REPO) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 gfx950 correction)"
-
-    final = AggregateResult.from_counters(last.cpu().numpy(), Pc, B, num_problems=Pc * world)
+    final = AggregateResult.from_counters(last.cpu().numpy(), Pc, B, num_problems=args.problems if c5 else Pc * world)
+    if c5:
+        workload = (f"C5: P={args.problems} x N={N} sharded by problem over {world} GPU(s) ({Pc} problems = {bytes_per_launch / 1e9:.2f} GB on rank 0); "
+                    f"step = vote + counters all-reduce + cell all-gather + {args.resamples}-resample bootstrap (class bound M={c5_state['M']}); "
+                    f"pass@k sweep k=1..1024 on the host, outside the timed region")
+    elif args.workload == "c3":
+        workload = (f"C3 streamed in problem-chunks: step = {Pc} problems x {B} budgets x {N} samples int32 "
+                    f"({bytes_per_launch / 1e9:.2f} GB) per GPU; 8 steps at 1 GPU = P=10k x B=8 x N=2^20")
+    else:
+        workload = (f"C2: step = one pass over {Pc} problems x {B} budgets x {N} samples int32 "
+                    f"({bytes_per_launch / 1e6:.1f} MB) per GPU, {R} distinct tensors cycled (cold Infinity Cache)")
     out = {
-        "metric": "sample-votes/sec (problems x samples), bit-exact vs CPU",
+        "metric": "sample-votes/sec (problems x samples)",
         "value": value,
         "unit": "sample-votes/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if c5 else "weak",
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic",
         "config": {
-            "workload": (f"C3 streamed in problem-chunks: step = {Pc} problems x {B} budgets x {N} samples int32 "
-                         f"({bytes_per_launch / 1e9:.2f} GB) per GPU; 8 steps at 1 GPU = P=10k x B=8 x N=2^20")
-                        if args.workload == "c3" else
-                        (f"C2: step = one pass over {Pc} problems x {B} budgets x {N} samples int32 "
-                         f"({bytes_per_launch / 1e6:.1f} MB) per GPU, {R} distinct tensors cycled (cold Infinity Cache)"),
-            "distribution": {0: "D0 uniform", 1: "D1 peaked", 2: "D2 degenerate", 3: "D3 tie"}[args.dist],
+            "workload": workload,
+            "distribution": DISTS[args.dist],
             "resident_chunks": R,
             "tokens_stream": bool(args.tokens),
             "parallelism": f"problems sharded over {world} GPU(s), one int64 all-reduce of {counters_size(B)} counters per step",
             "seed": args.seed,
             "launch": "hipGraph replay (memset + kernels captured per resident chunk)" if use_graph else "eager",
+            "backend": None if world == 1 else args.backend,
+            "rccl_ranks": rccl_ranks,
+            "hip_devices_visible": ndev,
+            "devices_shared_by_ranks": bool(args.share_device),
         },
         "roofline": {
             "bound": "hbm",
@@ -304,25 +402,59 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "traffic_source": traffic_src,
+            "traffic": ev.get("traffic"),
+            "traffic_measured_in_this_run": False if ev.get("traffic") is not None else None,
+            "traffic_source": ev.get("traffic_source"),
             "kernel": "scv_hist_argmax",
             "kernel_avg_ms": kern_avg_ns / 1e6,
             "launches_timed": launches,
             "algorithmic_bytes_per_launch": bytes_per_launch,
-            "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
+            "measured_read_ceiling_gbs": ev.get("read_ceiling_gbs"),
+            "frac_of_measured_read_ceiling": (achieved / ev["read_ceiling_gbs"]) if ev.get("read_ceiling_gbs") else None,
+            "read_ceiling_source": ev.get("read_ceiling_source"),
         },
         "parity": None,
         "accuracy_last_step": [round(final.accuracy(b), 6) for b in range(B)],
         "device": {"cus": eng.num_cus, "hbm_gb": round(eng.hbm_bytes / 1e9, 1)},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline(args.cpu_baseline_seconds, B, N, args.seed, args.dist, gpu_cells=first_cells,
-                            p_offset=slots[0][3])
-        out["parity"] = base.pop("parity")
-        out["cpu_baseline"] = base
+    if rank == 0 and not args.no_cpu_baseline:
+        if world == 1:
+            out["parity"], out["cpu_baseline"] = cpu_baseline(args, B, N, first_cells, first_off, last_cells, last_slot[3], args.steps > 0)
+        else:
+            # multi-rank lines carry no CPU baseline (contract: N = 1 only) but rank 0's shard is still checked
+            n = check_cells_vs_c_oracle(last_cells, min(16, last_cells.shape[0]), B, N, args.seed, args.dist, last_slot[3])
+            out["parity"] = f"bit-exact: rank 0's first {n} problems x {B} budgets x {N} votes of the last timed chunk vs oracle/scv_oracle.c"
+            out["cpu_baseline"] = None
     elif rank == 0:
         out["cpu_baseline"] = None
+    if out["parity"]:
+        out["metric"] += ", bit-exact vs CPU (see parity)"
+    else:
+        out["metric"] += " (parity not checked in this run)"
+
+    # ---- C5 epilogue (outside the timed region): gather the bootstrap slices, host floats, oracle check ----------
+    if c5:
+        d = c5_state["last"]
+        boot_all = passk.gather_bootstrap(d, args.resamples)
+        if rank == 0:
+            all_cells = cells_from_torch(d.cells)
+            t1 = time.perf_counter()
+            host = passk.finish_host(d.counters.cpu().numpy(), all_cells, boot_all.cpu().numpy(), args.problems, [N])
+            out["c5"] = {"accuracy": host["accuracy"], "accuracy_ci95": host["ci95"], "tie_classes_M": d.M,
+                         "pass_at_k": {str(k): v[0] for k, v in host["pass_at_k"].items()},
+                         "host_float_ms": (time.perf_counter() - t1) * 1e3,
+                         "device_pipeline_ms_minus_vote_kernel_ms": elapsed / max(args.steps, 1) * 1e3 - kern_avg_ns / 1e6,
+                         "semantics": "pass@k and the problem-level bootstrap are NEW (not in the reference): parity unpinned, checked vs the oracle only"}
+            if not args.no_cpu_baseline:
+                from oracle import coracle
+                rc, want_boot = coracle.bootstrap(all_cells, 0, args.resamples, c5_state["boot_seed"], d.M)
+                if rc != 0 or not np.array_equal(boot_all.cpu().numpy(), want_boot):
+                    sys.exit("PARITY FAILURE: bootstrap table differs from oracle scvo_bootstrap")
+                out["c5"]["bootstrap_parity"] = f"all {args.resamples} x {B} x {d.M} resample counters bit-exact vs oracle/scv_oracle.c"
+            if args.dump:
+                np.savez(args.dump, counters=d.counters.cpu().numpy(), cells=d.cells.cpu().numpy(), boot=boot_all.cpu().numpy())
+    elif rank == 0 and args.dump:
+        np.savez(args.dump, counters=last.cpu().numpy())
     if rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()

@@ -57,6 +57,7 @@ struct scv_ctx {
     int small_reg = 1;       // small path: 1 = register-resident variant for N <= 128 (measured +10 %), 2 = also for N <= 512 (measured slower)
     int tiny_n_max = 32;     // auto/small path: N <= this -> register-only kernel, several cells per wave
     int small_n_max = 512;   // auto (reg path off): N <= this -> wave-per-cell kernel (crossover measured: profiles/r01_crossover_d*.log)
+    int boot_lds = 1;        // bootstrap: LDS-resident code table when it fits (0: always the global-gather kernel)
     int reg_km = 1;          // reg path: batches in flight per wave = km x 4 KiB
     int reg_shape = 0;       // reg path: force a kernel shape (A/B runs), see launch_aggregate
     int reg_dense4 = 0;      // reg path, 512 < N <= 1024: 1 = dense bin scan instead of the sparse read-back (A/B option)
@@ -670,6 +671,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "prefetch")) ctx->prefetch = value != 0;
     else if (!strcmp(key, "path")) { if (value < 0 || value > 4) return fail(SCV_ERR_ARG, "path must be 0..4"); ctx->path = (int)value; }
     else if (!strcmp(key, "reg_dense4")) ctx->reg_dense4 = value != 0;
+    else if (!strcmp(key, "boot_lds")) ctx->boot_lds = value != 0;
     else if (!strcmp(key, "reg_km")) { if (value != 1 && value != 2 && value != 4) return fail(SCV_ERR_ARG, "reg_km must be 1, 2 or 4"); ctx->reg_km = (int)value; }
     else if (!strcmp(key, "reg_shape")) { if (value < 0 || value > 9999) return fail(SCV_ERR_ARG, "reg_shape out of range"); ctx->reg_shape = (int)value; }
     else if (!strcmp(key, "reg_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "reg_n_max < 0"); ctx->reg_n_max = (int)(value > 4096 ? 4096 : value); }
@@ -811,23 +813,30 @@ int scv_bootstrap(scv_ctx* ctx, const scv_cell* cells, int64_t P, int32_t B, int
     if (R == 0) return SCV_OK;
     hipStream_t s = ctx->stream;
     const size_t out_bytes = (size_t)R * B * M * sizeof(int64_t);
-    if (mem_kind == SCV_MEM_DEVICE) {
-        hipLaunchKernelGGL(scv::scv_bootstrap_k, dim3((unsigned)R), dim3(256), lds, s, cells, P, B, r_begin, seed, M,
-                           reinterpret_cast<unsigned long long*>(counts_out), ctx->d_err);
+    // LDS-resident kernel when the 2-byte code table + counters fit (P * B up to ~70 k cells); otherwise the
+    // global-gather kernel.  "boot_lds" = 0 forces the latter (A/B runs, tests).
+    const size_t lds_fast = (((size_t)B * M + 3) & ~(size_t)3) * sizeof(uint32_t) + (((size_t)P * B + 7) & ~(size_t)7) * sizeof(uint16_t);
+    const bool fast = ctx->boot_lds && lds_fast <= (size_t)144 * 1024;
+    auto launch_boot = [&](const scv_cell* d_cells, unsigned long long* d_out) -> int {
+        if (fast) {
+            int64_t grid = (int64_t)ctx->num_cus;                          // one 1024-thread workgroup per CU, R / grid resamples each
+            if (grid > R) grid = R;
+            SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scv::scv_bootstrap_lds_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast));
+            hipLaunchKernelGGL(scv::scv_bootstrap_lds_k, dim3((unsigned)grid), dim3(1024), lds_fast, s, d_cells, P, B, r_begin, r_end, seed, M, d_out, ctx->d_err);
+        } else {
+            hipLaunchKernelGGL(scv::scv_bootstrap_k, dim3((unsigned)R), dim3(256), lds, s, d_cells, P, B, r_begin, seed, M, d_out, ctx->d_err);
+        }
         SCV_HIP(hipGetLastError());
         ctx->err_dirty = true;
         return SCV_OK;
-    }
+    };
+    if (mem_kind == SCV_MEM_DEVICE) return launch_boot(cells, reinterpret_cast<unsigned long long*>(counts_out));
     const size_t cells_bytes = (size_t)P * B * sizeof(scv_cell);
     const size_t o_out = align_up(cells_bytes, 256);
     if (int rc = ensure_stage(ctx, o_out + out_bytes)) return rc;
     char* base = static_cast<char*>(ctx->d_stage);
     SCV_HIP(hipMemcpyAsync(base, cells, cells_bytes, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(scv::scv_bootstrap_k, dim3((unsigned)R), dim3(256), lds, s,
-                       reinterpret_cast<const scv_cell*>(base), P, B, r_begin, seed, M,
-                       reinterpret_cast<unsigned long long*>(base + o_out), ctx->d_err);
-    SCV_HIP(hipGetLastError());
-    ctx->err_dirty = true;
+    if (int rc = launch_boot(reinterpret_cast<const scv_cell*>(base), reinterpret_cast<unsigned long long*>(base + o_out))) return rc;
     SCV_HIP(hipMemcpyAsync(counts_out, base + o_out, out_bytes, hipMemcpyDeviceToHost, s));
     SCV_HIP(hipStreamSynchronize(s));
     uint32_t w = 0;

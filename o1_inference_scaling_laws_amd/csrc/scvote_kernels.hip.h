@@ -1784,4 +1784,59 @@ __global__ __launch_bounds__(256) void scv_bootstrap_k(const scv_cell* cells, in
     if (overflow) atomicOr(err_flag, 2u);
 }
 
+// LDS-resident variant: all the bootstrap looks at is (hit, n_modes) per cell -- 2 bytes.  Every
+// workgroup stages the whole [P, B] table once as u16 codes (hit ? n_modes : 0; 20 KB at P = 10^4, B = 1) and then
+// runs several resamples out of LDS: no 16-byte gathers from global per draw.  Class-1 hits (a strict win, by
+// far the commonest code) are counted per wave with a ballot + popcount and ONE LDS atomic per wave, so the 64
+// lanes of a wave do not serialise on the same counter; the rare tie classes use per-lane LDS atomics.
+// Same draws and the same int64 [R, B, M] output as scv_bootstrap_k / oracle scvo_bootstrap.
+__global__ __launch_bounds__(1024) void scv_bootstrap_lds_k(const scv_cell* cells, int64_t P, int32_t B, int32_t r_begin,
+                                                            int32_t r_end, uint64_t seed, int32_t M, unsigned long long* out,
+                                                            uint32_t* err_flag) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* cnt = lds;                                                   // [B * M]
+    uint16_t* tab = reinterpret_cast<uint16_t*>(lds + (((int64_t)B * M + 3) & ~(int64_t)3));   // [P * B]
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
+    const int64_t ncells = P * B;
+    const uint4* c4 = reinterpret_cast<const uint4*>(cells);
+    for (int64_t i = tid; i < ncells; i += T) {
+        const uint4 c = c4[i];
+        tab[i] = (c.w & 0xffu) ? (uint16_t)(c.z & 0xffffu) : (uint16_t)0;
+    }
+    bool overflow = false;
+    const int64_t BM = (int64_t)B * M;
+    for (int32_t r = r_begin + (int32_t)blockIdx.x; r < r_end; r += (int32_t)gridDim.x) {
+        for (int64_t i = tid; i < BM; i += T) cnt[i] = 0;
+        __syncthreads();                                                   // table staged (first pass) / counters zero
+        // uniform trip count per wave (the ballot needs the whole wave): draws past P contribute nothing.
+        // The generator argument seed + G * (r * P + j + 1) advances by G * T per iteration: one 64-bit add
+        // instead of a 64-bit multiply (integer multiplies are quarter rate and this kernel is bound by them).
+        uint64_t arg = seed + kGolden * ((uint64_t)r * (uint64_t)P + (uint64_t)tid + 1);
+        const uint64_t darg = kGolden * (uint64_t)T;
+        for (int64_t j0 = (int64_t)(tid - lane); j0 < P; j0 += T, arg += darg) {
+            const int64_t j = j0 + lane;
+            const bool live = j < P;
+            const uint64_t u = mix64(arg);
+            const int64_t idx = live ? (int64_t)mulhi32((uint32_t)(u >> 32), (uint32_t)P) : 0;
+            for (int32_t b = 0; b < B; ++b) {
+                const uint32_t code = live ? (uint32_t)tab[idx * B + b] : 0u;
+                const uint64_t ones = __ballot(code == 1u);
+                if (lane == 0 && ones) {
+                    if (M > 1) atomicAdd(&cnt[(int64_t)b * M + 1], (uint32_t)__popcll(ones));
+                }
+                if (code == 1u && M <= 1) overflow = true;
+                if (code > 1u) {
+                    if (code >= (uint32_t)M) overflow = true;
+                    else atomicAdd(&cnt[(int64_t)b * M + code], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        unsigned long long* o = out + (int64_t)(r - r_begin) * BM;
+        for (int64_t i = tid; i < BM; i += T) o[i] = cnt[i];
+        __syncthreads();                                                   // before the next resample re-zeroes cnt
+    }
+    if (overflow) atomicOr(err_flag, 2u);
+}
+
 }  // namespace scv

@@ -25,6 +25,19 @@ def all_reduce_counters(counters, group=None):
     return counters
 
 
+def all_gather_tensors(parts, tensor, group=None):
+    """dist.all_gather, except that the gloo backend (CPU tests, and the 1-GPU box's shared-device runs) cannot
+    gather CUDA tensors: there the exchange is staged through host copies.  RCCL gathers in place over xGMI."""
+    import torch.distributed as dist
+    if tensor.is_cuda and dist.get_backend(group) == "gloo":
+        host_parts = [p.cpu() for p in parts]
+        dist.all_gather(host_parts, tensor.cpu(), group=group)
+        for p, h in zip(parts, host_parts):
+            p.copy_(h)
+        return
+    dist.all_gather(parts, tensor, group=group)
+
+
 def all_gather_cells(cells_local, P: int, group=None):
     """Gather the per-cell table [P_local, B, 16] (uint8) of every rank into [P, B, 16]; needed by
     the bootstrap, which resamples over ALL problems."""
@@ -38,7 +51,7 @@ def all_gather_cells(cells_local, P: int, group=None):
     pad = torch.zeros((pmax,) + tuple(cells_local.shape[1:]), dtype=cells_local.dtype, device=cells_local.device)
     pad[: cells_local.shape[0]] = cells_local
     parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
+    all_gather_tensors(parts, pad, group)
     return torch.cat([parts[r][: sizes[r]] for r in range(world)], dim=0)
 
 
@@ -48,16 +61,37 @@ def aggregate_sharded(engine, answers_local, truth_local, num_problems: int, tok
     ``engine.aggregate_device`` (any object with that method: the HIP engine in production), the packed
     int64 counters are summed over the ranks with ONE all-reduce, and the reference's floats are taken
     over the GLOBAL number of problems.  Returns an ``AggregateResult`` whose counters are global and
-    whose cell table is this rank's block."""
-    from .engine import AggregateResult, cells_from_torch
+    whose cell table is this rank's block.
+
+    Data errors are collective: the device error word of every rank (SCV_ERR_DOMAIN: a vote outside bins
+    0..1023, which makes the counters invalid) rides in one extra word of the same all-reduce, and EVERY rank
+    raises ``DomainError`` when any rank saw one -- no rank returns counters the ABI documents as invalid, and
+    no rank is left waiting in a collective the others skipped."""
+    import torch
+    from ._lib import ERR_DOMAIN, DomainError
+    from .engine import AggregateResult, cells_from_torch, counters_size
     P_local, B = int(answers_local.shape[0]), int(answers_local.shape[1])
-    counters, cells, cell_tokens = engine.aggregate_device(
-        answers_local, truth_local, tokens=tokens_local, n_valid=n_valid, cells=None if want_cells else False)
-    all_reduce_counters(counters, group)
+    ncount = counters_size(B)
+    packed = torch.zeros(ncount + 1, dtype=torch.int64, device=answers_local.device)     # counters | error word
+    _, cells, cell_tokens = engine.aggregate_device(
+        answers_local, truth_local, tokens=tokens_local, n_valid=n_valid, counters=packed[:ncount],
+        cells=None if want_cells else False)
+    local_error = None
+    if hasattr(engine, "sync"):
+        try:
+            engine.sync()                       # DEVICE mode reports SCV_ERR_DOMAIN here and only here
+        except DomainError as e:
+            local_error = e
+            packed[ncount] = 1
+    all_reduce_counters(packed, group)
+    host = packed.cpu().numpy()
+    if host[ncount] != 0:
+        if local_error is not None:
+            raise local_error
+        raise DomainError(ERR_DOMAIN, "another rank saw a vote outside bins 0..1023; the all-reduced counters are invalid")
     host_cells = cells_from_torch(cells) if cells is not None else None
     host_ctok = cell_tokens.cpu().numpy() if cell_tokens is not None else None
-    return AggregateResult.from_counters(counters.cpu().numpy(), P_local, B, host_cells, host_ctok,
-                                         num_problems=num_problems)
+    return AggregateResult.from_counters(host[:ncount], P_local, B, host_cells, host_ctok, num_problems=num_problems)
 
 
 class CounterPipeline:

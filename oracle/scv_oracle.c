@@ -68,6 +68,11 @@ int scvo_synth_fill_i32(int32_t* answers, int32_t* tokens, int32_t* truth,
                         int64_t P, int32_t B, int64_t N, int64_t p_offset,
                         uint64_t seed, int dist) {
     if (P < 0 || B < 0 || N < 0 || dist < 0 || dist > 3) return -1;
+    /* problems are independent (closed form per element): spread them over the host cores so that the
+     * bench's wide parity check (hundreds of problems x 2^20 samples) does not wait on one core */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) if (P >= 4 && B * N >= (1 << 16))
+#endif
     for (int64_t pl = 0; pl < P; ++pl) {
         const int64_t p = p_offset + pl;
         const scvo_pparam pp = problem_params(seed, p);

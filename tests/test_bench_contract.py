@@ -1,18 +1,20 @@
-"""bench.py contract on the GPU box: one JSON line with the driver's keys (+ roofline, cpu_baseline), and
-the N > 1 control flow (two ranks, gloo, both on cuda:0 -- everything except RCCL itself)."""
+"""bench.py contract on the GPU box: one JSON line with the driver's keys (+ roofline, cpu_baseline), and the
+N > 1 control flow (two ranks, gloo, both on cuda:0 -- everything except RCCL itself) checked BIT FOR BIT against
+single-rank runs over the same global problem indices: the C3/C4 path (sharded chunks + one all-reduce of the
+packed counters) and the C5 path (cell all-gather + resample split)."""
 import json
 import os
 import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
         "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
-SMALL = ["--problems-per-step", "48", "--samples", str(1 << 16), "--steps", "3", "--warmup", "1"]
 
 
 def _last_json(text):
@@ -21,39 +23,63 @@ def _last_json(text):
     return json.loads(lines[0])
 
 
+def _bench(extra, ranks=1, timeout=900):
+    if ranks == 1:
+        cmd = [sys.executable, os.path.join(REPO, "bench.py"), *extra]
+    else:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(ranks), *extra,
+               "--backend", "gloo", "--share-device"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return _last_json(out.stdout)
+
+
 def test_single_gpu_line_has_the_contract_fields():
-    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *SMALL, "--cpu-baseline-seconds", "0.5"],
-                         capture_output=True, text=True, timeout=600, cwd=REPO)
-    assert out.returncode == 0, out.stderr[-2000:]
-    d = _last_json(out.stdout)
+    d = _bench(["--problems-per-step", "48", "--samples", str(1 << 16), "--steps", "3", "--warmup", "1", "--cpu-baseline-seconds", "0.5"])
     assert KEYS <= set(d)
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "int32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["hip_devices_visible"] >= 1 and d["config"]["rccl_ranks"] is None
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    assert r["traffic"] is None and r["traffic_measured_in_this_run"] is None     # not the default workload: nothing injected
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
-    assert d["parity"].startswith("bit-exact")
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c and "statistics.multimode" in c["what"]
+    assert c["all_cores"]["value"] > 0 and c["c_port"]["value"] > c["value"]      # C port beats the Python loop
+    assert d["parity"].startswith("bit-exact") and "statistics.multimode" in d["parity"] and "bit-exact" in d["metric"]
     assert abs(d["value"] - 48 * 8 * (1 << 16) * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-9
 
 
-def test_two_ranks_share_the_gpu_over_gloo():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", *SMALL,
-           "--backend", "gloo", "--share-device"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO)
-    assert out.returncode == 0, out.stderr[-3000:]
-    d = _last_json(out.stdout)
-    assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and d["parity"] is None
-    single = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *SMALL, "--no-cpu-baseline"],
-                            capture_output=True, text=True, timeout=600, cwd=REPO)
-    one = _last_json(single.stdout)
-    # weak scaling: rank r streams its own chunks, accuracy is over all problems of the last step --
-    # same generator, so both runs sit at the same accuracy to within sampling of different problems
-    assert all(0.0 <= a <= 1.0 for a in d["accuracy_last_step"]) and len(d["accuracy_last_step"]) == 8
-    assert abs(d["accuracy_last_step"][0] - one["accuracy_last_step"][0]) < 0.2
+def test_two_ranks_equal_one_rank_word_for_word(tmp_path):
+    """Weak scaling: step s of a G-rank run covers global problems [s G Pc, (s+1) G Pc).  Two ranks x 48 problems must
+    give the SAME all-reduced counters (8216 int64 words) as one rank x 96 problems."""
+    common = ["--samples", str(1 << 15), "--steps", "3", "--warmup", "1", "--resident", "4"]
+    two = _bench(["--problems-per-step", "48", *common, "--dump", str(tmp_path / "two.npz")], ranks=2)
+    one = _bench(["--problems-per-step", "96", *common, "--dump", str(tmp_path / "one.npz"), "--no-cpu-baseline"])
+    assert two["n_gpus"] == 2 and two["cpu_baseline"] is None and two["parity"].startswith("bit-exact: rank 0")
+    assert two["config"]["backend"] == "gloo" and two["config"]["devices_shared_by_ranks"] is True
+    a, b = np.load(tmp_path / "two.npz")["counters"], np.load(tmp_path / "one.npz")["counters"]
+    assert a.shape == b.shape == (8 * 1027,) and np.array_equal(a, b) and a.sum() > 0
+    assert two["accuracy_last_step"] == one["accuracy_last_step"]
+
+
+def test_c5_two_ranks_equal_one_rank_and_oracle(tmp_path):
+    """C5 (vote -> counters all-reduce -> cell all-gather -> R/G resamples per rank -> gather): counters, the
+    gathered cell table and the whole bootstrap table of a 2-rank run equal the 1-rank run's, which bench.py
+    itself compares with the oracle (cells + all resample counters)."""
+    common = ["--workload", "c5", "--problems", "300", "--samples", str(1 << 14), "--resamples", "101", "--steps", "2", "--warmup", "1", "--dist", "3"]
+    one = _bench([*common, "--dump", str(tmp_path / "one.npz"), "--cpu-baseline-seconds", "0.3"])
+    two = _bench([*common, "--dump", str(tmp_path / "two.npz"), "--no-cpu-baseline"], ranks=2)
+    assert one["scaling"] == "strong" and "bootstrap_parity" in one["c5"] and one["parity"].startswith("bit-exact")
+    a, b = np.load(tmp_path / "one.npz"), np.load(tmp_path / "two.npz")
+    for k in ("counters", "cells", "boot"):
+        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+    assert a["boot"].shape[0] == 101 and a["cells"].shape[:2] == (300, 1)
+    assert one["c5"]["pass_at_k"] == two["c5"]["pass_at_k"] and one["c5"]["accuracy_ci95"] == two["c5"]["accuracy_ci95"]
+    assert abs(one["value"] - 300 * (1 << 14) * 2 / (one["ms_per_step"] * 2e-3)) / one["value"] < 1e-9

@@ -54,8 +54,17 @@ class _CpuDeviceEngine:
         out = coracle.aggregate(answers.numpy(), truth.numpy(), tokens=None if tokens is None else tokens.numpy(),
                                 n_valid=None if n_valid is None else n_valid.numpy())
         cnt = torch.from_numpy(_pack(out).copy())
+        if counters is not None:
+            counters.add_(cnt)                  # DEVICE mode accumulates into the caller's buffer
+            cnt = counters
         c = torch.from_numpy(out["cells"].view(np.uint8).reshape(answers.shape[0], answers.shape[1], 16).copy())
+        self.rc = out["rc"]
         return cnt, (None if cells is False else c), (torch.from_numpy(out["cell_tokens"]) if tokens is not None else None)
+
+    def sync(self):
+        from o1_inference_scaling_laws_amd._lib import ERR_DOMAIN, DomainError
+        if getattr(self, "rc", 0) == ERR_DOMAIN:
+            raise DomainError(ERR_DOMAIN, "a vote outside bins 0..1023 was seen; results are invalid")
 
 
 def _worker_api(rank, world, port, q):
@@ -73,6 +82,42 @@ def _worker_api(rank, world, port, q):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def _worker_domain(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from o1_inference_scaling_laws_amd._lib import DomainError
+        lo, hi = scv_dist.shard_bounds(P, rank, world)
+        a, _, tr = coracle.synth_fill(hi - lo, B, N, SEED, 1, p_offset=lo)
+        if rank == 1:
+            a[3, 1, 7] = 5000                   # only rank 1 holds an out-of-domain vote
+        try:
+            scv_dist.aggregate_sharded(_CpuDeviceEngine(), torch.from_numpy(a), torch.from_numpy(tr), P)
+            q.put((rank, "no error"))
+        except DomainError as e:
+            q.put((rank, "local" if "was seen" in str(e) else "remote"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_domain_error_is_collective():
+    """a rank with an out-of-domain vote must not return invalid counters, and the other ranks must
+    fail with it (the error word rides in the counters' all-reduce), not hang or return silently."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_domain, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {0: "remote", 1: "local", 2: "remote"}
 
 
 def test_aggregate_sharded_api_three_ranks():

@@ -650,6 +650,62 @@ def test_bootstrap_bit_exact_vs_oracle(hip_engine):
         hip_engine.bootstrap(cells, 0, 10, 0xB007, 3)   # class 3 present, M too small
 
 
+@pytest.mark.parametrize("boot_lds", [0, 1])
+@pytest.mark.parametrize("shape", [(10000, 1, 64, 1), (3000, 8, 40, 3), (257, 4, 96, 3), (1, 1, 8, 2), (70000, 1, 4, 0), (90000, 2, 3, 3)])
+def test_bootstrap_kernels_bit_exact(hip_engine, boot_lds, shape):
+    """Both bootstrap kernels (LDS-resident 2-byte code table / global 16-byte gathers) against scvo_bootstrap:
+    C5's shape (P = 10^4, B = 1), several budgets, tie classes, P * B beyond the LDS table (falls back), every M."""
+    P, B, N, dist = shape
+    a, _, tr = coracle.synth_fill(P, B, N, 31, dist)
+    cells = coracle.aggregate(a, tr)["cells"]
+    mmax = int(cells["n_modes"][cells["hit"] == 1].max(initial=0))
+    hip_engine.set_option("boot_lds", boot_lds)
+    try:
+        for (r0, r1, M) in ((0, 300, mmax + 1), (5, 18, 1025 if B <= 2 else mmax + 2), (7, 7, 4)):
+            rc, want = coracle.bootstrap(cells, r0, r1, 0xC0FFEE, M)
+            assert rc == 0
+            got = hip_engine.bootstrap(cells, r0, r1, 0xC0FFEE, M)
+            assert got.shape == want.shape and np.array_equal(got, want)
+        if mmax >= 1:
+            with pytest.raises(_lib.ScvError):
+                hip_engine.bootstrap(cells, 0, 50, 0xC0FFEE, mmax)        # largest class present does not fit
+    finally:
+        hip_engine.set_option("boot_lds", 1)
+
+
+def test_config_C5_pipeline_full_cell_size_bit_exact(hip_engine):
+    """BASELINE config 5 at its real cell size (N = 2^20), on as many problems as the test budget allows: vote ->
+    counters -> cell table -> 1000-resample bootstrap -> k-sweep through passk.evaluate_device; EVERY cell, the
+    counters and the WHOLE bootstrap table against the oracle; pass@k against the combinatorial definition."""
+    import math
+    import torch
+    from o1_inference_scaling_laws_amd import passk, scoring
+    P, B, N, R, seed = 64, 1, 1 << 20, 1000, 55
+    dev = torch.device("cuda:0")
+    ans = torch.empty((P, B, N), dtype=torch.int32, device=dev)
+    tr = torch.empty((P,), dtype=torch.int32, device=dev)
+    hip_engine.synth_fill_device(ans, None, tr, P=P, B=B, N=N, seed=seed, dist=3)      # D3: exact 2- and 3-way ties
+    d = passk.evaluate_device(hip_engine, ans, tr, P, R, seed ^ 0xB007)
+    hip_engine.sync()
+    a, _, trc = coracle.synth_fill(P, B, N, seed, 3)
+    want = coracle.aggregate_mt(a, trc, 16)
+    got_cells = cells_from_torch(d.cells)
+    for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+        assert np.array_equal(got_cells[f], want["cells"][f]), f
+    got = AggregateResult.from_counters(d.counters.cpu().numpy(), P, B)
+    assert np.array_equal(got.tie_class_hits, want["tie_class_hits"]) and np.array_equal(got.truth_count_sum, want["truth_count_sum"])
+    assert d.M == 4 and (d.r0, d.r1) == (0, R)
+    rc, want_boot = coracle.bootstrap(want["cells"], 0, R, seed ^ 0xB007, d.M)
+    assert rc == 0 and np.array_equal(d.boot.cpu().numpy(), want_boot)
+    host = passk.finish_host(d.counters.cpu().numpy(), got_cells, d.boot.cpu().numpy(), P, [N])
+    assert host["accuracy"][0] == got.accuracy(0) and host["ci95"][0][0] <= host["accuracy"][0] <= host["ci95"][0][1]
+    acc_slow, lo, hi = scoring.bootstrap_percentiles(want_boot, P)
+    assert np.array_equal(host["bootstrap_accuracy"], acc_slow) and [float(lo[0]), float(hi[0])] == host["ci95"][0]
+    for k in (1, 2, 64, 1024):                                  # unbiased estimator 1 - C(n-c, k) / C(n, k), exact rational
+        exact = np.mean([1 - math.comb(N - int(c), k) / math.comb(N, k) for c in got_cells["truth_count"][:, 0]])
+        assert abs(host["pass_at_k"][k][0] - exact) < 1e-9
+
+
 def test_bootstrap_device_fused_no_host_roundtrip(hip_engine):
     ans, _, tr, counters, cells, _ = _device_run(hip_engine, 500, 2, 4096, 5, 3)
     out = hip_engine.bootstrap_device(cells, 0, 100, 42, 4)
