@@ -38,7 +38,8 @@ extern "C" {
 #define SCV_TIE_CLASSES 1025      /* tie_class_hits[b][m], m = n_modes in 0..1024               */
 
 /* mem_kind: where every pointer argument of a call lives. */
-#define SCV_MEM_HOST 0            /* host pointers; the library stages through HBM and syncs    */
+#define SCV_MEM_HOST 0            /* host pointers; staged through HBM in problem-chunks by a 3-stage
+                                     pipeline (threads -> pinned bounce -> DMA -> kernel); blocking */
 #define SCV_MEM_DEVICE 1          /* device pointers; async on the ctx stream, caller syncs     */
 
 /* scv_create flags */
@@ -102,10 +103,14 @@ int scv_sync(scv_ctx* ctx);
 int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unroll);
 /* Launch options (measurement / tests): "grid" (> 0: exact persistent grid, 0: derive from the CU
  * count), "balance" (default 1: shrink the grid so all workgroups stream the same number of items),
- * "path" (0 auto | 1 streaming whole cells | 2 streaming split-N + merge | 3 small-N wave-per-cell),
+ * "path" (0 auto | 1 streaming whole cells | 2 streaming split-N + merge | 3 small-N wave-per-cell | 4 register-resident cells),
  * "segs" (split-N segments per cell, 0 auto), "sorted" (default 1: budgets traversed in descending
  * n_valid order), "small_n_max" (auto: N <= this uses the small-N kernel), "tiny_n_max" (<= 32: N <= this
  * uses the register-only several-cells-per-wave kernel inside the small path), "auto_geometry" (default 1),
+ * "host_pipeline" (default 1; 0: the serial round-1 staging loop), "stage_mb" (HOST-mode chunk size,
+ * default 128), "copy_threads" (default 16: threads filling the pinned bounce slots), "reg_n_max" (default 4096: 32 < N <=
+ * this uses the register-resident cell kernels; 0 restores the round-1 dispatch), "reg_shape" / "reg_km" / "reg_dense4" (force a
+ * register-kernel shape for A/B runs), "boot_lds" (default 1: LDS-resident bootstrap table),
  * "fused_counters_max" (cells at or below, or problem rows >= 4 MiB: per-cell atomics inside the hot
  * kernel; otherwise a separate reduction of the cell table; 0 forces the reduction), "small_reg", "pin_host" (default 0; 1: HOST-mode calls hipHostRegister caller buffers
  * of 32 MiB or more for the duration of the call -- measured no faster than pageable copies), "prefetch"
@@ -184,6 +189,16 @@ int scv_synth_fill_i32(scv_ctx* ctx, int32_t* answers, int32_t* tokens, int32_t*
 int scv_last_kernel_ns(scv_ctx* ctx, uint64_t* ns_out);
 /* Sum and count of all timed launches since the previous call (resets the accumulators). */
 int scv_drain_kernel_ns(scv_ctx* ctx, uint64_t* total_ns_out, uint64_t* launches_out);
+
+/*
+ * Pinned (page-locked) host memory for HOST-mode inputs.  The reference keeps its samples in one JSON cache
+ * (o1.py:50-68); an extractor that writes the answers / tokens tensors straight into a buffer from here lets
+ * SCV_MEM_HOST calls DMA them in place (the staging pipeline otherwise copies pageable memory into pinned
+ * bounce slots with worker threads first).  Any hipHostMalloc / hipHostRegister'ed buffer is recognised the
+ * same way; these two entry points only spare a ctypes caller a HIP binding of its own.
+ */
+int scv_host_alloc(void** out, size_t bytes);
+int scv_host_free(void* p);
 
 int scv_device_count(void);
 /* Static properties of the ctx device: [0]=CU count, [1]=LDS bytes per workgroup max, [2]=clock kHz, [3]=HBM bytes. */

@@ -53,6 +53,8 @@ def load():
     L.scv_synth_fill_i32.argtypes = [p, p, p, p, i64, i32, i64, i64, u64, C.c_int]
     L.scv_last_kernel_ns.argtypes = [p, C.POINTER(u64)]
     L.scv_drain_kernel_ns.argtypes = [p, C.POINTER(u64), C.POINTER(u64)]
+    L.scv_host_alloc.argtypes = [C.POINTER(p), C.c_size_t]
+    L.scv_host_free.argtypes = [p]
     L.scv_device_count.argtypes = []
     L.scv_device_info.argtypes = [p, C.POINTER(i64 * 4)]
     L.scv_last_error.argtypes = []
@@ -61,7 +63,7 @@ def load():
     L.scv_version.restype = C.c_char_p
     for name in ("scv_create", "scv_destroy", "scv_set_stream", "scv_sync", "scv_set_tuning", "scv_set_option", "scv_aggregate_i32", "scv_aggregate_prefix_i32",
                  "scv_bootstrap", "scv_synth_fill_i32", "scv_last_kernel_ns", "scv_drain_kernel_ns",
-                 "scv_device_count", "scv_device_info"):
+                 "scv_device_count", "scv_device_info", "scv_host_alloc", "scv_host_free"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -10,7 +10,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -36,6 +41,84 @@ int fail(int code, const char* fmt, ...) {
 struct EventPair { hipEvent_t a, b; };
 
 }  // namespace
+
+// ---- HOST-mode ingestion pipeline -----------------------------------------------------
+// Real (non-synthetic) answer tensors arrive in pageable host memory, and then the 63 GB/s PCIe link -- not HBM --
+// bounds end-to-end votes/s.  A pageable hipMemcpyAsync goes through the runtime's own bounce buffers with one
+// copying thread (measured 38-46 GB/s, and it blocks the host).  Here the chunk loop is a three-stage pipeline:
+//   worker threads   memcpy chunk i+1 of the caller's buffers into a PINNED bounce slot   (several cores)
+//   copy stream      DMA slot -> HBM slot of chunk i                                       (one 55+ GB/s transfer)
+//   compute stream   hot-path kernel(s) on chunk i-1, cell table back to the caller
+// with two bounce slots, two HBM slots and events between the stages.  Buffers the caller has already pinned
+// (hipHostMalloc / hipHostRegister: scv_host_alloc) skip the bounce and are DMA'd in place.
+struct HostPipe {
+    static constexpr int kSlots = 2;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t landed[kSlots] = {nullptr, nullptr};      // H2D of the slot finished (bounce slot reusable, kernel may start)
+    hipEvent_t consumed[kSlots] = {nullptr, nullptr};    // kernel + cell D2H on the slot finished (HBM slot reusable)
+    void* bounce[kSlots] = {nullptr, nullptr};           // pinned host memory
+    size_t bounce_bytes = 0;
+    void* dslot[kSlots] = {nullptr, nullptr};            // HBM
+    size_t dslot_bytes = 0;
+    // worker threads for the pageable -> pinned copies
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::function<void()>> jobs;
+    size_t next_job = 0, jobs_done = 0;
+    bool stop = false;
+
+    void worker_loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || next_job < jobs.size(); });
+            if (stop) return;
+            const size_t j = next_job++;
+            lk.unlock();
+            jobs[j]();
+            lk.lock();
+            if (++jobs_done == jobs.size()) cv_done.notify_all();
+        }
+    }
+    void start(int nthreads) {
+        for (int i = (int)workers.size(); i < nthreads; ++i) workers.emplace_back([this] { worker_loop(); });
+    }
+    // run the pieces on the workers (the caller takes pieces too) and return when all are done
+    void run(std::vector<std::function<void()>>&& pieces) {
+        if (pieces.empty()) return;
+        if (workers.empty()) { for (auto& f : pieces) f(); return; }
+        std::unique_lock<std::mutex> lk(mu);
+        jobs = std::move(pieces);
+        next_job = 0; jobs_done = 0;
+        cv_work.notify_all();
+        while (next_job < jobs.size()) {                 // the calling thread is a worker too
+            const size_t j = next_job++;
+            lk.unlock();
+            jobs[j]();
+            lk.lock();
+            ++jobs_done;
+        }
+        cv_done.wait(lk, [&] { return jobs_done == jobs.size(); });
+        jobs.clear();
+        next_job = 0; jobs_done = 0;
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto& t : workers) t.join();
+        workers.clear();
+        for (int k = 0; k < kSlots; ++k) {
+            if (landed[k]) (void)hipEventDestroy(landed[k]);
+            if (consumed[k]) (void)hipEventDestroy(consumed[k]);
+            if (bounce[k]) (void)hipHostFree(bounce[k]);
+            if (dslot[k]) (void)hipFree(dslot[k]);
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    }
+};
 
 struct scv_ctx {
     int device = 0;
@@ -81,6 +164,10 @@ struct scv_ctx {
     // HOST-mode staging (grown on demand)
     void* d_stage = nullptr;
     size_t d_stage_bytes = 0;
+    HostPipe* pipe = nullptr;       // HOST-mode ingestion pipeline (created on the first HOST call)
+    int host_pipeline = 1;          // 0: the round-1 serial staging loop (A/B runs)
+    int stage_mb = 128;             // HOST mode: chunk size (votes + tokens) of the staging pipeline
+    int copy_threads = 16;          // HOST mode: threads copying pageable caller memory into the pinned bounce slots
 };
 
 namespace {
@@ -601,6 +688,9 @@ int scv_create(scv_ctx** out, int device, uint32_t flags) {
     ctx->path = env_int("SCV_PATH", 0);
     ctx->sorted = env_int("SCV_SORTED", 1);
     ctx->small_n_max = env_int("SCV_SMALL_N_MAX", ctx->small_n_max);
+    ctx->copy_threads = env_int("SCV_COPY_THREADS", ctx->copy_threads);
+    ctx->host_pipeline = env_int("SCV_HOST_PIPELINE", ctx->host_pipeline);
+    if (ctx->copy_threads < 1) ctx->copy_threads = 1;
     if (getenv("SCV_COPIES") || getenv("SCV_THREADS") || getenv("SCV_WG_PER_CU") || getenv("SCV_UNROLL")) ctx->user_tuned = true;
     if (!valid_copies(ctx->copies) || !valid_threads(ctx->threads) || !valid_unroll(ctx->unroll) || ctx->wg_per_cu < 1) {
         int code = fail(SCV_ERR_ARG, "bad SCV_* tuning environment");
@@ -617,6 +707,7 @@ int scv_destroy(scv_ctx* ctx) {
     (void)guard_.enter(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    if (ctx->pipe) { ctx->pipe->shutdown(); delete ctx->pipe; ctx->pipe = nullptr; }
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
     if (ctx->d_cells) (void)hipFree(ctx->d_cells);
@@ -682,6 +773,9 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "small_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "small_n_max < 0"); ctx->small_n_max = (int)(value > 32768 ? 32768 : value); }
     else if (!strcmp(key, "auto_geometry")) ctx->user_tuned = value == 0;
     else if (!strcmp(key, "pin_host")) ctx->pin_host = value != 0;
+    else if (!strcmp(key, "host_pipeline")) ctx->host_pipeline = value != 0;
+    else if (!strcmp(key, "stage_mb")) { if (value < 1 || value > 65536) return fail(SCV_ERR_ARG, "stage_mb out of range"); ctx->stage_mb = (int)value; }
+    else if (!strcmp(key, "copy_threads")) { if (value < 1 || value > 256) return fail(SCV_ERR_ARG, "copy_threads out of range"); ctx->copy_threads = (int)value; }
     else if (!strcmp(key, "fused_counters_max")) { if (value < 0) return fail(SCV_ERR_ARG, "fused_counters_max < 0"); ctx->fused_counters_max = (int)(value > (1 << 30) ? (1 << 30) : value); }
     else return fail(SCV_ERR_ARG, "unknown option '%s'", key);
     return SCV_OK;
@@ -691,27 +785,12 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
 
 namespace {
 
-// Shared body of scv_aggregate_i32 (dense: rows of B*N votes per problem) and
-// scv_aggregate_prefix_i32 (prefix: one row of N votes per problem).
-int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
-                     const int32_t* truth, int64_t P, int32_t B, int64_t N, int mem_kind, scv_cell* cells_out,
-                     int64_t* cell_tokens_out, int64_t* tie_class_hits_out, int64_t* token_sum_out,
-                     int64_t* truth_count_sum_out) {
-    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
-    if (P < 0 || B < 0 || N < 0) return fail(SCV_ERR_ARG, "negative shape P=%lld B=%d N=%lld", (long long)P, B, (long long)N);
-    if (N > 0x7fffffffll) return fail(SCV_ERR_ARG, "N=%lld exceeds 2^31-1 (cell counts are u32)", (long long)N);
-    if (P > 0 && B > 0 && !truth) return fail(SCV_ERR_ARG, "truth is NULL");
-    if (P > 0 && B > 0 && N > 0 && !answers) return fail(SCV_ERR_ARG, "answers is NULL");
-    if (prefix && B > 0 && !n_valid) return fail(SCV_ERR_ARG, "prefix mode needs n_valid");
-    if (prefix && B > scv::kMaxSortedB) return fail(SCV_ERR_ARG, "prefix mode supports at most %d budgets", scv::kMaxSortedB);
-    if (mem_kind != SCV_MEM_HOST && mem_kind != SCV_MEM_DEVICE) return fail(SCV_ERR_ARG, "bad mem_kind %d", mem_kind);
-    SCV_ENTER(ctx);
+// The round-1 HOST path, kept for A/B runs (option "host_pipeline" = 0): one staging block, copy -> kernel ->
+// sync per chunk, pageable copies through the runtime's bounce buffers.
+int host_serial(scv_ctx* ctx, bool prefix, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
+                const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells_out, int64_t* cell_tokens_out,
+                int64_t* tie_class_hits_out, int64_t* token_sum_out, int64_t* truth_count_sum_out) {
     auto launch = prefix ? launch_prefix : launch_aggregate;
-
-    if (mem_kind == SCV_MEM_DEVICE)
-        return launch(ctx, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
-                      tie_class_hits_out, token_sum_out, truth_count_sum_out);
-
     // ---- HOST: stage problem-chunks through HBM ------------------------------------------------
     const size_t row_bytes = (prefix ? (size_t)1 : (size_t)B) * (size_t)N * sizeof(int32_t);   // votes of one problem
     // Pageable host memory is copied through the runtime's bounce buffers at a fraction of the link
@@ -777,6 +856,191 @@ int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const in
     uint32_t w = 0;
     if (int rc = fetch_err(ctx, &w)) return rc;
     return check_err_word(ctx, w);
+}
+
+bool is_pinned_host(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeHost;
+}
+
+int ensure_pipe(scv_ctx* ctx, size_t bounce_bytes, size_t dslot_bytes) {
+    if (!ctx->pipe) {
+        ctx->pipe = new (std::nothrow) HostPipe();
+        if (!ctx->pipe) return fail(SCV_ERR_ALLOC, "out of host memory");
+        SCV_HIP(hipStreamCreateWithFlags(&ctx->pipe->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < HostPipe::kSlots; ++k) {
+            SCV_HIP(hipEventCreateWithFlags(&ctx->pipe->landed[k], hipEventDisableTiming));
+            SCV_HIP(hipEventCreateWithFlags(&ctx->pipe->consumed[k], hipEventDisableTiming));
+        }
+    }
+    HostPipe* hp = ctx->pipe;
+    int nthreads = ctx->copy_threads - 1;                      // the calling thread copies too
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && nthreads > hw - 1) nthreads = hw - 1;
+    if (nthreads > 0) hp->start(nthreads);
+    if (bounce_bytes > hp->bounce_bytes) {
+        for (int k = 0; k < HostPipe::kSlots; ++k) {
+            if (hp->bounce[k]) { SCV_HIP(hipHostFree(hp->bounce[k])); hp->bounce[k] = nullptr; }
+            SCV_HIP(hipHostMalloc(&hp->bounce[k], bounce_bytes, hipHostMallocDefault));
+        }
+        hp->bounce_bytes = bounce_bytes;
+    }
+    if (dslot_bytes > hp->dslot_bytes) {
+        for (int k = 0; k < HostPipe::kSlots; ++k) {
+            if (hp->dslot[k]) { SCV_HIP(hipFree(hp->dslot[k])); hp->dslot[k] = nullptr; }
+            SCV_HIP(hipMalloc(&hp->dslot[k], dslot_bytes));
+        }
+        hp->dslot_bytes = dslot_bytes;
+    }
+    return SCV_OK;
+}
+
+// memcpy split over the pipe's worker threads (pieces of >= 1 MiB, 64-byte aligned cuts)
+void add_copy_pieces(std::vector<std::function<void()>>& pieces, void* dst, const void* src, size_t bytes, int parts) {
+    if (!bytes) return;
+    size_t piece = (bytes + parts - 1) / parts;
+    if (piece < ((size_t)1 << 20)) piece = (size_t)1 << 20;
+    piece = (piece + 63) & ~(size_t)63;
+    for (size_t off = 0; off < bytes; off += piece) {
+        const size_t n = bytes - off < piece ? bytes - off : piece;
+        char* d = static_cast<char*>(dst) + off;
+        const char* c = static_cast<const char*>(src) + off;
+        pieces.emplace_back([d, c, n] { memcpy(d, c, n); });
+    }
+}
+
+// HOST mode: the three-stage ingestion pipeline described at HostPipe.
+int host_pipelined(scv_ctx* ctx, bool prefix, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
+                   const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells_out, int64_t* cell_tokens_out,
+                   int64_t* tie_class_hits_out, int64_t* token_sum_out, int64_t* truth_count_sum_out) {
+    auto launch = prefix ? launch_prefix : launch_aggregate;
+    const size_t row_bytes = (prefix ? (size_t)1 : (size_t)B) * (size_t)N * sizeof(int32_t);   // votes of one problem
+    const size_t row_elems = row_bytes / sizeof(int32_t);
+    const size_t per_problem = row_bytes * (tokens ? 2 : 1) + sizeof(int32_t);
+    const size_t total = per_problem * (size_t)P;
+    // chunk: at most stage_mb, and small enough that a call of a few tens of MB still overlaps copy and DMA
+    size_t target = (size_t)(ctx->stage_mb > 0 ? ctx->stage_mb : 128) << 20;
+    if (const char* e = getenv("SCV_STAGE_MB")) { if (*e) target = (size_t)atoi(e) << 20; }
+    if (total / 8 < target) target = total / 8 > ((size_t)4 << 20) ? total / 8 : ((size_t)4 << 20);
+    int64_t chunk = per_problem ? (int64_t)(target / per_problem) : P;
+    if (chunk < 1) chunk = 1;
+    if (chunk > P) chunk = P;
+    // slot layout: inputs [answers | tokens | truth], outputs [cells | cell_tokens]
+    size_t off = 0;
+    const size_t o_ans = off; off = align_up(off + (size_t)chunk * row_bytes, 256);
+    const size_t o_tok = off; off = align_up(off + (tokens ? (size_t)chunk * row_bytes : 0), 256);
+    const size_t o_truth = off; off = align_up(off + (size_t)chunk * sizeof(int32_t), 256);
+    const size_t in_bytes = off;
+    const size_t o_cells = off; off = align_up(off + (size_t)chunk * B * sizeof(scv_cell), 256);
+    const size_t o_ctok = off; off = align_up(off + (size_t)chunk * B * sizeof(int64_t), 256);
+    const size_t slot_bytes = off > 0 ? off : 256;
+    if (int rc = ensure_pipe(ctx, slot_bytes, slot_bytes)) return rc;
+    HostPipe* hp = ctx->pipe;
+    // per-call device block: n_valid + counters
+    const size_t counters_bytes = ((size_t)B * SCV_TIE_CLASSES + 2 * (size_t)B) * sizeof(int64_t);
+    const size_t o_nv = 0, o_cnt = align_up((size_t)B * sizeof(int32_t), 256);
+    if (int rc = ensure_stage(ctx, o_cnt + align_up(counters_bytes, 256) + 256)) return rc;
+    char* sbase = static_cast<char*>(ctx->d_stage);
+    int64_t* d_tie = reinterpret_cast<int64_t*>(sbase + o_cnt);
+    int64_t* d_tok = d_tie + (size_t)B * SCV_TIE_CLASSES;
+    int64_t* d_ts = d_tok + B;
+    hipStream_t s = ctx->stream, cs = hp->copy_stream;
+    SCV_HIP(hipMemsetAsync(sbase + o_cnt, 0, counters_bytes > 0 ? counters_bytes : 1, s));
+    if (n_valid && B > 0) SCV_HIP(hipMemcpyAsync(sbase + o_nv, n_valid, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    // buffers the caller pinned are DMA'd in place; pageable ones go through the pinned bounce slots
+    const bool pin_a = is_pinned_host(answers), pin_t = !tokens || is_pinned_host(tokens);
+    const int parts = ctx->copy_threads > 0 ? ctx->copy_threads : 1;
+
+    struct InFlight { int64_t p0 = 0, pc = 0; bool used = false; } slotinfo[HostPipe::kSlots];
+    auto retire = [&](int k) -> int {                      // chunk in slot k is done: hand its cell table to the caller
+        if (!slotinfo[k].used) return SCV_OK;
+        SCV_HIP(hipEventSynchronize(hp->consumed[k]));
+        const char* bb = static_cast<const char*>(hp->bounce[k]);
+        const int64_t p0 = slotinfo[k].p0, pc = slotinfo[k].pc;
+        if (cells_out && B > 0) memcpy(cells_out + (size_t)p0 * B, bb + o_cells, (size_t)pc * B * sizeof(scv_cell));
+        if (cell_tokens_out && B > 0) memcpy(cell_tokens_out + (size_t)p0 * B, bb + o_ctok, (size_t)pc * B * sizeof(int64_t));
+        slotinfo[k].used = false;
+        return SCV_OK;
+    };
+
+    int64_t idx = 0;
+    for (int64_t p0 = 0; p0 < P; p0 += chunk, ++idx) {
+        const int k = (int)(idx % HostPipe::kSlots);
+        const int64_t pc = (P - p0 < chunk) ? (P - p0) : chunk;
+        if (int rc = retire(k)) return rc;                 // slot k (bounce + HBM) is free again
+        char* bb = static_cast<char*>(hp->bounce[k]);
+        char* db = static_cast<char*>(hp->dslot[k]);
+        // stage 1: caller memory -> pinned bounce slot (worker threads); overlaps the DMA of the previous chunk
+        std::vector<std::function<void()>> pieces;
+        if (!pin_a) add_copy_pieces(pieces, bb + o_ans, answers + (size_t)p0 * row_elems, (size_t)pc * row_bytes, parts);
+        if (tokens && !pin_t) add_copy_pieces(pieces, bb + o_tok, tokens + (size_t)p0 * row_elems, (size_t)pc * row_bytes, parts);
+        memcpy(bb + o_truth, truth + p0, (size_t)pc * sizeof(int32_t));
+        hp->run(std::move(pieces));
+        // stage 2: DMA to the HBM slot on the copy stream
+        const void* src_a = pin_a ? static_cast<const void*>(answers + (size_t)p0 * row_elems) : static_cast<const void*>(bb + o_ans);
+        if (row_bytes) SCV_HIP(hipMemcpyAsync(db + o_ans, src_a, (size_t)pc * row_bytes, hipMemcpyHostToDevice, cs));
+        if (tokens && row_bytes) {
+            const void* src_t = pin_t ? static_cast<const void*>(tokens + (size_t)p0 * row_elems) : static_cast<const void*>(bb + o_tok);
+            SCV_HIP(hipMemcpyAsync(db + o_tok, src_t, (size_t)pc * row_bytes, hipMemcpyHostToDevice, cs));
+        }
+        SCV_HIP(hipMemcpyAsync(db + o_truth, bb + o_truth, (size_t)pc * sizeof(int32_t), hipMemcpyHostToDevice, cs));
+        SCV_HIP(hipEventRecord(hp->landed[k], cs));
+        // stage 3: hot path on the compute stream, cell table back into the pinned slot
+        SCV_HIP(hipStreamWaitEvent(s, hp->landed[k], 0));
+        if (int rc = launch(ctx, reinterpret_cast<const int32_t*>(db + o_ans),
+                            tokens ? reinterpret_cast<const int32_t*>(db + o_tok) : nullptr,
+                            n_valid ? reinterpret_cast<const int32_t*>(sbase + o_nv) : nullptr,
+                            reinterpret_cast<const int32_t*>(db + o_truth), pc, B, N,
+                            reinterpret_cast<scv_cell*>(db + o_cells), reinterpret_cast<int64_t*>(db + o_ctok), d_tie, d_tok, d_ts))
+            return rc;
+        if (cells_out && B > 0) SCV_HIP(hipMemcpyAsync(bb + o_cells, db + o_cells, (size_t)pc * B * sizeof(scv_cell), hipMemcpyDeviceToHost, s));
+        if (cell_tokens_out && B > 0) SCV_HIP(hipMemcpyAsync(bb + o_ctok, db + o_ctok, (size_t)pc * B * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        SCV_HIP(hipEventRecord(hp->consumed[k], s));
+        // the copy stream may not overwrite this HBM slot before the kernel has consumed it (next use: chunk idx + 2,
+        // whose retire(k) synchronises the host on consumed[k] before anything is enqueued)
+        slotinfo[k].p0 = p0; slotinfo[k].pc = pc; slotinfo[k].used = true;
+    }
+    for (int k = 0; k < HostPipe::kSlots; ++k)
+        if (int rc = retire(k)) return rc;
+    if (B > 0) {
+        if (tie_class_hits_out) SCV_HIP(hipMemcpyAsync(tie_class_hits_out, d_tie, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        if (token_sum_out) SCV_HIP(hipMemcpyAsync(token_sum_out, d_tok, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        if (truth_count_sum_out) SCV_HIP(hipMemcpyAsync(truth_count_sum_out, d_ts, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    }
+    SCV_HIP(hipStreamSynchronize(s));
+    uint32_t w = 0;
+    if (int rc = fetch_err(ctx, &w)) return rc;
+    return check_err_word(ctx, w);
+}
+
+// Shared body of scv_aggregate_i32 (dense: rows of B*N votes per problem) and
+// scv_aggregate_prefix_i32 (prefix: one row of N votes per problem).
+int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
+                     const int32_t* truth, int64_t P, int32_t B, int64_t N, int mem_kind, scv_cell* cells_out,
+                     int64_t* cell_tokens_out, int64_t* tie_class_hits_out, int64_t* token_sum_out,
+                     int64_t* truth_count_sum_out) {
+    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+    if (P < 0 || B < 0 || N < 0) return fail(SCV_ERR_ARG, "negative shape P=%lld B=%d N=%lld", (long long)P, B, (long long)N);
+    if (N > 0x7fffffffll) return fail(SCV_ERR_ARG, "N=%lld exceeds 2^31-1 (cell counts are u32)", (long long)N);
+    if (P > 0 && B > 0 && !truth) return fail(SCV_ERR_ARG, "truth is NULL");
+    if (P > 0 && B > 0 && N > 0 && !answers) return fail(SCV_ERR_ARG, "answers is NULL");
+    if (prefix && B > 0 && !n_valid) return fail(SCV_ERR_ARG, "prefix mode needs n_valid");
+    if (prefix && B > scv::kMaxSortedB) return fail(SCV_ERR_ARG, "prefix mode supports at most %d budgets", scv::kMaxSortedB);
+    if (mem_kind != SCV_MEM_HOST && mem_kind != SCV_MEM_DEVICE) return fail(SCV_ERR_ARG, "bad mem_kind %d", mem_kind);
+    SCV_ENTER(ctx);
+    auto launch = prefix ? launch_prefix : launch_aggregate;
+
+    if (mem_kind == SCV_MEM_DEVICE)
+        return launch(ctx, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
+                      tie_class_hits_out, token_sum_out, truth_count_sum_out);
+
+    if (ctx->host_pipeline)
+        return host_pipelined(ctx, prefix, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
+                              tie_class_hits_out, token_sum_out, truth_count_sum_out);
+    return host_serial(ctx, prefix, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
+                       tie_class_hits_out, token_sum_out, truth_count_sum_out);
 }
 
 }  // namespace
@@ -889,6 +1153,20 @@ int scv_drain_kernel_ns(scv_ctx* ctx, uint64_t* total_ns_out, uint64_t* launches
     *total_ns_out = (uint64_t)total;
     *launches_out = ctx->events_used;
     ctx->events_used = 0;
+    return SCV_OK;
+}
+
+int scv_host_alloc(void** out, size_t bytes) {
+    if (!out) return fail(SCV_ERR_ARG, "scv_host_alloc: out is NULL");
+    *out = nullptr;
+    if (bytes == 0) return SCV_OK;
+    SCV_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return SCV_OK;
+}
+
+int scv_host_free(void* p) {
+    if (!p) return SCV_OK;
+    SCV_HIP(hipHostFree(p));
     return SCV_OK;
 }
 

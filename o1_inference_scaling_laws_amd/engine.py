@@ -69,6 +69,22 @@ def _np_ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def pinned_empty(shape, dtype=np.int32) -> np.ndarray:
+    """numpy array over page-locked host memory (scv_host_alloc): HOST-mode calls DMA such inputs in place instead
+    of copying them through the pinned bounce slots first.  The memory is released when the array is collected."""
+    import weakref
+    L = _lib.load()
+    nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+    if nbytes == 0:
+        return np.empty(shape, dtype=dtype)
+    ptr = C.c_void_p()
+    check(L.scv_host_alloc(C.byref(ptr), nbytes))
+    buf = (C.c_char * nbytes).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+    weakref.finalize(buf, L.scv_host_free, C.c_void_p(ptr.value))
+    return arr
+
+
 class Engine:
     """One context per GPU per process (one process per GPU under torch.distributed)."""
 

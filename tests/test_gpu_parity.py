@@ -96,6 +96,40 @@ def test_host_mode_streams_problem_chunks(hip_engine, monkeypatch):
     assert n >= 10 and total > 0
 
 
+@pytest.mark.parametrize("pipeline,threads", [(0, 1), (1, 1), (1, 5)])
+def test_host_mode_pipeline_and_pinned_sources(hip_engine, monkeypatch, pipeline, threads):
+    """the three-stage HOST ingestion pipeline (worker threads -> pinned bounce slots -> DMA ->
+    kernel, two slots in flight) against the serial loop and the oracle: many chunks, a chunk size that does not
+    divide P, tokens, ragged budgets, pageable and pinned (DMA in place) sources, every output."""
+    from o1_inference_scaling_laws_amd.engine import pinned_empty
+    monkeypatch.setenv("SCV_STAGE_MB", "1")
+    a, t, tr = coracle.synth_fill(203, 2, 9001, 77, 1, want_tokens=True)    # 14.6 MB of votes + tokens -> ~15 chunks
+    nv = np.array([9001, 77], dtype=np.int32)
+    want = oracle(a, tr, tokens=t, n_valid=nv)
+    hip_engine.set_option("host_pipeline", pipeline)
+    hip_engine.set_option("copy_threads", threads)
+    try:
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
+        assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
+        ap, tp = pinned_empty(a.shape), pinned_empty(t.shape)
+        ap[...] = a
+        tp[...] = t
+        assert_results_equal(hip_engine.aggregate(ap, tr, tokens=tp, n_valid=nv), want)       # both pinned
+        assert_results_equal(hip_engine.aggregate(ap, tr, tokens=t, n_valid=nv), want)        # mixed
+        got = hip_engine.aggregate(a, tr, tokens=t, n_valid=nv, want_cells=False)             # counters only
+        assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum)
+        # small calls (one chunk, fewer problems than slots) and a domain error in the middle of a long call
+        assert_results_equal(hip_engine.aggregate(a[:1], tr[:1], tokens=t[:1]), oracle(a[:1], tr[:1], tokens=t[:1]))
+        bad = a.copy()
+        bad[150, 1, 8000] = 4096
+        with pytest.raises(_lib.DomainError):
+            hip_engine.aggregate(bad, tr)
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)         # the ctx recovers
+    finally:
+        hip_engine.set_option("host_pipeline", 1)
+        hip_engine.set_option("copy_threads", 16)
+
+
 def test_empty_shapes(hip_engine):
     for shape in [(0, 3, 16), (4, 0, 16), (4, 2, 0)]:
         P, B, N = shape
