@@ -140,6 +140,12 @@ struct scv_ctx {
     int small_reg = 1;       // small path: 1 = register-resident variant for N <= 128 (measured +10 %), 2 = also for N <= 512 (measured slower)
     int tiny_n_max = 32;     // auto/small path: N <= this -> register-only kernel, several cells per wave
     int small_n_max = 512;   // auto (reg path off): N <= this -> wave-per-cell kernel (crossover measured: profiles/r01_crossover_d*.log)
+    int overwrite_counters = 0;  // DEVICE mode: per-budget outputs are overwritten instead of accumulated into (no caller memset)
+    int ticket_merge = 0;    // split-N: 1 = merge inside the launch (last-arriver tree) instead of a second launch; measured 0-9 % slower than the merge kernel, off
+    void* d_tickets = nullptr;   // arrival counters of the single-launch modes (all zero between launches)
+    size_t d_tickets_words = 0;
+    void* d_partial2 = nullptr;  // split-N group histograms
+    size_t d_partial2_bytes = 0;
     int boot_lds = 1;        // bootstrap: LDS-resident code table when it fits (0: always the global-gather kernel)
     int reg_km = 1;          // reg path: batches in flight per wave = km x 4 KiB
     int reg_shape = 0;       // reg path: force a kernel shape (A/B runs), see launch_aggregate
@@ -295,6 +301,26 @@ int ensure_cells(scv_ctx* ctx, size_t bytes) {
     return SCV_OK;
 }
 
+// Arrival counters: zero when allocated, and every counter is reset by the workgroup that completes it, so the
+// buffer is all-zero again whenever no launch is in flight.
+int ensure_tickets(scv_ctx* ctx, size_t words) {
+    if (words <= ctx->d_tickets_words) return SCV_OK;
+    if (ctx->d_tickets) { SCV_HIP(hipStreamSynchronize(ctx->stream)); SCV_HIP(hipFree(ctx->d_tickets)); ctx->d_tickets = nullptr; ctx->d_tickets_words = 0; }
+    words = (words + 1023) & ~(size_t)1023;
+    SCV_HIP(hipMalloc(&ctx->d_tickets, words * sizeof(uint32_t)));
+    SCV_HIP(hipMemsetAsync(ctx->d_tickets, 0, words * sizeof(uint32_t), ctx->stream));
+    ctx->d_tickets_words = words;
+    return SCV_OK;
+}
+
+int ensure_partial2(scv_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->d_partial2_bytes) return SCV_OK;
+    if (ctx->d_partial2) { SCV_HIP(hipFree(ctx->d_partial2)); ctx->d_partial2 = nullptr; ctx->d_partial2_bytes = 0; }
+    SCV_HIP(hipMalloc(&ctx->d_partial2, bytes));
+    ctx->d_partial2_bytes = bytes;
+    return SCV_OK;
+}
+
 int ensure_partial(scv_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->d_partial_bytes) return SCV_OK;
     if (ctx->d_partial) { SCV_HIP(hipFree(ctx->d_partial)); ctx->d_partial = nullptr; ctx->d_partial_bytes = 0; }
@@ -329,13 +355,14 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.prefetch = ctx->prefetch;
     a.sorted = ctx->sorted;
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0;
+    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
 
     // per-budget counters: fused per-cell atomics for few cells, a separate reduction of the cell
     // table for many (same-address device atomics serialise at ~12 ns each)
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
-    const bool use_reduce = want_counters && reduce_counters_separately(ctx, ncells, B, N);
-    if (use_reduce) {
+    bool use_reduce = want_counters && reduce_counters_separately(ctx, ncells, B, N);
+    auto need_cell_scratch = [&]() -> int {          // the counters will be computed from the cell table: make sure there is one
         a.tie_hits = nullptr; a.token_sum = nullptr; a.truth_sum = nullptr;
         if (!a.cells || (tok && tok_sum && !a.cell_tokens)) {
             const size_t cb = (size_t)ncells * sizeof(scv_cell);
@@ -343,7 +370,10 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             if (!a.cells) a.cells = static_cast<scv_cell*>(ctx->d_cells);
             if (tok && !a.cell_tokens) a.cell_tokens = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->d_cells) + ((cb + 255) / 256) * 256);
         }
-    }
+        return SCV_OK;
+    };
+    if (use_reduce)
+        if (int rc = need_cell_scratch()) return rc;
     auto finish = [&](EventPair* ev_) -> int {
         if (use_reduce) {
             int64_t chunks = (P + 2047) / 2048;
@@ -364,6 +394,28 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     };
 
     int path = ctx->path;
+    // Overwrite semantics (option "overwrite_counters"): the streaming kernel turns its cell table into the counters
+    // with its last workgroup (single launch: no memset, no reduce launch) when the cells are few; every other
+    // regime gets a memset node in front and accumulates as usual.
+    const bool stream_path = (path == 1 || path == 2) || (path == 0 && !(N > ctx->tiny_n_max && N <= ctx->reg_n_max) && N > ctx->small_n_max);
+    bool overwrite_fused = false;
+    if (ctx->overwrite_counters && want_counters) {
+        if (stream_path && ncells <= 8192 && B <= 64) {
+            overwrite_fused = true;
+            use_reduce = false;
+            if (int rc = need_cell_scratch()) return rc;
+            if (int rc = ensure_tickets(ctx, 1)) return rc;
+            a.overwrite = 1;
+            a.tickets = static_cast<uint32_t*>(ctx->d_tickets);
+            a.ow_tie = reinterpret_cast<unsigned long long*>(tie);
+            a.ow_tok = reinterpret_cast<unsigned long long*>(tok_sum);
+            a.ow_truth = reinterpret_cast<unsigned long long*>(truth_sum);
+        } else {
+            if (tie) SCV_HIP(hipMemsetAsync(tie, 0, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), ctx->stream));
+            if (tok_sum) SCV_HIP(hipMemsetAsync(tok_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
+            if (truth_sum) SCV_HIP(hipMemsetAsync(truth_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
+        }
+    }
     if (path == 0) {
         if (N > ctx->tiny_n_max && N <= ctx->reg_n_max) path = 4;
         else path = (N <= ctx->small_n_max) ? 3 : 1;
@@ -490,12 +542,16 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         if (ctx->segs_override > 0) S = ctx->segs_override;
         else {
             S = slots / ncells;
-            const int64_t by_size = (N * 4) / (512 << 10);
+            // two launches: segments of at least 512 KiB (more, smaller ones only add fold / publish / merge work);
+            // merged inside the launch: down to 256 KiB, so that ONE huge cell still gets a workgroup on every CU
+            const int64_t by_size = (N * 4) / ((ctx->ticket_merge ? 256 : 512) << 10);
             if (S > by_size) S = by_size;
+            if (ctx->ticket_merge && S > 256) S = 256;
         }
         if (S > 4096) S = 4096;
         if (S < 1) S = 1;
     }
+    bool merge_in_launch = false;
     if (S > 1) {
         a.segs = (int32_t)S;
         a.seg_len = ((N + S - 1) / S + 3) & ~(int64_t)3;     // multiple of 4 votes: segments start 16-byte aligned in aligned rows
@@ -505,7 +561,33 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         if (int rc = ensure_partial(ctx, hist_bytes + items * sizeof(long long) + 256)) return rc;
         a.partial = static_cast<uint32_t*>(ctx->d_partial);
         a.partial_tok = reinterpret_cast<long long*>(static_cast<char*>(ctx->d_partial) + ((hist_bytes + 255) / 256) * 256);
+        if (ctx->ticket_merge && S <= 256) {
+            // merge inside the launch: groups of <= 16 segments, then <= 16 groups (scv::merge_split_cell)
+            merge_in_launch = true;
+            const int64_t G = (S + 15) / 16;
+            a.ticket_merge = 1;
+            a.ngroups = (int32_t)G;
+            const size_t h2 = (size_t)ncells * (size_t)G * scv::kBins * sizeof(uint32_t);
+            if (int rc = ensure_partial2(ctx, h2 + (size_t)ncells * G * sizeof(long long) + 256)) return rc;
+            a.partial2 = static_cast<uint32_t*>(ctx->d_partial2);
+            a.partial2_tok = reinterpret_cast<long long*>(static_cast<char*>(ctx->d_partial2) + ((h2 + 255) / 256) * 256);
+            if (int rc = ensure_tickets(ctx, 1 + (size_t)ncells * G + (size_t)ncells)) return rc;
+            a.tickets = static_cast<uint32_t*>(ctx->d_tickets);
+        }
     }
+    if (a.overwrite && S > 1 && !merge_in_launch) {
+        // split cells finished by the merge KERNEL: the main launch's last workgroup would read an unfinished cell
+        // table.  Overwrite = memset node + accumulate here.
+        a.overwrite = 0;
+        a.ow_tie = a.ow_tok = a.ow_truth = nullptr;
+        a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
+        a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
+        a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
+        if (tie) SCV_HIP(hipMemsetAsync(tie, 0, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), ctx->stream));
+        if (tok_sum) SCV_HIP(hipMemsetAsync(tok_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
+        if (truth_sum) SCV_HIP(hipMemsetAsync(truth_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
+    }
+    if (a.overwrite || a.ticket_merge) a.tickets = static_cast<uint32_t*>(ctx->d_tickets);   // (the buffer may have grown)
     const int64_t nitems = ncells * S;
     int64_t grid = slots;
     if (ctx->grid_override > 0) grid = ctx->grid_override;
@@ -523,7 +605,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)threads), lds, ctx->stream, a);
     SCV_HIP(hipGetLastError());
-    if (S > 1) {
+    if (S > 1 && !merge_in_launch) {
         int64_t mgrid = ncells < (int64_t)ctx->num_cus * 8 ? ncells : (int64_t)ctx->num_cus * 8;
         if (tok) hipLaunchKernelGGL((scv::scv_merge_partials<true>), dim3((unsigned)mgrid), dim3(1024), 0, ctx->stream, a);
         else hipLaunchKernelGGL((scv::scv_merge_partials<false>), dim3((unsigned)mgrid), dim3(1024), 0, ctx->stream, a);
@@ -549,6 +631,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     a.err_flag = ctx->d_err;
     a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.prefetch = 0; a.sorted = 1;
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0;
+    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
     const bool use_reduce = want_counters && reduce_counters_separately(ctx, ncells, B, N);
@@ -560,6 +643,11 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
             if (!a.cells) a.cells = static_cast<scv_cell*>(ctx->d_cells);
             if (tok && !a.cell_tokens) a.cell_tokens = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->d_cells) + ((cb + 255) / 256) * 256);
         }
+    }
+    if (ctx->overwrite_counters && want_counters) {      // overwrite semantics: a memset node in front (no fused variant here)
+        if (tie) SCV_HIP(hipMemsetAsync(tie, 0, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), ctx->stream));
+        if (tok_sum) SCV_HIP(hipMemsetAsync(tok_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
+        if (truth_sum) SCV_HIP(hipMemsetAsync(truth_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
     }
     EventPair* ev = nullptr;
     if (int rc = next_event_pair(ctx, &ev)) return rc;
@@ -710,6 +798,8 @@ int scv_destroy(scv_ctx* ctx) {
     if (ctx->pipe) { ctx->pipe->shutdown(); delete ctx->pipe; ctx->pipe = nullptr; }
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+    if (ctx->d_partial2) (void)hipFree(ctx->d_partial2);
+    if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
     if (ctx->d_cells) (void)hipFree(ctx->d_cells);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -763,6 +853,8 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "path")) { if (value < 0 || value > 4) return fail(SCV_ERR_ARG, "path must be 0..4"); ctx->path = (int)value; }
     else if (!strcmp(key, "reg_dense4")) ctx->reg_dense4 = value != 0;
     else if (!strcmp(key, "boot_lds")) ctx->boot_lds = value != 0;
+    else if (!strcmp(key, "overwrite_counters")) ctx->overwrite_counters = value != 0;
+    else if (!strcmp(key, "ticket_merge")) ctx->ticket_merge = value != 0;
     else if (!strcmp(key, "reg_km")) { if (value != 1 && value != 2 && value != 4) return fail(SCV_ERR_ARG, "reg_km must be 1, 2 or 4"); ctx->reg_km = (int)value; }
     else if (!strcmp(key, "reg_shape")) { if (value < 0 || value > 9999) return fail(SCV_ERR_ARG, "reg_shape out of range"); ctx->reg_shape = (int)value; }
     else if (!strcmp(key, "reg_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "reg_n_max < 0"); ctx->reg_n_max = (int)(value > 4096 ? 4096 : value); }
@@ -1036,6 +1128,9 @@ int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const in
         return launch(ctx, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
                       tie_class_hits_out, token_sum_out, truth_count_sum_out);
 
+    // HOST mode accumulates its own zeroed counters over the chunks: the DEVICE-mode overwrite option must not apply
+    struct Restore { scv_ctx* c; int v; ~Restore() { c->overwrite_counters = v; } } restore{ctx, ctx->overwrite_counters};
+    ctx->overwrite_counters = 0;
     if (ctx->host_pipeline)
         return host_pipelined(ctx, prefix, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
                               tie_class_hits_out, token_sum_out, truth_count_sum_out);

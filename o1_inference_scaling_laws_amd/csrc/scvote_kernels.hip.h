@@ -67,6 +67,16 @@ struct AggArgs {
     int32_t segs;           // split-N: segments per cell (1 = whole cells)
     int64_t seg_len;        // split-N: votes per segment
     int32_t wave_lds_words; // register-resident kernels: LDS words per wave (histograms + n_valid cache)
+    // single-launch modes of the streaming kernel (agent-scope hand-offs inside the launch, no second kernel):
+    uint32_t* tickets;      // [0] workgroups finished | [1 ..] split-N arrival counters; all zero between launches
+    int32_t overwrite;      // != 0: per-budget counters are OVERWRITTEN by the last workgroup to finish (from the cell table)
+    unsigned long long* ow_tie;     // overwrite outputs (tie_hits / token_sum / truth_sum are NULL in this mode)
+    unsigned long long* ow_tok;
+    unsigned long long* ow_truth;
+    int32_t ticket_merge;   // != 0: split-N cells are merged by the last segment to arrive (2-level tree, fan-in 16)
+    int32_t ngroups;        // split-N: groups of <= 16 segments per cell
+    uint32_t* partial2;     // split-N: [ncells * ngroups][1024] group histograms
+    long long* partial2_tok;
     uint32_t* partial;      // split-N: [ncells * segs][1024] partial histograms
     long long* partial_tok; // split-N: [ncells * segs] partial token sums
 };
@@ -114,6 +124,16 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
     const unsigned long long s2 = wave_sum_u32((uint32_t)((u >> 43) & 0x1fffffu));
     return (long long)(s0 + (s1 << 22) + (s2 << 43));
 }
+
+// Agent-scope relaxed accesses (global_store / global_load ... sc1): stores are written through, loads bypass the
+// CU's L1, so data handed from one workgroup to another INSIDE a launch needs no release / acquire fence -- only
+// that every storing wave drains its stores (s_waitcnt vmcnt(0)) before the arrival counter is bumped
+// (guide: cdna_hip_programming.md Guideline 16, recipe R1).
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int RL2>
 __device__ __forceinline__ void vote(uint32_t* hist, uint32_t copy, uint32_t v, uint32_t& bad) {
@@ -285,9 +305,16 @@ __device__ __forceinline__ void finalize_cell(const AggArgs& a, uint32_t* red, c
             rec.y = tc;
             rec.z = (n_modes & 0xffffu) | ((any ? (min_mode & 0xffffu) : 0xffffu) << 16);
             rec.w = hit;
-            reinterpret_cast<uint4*>(a.cells)[cell] = rec;
+            if (a.overwrite) {                         // read by the last workgroup of this launch: write through
+                unsigned long long* c8 = reinterpret_cast<unsigned long long*>(a.cells) + 2 * cell;
+                st_agent(c8, (unsigned long long)rec.x | ((unsigned long long)rec.y << 32));
+                st_agent(c8 + 1, (unsigned long long)rec.z | ((unsigned long long)rec.w << 32));
+            } else reinterpret_cast<uint4*>(a.cells)[cell] = rec;
         }
-        if (a.cell_tokens) a.cell_tokens[cell] = tok;
+        if (a.cell_tokens) {
+            if (a.overwrite) st_agent(reinterpret_cast<unsigned long long*>(a.cell_tokens) + cell, (unsigned long long)tok);
+            else a.cell_tokens[cell] = tok;
+        }
         // o1.py:238-240 as integers: tie-class counter, token sum, truth-count sum
         if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
         if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
@@ -417,6 +444,141 @@ __device__ __forceinline__ void describe_item(const AggArgs& a, bool use_ord, co
     it.nvec = (n - it.head) >> 2;
 }
 
+// ---- single-launch epilogues of the streaming kernel ------------------------------------------------
+//
+// (a) counters without a memset or a reduce launch: every workgroup bumps tickets[0] when it has finished its
+//     items; the one that finds gridDim.x - 1 there knows every cell record of the launch has been written (write-
+//     through) and OVERWRITES the per-budget counters from the cell table (o1.py:236-245 as integers).
+// (b) split-N without a merge launch: see merge_split_cell below.
+template <int T, bool TOK>
+__device__ __forceinline__ void overwrite_counters_from_cells(const AggArgs& a, uint32_t* lds, int lds_words /* >= 4096 */, int tid) {
+    // budgets are handled GB at a time, all in parallel: LDS holds GB tie-class rows of 1025 words + 2 * GB 64-bit sums
+    const unsigned long long* c8 = reinterpret_cast<const unsigned long long*>(a.cells);
+    const int32_t fit = (lds_words - 16) / (SCV_TIE_CLASSES + 4);           // 3 at the smallest histogram (R = 4), 15 at R = 16
+    const int32_t GB = a.B < fit ? a.B : fit;
+    uint32_t* tie = lds;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + ((GB * SCV_TIE_CLASSES + 1) & ~1));   // [GB] truth sums, [GB] token sums
+    for (int32_t b0 = 0; b0 < a.B; b0 += GB) {
+        const int32_t nb = a.B - b0 < GB ? a.B - b0 : GB;
+        for (int i = tid; i < nb * SCV_TIE_CLASSES; i += T) tie[i] = 0;
+        if (tid < 2 * GB) acc[tid] = 0;
+        __syncthreads();
+        // thread -> (problem, budget of the group): consecutive threads read consecutive cells of one problem row
+        const int64_t work = a.P * nb;
+        for (int64_t w = tid; w < work; w += T) {
+            const int64_t p = w / nb;
+            const int32_t bl = (int32_t)(w - p * nb);
+            const int64_t cell = p * a.B + b0 + bl;
+            const unsigned long long lo = ld_agent(c8 + 2 * cell), hi = ld_agent(c8 + 2 * cell + 1);
+            if ((hi >> 32) & 0xffu) atomicAdd(&tie[bl * SCV_TIE_CLASSES + ((uint32_t)hi & 0xffffu)], 1u);
+            atomicAdd(&acc[bl], lo >> 32);
+            if (TOK && a.ow_tok) atomicAdd(&acc[GB + bl], ld_agent(reinterpret_cast<const unsigned long long*>(a.cell_tokens) + cell));
+        }
+        __syncthreads();
+        if (a.ow_tie)
+            for (int i = tid; i < nb * SCV_TIE_CLASSES; i += T) a.ow_tie[(int64_t)b0 * SCV_TIE_CLASSES + i] = tie[i];
+        if (tid < nb) {
+            if (a.ow_truth) a.ow_truth[b0 + tid] = acc[tid];
+            if (a.ow_tok) a.ow_tok[b0 + tid] = TOK ? acc[GB + tid] : 0ull;
+        }
+        __syncthreads();
+    }
+}
+
+// (b) A cell split over S segments (one workgroup each): a segment publishes its 1024-bin partial histogram write-
+//     through and bumps the arrival counter of its GROUP of <= 16 segments; the last arriver of a group sums the
+//     group's partials (<= 64 KB) and, when the cell has several groups, publishes the group histogram and bumps the
+//     cell's counter; the last group sums <= 16 group histograms and finishes the cell.  Nobody waits: a workgroup
+//     that is not last simply goes on to its next item.  Counters are reset by the workgroup that completes them,
+//     so the state is all-zero again when the launch ends (graph replays included).
+//     Returns true (to every thread) when this workgroup finished the cell; then cnt / tsum hold the totals.
+template <int T, bool TOK>
+__device__ __forceinline__ bool merge_split_cell(const AggArgs& a, uint32_t* red, uint32_t (&cnt)[kBins / T], long long& tsum,
+                                                 int tid, int64_t cell, int32_t seg) {
+    constexpr int NB = kBins / T;
+    constexpr int F = 16;
+    const int32_t S = a.segs, G = a.ngroups;
+    const int32_t g = seg / F;
+    const int32_t gs = (S - g * F) < F ? (S - g * F) : F;
+    // publish this segment
+    uint32_t* out = a.partial + ((cell * S + seg) << 10);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) st_agent(out + tid + k * T, cnt[k]);
+    {
+        const long long wt = TOK ? wave_sum_i64(tsum) : 0;
+        if (TOK && (tid & 63) == 0) {
+            red[64 + 2 * (tid >> 6)] = (uint32_t)((unsigned long long)wt & 0xffffffffull);
+            red[65 + 2 * (tid >> 6)] = (uint32_t)((unsigned long long)wt >> 32);
+        }
+    }
+    drain_stores();                                   // every storing wave, before the arrival is announced
+    __syncthreads();
+    if (tid == 0) {
+        if (TOK) {
+            long long tok = 0;
+            for (int w = 0; w < T / 64; ++w) tok += (long long)(((unsigned long long)red[65 + 2 * w] << 32) | red[64 + 2 * w]);
+            st_agent(reinterpret_cast<unsigned long long*>(a.partial_tok) + cell * S + seg, (unsigned long long)tok);
+            drain_stores();
+        }
+        uint32_t* t1 = a.tickets + 1 + cell * G + g;
+        const uint32_t arrived = atomicAdd(t1, 1u);
+        red[50] = (arrived == (uint32_t)gs - 1u) ? 1u : 0u;
+        if (red[50]) st_agent(t1, 0u);
+    }
+    __syncthreads();
+    if (!red[50]) { __syncthreads(); return false; }  // (second barrier: red[50] may be rewritten by the next item)
+    // last of the group: sum the group's partials
+    const uint32_t* in = a.partial + ((cell * S + (int64_t)g * F) << 10);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        uint32_t sum = 0;
+        for (int32_t q = 0; q < gs; ++q) sum += ld_agent(in + ((int64_t)q << 10) + tid + k * T);
+        cnt[k] = sum;
+    }
+    tsum = 0;
+    if (TOK && tid < gs) tsum = (long long)ld_agent(reinterpret_cast<const unsigned long long*>(a.partial_tok) + cell * S + (int64_t)g * F + tid);
+    __syncthreads();                                  // everyone has read red[50]
+    if (G == 1) return true;
+    // several groups: publish the group histogram, the last group finishes the cell
+    uint32_t* out2 = a.partial2 + ((cell * G + g) << 10);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) st_agent(out2 + tid + k * T, cnt[k]);
+    {
+        const long long wt = TOK ? wave_sum_i64(tsum) : 0;
+        if (TOK && (tid & 63) == 0) {
+            red[64 + 2 * (tid >> 6)] = (uint32_t)((unsigned long long)wt & 0xffffffffull);
+            red[65 + 2 * (tid >> 6)] = (uint32_t)((unsigned long long)wt >> 32);
+        }
+    }
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) {
+        if (TOK) {
+            long long tok = 0;
+            for (int w = 0; w < T / 64; ++w) tok += (long long)(((unsigned long long)red[65 + 2 * w] << 32) | red[64 + 2 * w]);
+            st_agent(reinterpret_cast<unsigned long long*>(a.partial2_tok) + cell * G + g, (unsigned long long)tok);
+            drain_stores();
+        }
+        uint32_t* t2 = a.tickets + 1 + a.ncells * G + cell;
+        const uint32_t arrived = atomicAdd(t2, 1u);
+        red[50] = (arrived == (uint32_t)G - 1u) ? 1u : 0u;
+        if (red[50]) st_agent(t2, 0u);
+    }
+    __syncthreads();
+    if (!red[50]) { __syncthreads(); return false; }
+    const uint32_t* in2 = a.partial2 + ((cell * G) << 10);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        uint32_t sum = 0;
+        for (int32_t q = 0; q < G; ++q) sum += ld_agent(in2 + ((int64_t)q << 10) + tid + k * T);
+        cnt[k] = sum;
+    }
+    tsum = 0;
+    if (TOK && tid < G) tsum = (long long)ld_agent(reinterpret_cast<const unsigned long long*>(a.partial2_tok) + cell * G + tid);
+    __syncthreads();
+    return true;
+}
+
 // ---- kernel 1: streaming histogram / argmax (large N) -------------------------------------------
 // RL2 = log2(copies), T = threads per workgroup, U = 16-byte loads in flight per lane.
 template <int RL2, int T, int U, bool TOK>
@@ -496,7 +658,15 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
 
         uint32_t cnt[NB];
         fold_copies<RL2, T, true>(hist, tid, cnt);     // and zero them for the next item
-        if (S > 1) {
+        if (S > 1 && a.ticket_merge) {
+            // split-N, single launch: the last segment (group) to arrive merges and finishes the cell
+            const int32_t seg = (int32_t)(item - cell * S);
+            if (merge_split_cell<T, TOK>(a, red, cnt, tsum, tid, cell, seg)) {
+                if (tid == 0) red[48] = 0;
+                __syncthreads();
+                finalize_cell<T, TOK>(a, red, cnt, tsum, tid, cell, b, a.truth[p]);
+            }
+        } else if (S > 1) {
             // split-N: publish the partial histogram; scv_merge_partials finishes the cell
             uint32_t* out = a.partial + (item << 10);
 #pragma unroll
@@ -524,6 +694,18 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
         cur_lo = nxt_lo;
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
+    if (a.overwrite) {
+        // the last workgroup to finish turns the cell table into the per-budget counters (overwriting them)
+        drain_stores();                               // thread 0's write-through cell records
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t arrived = atomicAdd(a.tickets, 1u);
+            red[50] = (arrived == gridDim.x - 1u) ? 1u : 0u;
+            if (red[50]) st_agent(a.tickets, 0u);
+        }
+        __syncthreads();
+        if (red[50]) overwrite_counters_from_cells<T, TOK>(a, hist, kBins * R, tid);
+    }
 }
 
 // ---- kernel 1b: merge the partial histograms of split cells -------------------------------------

@@ -109,12 +109,14 @@ class CounterPipeline:
         import torch.distributed as dist
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
-    def acquire(self, i: int):
+    def acquire(self, i: int, zero: bool = True):
+        """``zero=False`` for evaluations that overwrite their counters (Engine.aggregate_device(overwrite=True))."""
         k = i % len(self.buffers)
         if self.pending[k] is not None:
             self.pending[k].wait()
             self.pending[k] = None
-        self.buffers[k].zero_()
+        if zero:
+            self.buffers[k].zero_()
         return self.buffers[k]
 
     def publish(self, i: int):

@@ -101,6 +101,7 @@ class Engine:
         check(self._L.scv_device_info(self._ctx, C.byref(info)))
         self.num_cus, self.lds_bytes, self.clock_khz, self.hbm_bytes = (int(x) for x in info)
         self._bound_stream = None
+        self._overwrite = False
         self.timing = timing
 
     def close(self):
@@ -219,10 +220,12 @@ class Engine:
     # ---- DEVICE mode (torch tensors; asynchronous on torch's current stream) --------------------
 
     def aggregate_device(self, answers, truth, tokens=None, n_valid=None, counters=None, cells=None,
-                         cell_tokens=None):
+                         cell_tokens=None, overwrite=False):
         """answers torch.int32 cuda [P,B,N].  Accumulates into ``counters`` (int64 [counters_size(B)],
         allocated zeroed if None) and writes ``cells`` (uint8 [P,B,16], allocated if None; pass False
-        to skip).  Returns (counters, cells, cell_tokens).  Does not synchronise."""
+        to skip).  ``overwrite=True``: the counters are overwritten instead (no zeroing by the caller; with
+        few long cells the whole evaluation is then ONE kernel launch).  Returns (counters, cells, cell_tokens).
+        Does not synchronise."""
         import torch
         if not (answers.is_cuda and answers.dtype == torch.int32 and answers.is_contiguous() and answers.dim() == 3):
             raise ValueError("answers must be a contiguous CUDA int32 tensor [P, B, N]")
@@ -250,13 +253,17 @@ class Engine:
             cell_tokens = torch.empty((P, B), dtype=torch.int64, device=dev)
         base = counters.data_ptr()
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        if overwrite != self._overwrite:
+            check(self._L.scv_set_option(self._ctx, b"overwrite_counters", int(bool(overwrite))))
+            self._overwrite = bool(overwrite)
         check(self._L.scv_aggregate_i32(
             self._ctx, ptr(answers), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, _lib.MEM_DEVICE,
             ptr(cells), ptr(cell_tokens),
             C.c_void_p(base), C.c_void_p(base + 8 * B * TIE_CLASSES), C.c_void_p(base + 8 * (B * TIE_CLASSES + B))))
         return counters, cells, cell_tokens
 
-    def aggregate_prefix_device(self, pool, truth, n_valid, tokens=None, counters=None, cells=None, cell_tokens=None):
+    def aggregate_prefix_device(self, pool, truth, n_valid, tokens=None, counters=None, cells=None, cell_tokens=None,
+                                overwrite=False):
         """pool torch.int32 cuda [P,N], n_valid torch.int32 cuda [B].  Asynchronous; see aggregate_device."""
         import torch
         if not (pool.is_cuda and pool.dtype == torch.int32 and pool.is_contiguous() and pool.dim() == 2):
@@ -281,6 +288,9 @@ class Engine:
             cell_tokens = torch.empty((P, B), dtype=torch.int64, device=dev)
         base = counters.data_ptr()
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        if overwrite != self._overwrite:
+            check(self._L.scv_set_option(self._ctx, b"overwrite_counters", int(bool(overwrite))))
+            self._overwrite = bool(overwrite)
         check(self._L.scv_aggregate_prefix_i32(
             self._ctx, ptr(pool), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, _lib.MEM_DEVICE,
             ptr(cells), ptr(cell_tokens),

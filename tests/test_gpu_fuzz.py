@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1), ("small_n_max", 512),
             ("tiny_n_max", 32), ("small_reg", 1), ("prefetch", 1), ("stagger_vecs", 0), ("plain_loads", 0),
-            ("fused_counters_max", 4096), ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0))
+            ("fused_counters_max", 4096), ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0))
 
 
 def _draw(rng):
@@ -44,7 +44,8 @@ def _draw(rng):
     if rng.random() < 0.6:
         opts["path"] = int(rng.integers(0, 5))
         if opts["path"] == 2:
-            opts["segs"] = int(rng.choice([0, 2, 3, 5, 16]))
+            opts["segs"] = int(rng.choice([0, 2, 3, 5, 16, 40]))
+            opts["ticket_merge"] = int(rng.integers(0, 2))        # merge kernel / last-arriver merge inside the launch
     if rng.random() < 0.3:
         opts["sorted"] = int(rng.integers(0, 2))
     if rng.random() < 0.3:

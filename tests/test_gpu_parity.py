@@ -206,7 +206,7 @@ def _with_options(eng, opts):
         def __exit__(self_, *exc):
             for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
                          ("small_n_max", 512), ("tiny_n_max", 32), ("small_reg", 1), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096),
-                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0)):
+                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0)):
                 eng.set_option(k, v)
     return _Ctx()
 
@@ -328,6 +328,71 @@ def test_split_n_path(hip_engine, segs, shape, dist):
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
         assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
+
+
+@pytest.mark.parametrize("ticket_merge", [0, 1])
+@pytest.mark.parametrize("segs,shape,dist", [(17, (2, 2, 200003), 1), (40, (3, 1, 300000), 3), (256, (1, 1, 1 << 20), 1), (255, (2, 1, 700001), 0),
+                                             (300, (1, 2, 400000), 1), (16, (5, 3, 99999), 2), (33, (1, 1, 66), 1)])
+def test_split_n_merge_inside_the_launch(hip_engine, ticket_merge, segs, shape, dist):
+    """Split cells merged by the last-arriving segment (group tree, fan-in 16; > 256 segments fall back to the merge
+    kernel) vs the two-launch path vs the oracle: one and two levels, ragged last groups, tokens, repeated calls on
+    the same context (every arrival counter must be back at zero), also under the overwrite-counters mode."""
+    import torch
+    P, B, N = shape
+    a, t, tr = coracle.synth_fill(P, B, N, 800 + segs, dist, want_tokens=True)
+    nv = np.array([N - 5 * b for b in range(B)], dtype=np.int32)
+    with _with_options(hip_engine, {"path": 2, "segs": segs, "ticket_merge": ticket_merge}):
+        for rep in range(3):
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
+            assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
+        dev = torch.device("cuda:0")
+        ad, td, trd = torch.from_numpy(a).to(dev), torch.from_numpy(t).to(dev), torch.from_numpy(tr).to(dev)
+        counters = torch.full((counters_size(B),), -12345, dtype=torch.int64, device=dev)      # garbage: must be overwritten
+        for rep in range(2):
+            c, cells, ctok = hip_engine.aggregate_device(ad, trd, tokens=td, counters=counters, overwrite=True)
+            hip_engine.sync()
+            got = AggregateResult.from_counters(c.cpu().numpy(), P, B, cells_from_torch(cells), ctok.cpu().numpy())
+            assert_results_equal(got, oracle(a, tr, tokens=t))
+    hip_engine.set_option("ticket_merge", 0)
+
+
+@pytest.mark.parametrize("shape,opts", [((30, 8, 1 << 17), {}), ((30, 8, 1 << 17), {"path": 2, "segs": 3}), ((7, 3, 5000), {"path": 1}),
+                                        ((900, 2, 4100), {"path": 1}), ((5000, 2, 600), {}), ((2000, 3, 9), {}), ((300, 4, 3000), {}),
+                                        ((3, 70, 20000), {"path": 1})])
+def test_overwrite_counters_mode(hip_engine, shape, opts):
+    """aggregate_device(overwrite=True): the per-budget counters are OVERWRITTEN -- by the streaming kernel's last
+    workgroup when the cells are few (ONE launch, no memset), by a memset node + the usual path otherwise.
+    Garbage-prefilled counters, tokens with and without, ragged n_valid, cells requested or not, repeated calls."""
+    import torch
+    P, B, N = shape
+    a, t, tr = coracle.synth_fill(P, B, N, 41, 1, want_tokens=True)
+    nv = np.array([max(1, N >> b) for b in range(B)], dtype=np.int32)
+    dev = torch.device("cuda:0")
+    ad, td, trd, nvd = (torch.from_numpy(x).to(dev) for x in (a, t, tr, nv))
+    counters = torch.empty((counters_size(B),), dtype=torch.int64, device=dev)
+    with _with_options(hip_engine, opts):
+        for rep, (tok, nvx, want_cells) in enumerate([(td, None, True), (None, nvd, True), (td, nvd, False), (None, None, False)]):
+            counters.fill_(-7 - rep)
+            c, cells, ctok = hip_engine.aggregate_device(ad, trd, tokens=tok, n_valid=nvx, counters=counters, overwrite=True,
+                                                         cells=None if want_cells else False)
+            hip_engine.sync()
+            want = oracle(a, tr, tokens=None if tok is None else t, n_valid=None if nvx is None else nv)
+            got = AggregateResult.from_counters(c.cpu().numpy(), P, B)
+            assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.truth_count_sum, want.truth_count_sum)
+            assert np.array_equal(got.token_sum, want.token_sum if tok is not None else np.zeros(B, dtype=np.int64))
+            if want_cells:
+                gc = cells_from_torch(cells)
+                for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+                    assert np.array_equal(gc[f], want.cells[f]), f
+                if tok is not None:
+                    assert np.array_equal(ctok.cpu().numpy(), want.cell_tokens)
+        # and accumulate mode still accumulates afterwards
+        counters.zero_()
+        hip_engine.aggregate_device(ad, trd, counters=counters)
+        hip_engine.aggregate_device(ad, trd, counters=counters)
+        hip_engine.sync()
+        want = oracle(a, tr)
+        assert np.array_equal(AggregateResult.from_counters(counters.cpu().numpy(), P, B).tie_class_hits, 2 * want.tie_class_hits)
 
 
 @pytest.mark.parametrize("prefetch", [0, 1])
