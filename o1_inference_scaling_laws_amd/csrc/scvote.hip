@@ -218,14 +218,28 @@ KernelFn pick_u(int u, bool tok) {
     default: return pick_tok<RL2, T, 4>(tok);
     }
 }
+// variants with the single-launch epilogues compiled in (XTRA): unroll 4 only
+template <int RL2, int T>
+KernelFn pick_xtra(bool tok) {
+    return tok ? (KernelFn)scv::scv_hist_argmax<RL2, T, 4, true, true> : (KernelFn)scv::scv_hist_argmax<RL2, T, 4, false, true>;
+}
 template <int RL2>
-KernelFn pick_t(int t, int u, bool tok) {
+KernelFn pick_t(int t, int u, bool tok, bool xtra) {
     switch (t) {
-    case 256: return pick_u<RL2, 256>(u, tok);
-    case 1024: return pick_u<RL2, 1024>(u, tok);
-    default: return pick_u<RL2, 512>(u, tok);
+    case 256: return xtra ? pick_xtra<RL2, 256>(tok) : pick_u<RL2, 256>(u, tok);
+    case 1024: return xtra ? pick_xtra<RL2, 1024>(tok) : pick_u<RL2, 1024>(u, tok);
+    default: return xtra ? pick_xtra<RL2, 512>(tok) : pick_u<RL2, 512>(u, tok);
     }
 }
+KernelFn pick_kernel(int copies, int t, int u, bool tok, bool xtra) {
+    switch (copies) {
+    case 4: return pick_t<2>(t, u, tok, xtra);
+    case 8: return pick_t<3>(t, u, tok, xtra);
+    case 32: return pick_t<5>(t, u, tok, xtra);
+    default: return pick_t<4>(t, u, tok, xtra);
+    }
+}
+
 template <int G, int V, int K, bool DENSE>
 KernelFn pick_reg_gv(bool tok, bool vec) {
     if (tok) return vec ? (KernelFn)scv::scv_reg_cells<G, V, K, true, true, DENSE> : (KernelFn)scv::scv_reg_cells<G, V, K, true, false, DENSE>;
@@ -242,7 +256,8 @@ KernelFn pick_reg_km(int g, int v, bool tok, bool vec) {
 }
 KernelFn pick_reg_kernel(int g, int v, bool tok, bool vec, bool dense4, int km) {
     if (g == 64 && v == 4 && dense4) return pick_reg_gv<64, 4, 1, true>(tok, vec);
-    return km == 4 ? pick_reg_km<4>(g, v, tok, vec) : (km == 2 ? pick_reg_km<2>(g, v, tok, vec) : pick_reg_km<1>(g, v, tok, vec));
+    (void)km;   // 8 and 16 KiB in flight per wave (KM = 2, 4) were measured equal / slower (profiles/r02 notes): not instantiated
+    return pick_reg_km<1>(g, v, tok, vec);
 }
 // long cells: V vectors per lane per part, H parts per cell (capacity 256 * V * H votes), dense bin scan
 template <int V, int H>
@@ -253,15 +268,6 @@ KernelFn pick_dense_vh(bool tok, bool vec) {
 KernelFn pick_dense_kernel(int v, int h, bool tok, bool vec) {
     if (v == 4) return h == 1 ? pick_dense_vh<4, 1>(tok, vec) : (h == 2 ? pick_dense_vh<4, 2>(tok, vec) : pick_dense_vh<4, 4>(tok, vec));
     return h == 1 ? pick_dense_vh<8, 1>(tok, vec) : pick_dense_vh<8, 2>(tok, vec);
-}
-
-KernelFn pick_kernel(int copies, int t, int u, bool tok) {
-    switch (copies) {
-    case 4: return pick_t<2>(t, u, tok);
-    case 8: return pick_t<3>(t, u, tok);
-    case 32: return pick_t<5>(t, u, tok);
-    default: return pick_t<4>(t, u, tok);
-    }
 }
 
 // Every entry point runs on the ctx device and leaves the caller's current HIP device as it found it
@@ -600,7 +606,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         grid = (nitems + rounds - 1) / rounds;
     }
 
-    KernelFn fn = pick_kernel(copies, threads, unroll, tok);
+    KernelFn fn = pick_kernel(copies, threads, unroll, tok, a.overwrite != 0 || a.ticket_merge != 0);
     SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)threads), lds, ctx->stream, a);

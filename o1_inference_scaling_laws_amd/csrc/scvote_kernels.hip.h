@@ -243,7 +243,7 @@ struct CellWalker {
 //
 // statistics.multimode (statistics.py:599-601) + o1.py:204-213 on per-thread bin counts cnt[k]
 // (bin = tid + k*T).  Precondition: red[48] was zeroed by thread 0 before the last barrier.
-template <int T, bool TOK>
+template <int T, bool TOK, bool XTRA = false>
 __device__ __forceinline__ void finalize_cell(const AggArgs& a, uint32_t* red, const uint32_t (&cnt)[kBins / T],
                                               long long tsum, int tid, int64_t cell, int32_t b, int32_t truth) {
     constexpr int NB = kBins / T;
@@ -305,14 +305,14 @@ __device__ __forceinline__ void finalize_cell(const AggArgs& a, uint32_t* red, c
             rec.y = tc;
             rec.z = (n_modes & 0xffffu) | ((any ? (min_mode & 0xffffu) : 0xffffu) << 16);
             rec.w = hit;
-            if (a.overwrite) {                         // read by the last workgroup of this launch: write through
+            if (XTRA && a.overwrite) {                 // read by the last workgroup of this launch: write through
                 unsigned long long* c8 = reinterpret_cast<unsigned long long*>(a.cells) + 2 * cell;
                 st_agent(c8, (unsigned long long)rec.x | ((unsigned long long)rec.y << 32));
                 st_agent(c8 + 1, (unsigned long long)rec.z | ((unsigned long long)rec.w << 32));
             } else reinterpret_cast<uint4*>(a.cells)[cell] = rec;
         }
         if (a.cell_tokens) {
-            if (a.overwrite) st_agent(reinterpret_cast<unsigned long long*>(a.cell_tokens) + cell, (unsigned long long)tok);
+            if (XTRA && a.overwrite) st_agent(reinterpret_cast<unsigned long long*>(a.cell_tokens) + cell, (unsigned long long)tok);
             else a.cell_tokens[cell] = tok;
         }
         // o1.py:238-240 as integers: tie-class counter, token sum, truth-count sum
@@ -581,7 +581,10 @@ __device__ __forceinline__ bool merge_split_cell(const AggArgs& a, uint32_t* red
 
 // ---- kernel 1: streaming histogram / argmax (large N) -------------------------------------------
 // RL2 = log2(copies), T = threads per workgroup, U = 16-byte loads in flight per lane.
-template <int RL2, int T, int U, bool TOK>
+// XTRA: the single-launch epilogues (overwrite-counters, split-N merge inside the launch) are compiled in.  They are
+// a separate instantiation so that the default hot path keeps round 1's register allocation (with them in, the
+// headline variant went from 0 to 36 bytes of scratch and from 18 to 41 spilled SGPRs).
+template <int RL2, int T, int U, bool TOK, bool XTRA = false>
 __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
     constexpr int R = 1 << RL2;
     constexpr int NB = kBins / T;        // bins folded per thread in the epilogue
@@ -658,13 +661,13 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
 
         uint32_t cnt[NB];
         fold_copies<RL2, T, true>(hist, tid, cnt);     // and zero them for the next item
-        if (S > 1 && a.ticket_merge) {
+        if (XTRA && S > 1 && a.ticket_merge) {
             // split-N, single launch: the last segment (group) to arrive merges and finishes the cell
             const int32_t seg = (int32_t)(item - cell * S);
             if (merge_split_cell<T, TOK>(a, red, cnt, tsum, tid, cell, seg)) {
                 if (tid == 0) red[48] = 0;
                 __syncthreads();
-                finalize_cell<T, TOK>(a, red, cnt, tsum, tid, cell, b, a.truth[p]);
+                finalize_cell<T, TOK, XTRA>(a, red, cnt, tsum, tid, cell, b, a.truth[p]);
             }
         } else if (S > 1) {
             // split-N: publish the partial histogram; scv_merge_partials finishes the cell
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
                 a.partial_tok[item] = tok;
             }
         } else {
-            finalize_cell<T, TOK>(a, red, cnt, tsum, tid, cell, b, a.truth[p]);
+            finalize_cell<T, TOK, XTRA>(a, red, cnt, tsum, tid, cell, b, a.truth[p]);
             // the next item's votes may start: the histogram was re-zeroed before B2, and `red` is
             // next written after the next B1, which thread 0 only reaches after finalize_cell.
         }
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
         cur_lo = nxt_lo;
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
-    if (a.overwrite) {
+    if (XTRA && a.overwrite) {
         // the last workgroup to finish turns the cell table into the per-budget counters (overwriting them)
         drain_stores();                               // thread 0's write-through cell records
         __syncthreads();

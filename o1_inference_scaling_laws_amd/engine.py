@@ -374,6 +374,55 @@ class MultiDeviceEngine:
         tokens = None if tokens is None else np.ascontiguousarray(tokens, dtype=np.int32)
         return self._run("aggregate", answers, truth, {"tokens": tokens}, {"n_valid": n_valid, "want_cells": want_cells})
 
+    # ---- DEVICE mode: shards already resident on their GPUs ------------------------------------------------
+
+    def scatter(self, answers, truth, tokens=None):
+        """Host arrays -> one shard per engine (contiguous blocks of problems, dist.shard_bounds), each on its
+        engine's device: [(answers_g, truth_g, tokens_g)].  Convenience for callers that start from host data and
+        then evaluate repeatedly on the device."""
+        import torch
+        from .dist import shard_bounds
+        P, G = int(answers.shape[0]), len(self.engines)
+        out = []
+        for g, e in enumerate(self.engines):
+            lo, hi = shard_bounds(P, g, G)
+            dev = torch.device("cuda", e.device)
+            cut = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x[lo:hi], dtype=np.int32)).to(dev)  # noqa: E731
+            out.append((cut(answers), cut(truth), cut(tokens)))
+        return out
+
+    def aggregate_device(self, shards, n_valid=None, want_cells=True, destination=None):
+        """Single-process, several GPUs, data resident: ``shards[g] = (answers_g, truth_g, tokens_g | None)`` are torch
+        tensors on engine g's device (any split of the problems; ``scatter`` makes block shards).  Every engine launches
+        on its own device's current stream (asynchronously, from this one thread), then the packed int64 counters
+        (65.7 KB at B = 8) are summed onto ``destination`` (default: the first engine's device) with
+        ``torch.cuda.comm.reduce_add`` -- single-process RCCL over xGMI when the shards sit on distinct GPUs, plain
+        copies + adds when contexts share a GPU (the 1-GPU test box).  Integer sums: bit-exact, order-independent
+        (SURVEY 8e).  Returns (counters on destination, [cells_g], [cell_tokens_g]); does not synchronise the host.
+        ``n_valid``: host int array [B] (copied to every device) or None."""
+        import torch
+        if len(shards) != len(self.engines):
+            raise ValueError("one shard per engine")
+        outs = []
+        for e, (ans, tr, tok) in zip(self.engines, shards):
+            dev = ans.device
+            with torch.cuda.device(dev):
+                nv = None if n_valid is None else torch.as_tensor(np.asarray(n_valid, dtype=np.int32), device=dev)
+                outs.append(e.aggregate_device(ans, tr, tokens=tok, n_valid=nv, cells=None if want_cells else False))
+        dest = torch.device("cuda", self.engines[0].device) if destination is None else torch.device(destination)
+        counters = [o[0] for o in outs]
+        if len({c.device for c in counters}) == len(counters) and len(counters) > 1:
+            total = torch.cuda.comm.reduce_add(counters, destination=dest.index)
+        else:                                   # contexts sharing a GPU: same algebra without the collective
+            total = counters[0].to(dest, copy=True)
+            for c in counters[1:]:
+                total += c.to(dest)
+        return total, [o[1] for o in outs], [o[2] for o in outs]
+
+    def sync(self):
+        for e in self.engines:
+            e.sync()
+
     def aggregate_prefix(self, pool, truth, n_valid, tokens=None, want_cells=True) -> AggregateResult:
         pool = np.ascontiguousarray(pool, dtype=np.int32)
         truth = np.ascontiguousarray(truth, dtype=np.int32)

@@ -836,6 +836,31 @@ def test_multi_device_engine_single_process(golden, tmp_path):
         assert_results_equal(every.aggregate(a, tr, tokens=t, n_valid=nv), want)
 
 
+def test_multi_device_engine_device_mode_single_process():
+    """single-process DEVICE-mode sharding -- every context launches on its own stream from one
+    thread, counters summed on the destination device (torch.cuda.comm.reduce_add = single-process RCCL when the
+    contexts sit on distinct GPUs; here three contexts share cuda:0, which exercises the control flow and the
+    algebra).  Counters and cell tables equal the single-engine / oracle result; the caller's current device and
+    stream are untouched."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import MultiDeviceEngine
+    a, t, tr = coracle.synth_fill(101, 3, 5003, 19, 3, want_tokens=True)
+    nv = np.array([5003, 100, 7], dtype=np.int32)
+    want = oracle(a, tr, tokens=t, n_valid=nv)
+    before = torch.cuda.current_device()
+    with MultiDeviceEngine(devices=[0, 0, 0]) as me:
+        shards = me.scatter(a, tr, tokens=t)
+        assert [int(s[0].shape[0]) for s in shards] == [33, 34, 34]
+        for rep in range(2):
+            counters, cells, ctoks = me.aggregate_device(shards, n_valid=nv)
+            me.sync()
+            got = AggregateResult.from_counters(counters.cpu().numpy(), 101, 3,
+                                                np.concatenate([cells_from_torch(c) for c in cells], axis=0),
+                                                np.concatenate([c.cpu().numpy() for c in ctoks], axis=0))
+            assert_results_equal(got, want)
+    assert torch.cuda.current_device() == before
+
+
 def test_kernel_timing_is_reported(hip_engine):
     hip_engine.drain_kernel_ns()
     a, _, tr = coracle.synth_fill(4, 2, 4096, 1, 0)
