@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--resident", type=int, default=2, help="distinct chunks kept in HBM and cycled")
     ap.add_argument("--tokens", action="store_true", help="also stream the tokens tensor (8 B/vote)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-read-ceiling", action="store_true", help="skip the pure-read probe after the timed region")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=5.0, help="single-core Python reference arithmetic")
     ap.add_argument("--parity-problems", type=int, default=256, help="problems of the last timed chunk checked vs the C oracle")
     ap.add_argument("--copies", type=int, default=0)
@@ -175,6 +176,22 @@ def cpu_baseline(args, B, N, gpu_first_cells, first_off, gpu_last_cells, last_of
 
 
 # ---- helpers -------------------------------------------------------------------------------------------------
+
+def measure_read_ceiling(cells: int):
+    """Pure-read ceiling of THIS box, measured right after the timed region by tools/hbm_probe.bin --quick (a separate
+    process: best of four read-only kernels over `cells` x 4 MiB).  None when the probe binary is not built."""
+    probe = os.path.join(REPO, "tools", "hbm_probe.bin")
+    if not os.path.exists(probe):
+        return None
+    try:
+        out = subprocess.run([probe, str(cells), "--quick"], capture_output=True, text=True, timeout=120)
+    except (OSError, subprocess.TimeoutExpired):
+        return None
+    for line in out.stdout.splitlines():
+        if line.startswith("READ_CEILING_GBPS"):
+            return float(line.split()[1])
+    return None
+
 
 def committed_evidence():
     """Numbers measured in SEPARATE profiled runs of this command and committed under profiles/ (labelled as such
@@ -360,6 +377,12 @@ def main():
     bytes_per_launch = votes_per_step_per_gpu * BYTES_PER_VOTE * (2 if args.tokens else 1)
     achieved = bytes_per_launch / (kern_avg_ns * 1e-9) / 1e9
     ev = committed_evidence() if (Pc, B, N, args.tokens, args.workload) == (1250, 8, 1 << 20, False, "c3") else {}
+    # the read ceiling of THIS box, measured now (rank 0 of a single-GPU default run; the probe allocates its own 41.9 GB)
+    if rank == 0 and world == 1 and ev and not args.no_read_ceiling:
+        live = measure_read_ceiling(chunk_bytes // (4 << 20))
+        if live:
+            ev["read_ceiling_gbs"] = live
+            ev["read_ceiling_source"] = "tools/hbm_probe.bin --quick run by this process right after the timed region, same box (best of 4 read-only kernels)"
 
     final = AggregateResult.from_counters(last.cpu().numpy(), Pc, B, num_problems=args.problems if c5 else Pc * world)
     if c5:

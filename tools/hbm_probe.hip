@@ -5,6 +5,8 @@
 // FETCH_SIZE half-count is calibrated (MI355X_MICROARCH.md, HBM section).
 //
 //   hbm_probe.bin [cells=10000]          sweep of read variants over cells x 4 MiB (10000 = the bench chunk)
+//   hbm_probe.bin [cells] --quick        the best four variants only (bench.py runs this beside its timed region)
+//   hbm_probe.bin [cells] --short        what wave-per-batch kernels can pull: 2-8 KiB steps, 4-32 waves per CU
 //   hbm_probe.bin [cells] --calib        3 launches of ONE variant (read_cells_pipe<4>, grid 250 x 1024) and nothing
 //                                        else: run under `rocprofv3 --pmc FETCH_SIZE` to get FETCH_SIZE per launch
 //                                        for exactly cells * 4 MiB of algorithmic reads
@@ -117,10 +119,11 @@ double time_ms(F f, int reps = 5) {
 
 int main(int argc, char** argv) {
     long ncells = 10000;
-    bool calib = false, shortcells = false;
+    bool calib = false, shortcells = false, quick = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--calib")) calib = true;
         else if (!strcmp(argv[i], "--short")) shortcells = true;
+        else if (!strcmp(argv[i], "--quick")) quick = true;
         else ncells = atol(argv[i]);
     }
     const long cell_bytes = 4l << 20;
@@ -138,6 +141,18 @@ int main(int argc, char** argv) {
         return 0;
     }
     struct Cfg { int grid, threads; };
+    if (quick) {
+        // the four best variants of the full sweep + the vote kernel's own geometry: what bench.py runs next to its
+        // timed region so that kernel and ceiling come from the SAME box (boxes of the pool differ by +-3 %)
+        double best = 0;
+        auto upd = [&](const char* name, double ms) { const double g = bytes / ms / 1e6; printf("quick   %-28s %6.0f GB/s\n", name, g); if (g > best) best = g; };
+        upd("cells U2 nt 512 x 512", time_ms([&] { read_cells<2, true><<<512, 512>>>(buf, cell_vecs, ncells, sink); }, 3));
+        upd("cells U2 nt 1000 x 256", time_ms([&] { read_cells<2, true><<<1000, 256>>>(buf, cell_vecs, ncells, sink); }, 3));
+        upd("pipe U4 nt 1000 x 256", time_ms([&] { read_cells_pipe<4, true><<<1000, 256>>>(buf, cell_vecs, ncells, sink); }, 3));
+        upd("cells U4 nt 250 x 1024", time_ms([&] { read_cells<4, true><<<250, 1024>>>(buf, cell_vecs, ncells, sink); }, 3));
+        printf("READ_CEILING_GBPS %.0f\n", best);
+        return 0;
+    }
     if (shortcells) {
         // what a wave-per-batch kernel can pull: every wave streams 4 KiB (U = 4) or 8 KiB (U = 8) steps of its own,
         // one step in flight behind the one being consumed; G waves per CU as 64- or 256-thread workgroups

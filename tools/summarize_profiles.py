@@ -62,7 +62,7 @@ if pmc:
                      f"active cycles per 64-vote ds_add_u32 = {avg['SQ_LDS_IDX_ACTIVE']/(algo/4/64):.2f}.")
     json.dump({"pmc_avg": avg, "hbm_traffic_bytes": (avg.get("FETCH_SIZE", 0) * 2048 + avg.get("WRITE_SIZE", 0) * 1024)},
               open(os.path.join(P, f"{tag}_pmc.json"), "w"), indent=1)
-for name in ("bench.json", "hbm_probe.log", "sweep.log", "sweep_full.log", "sweep_stagger.log"):
+for name in ("bench.json", "hbm_probe.log"):
     src = os.path.join(G, name)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
