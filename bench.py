@@ -387,7 +387,8 @@ def main():
     final = AggregateResult.from_counters(last.cpu().numpy(), Pc, B, num_problems=args.problems if c5 else Pc * world)
     if c5:
         workload = (f"C5: P={args.problems} x N={N} sharded by problem over {world} GPU(s) ({Pc} problems = {bytes_per_launch / 1e9:.2f} GB on rank 0); "
-                    f"step = vote + counters all-reduce + cell all-gather + {args.resamples}-resample bootstrap (class bound M={c5_state['M']}); "
+                    f"step = vote + counters all-reduce + cell all-gather + {args.resamples}-resample bootstrap (class bound M={c5_state['M']}; "
+                    f"with one rank vote and bootstrap are one call, one kernel launch when the shape allows); "
                     f"pass@k sweep k=1..1024 on the host, outside the timed region")
     elif args.workload == "c3":
         workload = (f"C3 streamed in problem-chunks: step = {Pc} problems x {B} budgets x {N} samples int32 "
@@ -469,6 +470,8 @@ def main():
                          "pass_at_k": {str(k): v[0] for k, v in host["pass_at_k"].items()},
                          "host_float_ms": (time.perf_counter() - t1) * 1e3,
                          "device_pipeline_ms_minus_vote_kernel_ms": elapsed / max(args.steps, 1) * 1e3 - kern_avg_ns / 1e6,
+                         "vote_and_bootstrap_in_one_launch": eng.stat("boot_fused") > 0 and eng.stat("boot_separate") == 0,
+                         "evaluations_fused_into_one_launch": eng.stat("boot_fused"), "evaluations_as_two_launches": eng.stat("boot_separate"),
                          "semantics": "pass@k and the problem-level bootstrap are NEW (not in the reference): parity unpinned, checked vs the oracle only"}
             if not args.no_cpu_baseline:
                 from oracle import coracle

@@ -167,6 +167,25 @@ int scv_bootstrap(scv_ctx* ctx, const scv_cell* cells, int64_t P, int32_t B,
                   int64_t* counts_out);
 
 /*
+ * Vote + bootstrap in ONE call (DEVICE pointers; BASELINE config 5 on one GPU): scv_aggregate_i32 followed by
+ * scv_bootstrap over the cell table it has just written, with the same outputs as the two calls.  When the shape
+ * allows it (whole-cell streaming kernel, the [P, B] code table fits the workgroup's LDS, the persistent grid is
+ * resident at once) both run in ONE kernel launch: all workgroups meet at a grid barrier after their last cell and
+ * then share the resamples.  Otherwise (or with option "boot_fused" = 0) the bootstrap kernel is queued behind the
+ * vote kernel on the same stream.  cells_out and counts_out are required.  Asynchronous like every DEVICE-mode call;
+ * a grid barrier that times out (the grid was not co-resident after all) is reported by scv_sync as an error.
+ */
+int scv_aggregate_bootstrap_i32(scv_ctx* ctx,
+                                const int32_t* answers, const int32_t* tokens,
+                                const int32_t* n_valid, const int32_t* truth,
+                                int64_t P, int32_t B, int64_t N,
+                                scv_cell* cells_out, int64_t* cell_tokens_out,
+                                int64_t* tie_class_hits_out, int64_t* token_sum_out,
+                                int64_t* truth_count_sum_out,
+                                int32_t r_begin, int32_t r_end, uint64_t seed, int32_t M,
+                                int64_t* counts_out);
+
+/*
  * Closed-form integer synthetic generator, evaluated ON DEVICE (config C3 is 335.5 GB and cannot
  * be shipped).  Element (p, b, i) depends only on (seed, dist, p_offset + p, b, i, B, N), so shards
  * and the CPU mirror (o1_inference_scaling_laws_amd/synth.py) produce identical tensors.
@@ -199,6 +218,11 @@ int scv_drain_kernel_ns(scv_ctx* ctx, uint64_t* total_ns_out, uint64_t* launches
  */
 int scv_host_alloc(void** out, size_t bytes);
 int scv_host_free(void* p);
+
+/* How often this ctx took a single-launch form (monotonic counters, for tests and bench lines): "boot_fused" /
+ * "boot_separate" (scv_aggregate_bootstrap_i32: one launch / two), "overwrite_fused" (counters overwritten by the
+ * vote kernel's last workgroup), "merge_in_launch" (split-N merged by the last-arriving segment). */
+int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out);
 
 int scv_device_count(void);
 /* Static properties of the ctx device: [0]=CU count, [1]=LDS bytes per workgroup max, [2]=clock kHz, [3]=HBM bytes. */

@@ -146,6 +146,9 @@ struct scv_ctx {
     size_t d_tickets_words = 0;
     void* d_partial2 = nullptr;  // split-N group histograms
     size_t d_partial2_bytes = 0;
+    int64_t stat_boot_fused = 0, stat_boot_separate = 0, stat_overwrite_fused = 0, stat_merge_in_launch = 0;   // scv_get_stat
+    int boot_fused = 1;      // scv_aggregate_bootstrap_i32: run the bootstrap inside the vote launch when the shape allows it
+    struct BootReq { int32_t r0, r1, M; uint64_t seed; int64_t* out; bool fused; }* boot_req = nullptr;   // set for the duration of one call
     int boot_lds = 1;        // bootstrap: LDS-resident code table when it fits (0: always the global-gather kernel)
     int reg_km = 1;          // reg path: batches in flight per wave = km x 4 KiB
     int reg_shape = 0;       // reg path: force a kernel shape (A/B runs), see launch_aggregate
@@ -361,7 +364,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.prefetch = ctx->prefetch;
     a.sorted = ctx->sorted;
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0;
-    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
+    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
 
     // per-budget counters: fused per-cell atomics for few cells, a separate reduction of the cell
@@ -408,9 +411,10 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     if (ctx->overwrite_counters && want_counters) {
         if (stream_path && ncells <= 8192 && B <= 64) {
             overwrite_fused = true;
+            ctx->stat_overwrite_fused += 1;
             use_reduce = false;
             if (int rc = need_cell_scratch()) return rc;
-            if (int rc = ensure_tickets(ctx, 1)) return rc;
+            if (int rc = ensure_tickets(ctx, 4)) return rc;
             a.overwrite = 1;
             a.tickets = static_cast<uint32_t*>(ctx->d_tickets);
             a.ow_tie = reinterpret_cast<unsigned long long*>(tie);
@@ -570,6 +574,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         if (ctx->ticket_merge && S <= 256) {
             // merge inside the launch: groups of <= 16 segments, then <= 16 groups (scv::merge_split_cell)
             merge_in_launch = true;
+            ctx->stat_merge_in_launch += 1;
             const int64_t G = (S + 15) / 16;
             a.ticket_merge = 1;
             a.ngroups = (int32_t)G;
@@ -577,7 +582,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             if (int rc = ensure_partial2(ctx, h2 + (size_t)ncells * G * sizeof(long long) + 256)) return rc;
             a.partial2 = static_cast<uint32_t*>(ctx->d_partial2);
             a.partial2_tok = reinterpret_cast<long long*>(static_cast<char*>(ctx->d_partial2) + ((h2 + 255) / 256) * 256);
-            if (int rc = ensure_tickets(ctx, 1 + (size_t)ncells * G + (size_t)ncells)) return rc;
+            if (int rc = ensure_tickets(ctx, 4 + (size_t)ncells * G + (size_t)ncells)) return rc;
             a.tickets = static_cast<uint32_t*>(ctx->d_tickets);
         }
     }
@@ -606,7 +611,26 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         grid = (nitems + rounds - 1) / rounds;
     }
 
-    KernelFn fn = pick_kernel(copies, threads, unroll, tok, a.overwrite != 0 || a.ticket_merge != 0);
+    // bootstrap inside this launch (scv_aggregate_bootstrap_i32): whole cells only, code table + counters in the
+    // histogram's LDS, and the whole grid resident at once (it meets at a grid barrier)
+    if (ctx->boot_req && ctx->boot_fused && S == 1 && a.cells && unroll == 4) {
+        const scv_ctx::BootReq& rq = *ctx->boot_req;
+        const size_t need_words = (((size_t)B * rq.M + 3) & ~(size_t)3) + ((size_t)ncells + 1) / 2;
+        KernelFn fx = pick_kernel(copies, threads, 4, tok, true);
+        int per_cu = 0;
+        SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SCV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fx), threads, lds));
+        if (need_words <= (size_t)scv::kBins * copies && grid <= (int64_t)per_cu * ctx->num_cus && P <= 0xFFFFFFFFll) {
+            if (int rc = ensure_tickets(ctx, 4)) return rc;
+            a.boot = 1;
+            a.boot_r0 = rq.r0; a.boot_r1 = rq.r1; a.boot_M = rq.M; a.boot_seed = rq.seed;
+            a.boot_out = reinterpret_cast<unsigned long long*>(rq.out);
+            a.tickets = static_cast<uint32_t*>(ctx->d_tickets);
+            ctx->boot_req->fused = true;
+            ctx->stat_boot_fused += 1;
+        }
+    }
+    KernelFn fn = pick_kernel(copies, threads, unroll, tok, a.overwrite != 0 || a.ticket_merge != 0 || a.boot != 0);
     SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)threads), lds, ctx->stream, a);
@@ -637,7 +661,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     a.err_flag = ctx->d_err;
     a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.prefetch = 0; a.sorted = 1;
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0;
-    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
+    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
     const bool use_reduce = want_counters && reduce_counters_separately(ctx, ncells, B, N);
@@ -716,6 +740,11 @@ int fetch_err(scv_ctx* ctx, uint32_t* out, bool force = false) {
 int check_err_word(scv_ctx* ctx, uint32_t w) {
     if ((w & 1u) && !(ctx->flags & SCV_FLAG_CLAMP_TO_INVALID_BIN))
         return fail(SCV_ERR_DOMAIN, "a vote outside bins 0..1023 was seen; results are invalid");
+    if (w & 4u) {
+        // the fused bootstrap's grid barrier timed out (the grid was not co-resident): its state is undefined now
+        if (ctx->d_tickets) (void)hipMemsetAsync(ctx->d_tickets, 0, 4 * sizeof(uint32_t), ctx->stream);
+        return fail(SCV_ERR_ARG, "fused bootstrap: grid barrier timed out; rerun with option boot_fused = 0");
+    }
     if (w & 2u) return fail(SCV_ERR_ARG, "bootstrap: a drawn hit had n_modes >= M");
     return SCV_OK;
 }
@@ -859,6 +888,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "path")) { if (value < 0 || value > 4) return fail(SCV_ERR_ARG, "path must be 0..4"); ctx->path = (int)value; }
     else if (!strcmp(key, "reg_dense4")) ctx->reg_dense4 = value != 0;
     else if (!strcmp(key, "boot_lds")) ctx->boot_lds = value != 0;
+    else if (!strcmp(key, "boot_fused")) ctx->boot_fused = value != 0;
     else if (!strcmp(key, "overwrite_counters")) ctx->overwrite_counters = value != 0;
     else if (!strcmp(key, "ticket_merge")) ctx->ticket_merge = value != 0;
     else if (!strcmp(key, "reg_km")) { if (value != 1 && value != 2 && value != 4) return fail(SCV_ERR_ARG, "reg_km must be 1, 2 or 4"); ctx->reg_km = (int)value; }
@@ -1209,6 +1239,27 @@ int scv_bootstrap(scv_ctx* ctx, const scv_cell* cells, int64_t P, int32_t B, int
     return check_err_word(ctx, w);
 }
 
+int scv_aggregate_bootstrap_i32(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
+                                const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells_out,
+                                int64_t* cell_tokens_out, int64_t* tie_class_hits_out, int64_t* token_sum_out,
+                                int64_t* truth_count_sum_out, int32_t r_begin, int32_t r_end, uint64_t seed, int32_t M,
+                                int64_t* counts_out) {
+    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+    if (!cells_out || !counts_out) return fail(SCV_ERR_ARG, "aggregate_bootstrap: cells_out and counts_out are required");
+    if (P <= 0 || P > 0xFFFFFFFFll || B <= 0 || M <= 0 || r_end < r_begin || r_begin < 0)
+        return fail(SCV_ERR_ARG, "aggregate_bootstrap: bad shape P=%lld B=%d M=%d r=[%d,%d)", (long long)P, B, M, r_begin, r_end);
+    if ((size_t)B * M * sizeof(uint32_t) > 64 * 1024) return fail(SCV_ERR_ARG, "bootstrap: B*M=%lld counters exceed 64 KiB of LDS", (long long)B * M);
+    scv_ctx::BootReq rq{r_begin, r_end, M, seed, counts_out, false};
+    if (r_end > r_begin) ctx->boot_req = &rq;
+    const int rc = scv_aggregate_i32(ctx, answers, tokens, n_valid, truth, P, B, N, SCV_MEM_DEVICE, cells_out, cell_tokens_out,
+                                     tie_class_hits_out, token_sum_out, truth_count_sum_out);
+    ctx->boot_req = nullptr;
+    if (rc != SCV_OK || rq.fused || r_end == r_begin) return rc;
+    // shape or occupancy did not allow the fused form: the bootstrap is queued behind the vote on the same stream
+    ctx->stat_boot_separate += 1;
+    return scv_bootstrap(ctx, cells_out, P, B, r_begin, r_end, seed, M, SCV_MEM_DEVICE, counts_out);
+}
+
 int scv_synth_fill_i32(scv_ctx* ctx, int32_t* answers, int32_t* tokens, int32_t* truth, int64_t P, int32_t B,
                        int64_t N, int64_t p_offset, uint64_t seed, int dist) {
     if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
@@ -1268,6 +1319,16 @@ int scv_host_alloc(void** out, size_t bytes) {
 int scv_host_free(void* p) {
     if (!p) return SCV_OK;
     SCV_HIP(hipHostFree(p));
+    return SCV_OK;
+}
+
+int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
+    if (!ctx || !key || !out) return fail(SCV_ERR_ARG, "NULL argument");
+    if (!strcmp(key, "boot_fused")) *out = ctx->stat_boot_fused;
+    else if (!strcmp(key, "boot_separate")) *out = ctx->stat_boot_separate;
+    else if (!strcmp(key, "overwrite_fused")) *out = ctx->stat_overwrite_fused;
+    else if (!strcmp(key, "merge_in_launch")) *out = ctx->stat_merge_in_launch;
+    else return fail(SCV_ERR_ARG, "unknown stat '%s'", key);
     return SCV_OK;
 }
 

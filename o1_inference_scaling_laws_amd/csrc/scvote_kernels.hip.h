@@ -68,11 +68,16 @@ struct AggArgs {
     int64_t seg_len;        // split-N: votes per segment
     int32_t wave_lds_words; // register-resident kernels: LDS words per wave (histograms + n_valid cache)
     // single-launch modes of the streaming kernel (agent-scope hand-offs inside the launch, no second kernel):
-    uint32_t* tickets;      // [0] workgroups finished | [1 ..] split-N arrival counters; all zero between launches
+    uint32_t* tickets;      // [0] workgroups finished | [1] barrier arrivals | [2] barrier generation | [4 ..] split-N arrival
+                            // counters; [0], [1] and [4 ..] are zero between launches, [2] only ever grows
     int32_t overwrite;      // != 0: per-budget counters are OVERWRITTEN by the last workgroup to finish (from the cell table)
     unsigned long long* ow_tie;     // overwrite outputs (tie_hits / token_sum / truth_sum are NULL in this mode)
     unsigned long long* ow_tok;
     unsigned long long* ow_truth;
+    int32_t boot;           // != 0: after the vote, ALL workgroups meet at a grid barrier and run the bootstrap (one launch)
+    int32_t boot_r0, boot_r1, boot_M;
+    uint64_t boot_seed;
+    unsigned long long* boot_out;   // [r1 - r0][B][M]
     int32_t ticket_merge;   // != 0: split-N cells are merged by the last segment to arrive (2-level tree, fan-in 16)
     int32_t ngroups;        // split-N: groups of <= 16 segments per cell
     uint32_t* partial2;     // split-N: [ncells * ngroups][1024] group histograms
@@ -305,14 +310,14 @@ __device__ __forceinline__ void finalize_cell(const AggArgs& a, uint32_t* red, c
             rec.y = tc;
             rec.z = (n_modes & 0xffffu) | ((any ? (min_mode & 0xffffu) : 0xffffu) << 16);
             rec.w = hit;
-            if (XTRA && a.overwrite) {                 // read by the last workgroup of this launch: write through
+            if (XTRA && (a.overwrite | a.boot)) {      // read by other workgroups of this launch: write through
                 unsigned long long* c8 = reinterpret_cast<unsigned long long*>(a.cells) + 2 * cell;
                 st_agent(c8, (unsigned long long)rec.x | ((unsigned long long)rec.y << 32));
                 st_agent(c8 + 1, (unsigned long long)rec.z | ((unsigned long long)rec.w << 32));
             } else reinterpret_cast<uint4*>(a.cells)[cell] = rec;
         }
         if (a.cell_tokens) {
-            if (XTRA && a.overwrite) st_agent(reinterpret_cast<unsigned long long*>(a.cell_tokens) + cell, (unsigned long long)tok);
+            if (XTRA && (a.overwrite | a.boot)) st_agent(reinterpret_cast<unsigned long long*>(a.cell_tokens) + cell, (unsigned long long)tok);
             else a.cell_tokens[cell] = tok;
         }
         // o1.py:238-240 as integers: tie-class counter, token sum, truth-count sum
@@ -444,6 +449,16 @@ __device__ __forceinline__ void describe_item(const AggArgs& a, bool use_ord, co
     it.nvec = (n - it.head) >> 2;
 }
 
+// splitmix64 finaliser and friends (spec: include/scvote.h); used by the generator and by both bootstrap kernels
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__device__ __forceinline__ uint32_t mulhi32(uint32_t x, uint32_t n) { return __umulhi(x, n); }
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+
 // ---- single-launch epilogues of the streaming kernel ------------------------------------------------
 //
 // (a) counters without a memset or a reduce launch: every workgroup bumps tickets[0] when it has finished its
@@ -485,6 +500,52 @@ __device__ __forceinline__ void overwrite_counters_from_cells(const AggArgs& a, 
     }
 }
 
+// (c) Bootstrap in the SAME launch as the vote (north_star: "fused in the same launch").  The problem-
+//     level bootstrap needs every cell of the launch, so all workgroups meet at a grid barrier after their last
+//     cell (one arrival counter + a generation word; the grid is sized to be co-resident by the host and the spin is
+//     bounded: a timeout raises error bit 4 and the host falls back to the separate launch).  Then every workgroup
+//     stages the write-through cell table as 2-byte codes in the LDS that held its histogram and runs its share of
+//     the resamples exactly as scv_bootstrap_lds_k does.
+template <int T>
+__device__ __forceinline__ void bootstrap_in_launch(const AggArgs& a, uint32_t* lds, int tid, bool& overflow) {
+    const int lane = tid & 63;
+    const int64_t BM = (int64_t)a.B * a.boot_M;
+    uint32_t* cnt = lds;
+    uint16_t* tab = reinterpret_cast<uint16_t*>(lds + ((BM + 3) & ~(int64_t)3));
+    const unsigned long long* c8 = reinterpret_cast<const unsigned long long*>(a.cells);
+    for (int64_t i = tid; i < a.ncells; i += T) {
+        const unsigned long long hi = ld_agent(c8 + 2 * i + 1);            // n_modes | min_mode << 16 | hit << 32
+        tab[i] = ((hi >> 32) & 0xffu) ? (uint16_t)(hi & 0xffffu) : (uint16_t)0;
+    }
+    const int32_t M = a.boot_M;
+    for (int32_t r = a.boot_r0 + (int32_t)blockIdx.x; r < a.boot_r1; r += (int32_t)gridDim.x) {
+        for (int64_t i = tid; i < BM; i += T) cnt[i] = 0;
+        __syncthreads();
+        uint64_t arg = a.boot_seed + kGolden * ((uint64_t)r * (uint64_t)a.P + (uint64_t)tid + 1);
+        const uint64_t darg = kGolden * (uint64_t)T;
+        for (int64_t j0 = (int64_t)(tid - lane); j0 < a.P; j0 += T, arg += darg) {
+            const int64_t j = j0 + lane;
+            const bool live = j < a.P;
+            const uint64_t u = mix64(arg);
+            const int64_t idx = live ? (int64_t)mulhi32((uint32_t)(u >> 32), (uint32_t)a.P) : 0;
+            for (int32_t b = 0; b < a.B; ++b) {
+                const uint32_t code = live ? (uint32_t)tab[idx * a.B + b] : 0u;
+                const uint64_t ones = __ballot(code == 1u);
+                if (lane == 0 && ones && M > 1) atomicAdd(&cnt[(int64_t)b * M + 1], (uint32_t)__popcll(ones));
+                if (code == 1u && M <= 1) overflow = true;
+                if (code > 1u) {
+                    if (code >= (uint32_t)M) overflow = true;
+                    else atomicAdd(&cnt[(int64_t)b * M + code], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        unsigned long long* o = a.boot_out + (int64_t)(r - a.boot_r0) * BM;
+        for (int64_t i = tid; i < BM; i += T) o[i] = cnt[i];
+        __syncthreads();
+    }
+}
+
 // (b) A cell split over S segments (one workgroup each): a segment publishes its 1024-bin partial histogram write-
 //     through and bumps the arrival counter of its GROUP of <= 16 segments; the last arriver of a group sums the
 //     group's partials (<= 64 KB) and, when the cell has several groups, publishes the group histogram and bumps the
@@ -520,7 +581,7 @@ __device__ __forceinline__ bool merge_split_cell(const AggArgs& a, uint32_t* red
             st_agent(reinterpret_cast<unsigned long long*>(a.partial_tok) + cell * S + seg, (unsigned long long)tok);
             drain_stores();
         }
-        uint32_t* t1 = a.tickets + 1 + cell * G + g;
+        uint32_t* t1 = a.tickets + 4 + cell * G + g;
         const uint32_t arrived = atomicAdd(t1, 1u);
         red[50] = (arrived == (uint32_t)gs - 1u) ? 1u : 0u;
         if (red[50]) st_agent(t1, 0u);
@@ -559,7 +620,7 @@ __device__ __forceinline__ bool merge_split_cell(const AggArgs& a, uint32_t* red
             st_agent(reinterpret_cast<unsigned long long*>(a.partial2_tok) + cell * G + g, (unsigned long long)tok);
             drain_stores();
         }
-        uint32_t* t2 = a.tickets + 1 + a.ncells * G + cell;
+        uint32_t* t2 = a.tickets + 4 + a.ncells * G + cell;
         const uint32_t arrived = atomicAdd(t2, 1u);
         red[50] = (arrived == (uint32_t)G - 1u) ? 1u : 0u;
         if (red[50]) st_agent(t2, 0u);
@@ -708,6 +769,31 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
         }
         __syncthreads();
         if (red[50]) overwrite_counters_from_cells<T, TOK>(a, hist, kBins * R, tid);
+    }
+    if (XTRA && a.boot) {
+        drain_stores();                               // thread 0's write-through cell records
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t g0 = ld_agent(a.tickets + 2);          // read BEFORE arriving: it can only change after we have
+            const uint32_t arrived = atomicAdd(a.tickets + 1, 1u);
+            uint32_t ok = 1;
+            if (arrived == gridDim.x - 1u) {
+                st_agent(a.tickets + 1, 0u);
+                atomicAdd(a.tickets + 2, 1u);                     // release everybody
+            } else {
+                uint32_t spins = 0;
+                while (ld_agent(a.tickets + 2) == g0) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 20)) { ok = 0; break; }  // not co-resident after all: give up loudly
+                }
+            }
+            red[51] = ok;
+            if (!ok) atomicOr(a.err_flag, 4u);
+        }
+        __syncthreads();
+        bool overflow = false;
+        if (red[51]) bootstrap_in_launch<T>(a, hist, tid, overflow);
+        if (overflow) atomicOr(a.err_flag, 2u);
     }
 }
 
@@ -1872,16 +1958,6 @@ __global__ __launch_bounds__(T) void scv_small_prefix(const AggArgs a) {
 }
 
 // ---- synthetic generator ------------------------------------------------------------------------
-
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27; z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return z;
-}
-__device__ __forceinline__ uint32_t mulhi32(uint32_t x, uint32_t n) { return __umulhi(x, n); }
-
-constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
 
 struct ProblemParams { uint32_t truth, q_num, d[4]; };
 

@@ -145,6 +145,12 @@ class Engine:
     def sync(self):
         check(self._L.scv_sync(self._ctx))
 
+    def stat(self, key: str) -> int:
+        """Monotonic counters of the single-launch forms taken by this context (scv_get_stat)."""
+        v = C.c_int64()
+        check(self._L.scv_get_stat(self._ctx, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def drain_kernel_ns(self):
         """(total_ns, launches) of the timed hot-path launches since the previous drain."""
         tot, n = C.c_uint64(), C.c_uint64()
@@ -261,6 +267,43 @@ class Engine:
             ptr(cells), ptr(cell_tokens),
             C.c_void_p(base), C.c_void_p(base + 8 * B * TIE_CLASSES), C.c_void_p(base + 8 * (B * TIE_CLASSES + B))))
         return counters, cells, cell_tokens
+
+    def aggregate_bootstrap_device(self, answers, truth, r_begin: int, r_end: int, seed: int, M: int, tokens=None,
+                                   n_valid=None, counters=None, cells=None, cell_tokens=None, out=None, overwrite=False):
+        """Vote + problem-level bootstrap in ONE call (scv_aggregate_bootstrap_i32): ``aggregate_device`` followed by
+        ``bootstrap_device`` over the cell table it writes -- in a single kernel launch when the shape allows it
+        (all workgroups meet at a grid barrier after their last cell and share the resamples).  Returns
+        (counters, cells, cell_tokens, boot int64 [r_end - r_begin, B, M]).  Asynchronous."""
+        import torch
+        if not (answers.is_cuda and answers.dtype == torch.int32 and answers.is_contiguous() and answers.dim() == 3):
+            raise ValueError("answers must be a contiguous CUDA int32 tensor [P, B, N]")
+        P, B, N = answers.shape
+        dev = answers.device
+        self._check_device(answers, "answers")
+        for name, t, shape in (("truth", truth, (P,)), ("tokens", tokens, (P, B, N)), ("n_valid", n_valid, (B,))):
+            if t is None:
+                continue
+            if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == shape and t.device == dev):
+                raise ValueError(f"{name} must be a contiguous CUDA int32 tensor {shape} on {dev}")
+        self.use_torch_stream()
+        if counters is None:
+            counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
+        if cells is None:
+            cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
+        if cell_tokens is None and tokens is not None:
+            cell_tokens = torch.empty((P, B), dtype=torch.int64, device=dev)
+        if out is None:
+            out = torch.empty((r_end - r_begin, B, M), dtype=torch.int64, device=dev)
+        if overwrite != self._overwrite:
+            check(self._L.scv_set_option(self._ctx, b"overwrite_counters", int(bool(overwrite))))
+            self._overwrite = bool(overwrite)
+        base = counters.data_ptr()
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        check(self._L.scv_aggregate_bootstrap_i32(
+            self._ctx, ptr(answers), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, ptr(cells), ptr(cell_tokens),
+            C.c_void_p(base), C.c_void_p(base + 8 * B * TIE_CLASSES), C.c_void_p(base + 8 * (B * TIE_CLASSES + B)),
+            r_begin, r_end, seed, M, ptr(out)))
+        return counters, cells, cell_tokens, out
 
     def aggregate_prefix_device(self, pool, truth, n_valid, tokens=None, counters=None, cells=None, cell_tokens=None,
                                 overwrite=False):

@@ -11,7 +11,9 @@ Device pipeline per rank, all on torch's current stream, no host round trip of p
   4. scv_bootstrap for resamples [r R/G, (r+1) R/G) -> int64 [R/G, B, M], LDS-resident code table
   5. (host, once) all_gather of the bootstrap slices; accuracy CI; pass@k sweep from truth_count
 
-With one rank steps 2-3 are no-ops and the whole evaluation is two kernel launches back to back.
+With one rank steps 2-3 are no-ops and vote + bootstrap are ONE kernel launch (the workgroups meet at a grid
+barrier after their last cell and share the resamples; scv_aggregate_bootstrap_i32), or two launches back to back
+when the shape does not allow the fused form.
 """
 from __future__ import annotations
 
@@ -45,14 +47,22 @@ def class_bound(counters, B: int) -> int:
 
 def evaluate_device(engine, answers_local, truth_local, num_problems: int, resamples: int, seed: int,
                     M: int | None = None, tokens_local=None, n_valid=None, group=None, counters=None,
-                    cells_local=None, boot_out=None) -> C5Device:
-    """Steps 1-4 for this rank.  ``M=None`` derives the class bound from the counters (host sync)."""
+                    cells_local=None, boot_out=None, fused: bool = True) -> C5Device:
+    """Steps 1-4 for this rank.  ``M=None`` derives the class bound from the counters (host sync); with one rank
+    and a known M the vote and the bootstrap are one call (``fused=False`` keeps them as two launches)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank(group) if world > 1 else 0
     B = int(answers_local.shape[1])
     if counters is not None:
         counters.zero_()
+    if world == 1 and M is not None and fused and hasattr(engine, "aggregate_bootstrap_device"):
+        # one rank: the cell table is complete after the vote, so vote + bootstrap go down as ONE call -- one kernel
+        # launch when the shape allows it (scv_aggregate_bootstrap_i32)
+        counters, cells, _, boot = engine.aggregate_bootstrap_device(
+            answers_local, truth_local, 0, resamples, seed, M, tokens=tokens_local, n_valid=n_valid, counters=counters,
+            cells=cells_local, out=boot_out)
+        return C5Device(counters, cells, boot, 0, resamples, M)
     counters, cells, _ = engine.aggregate_device(answers_local, truth_local, tokens=tokens_local, n_valid=n_valid,
                                                  counters=counters, cells=cells_local)
     scv_dist.all_reduce_counters(counters, group)

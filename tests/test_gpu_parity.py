@@ -805,6 +805,52 @@ def test_config_C5_pipeline_full_cell_size_bit_exact(hip_engine):
         assert abs(host["pass_at_k"][k][0] - exact) < 1e-9
 
 
+@pytest.mark.parametrize("shape,dist,fused", [((3000, 1, 70000), 1, 1), ((3000, 1, 70000), 1, 0), ((600, 4, 40000), 3, 1), ((70, 8, 1 << 17), 3, 1),
+                                              ((500, 2, 3000), 3, 1), ((20000, 3, 5000), 1, 1), ((9, 1, 1 << 20), 3, 1)])
+def test_vote_and_bootstrap_in_one_call(hip_engine, shape, dist, fused):
+    """scv_aggregate_bootstrap_i32: the vote and the bootstrap of its own cell table in one call -- ONE kernel launch
+    (grid barrier + resamples inside the vote kernel) when the shape allows it, two queued launches otherwise (short
+    cells, table too large for the LDS, option boot_fused = 0).  Counters, cells and the whole resample table vs the
+    oracle; repeated calls (the barrier's counter / generation state must stay consistent); tokens."""
+    import torch
+    P, B, N = shape
+    dev = torch.device("cuda:0")
+    ans = torch.empty((P, B, N), dtype=torch.int32, device=dev)
+    tok = torch.empty((P, B, N), dtype=torch.int32, device=dev)
+    tr = torch.empty((P,), dtype=torch.int32, device=dev)
+    hip_engine.synth_fill_device(ans, tok, tr, P=P, B=B, N=N, seed=123, dist=dist)
+    a, t, trc = coracle.synth_fill(P, B, N, 123, dist, want_tokens=True)
+    want = coracle.aggregate_mt(a, trc, 16, tokens=t)
+    M = int(want["cells"]["n_modes"][want["cells"]["hit"] == 1].max(initial=0)) + 1
+    rc, want_boot = coracle.bootstrap(want["cells"], 2, 131, 99, M)
+    assert rc == 0
+    hip_engine.set_option("boot_fused", fused)
+    one0, two0 = hip_engine.stat("boot_fused"), hip_engine.stat("boot_separate")
+    # the fused form needs whole-cell streaming (N > 4096) and the [P, B] code table in the workgroup's LDS
+    expect_fused = bool(fused) and N > 4096 and P * B <= 30000 and not (2 * P * B <= 256 and 4 * N >= (1 << 20))   # (few huge cells are split)
+    try:
+        hip_engine.drain_kernel_ns()
+        for rep in range(3):
+            counters, cells, ctok, boot = hip_engine.aggregate_bootstrap_device(ans, tr, 2, 131, 99, M, tokens=tok if rep == 1 else None)
+            hip_engine.sync()
+            gc = cells_from_torch(cells)
+            for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+                assert np.array_equal(gc[f], want["cells"][f]), f
+            got = AggregateResult.from_counters(counters.cpu().numpy(), P, B)
+            assert np.array_equal(got.tie_class_hits, want["tie_class_hits"])
+            assert np.array_equal(boot.cpu().numpy(), want_boot)
+            if rep == 1:
+                assert np.array_equal(ctok.cpu().numpy(), want["cell_tokens"]) and np.array_equal(got.token_sum, want["token_sum"])
+        assert (hip_engine.stat("boot_fused") - one0, hip_engine.stat("boot_separate") - two0) == ((3, 0) if expect_fused else (0, 3))
+        # a class bound that is too small is reported at sync, whichever form ran
+        if M > 1:
+            hip_engine.aggregate_bootstrap_device(ans, tr, 0, 40, 99, M - 1)
+            with pytest.raises(_lib.ScvError):
+                hip_engine.sync()
+    finally:
+        hip_engine.set_option("boot_fused", 1)
+
+
 def test_bootstrap_device_fused_no_host_roundtrip(hip_engine):
     ans, _, tr, counters, cells, _ = _device_run(hip_engine, 500, 2, 4096, 5, 3)
     out = hip_engine.bootstrap_device(cells, 0, 100, 42, 4)
