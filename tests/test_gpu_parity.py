@@ -4,6 +4,8 @@ through size-independent properties.  Integer work => the bar is bit-exact every
 
 Run on the GPU box:  python -m pytest tests -m gpu -x -q
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -583,16 +585,19 @@ def test_config_C3_cell_size_properties(hip_engine):
     (1) sampled problems bit-exact vs the oracle on CPU-regenerated rows, (2) invariants of every
     cell, (3) shard additivity, (4) duplication: a cell voted twice doubles counts, keeps modes."""
     import torch
-    P, B, N, seed = 96, 8, 1 << 20, 31337
+    P, B, N, seed = 256, 8, 1 << 20, 31337
     ans, _, tr, counters, cells, _ = _device_run(hip_engine, P, B, N, seed, 1, p_offset=5000)
     c = cells_from_torch(cells)
     cnt = counters.cpu().numpy()
-    # (1)
-    for p in (0, 37, 95):
-        a, _, trc = coracle.synth_fill(1, B, N, seed, 1, p_offset=5000 + p)
-        want = coracle.aggregate(a, trc)["cells"]
+    # (1) EVERY cell of the slab (256 problems x 8 budgets x 2^20 votes, the size bench.py checks too) vs the oracle,
+    #     regenerated on the CPU in slabs of 32 problems spread over the host cores
+    threads = min(os.cpu_count() or 1, 32)
+    for lo in range(0, P, 32):
+        a, _, trc = coracle.synth_fill(32, B, N, seed, 1, p_offset=5000 + lo)
+        want = coracle.aggregate_mt(a, trc, threads)
+        assert want["rc"] == 0
         for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
-            assert np.array_equal(c[f][p], want[f][0]), (p, f)
+            assert np.array_equal(c[f][lo:lo + 32], want["cells"][f]), (lo, f)
     # (2)
     assert (c["truth_count"] <= c["max_count"]).all() and (c["max_count"] <= N).all()
     assert ((c["truth_count"] == c["max_count"]) == (c["hit"] == 1)).all()
@@ -602,7 +607,7 @@ def test_config_C3_cell_size_properties(hip_engine):
     assert np.array_equal(cnt[B * 1025 + B:], c["truth_count"].astype(np.int64).sum(axis=0))
     # (3)
     acc = torch.zeros(counters_size(B), dtype=torch.int64, device="cuda:0")
-    for lo, hi in ((0, 11), (11, 64), (64, 96)):
+    for lo, hi in ((0, 11), (11, 64), (64, 256)):
         hip_engine.aggregate_device(ans[lo:hi], tr[lo:hi], counters=acc, cells=False)
     hip_engine.sync()
     assert np.array_equal(acc.cpu().numpy(), cnt)
