@@ -238,7 +238,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rccl_ranks = None
-    if world > 1:
+    # SCV_FORCE_COLLECTIVES=1 (under torchrun --nproc-per-node 1): a ONE-rank process group whose collectives really
+    # run, so a 1-GPU box executes the RCCL calls of the N > 1 path (tests/test_bench_contract.py)
+    force = os.environ.get("SCV_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -324,7 +327,7 @@ def main():
     def fence():
         pipe.drain()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if world > 1 or force:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -358,7 +361,7 @@ def main():
         kern_ns, launches = int(elapsed * 1e9), args.steps    # no events inside a graph: wall clock per step (upper bound)
     else:
         kern_ns, launches = eng.drain_kernel_ns()
-    if world > 1:
+    if world > 1 or force:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -417,7 +420,8 @@ def main():
             "parallelism": f"problems sharded over {world} GPU(s), one int64 all-reduce of {counters_size(B)} counters per step",
             "seed": args.seed,
             "launch": "hipGraph replay (memset + kernels captured per resident chunk)" if use_graph else "eager",
-            "backend": None if world == 1 else args.backend,
+            "backend": args.backend if (world > 1 or force) else None,
+            "collectives_forced_on_one_rank": bool(force),
             "rccl_ranks": rccl_ranks,
             "hip_devices_visible": ndev,
             "devices_shared_by_ranks": bool(args.share_device),
@@ -486,7 +490,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if world > 1 or force:
         dist.destroy_process_group()
 
 

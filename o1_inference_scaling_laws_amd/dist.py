@@ -17,10 +17,21 @@ def shard_bounds(P: int, rank: int, world: int):
     return (rank * P) // world, ((rank + 1) * P) // world
 
 
+def collectives_active(group=None) -> bool:
+    """True when the exchange steps must really run: a process group with more than one rank -- or with ONE rank when
+    SCV_FORCE_COLLECTIVES=1, which is how a 1-GPU box exercises the RCCL calls themselves (int64 all-reduce, uint8 /
+    int64 all-gathers, barrier) under the same code path an 8-GPU node takes."""
+    import os
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("SCV_FORCE_COLLECTIVES") == "1"
+
+
 def all_reduce_counters(counters, group=None):
     """In-place SUM all-reduce of the packed per-budget counters (torch tensor, int64)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collectives_active(group):
         dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
     return counters
 
@@ -43,7 +54,7 @@ def all_gather_cells(cells_local, P: int, group=None):
     the bootstrap, which resamples over ALL problems."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_active(group):
         return cells_local
     world = dist.get_world_size(group)
     sizes = [shard_bounds(P, r, world)[1] - shard_bounds(P, r, world)[0] for r in range(world)]
@@ -106,8 +117,7 @@ class CounterPipeline:
         self.group = group
 
     def _distributed(self):
-        import torch.distributed as dist
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return collectives_active(self.group)
 
     def acquire(self, i: int, zero: bool = True):
         """``zero=False`` for evaluations that overwrite their counters (Engine.aggregate_device(overwrite=True))."""

@@ -56,7 +56,7 @@ def evaluate_device(engine, answers_local, truth_local, num_problems: int, resam
     B = int(answers_local.shape[1])
     if counters is not None:
         counters.zero_()
-    if world == 1 and M is not None and fused and hasattr(engine, "aggregate_bootstrap_device"):
+    if world == 1 and M is not None and fused and not scv_dist.collectives_active(group) and hasattr(engine, "aggregate_bootstrap_device"):
         # one rank: the cell table is complete after the vote, so vote + bootstrap go down as ONE call -- one kernel
         # launch when the shape allows it (scv_aggregate_bootstrap_i32)
         counters, cells, _, boot = engine.aggregate_bootstrap_device(
@@ -78,7 +78,7 @@ def gather_bootstrap(dev: C5Device, resamples: int, group=None):
     """All ranks' resample slices -> int64 [R, B, M] on every rank (step 5's exchange)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not scv_dist.collectives_active(group):
         return dev.boot
     world = dist.get_world_size(group)
     B = int(dev.boot.shape[1])

@@ -83,3 +83,32 @@ def test_c5_two_ranks_equal_one_rank_and_oracle(tmp_path):
     assert a["boot"].shape[0] == 101 and a["cells"].shape[:2] == (300, 1)
     assert one["c5"]["pass_at_k"] == two["c5"]["pass_at_k"] and one["c5"]["accuracy_ci95"] == two["c5"]["accuracy_ci95"]
     assert abs(one["value"] - 300 * (1 << 14) * 2 / (one["ms_per_step"] * 2e-3)) / one["value"] < 1e-9
+
+
+def test_rccl_calls_execute_on_one_rank(tmp_path):
+    """The gpurun boxes have one GPU, so RCCL across GPUs cannot run here; what CAN run is every RCCL call of the
+    N > 1 path on a one-rank NCCL process group (SCV_FORCE_COLLECTIVES=1): the async int64 all-reduce of the packed
+    counters behind each step, the MAX all-reduces of the timing, the barrier, and for C5 the uint8 all-gather of the
+    cell table and the int64 all-gather of the resample slices.  Results must equal the plain single-process run."""
+    env = dict(os.environ, SCV_FORCE_COLLECTIVES="1")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--backend", "nccl"]
+    c3 = ["--problems-per-step", "48", "--samples", str(1 << 15), "--steps", "3", "--warmup", "1", "--resident", "4"]
+    out = subprocess.run([*base, *c3, "--dump", str(tmp_path / "rccl.npz")], capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["config"]["rccl_ranks"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["collectives_forced_on_one_rank"] is True
+    plain = _bench([*c3, "--dump", str(tmp_path / "plain.npz"), "--no-cpu-baseline"])
+    assert np.array_equal(np.load(tmp_path / "rccl.npz")["counters"], np.load(tmp_path / "plain.npz")["counters"])
+    assert d["accuracy_last_step"] == plain["accuracy_last_step"]
+    c5 = ["--workload", "c5", "--problems", "300", "--samples", str(1 << 14), "--resamples", "101", "--steps", "2", "--warmup", "1", "--dist", "3"]
+    out = subprocess.run([*base, *c5, "--dump", str(tmp_path / "rccl5.npz")], capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    plain5 = _bench([*c5, "--dump", str(tmp_path / "plain5.npz"), "--no-cpu-baseline"])
+    a, b = np.load(tmp_path / "rccl5.npz"), np.load(tmp_path / "plain5.npz")
+    for k in ("counters", "cells", "boot"):
+        assert np.array_equal(a[k], b[k]), k
+    assert _last_json(out.stdout)["c5"]["pass_at_k"] == plain5["c5"]["pass_at_k"]
