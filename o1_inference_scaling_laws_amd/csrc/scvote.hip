@@ -138,6 +138,7 @@ struct scv_ctx {
     int segs_override = 0;   // > 0: segments per cell for path 2
     int sorted = 1;          // traverse budgets in descending n_valid order
     int small_reg = 1;       // small path: 1 = register-resident variant for N <= 128 (measured +10 %), 2 = also for N <= 512 (measured slower)
+    int tiny_lane = 1;       // N <= 32: 1 = one lane per cell (scv_lane_cells), 0 = the round-1 several-lanes-per-cell kernel
     int tiny_n_max = 32;     // auto/small path: N <= this -> register-only kernel, several cells per wave
     int small_n_max = 512;   // auto (reg path off): N <= this -> wave-per-cell kernel (crossover measured: profiles/r01_crossover_d*.log)
     int overwrite_counters = 0;  // DEVICE mode: per-budget outputs are overwritten instead of accumulated into (no caller memset)
@@ -483,6 +484,35 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         return finish(ev);
     }
 
+    if (path == 3 && N <= ctx->tiny_n_max && N <= 32 && ctx->tiny_lane && N >= 1) {
+        // ---- tiny cells, one lane per cell; counters accumulated in LDS and flushed by the same launch
+        const int nv = N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : 32));
+        const int threads = (nv == 32 || (nv == 16 && tok)) ? 512 : 1024;      // register budget: 2 x nv votes (+ tokens) per lane
+        const size_t lds = (((size_t)B * (nv + 1) + 1) & ~(size_t)1) * sizeof(uint32_t) + 2 * (size_t)B * sizeof(unsigned long long);
+        if (lds <= (size_t)60 * 1024) {
+            // counters come out of this launch: undo the separate-reduction setup
+            if (use_reduce) {
+                use_reduce = false;
+                a.cells = cells; a.cell_tokens = cell_tokens;
+                a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
+                a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
+                a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
+            }
+            a.wave_lds_words = ((N % 4 == 0) && (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0)) ? 1 : 0;   // "vec" flag
+            int64_t grid = (ncells + threads - 1) / threads;
+            if (grid > ctx->num_cus) grid = ctx->num_cus;            // one workgroup per CU: the flush costs one atomic per workgroup and counter
+            if (ctx->grid_override > 0) grid = ctx->grid_override;
+            if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+#define SCV_LANE(NVV, TT, TOKK) hipLaunchKernelGGL((scv::scv_lane_cells<NVV, TT, TOKK>), dim3((unsigned)grid), dim3(TT), lds, ctx->stream, a)
+            if (nv == 4) { if (tok) SCV_LANE(4, 1024, true); else SCV_LANE(4, 1024, false); }
+            else if (nv == 8) { if (tok) SCV_LANE(8, 1024, true); else SCV_LANE(8, 1024, false); }
+            else if (nv == 16) { if (tok) SCV_LANE(16, 512, true); else SCV_LANE(16, 1024, false); }
+            else { if (tok) SCV_LANE(32, 512, true); else SCV_LANE(32, 512, false); }
+#undef SCV_LANE
+            SCV_HIP(hipGetLastError());
+            return finish(ev);
+        }
+    }
     if (path == 3 && N <= ctx->tiny_n_max && N <= 32) {
         // ---- tiny cells: 64/G cells per wave, registers only
         const int G = N <= 8 ? 8 : (N <= 16 ? 16 : 32);
@@ -888,6 +918,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "path")) { if (value < 0 || value > 4) return fail(SCV_ERR_ARG, "path must be 0..4"); ctx->path = (int)value; }
     else if (!strcmp(key, "reg_dense4")) ctx->reg_dense4 = value != 0;
     else if (!strcmp(key, "boot_lds")) ctx->boot_lds = value != 0;
+    else if (!strcmp(key, "tiny_lane")) ctx->tiny_lane = value != 0;
     else if (!strcmp(key, "boot_fused")) ctx->boot_fused = value != 0;
     else if (!strcmp(key, "overwrite_counters")) ctx->overwrite_counters = value != 0;
     else if (!strcmp(key, "ticket_merge")) ctx->ticket_merge = value != 0;

@@ -1244,6 +1244,207 @@ __global__ __launch_bounds__(256) void scv_tiny_cells(const AggArgs a) {
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
 }
 
+// ---- kernel 1f': tiny cells, ONE LANE PER CELL (N <= 32; the reference's own N = 1, 2, 4, 8 .. 32) ----
+//
+// scv_tiny_cells spreads a cell over G lanes and pays ~10 (N = 8) to ~100 (N = 32) VALU wave-instructions per cell
+// in cross-lane rotations and group reductions (PMC: VALU-bound, profiles/r02_regimes_pmc_baseline.md), then a
+// second launch reduces the cell table into the counters.  Here every lane owns a whole cell in registers: it
+// loads its NV votes (lane-contiguous rows), counts equal pairs without any cross-lane traffic (3 instructions
+// per pair), and derives max count / #modes / min mode / truth count from its own registers: ~3 (NV = 8) to ~29
+// (NV = 32) wave-instructions per cell.  Votes past the valid prefix become unique sentinels that match nothing.
+// The per-budget counters are accumulated in LDS per workgroup (tie classes cannot exceed NV) and flushed with
+// one global atomic per non-zero counter -- one launch, and the cell table is written only if the caller wants it.
+template <int NV, int T, bool TOK>
+__global__ __launch_bounds__(T) void scv_lane_cells(const AggArgs a) {
+    constexpr int TC = NV + 1;                                       // tie classes 0..NV
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* tie = lds;                                             // [B][TC]
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + (((int64_t)a.B * TC + 1) & ~(int64_t)1));   // [B] truth sums | [B] token sums
+    const int tid = threadIdx.x;
+    const bool counters = a.tie_hits || a.truth_sum || (TOK && a.token_sum);
+    if (counters) {
+        for (int64_t i = tid; i < (int64_t)a.B * TC; i += T) tie[i] = 0;
+        for (int i = tid; i < 2 * a.B; i += T) acc[i] = 0;
+        __syncthreads();
+    }
+    const bool vec = a.wave_lds_words != 0;                          // host: N % 4 == 0 and 16-byte aligned bases
+    const int32_t N = (int32_t)a.N;
+    const int64_t stride = (int64_t)gridDim.x * T;
+    int64_t ncell = (int64_t)blockIdx.x * T + tid;                   // walker of the NEXT cell to load
+    int64_t np = ncell / a.B;
+    int32_t nb = (int32_t)(ncell - np * a.B);
+    const int64_t dp = stride / a.B;
+    const int32_t db = (int32_t)(stride - dp * a.B);
+
+    struct Cell {
+        uint32_t x[NV];
+        int32_t tk[TOK ? NV : 1];
+        int64_t cell;
+        int32_t b, truth;
+        uint32_t n;
+    };
+    // unconditional loads (a lane past the last cell reads cell 0; elements past N are not loaded: N is uniform)
+    auto load = [&](Cell& c) {
+        c.cell = ncell; c.b = nb;
+        const bool live = ncell < a.ncells;
+        c.n = live ? (uint32_t)valid_len(a, live ? nb : 0) : 0u;
+        c.truth = a.truth[live ? np : 0];
+        const int64_t off = (live ? ncell : 0) * a.N;
+        const int32_t* row = a.answers + off;
+        const int32_t* trow = TOK ? a.tokens + off : nullptr;
+        if (vec) {
+#pragma unroll
+            for (int k = 0; k < NV / 4; ++k) {
+                int4 q = make_int4(0, 0, 0, 0), y = make_int4(0, 0, 0, 0);
+                if (4 * k < N) {
+                    q = stream_load(reinterpret_cast<const int4*>(row) + k);
+                    if (TOK) y = stream_load(reinterpret_cast<const int4*>(trow) + k);
+                }
+                c.x[4 * k] = (uint32_t)q.x; c.x[4 * k + 1] = (uint32_t)q.y; c.x[4 * k + 2] = (uint32_t)q.z; c.x[4 * k + 3] = (uint32_t)q.w;
+                if (TOK) { c.tk[4 * k] = y.x; c.tk[4 * k + 1] = y.y; c.tk[4 * k + 2] = y.z; c.tk[4 * k + 3] = y.w; }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                c.x[i] = 0;
+                if (TOK) c.tk[i] = 0;
+                if (i < N) {
+                    c.x[i] = (uint32_t)__builtin_nontemporal_load(row + i);
+                    if (TOK) c.tk[i] = __builtin_nontemporal_load(trow + i);
+                }
+            }
+        }
+        ncell += stride; np += dp; nb += db;
+        if (nb >= a.B) { nb -= a.B; np += 1; }
+    };
+
+    uint32_t bad = 0;
+    auto count = [&](const Cell& c) {
+        const uint32_t n = c.n;
+        uint32_t x[NV], cnt[NV];
+        long long tok = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const bool on = (uint32_t)i < n;
+            const uint32_t v = c.x[i];
+            bad |= on ? v : 0u;
+            x[i] = on ? (v < 1023u ? v : 1023u) : (0xffff0000u + (uint32_t)i);   // an inactive slot matches nothing
+            cnt[i] = 1;
+            if (TOK) tok += on ? (long long)c.tk[i] : 0ll;
+        }
+        uint32_t best = 0, at_max = 0, tc = 0, n_modes_raw;
+        const uint32_t tcmp = (c.truth >= 0 && c.truth < kBins) ? (uint32_t)c.truth : 0xffffffffu;
+        if constexpr (NV <= 8) {
+            // o1.py:181-195 + statistics.py:599: count_i = #{ j : x_j == x_i }, every pair once (28 pairs at NV = 8)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+#pragma unroll
+                for (int j = i + 1; j < NV; ++j) {
+                    const uint32_t e = x[i] == x[j] ? 1u : 0u;
+                    cnt[i] += e;
+                    cnt[j] += e;
+                }
+            }
+            // one max over (count << 10 | 1023 - bin): max_count and the smallest modal bin together
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const uint32_t key = (uint32_t)i < n ? ((cnt[i] << 10) | (1023u - x[i])) : 0u;
+                cnt[i] = key;
+                best = key > best ? key : best;
+            }
+            const uint32_t thr = best & ~1023u;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                at_max += cnt[i] >= thr ? 1u : 0u;                   // inactive keys are 0: they only count when n == 0
+                tc += x[i] == tcmp ? 1u : 0u;
+            }
+            n_modes_raw = (best >> 10) ? exact_quotient(at_max, best >> 10) : 0u;   // votes at max / max = distinct modes
+        } else {
+            // 16 / 32 votes: the pair triangle (120 / 496 compares, each a live predicate) loses to a bitonic sorting
+            // network on min / max (80 / 240 exchanges, no predicates) followed by a run-length scan of the sorted votes:
+            // run_i = length of the run of equal values ending at i; a run of the maximal length is counted once, at its
+            // last element, so len(multimode) needs no division.  Inactive sentinels sort to the end and count for nothing.
+#pragma unroll
+            for (int k = 2; k <= NV; k <<= 1) {
+#pragma unroll
+                for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const uint32_t lo = x[i] < x[l] ? x[i] : x[l], hi = x[i] < x[l] ? x[l] : x[i];
+                            if ((i & k) == 0) { x[i] = lo; x[l] = hi; } else { x[i] = hi; x[l] = lo; }
+                        }
+                    }
+                }
+            }
+            uint32_t run = 0, prev = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                run = x[i] == prev ? run + 1u : 1u;
+                prev = x[i];
+                const uint32_t key = x[i] < 0xffff0000u ? ((run << 10) | (1023u - x[i])) : 0u;
+                cnt[i] = key;
+                best = key > best ? key : best;
+                tc += x[i] == tcmp ? 1u : 0u;
+            }
+            const uint32_t thr = best & ~1023u;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) at_max += (cnt[i] >= thr && cnt[i]) ? 1u : 0u;   // ends of maximal runs
+            n_modes_raw = at_max;
+        }
+        const uint32_t maxc = best >> 10;
+        if (c.cell < a.ncells) {
+            const bool any = maxc > 0;
+            const uint32_t n_modes = any ? n_modes_raw : 0u;
+            const uint32_t mm = 1023u - (best & 1023u);
+            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;                 // o1.py:206
+            if (a.cells) {
+                uint4 rec;
+                rec.x = maxc;
+                rec.y = tc;
+                rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
+                rec.w = hit;
+                reinterpret_cast<uint4*>(a.cells)[c.cell] = rec;
+            }
+            if (TOK && a.cell_tokens) a.cell_tokens[c.cell] = tok;
+            if (counters) {                                                       // o1.py:238-240 as integers, per workgroup in LDS
+                if (hit) atomicAdd(&tie[c.b * TC + (int32_t)n_modes], 1u);
+                if (tc) atomicAdd(&acc[c.b], (unsigned long long)tc);
+                if (TOK) atomicAdd(&acc[a.B + c.b], (unsigned long long)tok);
+            }
+        }
+    };
+
+    Cell ca, cb;
+    const int64_t last = a.ncells;                                   // lanes of a wave run the same number of steps
+    const int64_t first = (int64_t)blockIdx.x * T + tid - (tid & 63);
+    load(ca);
+    for (int64_t c0 = first; c0 < last; c0 += 2 * stride) {
+        const bool more = c0 + stride < last;
+        if (more) load(cb);
+        count(ca);
+        if (!more) break;
+        if (c0 + 2 * stride < last) load(ca);
+        count(cb);
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+    if (counters) {
+        __syncthreads();
+        for (int64_t i = tid; i < (int64_t)a.B * TC; i += T) {
+            const uint32_t v = tie[i];
+            if (v && a.tie_hits) {
+                const int64_t b = i / TC;
+                atomicAdd(&a.tie_hits[b * SCV_TIE_CLASSES + (i - b * TC)], (unsigned long long)v);
+            }
+        }
+        for (int i = tid; i < a.B; i += T) {
+            if (a.truth_sum && acc[i]) atomicAdd(&a.truth_sum[i], acc[i]);
+            if (TOK && a.token_sum && acc[a.B + i]) atomicAdd(&a.token_sum[i], acc[a.B + i]);
+        }
+    }
+}
+
 // ---- kernel 1g: register-resident cells (32 < N <= 4096), no barrier, no fold ---------------------
 //
 // PMC of the round-1 kernels in this range (profiles/r02_regimes_pmc_baseline.md): the wave-per-cell

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1), ("small_n_max", 512),
             ("tiny_n_max", 32), ("small_reg", 1), ("prefetch", 1), ("stagger_vecs", 0), ("plain_loads", 0),
-            ("fused_counters_max", 4096), ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0))
+            ("fused_counters_max", 4096), ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1))
 
 
 def _draw(rng):
@@ -56,6 +56,8 @@ def _draw(rng):
         opts["balance"] = 0
     if rng.random() < 0.2:
         opts["grid"] = int(rng.integers(1, 40))
+    if rng.random() < 0.25:
+        opts["tiny_lane"] = 0                                     # the round-1 several-lanes-per-cell kernel
     if rng.random() < 0.2:
         opts["tiny_n_max"] = 0
     if rng.random() < 0.2:

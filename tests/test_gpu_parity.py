@@ -208,7 +208,7 @@ def _with_options(eng, opts):
         def __exit__(self_, *exc):
             for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
                          ("small_n_max", 512), ("tiny_n_max", 32), ("small_reg", 1), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096),
-                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0)):
+                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1)):
                 eng.set_option(k, v)
     return _Ctx()
 
@@ -286,6 +286,31 @@ def test_tiny_cells_register_path(hip_engine, dist, shape):
         with _with_options(hip_engine, opts):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
             assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (700, 3, 1), (41, 11, 8), (3333, 5, 7), (6400, 8, 4), (1000, 3, 16), (777, 2, 17), (300, 7, 32),
+                                   (50000, 3, 4), (20000, 2, 12), (9000, 1, 31), (100, 200, 8)])
+def test_tiny_cells_one_lane_per_cell(hip_engine, dist, shape):
+    """scv_lane_cells (N <= 32): pair counting (NV = 4, 8) and the sorting-network path (NV = 16, 32), aligned and
+    unaligned rows, tokens, ragged n_valid incl. 0, narrow value ranges (heavy ties), counters fused through LDS with
+    many budgets, small forced grids (many cells per lane), cells requested or not -- and the round-1 kernel still agrees."""
+    P, B, N = shape
+    a, t, tr = coracle.synth_fill(P, B, N, 500 + dist, dist, want_tokens=True)
+    a2 = (a % 5).astype(np.int32)                                       # 5 distinct values: ties everywhere
+    tr2 = (tr % 5).astype(np.int32)
+    rng = np.random.default_rng(3)
+    nv = rng.integers(0, N + 1, size=(B,), dtype=np.int32)
+    for opts in ({}, {"grid": 3}, {"tiny_lane": 0}):
+        with _with_options(hip_engine, opts):
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
+            assert_results_equal(hip_engine.aggregate(a2, tr2, n_valid=nv), oracle(a2, tr2, n_valid=nv), check_tokens=False)
+            assert_results_equal(hip_engine.aggregate(a2, tr2, tokens=t, n_valid=nv), oracle(a2, tr2, tokens=t, n_valid=nv))
+            got = hip_engine.aggregate(a, tr, tokens=t, want_cells=False)
+            want = oracle(a, tr, tokens=t)
+            assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum)
+            assert np.array_equal(got.truth_count_sum, want.truth_count_sum)
+    hip_engine.set_option("tiny_lane", 1)
 
 
 def test_tiny_cells_reference_family_and_domain(hip_engine, golden):
