@@ -482,6 +482,18 @@ def test_many_budgets_beyond_grid_y_limit(hip_engine):
     assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), want, check_tokens=False)
 
 
+@pytest.mark.parametrize("shape", [(3, 600, 100), (2, 700, 8), (2, 520, 1500), (2, 513, 4200), (1, 3000, 30)])
+def test_more_budgets_than_the_n_valid_cache_holds(hip_engine, shape):
+    """B > 512: the register-resident kernels read n_valid from memory instead of their LDS cache, the lane kernel's LDS
+    counters grow with B (and fall back to the cell-table reduction when they no longer fit), sorted traversal is off."""
+    P, B, N = shape
+    a, t, tr = coracle.synth_fill(P, B, N, 71, 3, want_tokens=True)
+    rng = np.random.default_rng(5)
+    nv = rng.integers(0, N + 1, size=(B,), dtype=np.int32)
+    assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+    assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
+
+
 def test_auto_dispatch_covers_all_regimes(hip_engine):
     """auto: N <= 512 -> wave-per-cell; few big cells -> split-N; otherwise whole-cell streaming
     with the geometry picked from N (three bands)."""

@@ -240,3 +240,31 @@ def test_family_driver_sends_shared_pool_budgets_through_prefix_mode(tmp_path):
         assert [c for c in calls if c[0] == "dense"][0][1] == (9, 7, 1)
         cfg2 = o1_dropin.DropInConfig(model=TEST_MODEL, prompt=TEST_PROMPT, engine=DenseOnly(), helper_folder=str(tmp_path))
         assert got == o1_dropin._run_family(cfg2, ds, cache, o1_dropin.majority_vote_budgets(shade))
+
+
+def test_c5_host_floats_from_oracle_tables():
+    """passk.finish_host / scoring.bootstrap_percentiles_fast on tables produced by the oracle (no GPU): accuracy and
+    its CI per budget, the k-sweep, and equality of the vectorised percentile routine with the loop version."""
+    from o1_inference_scaling_laws_amd import passk
+    P, B, N = 400, 2, 64
+    a, _, tr = coracle.synth_fill(P, B, N, 9, 3)
+    out = coracle.aggregate(a, tr)
+    M = int(out["cells"]["n_modes"][out["cells"]["hit"] == 1].max()) + 1
+    rc, boot = coracle.bootstrap(out["cells"], 0, 300, 77, M)
+    assert rc == 0
+    packed = np.concatenate([out["tie_class_hits"].ravel(), out["token_sum"], out["truth_count_sum"]])
+    host = passk.finish_host(packed, out["cells"].view(coracle.CELL_DTYPE), boot, P, [N, N])
+    acc_slow, lo, hi = scoring.bootstrap_percentiles(boot, P)
+    assert np.array_equal(host["bootstrap_accuracy"], acc_slow)
+    for b in range(B):
+        assert host["accuracy"][b] == scoring.accuracy_from_tie_classes(out["tie_class_hits"][b], P)
+        assert host["ci95"][b] == [float(lo[b]), float(hi[b])] and lo[b] <= host["accuracy"][b] <= hi[b]
+        # every resample draws exactly P problems: class counts of one resample sum to at most P
+        assert (boot[:, b, :].sum(axis=1) <= P).all()
+    assert sorted(host["pass_at_k"]) == list(scoring.PASS_K_SWEEP)
+    c = out["cells"]["truth_count"][:, 0].astype(int)
+    for k in (1, 2, 8, 64):
+        exact = np.mean([1 - math.comb(N - ci, k) / math.comb(N, k) if N - ci >= k else 1.0 for ci in c])
+        assert abs(host["pass_at_k"][k][0] - exact) < 1e-12
+    ks = sorted(host["pass_at_k"])
+    assert all(host["pass_at_k"][ks[i]][0] <= host["pass_at_k"][ks[i + 1]][0] + 1e-15 for i in range(len(ks) - 1))
