@@ -138,6 +138,7 @@ struct scv_ctx {
     int segs_override = 0;   // > 0: segments per cell for path 2
     int sorted = 1;          // traverse budgets in descending n_valid order
     int small_reg = 1;       // small path: 1 = register-resident variant for N <= 128 (measured +10 %), 2 = also for N <= 512 (measured slower)
+    int tok_skew = 0;        // streaming kernel, tokens stream: 1 = read the token row rotated by half a row (measured: no effect, off)
     int tiny_lane = 1;       // N <= 32: 1 = one lane per cell (scv_lane_cells), 0 = the round-1 several-lanes-per-cell kernel
     int tiny_n_max = 32;     // auto/small path: N <= this -> register-only kernel, several cells per wave
     int small_n_max = 512;   // auto (reg path off): N <= this -> wave-per-cell kernel (crossover measured: profiles/r01_crossover_d*.log)
@@ -363,6 +364,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.stagger_vecs = ctx->stagger_vecs;
     a.plain_loads = ctx->plain_loads;
     a.prefetch = ctx->prefetch;
+    a.tok_skew = ctx->tok_skew;
     a.sorted = ctx->sorted;
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
@@ -689,7 +691,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
-    a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.prefetch = 0; a.sorted = 1;
+    a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.prefetch = 0; a.tok_skew = ctx->tok_skew; a.sorted = 1;
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
@@ -919,6 +921,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "reg_dense4")) ctx->reg_dense4 = value != 0;
     else if (!strcmp(key, "boot_lds")) ctx->boot_lds = value != 0;
     else if (!strcmp(key, "tiny_lane")) ctx->tiny_lane = value != 0;
+    else if (!strcmp(key, "tok_skew")) ctx->tok_skew = value != 0;
     else if (!strcmp(key, "boot_fused")) ctx->boot_fused = value != 0;
     else if (!strcmp(key, "overwrite_counters")) ctx->overwrite_counters = value != 0;
     else if (!strcmp(key, "ticket_merge")) ctx->ticket_merge = value != 0;

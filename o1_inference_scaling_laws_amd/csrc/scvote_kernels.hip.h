@@ -62,6 +62,7 @@ struct AggArgs {
     int32_t stagger_vecs;   // > 0: workgroup w starts each cell rotated by (w * stagger_vecs) 16-byte vectors
     int32_t plain_loads;    // != 0: ordinary loads instead of non-temporal ones
     int32_t prefetch;       // != 0: load the first tile of the next item before the current item's epilogue
+    int32_t tok_skew;       // != 0: the token row is read rotated by half a row against the vote row
     int64_t P;              // problems (for the budget-major traversal)
     int32_t sorted;         // != 0: traverse budgets in descending n_valid order
     int32_t segs;           // split-N: segments per cell (1 = whole cells)
@@ -361,12 +362,17 @@ __device__ __forceinline__ void stream_row(const AggArgs& a, uint32_t* hist, uin
         if (tok_vec) {
             const int4* t4 = reinterpret_cast<const int4*>(trow + head);
             constexpr int UT = U > 1 ? U / 2 : 1;
+            // Option tok_skew: the token row read ROTATED by half a row against the vote row (only its sum matters), in
+            // case reading two separately allocated tensors at the same offset made a workgroup's two streams collide on
+            // an HBM channel.  Measured: no effect (6.6-6.9 TB/s either way); off by default.
+            const int64_t skew = a.tok_skew ? (nvec >> 1) : 0;
+            auto tix = [&](int64_t k) -> int64_t { const int64_t j = k + skew; return j < nvec ? j : j - nvec; };
             for (; i + (int64_t)(UT - 1) * T < nvec; i += (int64_t)UT * T) {
                 int4 x[UT], y[UT];
 #pragma unroll
                 for (int u = 0; u < UT; ++u) {
                     x[u] = stream_load(v4 + i + (int64_t)u * T);
-                    y[u] = stream_load(t4 + i + (int64_t)u * T);
+                    y[u] = stream_load(t4 + tix(i + (int64_t)u * T));
                 }
 #pragma unroll
                 for (int u = 0; u < UT; ++u) {
@@ -376,7 +382,7 @@ __device__ __forceinline__ void stream_row(const AggArgs& a, uint32_t* hist, uin
             }
             for (; i < nvec; i += T) {
                 const int4 x = stream_load(v4 + i);
-                const int4 y = stream_load(t4 + i);
+                const int4 y = stream_load(t4 + tix(i));
                 vote4<RL2>(hist, copy, x, bad);
                 tsum += (long long)y.x + (long long)y.y + (long long)y.z + (long long)y.w;
             }
