@@ -178,7 +178,7 @@ struct scv_ctx {
     HostPipe* pipe = nullptr;       // HOST-mode ingestion pipeline (created on the first HOST call)
     int host_pipeline = 1;          // 0: the round-1 serial staging loop (A/B runs)
     int stage_mb = 128;             // HOST mode: chunk size (votes + tokens) of the staging pipeline
-    int copy_threads = 16;          // HOST mode: threads copying pageable caller memory into the pinned bounce slots
+    int copy_threads = 6;           // HOST mode (4-8 reach the link rate; 16+ were unstable: 30-55 GB/s run to run): threads copying pageable caller memory into the pinned bounce slots
 };
 
 namespace {

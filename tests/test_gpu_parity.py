@@ -129,7 +129,7 @@ def test_host_mode_pipeline_and_pinned_sources(hip_engine, monkeypatch, pipeline
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)         # the ctx recovers
     finally:
         hip_engine.set_option("host_pipeline", 1)
-        hip_engine.set_option("copy_threads", 16)
+        hip_engine.set_option("copy_threads", 6)
 
 
 def test_empty_shapes(hip_engine):
@@ -884,6 +884,13 @@ def test_vote_and_bootstrap_in_one_call(hip_engine, shape, dist, fused):
             if rep == 1:
                 assert np.array_equal(ctok.cpu().numpy(), want["cell_tokens"]) and np.array_equal(got.token_sum, want["token_sum"])
         assert (hip_engine.stat("boot_fused") - one0, hip_engine.stat("boot_separate") - two0) == ((3, 0) if expect_fused else (0, 3))
+        # together with the overwrite-counters epilogue (garbage-prefilled counters, no memset by the caller)
+        garbage = torch.full((counters_size(B),), -99, dtype=torch.int64, device=dev)
+        counters, cells, _, boot = hip_engine.aggregate_bootstrap_device(ans, tr, 2, 131, 99, M, counters=garbage, overwrite=True)
+        hip_engine.sync()
+        got = AggregateResult.from_counters(counters.cpu().numpy(), P, B)
+        assert np.array_equal(got.tie_class_hits, want["tie_class_hits"]) and np.array_equal(got.truth_count_sum, want["truth_count_sum"])
+        assert np.array_equal(boot.cpu().numpy(), want_boot) and np.array_equal(cells_from_torch(cells)["n_modes"], want["cells"]["n_modes"])
         # a class bound that is too small is reported at sync, whichever form ran
         if M > 1:
             hip_engine.aggregate_bootstrap_device(ans, tr, 0, 40, 99, M - 1)
