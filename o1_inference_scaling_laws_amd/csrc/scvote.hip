@@ -148,11 +148,13 @@ struct scv_ctx {
     size_t d_tickets_words = 0;
     void* d_partial2 = nullptr;  // split-N group histograms
     size_t d_partial2_bytes = 0;
-    int64_t stat_boot_fused = 0, stat_boot_separate = 0, stat_overwrite_fused = 0, stat_merge_in_launch = 0;   // scv_get_stat
+    int64_t stat_boot_fused = 0, stat_boot_separate = 0, stat_overwrite_fused = 0, stat_merge_in_launch = 0, stat_reg_lds_counters = 0;   // scv_get_stat
     int boot_fused = 1;      // scv_aggregate_bootstrap_i32: run the bootstrap inside the vote launch when the shape allows it
     struct BootReq { int32_t r0, r1, M; uint64_t seed; int64_t* out; bool fused; }* boot_req = nullptr;   // set for the duration of one call
     int boot_lds = 1;        // bootstrap: LDS-resident code table when it fits (0: always the global-gather kernel)
     int reg_km = 1;          // reg path: batches in flight per wave = km x 4 KiB
+    int reg_wpg = 0;         // reg path: waves per workgroup (0 = the kernel's own: all the waves a CU holds)
+    int reg_lds_counters = 1; // reg path: per-budget counters accumulate in LDS and are flushed by the same launch
     int reg_shape = 0;       // reg path: force a kernel shape (A/B runs), see launch_aggregate
     int reg_dense4 = 0;      // reg path, 512 < N <= 1024: 1 = dense bin scan instead of the sparse read-back (A/B option)
     int reg_n_max = 4096;    // auto: 32 < N <= this -> register-resident cells kernel (scv_reg_cells); 0 = off (round-1 dispatch)
@@ -245,32 +247,33 @@ KernelFn pick_kernel(int copies, int t, int u, bool tok, bool xtra) {
     }
 }
 
+struct RegKernel { KernelFn fn; int waves; };   // + the workgroup size (waves) the kernel was compiled for
 template <int G, int V, int K, bool DENSE>
-KernelFn pick_reg_gv(bool tok, bool vec) {
-    if (tok) return vec ? (KernelFn)scv::scv_reg_cells<G, V, K, true, true, DENSE> : (KernelFn)scv::scv_reg_cells<G, V, K, true, false, DENSE>;
-    return vec ? (KernelFn)scv::scv_reg_cells<G, V, K, false, true, DENSE> : (KernelFn)scv::scv_reg_cells<G, V, K, false, false, DENSE>;
+RegKernel pick_reg_gv(bool tok, bool vec) {
+    if (tok) return {vec ? (KernelFn)scv::scv_reg_cells<G, V, K, true, true, DENSE> : (KernelFn)scv::scv_reg_cells<G, V, K, true, false, DENSE>, scv::reg_cells_waves<G, V, true, DENSE>()};
+    return {vec ? (KernelFn)scv::scv_reg_cells<G, V, K, false, true, DENSE> : (KernelFn)scv::scv_reg_cells<G, V, K, false, false, DENSE>, scv::reg_cells_waves<G, V, false, DENSE>()};
 }
 // lanes per cell g, 16-byte vectors per lane v (capacity 4*g*v votes); short cells run K = 4 / v batches per
 // iteration (4 KiB of votes in flight per wave behind the batch being counted -- measured: 8 KiB is slower, the
 // waves wait on LDS, not on memory).
 template <int KM>
-KernelFn pick_reg_km(int g, int v, bool tok, bool vec) {
+RegKernel pick_reg_km(int g, int v, bool tok, bool vec) {
     if (g == 16) return v == 1 ? pick_reg_gv<16, 1, 4 * KM, false>(tok, vec) : (v == 2 ? pick_reg_gv<16, 2, 2 * KM, false>(tok, vec) : pick_reg_gv<16, 4, KM, false>(tok, vec));
     if (g == 32) return v == 1 ? pick_reg_gv<32, 1, 4 * KM, false>(tok, vec) : (v == 2 ? pick_reg_gv<32, 2, 2 * KM, false>(tok, vec) : pick_reg_gv<32, 4, KM, false>(tok, vec));
     return v == 1 ? pick_reg_gv<64, 1, 4 * KM, false>(tok, vec) : (v == 2 ? pick_reg_gv<64, 2, 2 * KM, false>(tok, vec) : pick_reg_gv<64, 4, KM, false>(tok, vec));
 }
-KernelFn pick_reg_kernel(int g, int v, bool tok, bool vec, bool dense4, int km) {
+RegKernel pick_reg_kernel(int g, int v, bool tok, bool vec, bool dense4, int km) {
     if (g == 64 && v == 4 && dense4) return pick_reg_gv<64, 4, 1, true>(tok, vec);
     (void)km;   // 8 and 16 KiB in flight per wave (KM = 2, 4) were measured equal / slower (profiles/r02 notes): not instantiated
     return pick_reg_km<1>(g, v, tok, vec);
 }
 // long cells: V vectors per lane per part, H parts per cell (capacity 256 * V * H votes), dense bin scan
 template <int V, int H>
-KernelFn pick_dense_vh(bool tok, bool vec) {
-    if (tok) return vec ? (KernelFn)scv::scv_reg_dense<V, H, true, true> : (KernelFn)scv::scv_reg_dense<V, H, true, false>;
-    return vec ? (KernelFn)scv::scv_reg_dense<V, H, false, true> : (KernelFn)scv::scv_reg_dense<V, H, false, false>;
+RegKernel pick_dense_vh(bool tok, bool vec) {
+    if (tok) return {vec ? (KernelFn)scv::scv_reg_dense<V, H, true, true> : (KernelFn)scv::scv_reg_dense<V, H, true, false>, scv::reg_dense_waves<V, true>()};
+    return {vec ? (KernelFn)scv::scv_reg_dense<V, H, false, true> : (KernelFn)scv::scv_reg_dense<V, H, false, false>, scv::reg_dense_waves<V, false>()};
 }
-KernelFn pick_dense_kernel(int v, int h, bool tok, bool vec) {
+RegKernel pick_dense_kernel(int v, int h, bool tok, bool vec) {
     if (v == 4) return h == 1 ? pick_dense_vh<4, 1>(tok, vec) : (h == 2 ? pick_dense_vh<4, 2>(tok, vec) : pick_dense_vh<4, 4>(tok, vec));
     return h == 1 ? pick_dense_vh<8, 1>(tok, vec) : pick_dense_vh<8, 2>(tok, vec);
 }
@@ -366,7 +369,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.prefetch = ctx->prefetch;
     a.tok_skew = ctx->tok_skew;
     a.sorted = ctx->sorted;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
 
@@ -460,16 +463,48 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         }
         const int64_t cpw = h ? 1 : 64 / g;
         const int64_t nbatches = (ncells + cpw - 1) / cpw;
-        constexpr int WPG = scv::kRegWavesPerWG;
-        a.wave_lds_words = (int32_t)(scv::kRegWaveWords + (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0));
-        const size_t lds = (size_t)WPG * a.wave_lds_words * sizeof(uint32_t);
-        KernelFn fn = h ? pick_dense_kernel(v, h, tok, vec) : pick_reg_kernel(g, v, tok, vec, ctx->reg_dense4 != 0, ctx->reg_km);
+        // 16 lanes per cell: 16-bit bins (8.3 KiB per wave); 32 / 64 lanes per cell and the dense scans: 32-bit bins (16.4 KiB)
+        const bool bins16 = h == 0 && g == 16;
+        a.wave_lds_words = (int32_t)((bins16 ? scv::kRegWaveWords16 : scv::kRegWaveWords) + (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0));
+        const RegKernel rk = h ? pick_dense_kernel(v, h, tok, vec) : pick_reg_kernel(g, v, tok, vec, ctx->reg_dense4 != 0, ctx->reg_km);
+        KernelFn fn = rk.fn;
+        // workgroup = all the waves of the shape a CU holds (16 / 12 / 8 / 4: the kernel's launch bounds), fewer when the
+        // n_valid cache makes 16 regions overflow the LDS, or when "reg_wpg" asks (A/B runs)
+        int WPG = rk.waves;
+        if (ctx->reg_wpg > 0 && ctx->reg_wpg < WPG) WPG = ctx->reg_wpg;
+        while (WPG > 4 && (int64_t)WPG * a.wave_lds_words * 4 + 1024 > ctx->lds_max) WPG -= 4;
+        size_t lds = (size_t)WPG * a.wave_lds_words * sizeof(uint32_t);
         SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // The grid is persistent, so it must not exceed what is resident at once (a surplus workgroup would start
         // only when another one has finished ALL its batches: measured 2x).  Ask the runtime.
         int per_cu = 0;
         SCV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), WPG * 64, lds));
         if (per_cu < 1) per_cu = 1;
+        // Per-budget counters in the LDS the resident workgroups leave free (no occupancy lost): [B][TCL] tie classes +
+        // 2 B sums per workgroup, flushed by the same launch -> no scv_reduce_cells launch, no cell scratch.  Tie
+        // classes that do not fit (TCL < min(N, 1024) + 1; only with many budgets) go to memory directly.
+        if (want_counters && ctx->reg_lds_counters) {
+            const int64_t spare_words = (ctx->lds_max / per_cu - (int64_t)lds) / 4 - 64;
+            const int64_t full = (N < 1024 ? N : 1024) + 1;
+            int64_t tcl = spare_words > 4 * (int64_t)B + 2 ? (spare_words - 4 * (int64_t)B - 2) / B : 0;
+            if (tcl > full) tcl = full;
+            if (tcl >= 8 || tcl == full) {
+                a.acc_classes = (int32_t)tcl;
+                lds += ((((size_t)B * tcl + 1) & ~(size_t)1) + 4 * (size_t)B) * sizeof(uint32_t);
+                if (use_reduce) {                                 // undo the separate-reduction setup
+                    use_reduce = false;
+                    a.cells = cells; a.cell_tokens = cell_tokens;
+                }
+                a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
+                a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
+                a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
+                SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                int again = 0;
+                SCV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&again, reinterpret_cast<const void*>(fn), WPG * 64, lds));
+                if (again >= 1 && again < per_cu) per_cu = again;   // (not expected: the region was sized from the spare LDS)
+                ctx->stat_reg_lds_counters += 1;
+            }
+        }
         int64_t grid = (int64_t)ctx->num_cus * per_cu;                     // workgroups of WPG independent waves
         if (ctx->grid_override > 0) grid = ctx->grid_override;
         const int64_t wgs_needed = (nbatches + WPG - 1) / WPG;
@@ -692,7 +727,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
     a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.prefetch = 0; a.tok_skew = ctx->tok_skew; a.sorted = 1;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
@@ -925,6 +960,8 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "boot_fused")) ctx->boot_fused = value != 0;
     else if (!strcmp(key, "overwrite_counters")) ctx->overwrite_counters = value != 0;
     else if (!strcmp(key, "ticket_merge")) ctx->ticket_merge = value != 0;
+    else if (!strcmp(key, "reg_lds_counters")) ctx->reg_lds_counters = value != 0;
+    else if (!strcmp(key, "reg_wpg")) { if (value != 0 && value != 4 && value != 8 && value != 12 && value != 16) return fail(SCV_ERR_ARG, "reg_wpg must be 0, 4, 8, 12 or 16"); ctx->reg_wpg = (int)value; }
     else if (!strcmp(key, "reg_km")) { if (value != 1 && value != 2 && value != 4) return fail(SCV_ERR_ARG, "reg_km must be 1, 2 or 4"); ctx->reg_km = (int)value; }
     else if (!strcmp(key, "reg_shape")) { if (value < 0 || value > 9999) return fail(SCV_ERR_ARG, "reg_shape out of range"); ctx->reg_shape = (int)value; }
     else if (!strcmp(key, "reg_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "reg_n_max < 0"); ctx->reg_n_max = (int)(value > 4096 ? 4096 : value); }
@@ -1361,6 +1398,7 @@ int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
     if (!strcmp(key, "boot_fused")) *out = ctx->stat_boot_fused;
     else if (!strcmp(key, "boot_separate")) *out = ctx->stat_boot_separate;
     else if (!strcmp(key, "overwrite_fused")) *out = ctx->stat_overwrite_fused;
+    else if (!strcmp(key, "reg_lds_counters")) *out = ctx->stat_reg_lds_counters;
     else if (!strcmp(key, "merge_in_launch")) *out = ctx->stat_merge_in_launch;
     else return fail(SCV_ERR_ARG, "unknown stat '%s'", key);
     return SCV_OK;

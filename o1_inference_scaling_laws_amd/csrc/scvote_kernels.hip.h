@@ -68,6 +68,8 @@ struct AggArgs {
     int32_t segs;           // split-N: segments per cell (1 = whole cells)
     int64_t seg_len;        // split-N: votes per segment
     int32_t wave_lds_words; // register-resident kernels: LDS words per wave (histograms + n_valid cache)
+    int32_t acc_classes;    // register-resident kernels: > 0 = per-budget counters accumulate in LDS (this many tie classes per
+                            // budget; larger classes go to memory directly) and are flushed once per workgroup
     // single-launch modes of the streaming kernel (agent-scope hand-offs inside the launch, no second kernel):
     uint32_t* tickets;      // [0] workgroups finished | [1] barrier arrivals | [2] barrier generation | [4 ..] split-N arrival
                             // counters; [0], [1] and [4 ..] are zero between launches, [2] only ever grows
@@ -1451,6 +1453,57 @@ __global__ __launch_bounds__(T) void scv_lane_cells(const AggArgs a) {
     }
 }
 
+// Per-workgroup accumulation of the per-budget counters (o1.py:238-240 as integers) for the register-resident
+// kernels: [B][TCL] tie-class hits (u32) and [B] truth-vote | [B] token sums (u64) live behind the waves' private
+// regions; one lane per cell adds to them with LDS atomics and the workgroup flushes the non-zero words with one
+// device atomic each when it has no cells left.  Replaces the separate scv_reduce_cells launch (12-15 us at
+// 10^5-10^6 cells) and, when the caller wants no cell table, every cell write.
+struct WgCounters {
+    uint32_t* tie;
+    unsigned long long* sums;
+    int32_t tcl;
+};
+__device__ __forceinline__ WgCounters wg_counters_begin(const AggArgs& a, uint32_t* region, int tid, int nthreads) {
+    WgCounters w;
+    w.tcl = a.acc_classes;
+    w.tie = region;
+    const int64_t tie_words = ((int64_t)a.B * w.tcl + 1) & ~(int64_t)1;
+    w.sums = reinterpret_cast<unsigned long long*>(region + tie_words);
+    if (w.tcl > 0) {
+        for (int64_t i = tid; i < tie_words + 4 * (int64_t)a.B; i += nthreads) region[i] = 0;
+        __syncthreads();
+    }
+    return w;
+}
+template <bool TOK>
+__device__ __forceinline__ void wg_counters_add(const AggArgs& a, const WgCounters& w, int32_t b, uint32_t hit, uint32_t n_modes,
+                                                uint32_t tc, long long tok) {
+    if (hit) {
+        if ((int32_t)n_modes < w.tcl) atomicAdd(&w.tie[(int64_t)b * w.tcl + (int32_t)n_modes], 1u);
+        else if (a.tie_hits) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
+    }
+    if (tc) atomicAdd(&w.sums[b], (unsigned long long)tc);
+    if (TOK) atomicAdd(&w.sums[a.B + b], (unsigned long long)tok);
+}
+template <bool TOK>
+__device__ __forceinline__ void wg_counters_flush(const AggArgs& a, const WgCounters& w, int tid, int nthreads) {
+    if (w.tcl <= 0) return;
+    __syncthreads();
+    if (a.tie_hits) {
+        for (int64_t i = tid; i < (int64_t)a.B * w.tcl; i += nthreads) {
+            const uint32_t v = w.tie[i];
+            if (v) {
+                const int64_t b = i / w.tcl;
+                atomicAdd(&a.tie_hits[b * SCV_TIE_CLASSES + (i - b * w.tcl)], (unsigned long long)v);
+            }
+        }
+    }
+    for (int i = tid; i < a.B; i += nthreads) {
+        if (a.truth_sum && w.sums[i]) atomicAdd(&a.truth_sum[i], w.sums[i]);
+        if (TOK && a.token_sum && w.sums[a.B + i]) atomicAdd(&a.token_sum[i], w.sums[a.B + i]);
+    }
+}
+
 // ---- kernel 1g: register-resident cells (32 < N <= 4096), no barrier, no fold ---------------------
 //
 // PMC of the round-1 kernels in this range (profiles/r02_regimes_pmc_baseline.md): the wave-per-cell
@@ -1504,19 +1557,30 @@ __device__ __forceinline__ long long cellgroup_sum_i64(long long v) {    // limb
     return (long long)(s0 + (s1 << 22) + (s2 << 43));
 }
 
-// key = count << kKeyShift | LDS byte address: 4 waves x 16.4 KB of LDS per workgroup need 17 address bits; counts are <= 4096 (13 bits)
-constexpr int kKeyShift = 17;
+// key = count << kKeyShift | LDS byte address: a workgroup may hold all 160 KiB of a CU's LDS (18 address bits); counts are <= 4096 (13 bits)
+constexpr int kKeyShift = 18;
 constexpr uint32_t kKeyMask = (1u << kKeyShift) - 1u;
 constexpr int kRegCellBins = 1025;                   // 1024 bins + one trash bin that absorbs the votes of inactive lanes
 constexpr int kRegHistWords = 4 * kRegCellBins;      // per wave: C cells x 1025 bins x R copies, C * R = 4
 constexpr int kRegWaveWords = kRegHistWords + 64;    // + one word per lane: the "wide truth bin" (see below)
-constexpr int kRegWavesPerWG = 4;                    // independent waves per workgroup (one per SIMD)
+// The waves of a workgroup are independent; a workgroup is ALL the waves a CU holds of the shape (launch bounds =
+// the occupancy the shape is meant to run at: 16 / 12 / 8 / 4 waves), so a launch is one workgroup per CU: the
+// end-of-launch counter flush then costs 256 device atomics per counter (12 ns each on one address), not 1024.
+template <int G, int V, bool TOK, bool DENSE>
+constexpr int reg_cells_waves() { return (DENSE || G > 16) ? 8 : (V <= 2 || !TOK ? 16 : 12); }
+template <int V, bool TOK>
+constexpr int reg_dense_waves() { return (V == 8 && TOK) ? 4 : 8; }
+// 16-bit counters (sparse kernels; a cell slot holds <= 1024 votes): copy c of a cell is an array of 1026 u16 bins
+// (1024 + trash + pad), so a wave's histograms take 8 KiB instead of 16 and twice the waves are resident
+constexpr int kRegCopyBytes16 = 2 * 1026;
+constexpr int kRegHist16Words = 4 * kRegCopyBytes16 / 4;
+constexpr int kRegWaveWords16 = kRegHist16Words + 64;
 
 // Per-vote state is ONE register holding the LDS byte address A of the vote's bin (all copies):
 //   A = cellbase + ((1023 - bin) << S), S = log2(4 R)   -> ds_add at A | copy*4, ds_read_b{32,64,128} at A,
-//   key = count << 17 | A                                 -> ds_write at (key & 0x7fff) | copy*4
+//   key = count << 18 | A                                 -> ds_write at (key & 0x3ffff) | copy*4
 // so a full cell costs ~13 instructions per vote: or (domain) . min . mad . or . ds_add | ds_read . 2 add .
-// lshl_or . max | cmp . addc | and_or . ds_write.  A is < 16400 + base < 2^15, counts are <= 4096 < 2^13.
+// lshl_or . max | cmp . addc | and_or . ds_write.  A is < 2^18 (160 KiB of LDS), counts are <= 4096 < 2^13.
 // LDS is addressed through address_space(3) pointers built from integers, so constant parts of an address
 // land in the instruction's offset field instead of a VALU add.
 //
@@ -1548,6 +1612,18 @@ __device__ __forceinline__ uint32_t lds_count(uint32_t A) {
 __device__ __forceinline__ void lds_add1(uint32_t addr) {
     __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>((uintptr_t)addr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ __forceinline__ void lds_add(uint32_t addr, uint32_t inc) {
+    __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>((uintptr_t)addr), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+// sum over the R copies of a 16-bit bin: R ds_read_u16 at immediate offsets (copy stride kRegCopyBytes16)
+template <int R>
+__device__ __forceinline__ uint32_t lds_count16(uint32_t A) {
+    uint32_t n = *reinterpret_cast<lds_u16*>((uintptr_t)A);
+    if (R >= 2) n += *reinterpret_cast<lds_u16*>((uintptr_t)(A + kRegCopyBytes16));
+    if (R == 4) { n += *reinterpret_cast<lds_u16*>((uintptr_t)(A + 2 * kRegCopyBytes16)); n += *reinterpret_cast<lds_u16*>((uintptr_t)(A + 3 * kRegCopyBytes16)); }
+    return n;
+}
 // KB - (vm << S) in one VALU instruction (the compiler prefers shift + subtract)
 template <int S>
 __device__ __forceinline__ uint32_t bin_address(uint32_t KB, uint32_t vm) {
@@ -1560,11 +1636,19 @@ __device__ __forceinline__ uint32_t bin_address(uint32_t KB, uint32_t vm) {
 // bytes in flight per wave), TOK tokens stream, VEC rows are 16-byte aligned (N % 4 == 0 and aligned bases:
 // dwordx4 loads); !VEC takes dword loads with a lane-contiguous element order.
 template <int G, int V, int K, bool TOK, bool VEC, bool DENSE>
-__global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_cells(const AggArgs a) {
+__global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void scv_reg_cells(const AggArgs a) {
     static_assert(!DENSE || G == 64, "the dense scan owns a whole wave per cell");
     constexpr int C = 64 / G;                 // cells per wave per batch
     constexpr int R = G / 16;                 // histogram copies per cell
-    constexpr int S = R == 4 ? 4 : (R == 2 ? 3 : 2);   // log2(bytes per bin)
+    // H16 (16 lanes per cell, one copy): 16-bit counters, a cell = 1026 u16 bins; a vote adds 1 << 16 (bin parity)
+    // to the WORD holding its bin (three more VALU per vote than 32-bit counters), reads and clears are 16-bit:
+    // 8 KiB of LDS per wave instead of 16, so 3-4 waves per SIMD are resident instead of 2 (measured +15-19 % at
+    // N = 64 ... 256).  With 2 / 4 copies (G = 32 / 64) the R reads per vote cost more than the occupancy gives
+    // (N = 1024: 59 -> 70 us), so those shapes and the dense scan keep 32-bit counters, [bin][copy].
+    constexpr bool H16 = !DENSE && G == 16;   // measured: with 2 / 4 copies the extra reads cost more than the occupancy gives
+    constexpr int S = H16 ? 1 : (R == 4 ? 4 : (R == 2 ? 3 : 2));   // log2(bytes between consecutive bins)
+    constexpr int WW = H16 ? kRegWaveWords16 : kRegWaveWords;
+    constexpr uint32_t CELLBYTES = H16 ? (uint32_t)(kRegCopyBytes16 * R) : (uint32_t)(kRegCellBins * R * 4);
     constexpr int E = 4 * V;                  // votes per lane per batch
     constexpr uint32_t CAP = 4u * G * V;      // votes per cell slot
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_wg[];
@@ -1577,16 +1661,17 @@ __global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_cells(const AggAr
     const int sub = lane / G, l = lane % G;
     {
         uint4* h4 = reinterpret_cast<uint4*>(smem);
-        for (int i = lane; i < kRegWaveWords / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < WW / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
     }
-    const uint32_t cellbase = base + (uint32_t)sub * (uint32_t)(kRegCellBins * R * 4);   // bytes
-    const uint32_t KB = cellbase + (1023u << S);        // address of bin 0 (histogram index 1023)
+    const WgCounters wgc = wg_counters_begin(a, smem_wg + (blockDim.x >> 6) * a.wave_lds_words, (int)threadIdx.x, (int)blockDim.x);
+    const uint32_t cellbase = base + (uint32_t)sub * CELLBYTES;   // bytes
+    const uint32_t KB = cellbase + (1023u << S);        // address of bin 0 (histogram index 1023), copy 0
     const uint32_t ATR = cellbase + (1024u << S);       // trash bin
-    const uint32_t copy4 = ((uint32_t)l & (R - 1)) * 4u;
-    const uint32_t TW = base + (uint32_t)kRegHistWords * 4u + (uint32_t)lane * 4u;   // this lane's word of the wide truth bin
+    const uint32_t copy4 = ((uint32_t)l & (R - 1)) * (H16 ? (uint32_t)kRegCopyBytes16 : 4u);   // this lane's copy, bytes
+    const uint32_t TW = base + (uint32_t)(WW - 64) * 4u + (uint32_t)lane * 4u;   // this lane's word of the wide truth bin
     // n_valid[B] cached behind the histograms (host sizes the region; B > kMaxSortedB reads it from memory):
     // a global load here would put a dependent memory round trip in front of every batch's loads
-    uint32_t* nv_lds = smem + kRegWaveWords;
+    uint32_t* nv_lds = smem + WW;
     const bool nv_cached = a.n_valid && a.B <= kMaxSortedB;
     if (nv_cached)
         for (int i = lane; i < a.B; i += 64) nv_lds[i] = (uint32_t)valid_len(a, i);
@@ -1598,8 +1683,8 @@ __global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_cells(const AggAr
         int32_t b, truth;
         uint32_t n;           // valid votes of this lane's cell (0 when the slot is past the last cell)
     };
-    const int64_t nwaves = (int64_t)gridDim.x * kRegWavesPerWG;
-    const int64_t wave = (int64_t)blockIdx.x * kRegWavesPerWG + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t stride = nwaves * C;                               // cells between consecutive batches of this wave
     int64_t ncell = wave * C + sub;                                  // walker state of the NEXT batch to load
     int64_t np = ncell / a.B;
@@ -1663,7 +1748,12 @@ __global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_cells(const AggAr
             }
             if (!DENSE) c.v[i] = A;                                 // a truth vote keeps its bin address: that bin reads 0 later
             // a vote for the truth goes to this lane's own word instead of the (shared, contended) histogram bin
-            lds_add1(A == AT ? TW : (A | copy4));
+            if (H16) {
+                // the word holding the 16-bit bin, and 1 or 1 << 16 by bit 1 of its address (v_alignbit_b32 takes the
+                // low 5 bits of the shift: (A << 3) & 31 = 16 * bit 1).  The truth word collects both halves.
+                const uint32_t inc = __builtin_amdgcn_alignbit(1u, 1u, A << 3);
+                lds_add((A == AT ? TW : (A + copy4)) & ~3u, inc);
+            } else lds_add1(A == AT ? TW : (A | copy4));
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -1678,8 +1768,8 @@ __global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_cells(const AggAr
             // two ds_reads in flight and the pass becomes a chain of LDS latencies: measured 48 % wave-wait)
             uint32_t cn[CH];
 #pragma unroll
-            for (int i = i0; i < i0 + CH; ++i) cn[i - i0] = lds_count<R>(c.v[i]);
-            __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, CH, 0);
+            for (int i = i0; i < i0 + CH; ++i) cn[i - i0] = H16 ? lds_count16<R>(c.v[i]) : lds_count<R>(c.v[i]);
+            __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, H16 ? CH * R : CH, 0);
             __builtin_amdgcn_sched_group_barrier(0x2 /* VALU */, CH * 6, 0);
 #pragma unroll
             for (int i = i0; i < i0 + CH; ++i) {
@@ -1700,10 +1790,14 @@ __global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_cells(const AggAr
 #pragma unroll
         for (int i = 0; i < E; ++i) at_max += c.v[i] >= thr ? 1u : 0u;   // inactive keys have count 0: they only count when max_count == 0
         tc = *reinterpret_cast<lds_u32*>((uintptr_t)TW);            // this lane's truth votes (summed over the cell below)
+        if (H16) tc = (tc & 0xffffu) + (tc >> 16);
         __builtin_amdgcn_wave_barrier();
         // pass 4: sparse clear (an inactive vote's key addresses the trash bin)
 #pragma unroll
-        for (int i = 0; i < E; ++i) *reinterpret_cast<lds_u32*>((uintptr_t)((c.v[i] & kKeyMask) | copy4)) = 0u;
+        for (int i = 0; i < E; ++i) {
+            if (H16) *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) + copy4)) = (uint16_t)0;
+            else *reinterpret_cast<lds_u32*>((uintptr_t)((c.v[i] & kKeyMask) | copy4)) = 0u;
+        }
         *reinterpret_cast<lds_u32*>((uintptr_t)TW) = 0u;
         __builtin_amdgcn_wave_barrier();
     };
@@ -1764,9 +1858,12 @@ __global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_cells(const AggAr
                 reinterpret_cast<uint4*>(a.cells)[c.cell] = rec;
             }
             if (a.cell_tokens) a.cell_tokens[c.cell] = tok;
-            if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)c.b * SCV_TIE_CLASSES + n_modes], 1ull);
-            if (TOK && a.token_sum) atomicAdd(&a.token_sum[c.b], (unsigned long long)tok);
-            if (a.truth_sum) atomicAdd(&a.truth_sum[c.b], (unsigned long long)tc);
+            if (wgc.tcl > 0) wg_counters_add<TOK>(a, wgc, c.b, hit, n_modes, tc, tok);
+            else {
+                if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)c.b * SCV_TIE_CLASSES + n_modes], 1ull);
+                if (TOK && a.token_sum) atomicAdd(&a.token_sum[c.b], (unsigned long long)tok);
+                if (a.truth_sum) atomicAdd(&a.truth_sum[c.b], (unsigned long long)tc);
+            }
         }
     };
 
@@ -1826,6 +1923,7 @@ __global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_cells(const AggAr
         step(bufb, bufa, it + 2 * istride < nbatches);
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
+    wg_counters_flush<TOK>(a, wgc, (int)threadIdx.x, (int)blockDim.x);
 }
 
 // ---- kernel 1h: register-streamed long cells (1024 < N <= 4096 and up), dense scan ----------------
@@ -1836,7 +1934,7 @@ __global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_cells(const AggAr
 // (N = 4096: 64 registers instead of 128 -> 2+ waves per SIMD instead of 1).  After the last part every lane
 // scans its 16 bins (ds_read_b128 at immediate offsets), zeroes them, and the wave reduces.
 template <int V, int H, bool TOK, bool VEC>
-__global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_dense(const AggArgs a) {
+__global__ __launch_bounds__((64 * reg_dense_waves<V, TOK>())) void scv_reg_dense(const AggArgs a) {
     constexpr int S = 4;                      // 16 bytes per bin (4 copies)
     constexpr int E = 4 * V;                  // votes per lane per part
     constexpr uint32_t PART = 256u * V;       // votes per part
@@ -1848,6 +1946,7 @@ __global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_dense(const AggAr
         uint4* h4 = reinterpret_cast<uint4*>(smem);
         for (int i = lane; i < kRegWaveWords / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
     }
+    const WgCounters wgc = wg_counters_begin(a, smem_wg + (blockDim.x >> 6) * a.wave_lds_words, (int)threadIdx.x, (int)blockDim.x);
     const uint32_t KB = base + (1023u << S);
     const uint32_t ATR = base + (1024u << S);
     const uint32_t copy4 = ((uint32_t)lane & 3u) * 4u;
@@ -1864,8 +1963,8 @@ __global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_dense(const AggAr
         int32_t tk[TOK ? E : 1];
         uint32_t nrel;        // valid votes of the cell minus the votes before this part (may be <= 0 as int)
     };
-    const int64_t nwaves = (int64_t)gridDim.x * kRegWavesPerWG;
-    const int64_t wave = (int64_t)blockIdx.x * kRegWavesPerWG + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int64_t ncell = wave;                     // cell whose parts are being loaded
     int64_t np = ncell / a.B;
     int32_t nb = (int32_t)(ncell - np * a.B);
@@ -1999,9 +2098,12 @@ __global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_dense(const AggAr
                 reinterpret_cast<uint4*>(a.cells)[cell] = rec;
             }
             if (a.cell_tokens) a.cell_tokens[cell] = tok;
-            if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
-            if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
-            if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
+            if (wgc.tcl > 0) wg_counters_add<TOK>(a, wgc, b, hit, n_modes, tc, tok);
+            else {
+                if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
+                if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
+                if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
+            }
         }
     };
 
@@ -2034,6 +2136,7 @@ __global__ __launch_bounds__(kRegWavesPerWG * 64) void scv_reg_dense(const AggAr
         count_part(pb);
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
+    wg_counters_flush<TOK>(a, wgc, (int)threadIdx.x, (int)blockDim.x);
 }
 
 // ---- kernel 1e: prefix budgets over one sample pool ---------------------------

@@ -208,7 +208,7 @@ def _with_options(eng, opts):
         def __exit__(self_, *exc):
             for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
                          ("small_n_max", 512), ("tiny_n_max", 32), ("small_reg", 1), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096),
-                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1)):
+                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_lds_counters", 1)):
                 eng.set_option(k, v)
     return _Ctx()
 
@@ -223,7 +223,7 @@ REG_SHAPES = [(700, 3, 33), (1200, 2, 64), (500, 4, 65), (301, 3, 100), (900, 2,
 def test_register_resident_cells_path(hip_engine, dist, shape):
     """scv_reg_cells: every (lanes per cell, vectors per lane, batches per iteration) variant, 16-byte aligned
     rows and not (N % 4), tokens, ragged n_valid, all-equal votes (dist 2), small forced grids (many
-    iterations per wave) and the reduce-kernel / fused-counter branches."""
+    iterations per wave), counters accumulated in LDS (default) and the reduce-kernel / per-cell-atomic branches."""
     P, B, N = shape
     a, t, tr = coracle.synth_fill(P, B, N, 900 + dist, dist, want_tokens=True)
     nv = np.array([max(0, N - 3 * b) if b % 2 else N >> (b // 2) for b in range(B)], dtype=np.int32)
@@ -231,8 +231,9 @@ def test_register_resident_cells_path(hip_engine, dist, shape):
     shapes = [g * 100 + v for g in (16, 32, 64) for v in (1, 2, 4) if 4 * g * v >= N]
     shapes += [1000 + 10 * v + h for v, h in ((4, 1), (4, 2), (4, 4), (8, 1), (8, 2)) if 256 * v * h >= N]
     pick = [shapes[(P + dist + i * 3) % len(shapes)] for i in range(3)]
-    for opts in ({"path": 4}, {"path": 4, "grid": 7, "fused_counters_max": 0, "reg_shape": pick[0]},
-                 {"path": 4, "grid": 64, "fused_counters_max": 1 << 30, "reg_shape": pick[1]}, {"path": 4, "reg_shape": pick[2], "reg_dense4": 1}):
+    for opts in ({"path": 4}, {"path": 4, "grid": 7, "fused_counters_max": 0, "reg_shape": pick[0], "reg_lds_counters": 0},
+                 {"path": 4, "grid": 64, "fused_counters_max": 1 << 30, "reg_shape": pick[1], "reg_lds_counters": 0},
+                 {"path": 4, "reg_shape": pick[2], "reg_dense4": 1, "grid": 5}):
         with _with_options(hip_engine, opts):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
             assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
@@ -254,6 +255,42 @@ def test_register_resident_cells_spare_bins_ties_and_domain(hip_engine):
         bad = a.copy(); bad[1, 0, 77] = 1024
         with pytest.raises(_lib.DomainError):
             hip_engine.aggregate(bad, np.zeros(3, dtype=np.int32))
+
+
+@pytest.mark.parametrize("shape", [(60, 200, 40), (30, 150, 300), (400, 3, 200), (10, 64, 1500), (3, 2000, 64), (2000, 1, 1024), (500, 40, 64)])
+def test_register_kernels_accumulate_counters_in_lds(hip_engine, shape):
+    """Counters of the register-resident kernels come out of the SAME launch (per-workgroup LDS tables flushed at
+    the end): equal to the oracle's with and without a cell table, with tie classes that do not fit the LDS
+    table (many budgets: all-distinct cells hit with n_modes = N and take the direct path), and the launch is
+    counted by scv_get_stat; shapes whose table cannot fit fall back to the cell-table reduction."""
+    import torch
+    P, B, N = shape
+    rng = np.random.default_rng(P + B + N)
+    a = rng.integers(0, 1000, size=(P, B, N), dtype=np.int32)
+    per = np.stack([rng.permutation(1024)[:min(N, 1024)] for _ in range(P)]).astype(np.int32)   # all-distinct rows (N <= 1024)
+    a[: P // 2, :, : per.shape[1]] = per[: P // 2, None, :]
+    if N > 1024:
+        a[: P // 2, :, 1024:] = a[: P // 2, :, :N - 1024]             # every value twice at most: still one big tie
+    tr = a[:, 0, 0].copy()
+    tr[::5] = 1023
+    t = rng.integers(-(1 << 20), 1 << 20, size=(P, B, N), dtype=np.int32)
+    nv = np.array([N if b % 3 else max(1, N // (1 + b % 7)) for b in range(B)], dtype=np.int32)
+    want = oracle(a, tr, tokens=t, n_valid=nv)
+    with _with_options(hip_engine, {"path": 4}):
+        before = hip_engine.stat("reg_lds_counters")
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
+        fits = hip_engine.stat("reg_lds_counters") > before
+        assert fits == (B <= 200)                                     # B = 2000: no room for 8 classes per budget
+        got = hip_engine.aggregate(a, tr, tokens=t, n_valid=nv, want_cells=False)
+        assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.truth_count_sum, want.truth_count_sum) and np.array_equal(got.token_sum, want.token_sum)
+        # device mode without a cell table: nothing but the votes is read and nothing but the counters written
+        dev = torch.device("cuda:0")
+        c, cells, _ = hip_engine.aggregate_device(torch.from_numpy(a).to(dev), torch.from_numpy(tr).to(dev), n_valid=torch.from_numpy(nv).to(dev), cells=False)
+        hip_engine.sync()
+        assert cells is None
+        from o1_inference_scaling_laws_amd.engine import AggregateResult
+        r = AggregateResult.from_counters(c.cpu().numpy(), P, B)
+        assert np.array_equal(r.tie_class_hits, want.tie_class_hits) and np.array_equal(r.truth_count_sum, want.truth_count_sum)
 
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3])

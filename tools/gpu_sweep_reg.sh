@@ -1,20 +1,20 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
-R=$(pwd)
-for sh in 1601 1604; do
-  d=$R/gpurun_out/kt_$sh; rm -rf $d; mkdir -p $d
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python $R/tools/one_case.py --P 200000 --B 4 --N 64 --rounds 3 --opt reg_shape=$sh > $d/run.log 2>&1)
-  echo "shape $sh"; python - <<PY
-import csv,glob
-for f in glob.glob("$d/*/*_kernel_stats.csv"):
-    for r in csv.DictReader(open(f)):
-        if "scv_reg" in r["Name"] or "reduce" in r["Name"]:
-            print("  ", r["Name"][:60], r["Calls"], "avg_us", float(r["AverageNs"])/1e3, "min_us", float(r["MinNs"])/1e3)
-PY
-done
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "register or lds or auto_dispatch or fused_and_reduced or more_budgets" 2>&1 | tail -5
+timeout 600 env SCV_FUZZ_SEEDS=200 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -3
 run() { python tools/one_case.py "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.readlines()[-1]); print('%-22s %-40s %8.1f us %8.1f GB/s' % (r['shape'], r['opts'], r['median_us'], r['GBps']))"; }
-run --P 200000 --B 4 --N 64 --opt fused_counters_max=1073741824
+for c in "200000 4 64" "100000 4 128" "50000 4 256" "25000 4 512" "12500 4 1024" "12500 4 2048" "6250 4 4096" "25000 32 64" "2000 8 100"; do
+  set -- $c
+  run --P $1 --B $2 --N $3
+  run --P $1 --B $2 --N $3 --opt reg_wpg=4
+  run --P $1 --B $2 --N $3 --opt reg_lds_counters=0
+done
 run --P 200000 --B 4 --N 64 --dist 0
-run --P 200000 --B 1 --N 256
-run --P 25000 --B 32 --N 64
+run --P 200000 --B 4 --N 64 --dist 3
+run --P 50000 --B 4 --N 256 --dist 0
+run --P 50000 --B 4 --N 256 --dist 3
+run --P 50000 --B 4 --N 256 --tokens
+run --P 12500 --B 4 --N 1024 --opt reg_dense4=1
+run --P 25000 --B 4 --N 512 --opt reg_shape=6402
+run --P 12500 --B 4 --N 1000
