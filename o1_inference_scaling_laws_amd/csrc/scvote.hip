@@ -463,8 +463,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         }
         const int64_t cpw = h ? 1 : 64 / g;
         const int64_t nbatches = (ncells + cpw - 1) / cpw;
-        // 16 lanes per cell: 16-bit bins (8.3 KiB per wave); 32 / 64 lanes per cell and the dense scans: 32-bit bins (16.4 KiB)
-        const bool bins16 = h == 0 && g == 16;
+        // sparse shapes count in 16 bits (8.3 KiB of LDS per wave); the dense scans keep 32-bit bins (16.4 KiB per wave)
+        const bool bins16 = h == 0 && !(g == 64 && v == 4 && ctx->reg_dense4 != 0);
         a.wave_lds_words = (int32_t)((bins16 ? scv::kRegWaveWords16 : scv::kRegWaveWords) + (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0));
         const RegKernel rk = h ? pick_dense_kernel(v, h, tok, vec) : pick_reg_kernel(g, v, tok, vec, ctx->reg_dense4 != 0, ctx->reg_km);
         KernelFn fn = rk.fn;

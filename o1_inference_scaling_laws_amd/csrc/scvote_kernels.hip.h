@@ -1567,7 +1567,12 @@ constexpr int kRegWaveWords = kRegHistWords + 64;    // + one word per lane: the
 // the occupancy the shape is meant to run at: 16 / 12 / 8 / 4 waves), so a launch is one workgroup per CU: the
 // end-of-launch counter flush then costs 256 device atomics per counter (12 ns each on one address), not 1024.
 template <int G, int V, bool TOK, bool DENSE>
-constexpr int reg_cells_waves() { return (DENSE || G > 16) ? 8 : (V <= 2 || !TOK ? 16 : 12); }
+constexpr int reg_cells_waves() {
+    if (DENSE) return 8;
+    if (G == 16) return (V <= 2 || !TOK) ? 16 : 12;
+    if (G == 32) return (V <= 2 || !TOK) ? 16 : 12;
+    return V <= 2 ? 16 : 12;
+}
 template <int V, bool TOK>
 constexpr int reg_dense_waves() { return (V == 8 && TOK) ? 4 : 8; }
 // 16-bit counters (sparse kernels; a cell slot holds <= 1024 votes): copy c of a cell is an array of 1026 u16 bins
@@ -1616,6 +1621,16 @@ __device__ __forceinline__ void lds_add(uint32_t addr, uint32_t inc) {
     __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>((uintptr_t)addr), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef unsigned short scv_v2h __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sum_halves(uint32_t w, uint32_t acc) {      // acc + w.lo + w.hi: v_dot2_u32_u16
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(scv_v2h, w), scv_v2h{1, 1}, acc, false);
+}
+// 16-bit counters, the R copies of a bin packed side by side (R = 2: one word, R = 4: two words)
+template <int R>
+__device__ __forceinline__ uint32_t lds_count_packed(uint32_t A) {
+    if (R == 4) { const scv_v2u q = *reinterpret_cast<lds_v2u*>((uintptr_t)A); return sum_halves(q.x, sum_halves(q.y, 0u)); }
+    return sum_halves(*reinterpret_cast<lds_u32*>((uintptr_t)A), 0u);
+}
 // sum over the R copies of a 16-bit bin: R ds_read_u16 at immediate offsets (copy stride kRegCopyBytes16)
 template <int R>
 __device__ __forceinline__ uint32_t lds_count16(uint32_t A) {
@@ -1640,15 +1655,19 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
     static_assert(!DENSE || G == 64, "the dense scan owns a whole wave per cell");
     constexpr int C = 64 / G;                 // cells per wave per batch
     constexpr int R = G / 16;                 // histogram copies per cell
-    // H16 (16 lanes per cell, one copy): 16-bit counters, a cell = 1026 u16 bins; a vote adds 1 << 16 (bin parity)
-    // to the WORD holding its bin (three more VALU per vote than 32-bit counters), reads and clears are 16-bit:
-    // 8 KiB of LDS per wave instead of 16, so 3-4 waves per SIMD are resident instead of 2 (measured +15-19 % at
-    // N = 64 ... 256).  With 2 / 4 copies (G = 32 / 64) the R reads per vote cost more than the occupancy gives
-    // (N = 1024: 59 -> 70 us), so those shapes and the dense scan keep 32-bit counters, [bin][copy].
-    constexpr bool H16 = !DENSE && G == 16;   // measured: with 2 / 4 copies the extra reads cost more than the occupancy gives
-    constexpr int S = H16 ? 1 : (R == 4 ? 4 : (R == 2 ? 3 : 2));   // log2(bytes between consecutive bins)
-    constexpr int WW = H16 ? kRegWaveWords16 : kRegWaveWords;
-    constexpr uint32_t CELLBYTES = H16 ? (uint32_t)(kRegCopyBytes16 * R) : (uint32_t)(kRegCellBins * R * 4);
+    // 16-bit counters for every sparse shape (a cell slot holds <= 1024 votes): 8 KiB of LDS per wave instead of
+    // 16, so 3-4 waves per SIMD are resident instead of 2 (measured +15-19 % at N = 64 ... 256).
+    //  H16 (G = 16, one copy): a cell = 1026 u16 bins; a vote adds 1 << 16 (bin parity) to the WORD holding its bin
+    //      (three more VALU per vote than 32-bit counters), reads and clears are 16-bit.
+    //  P16 (G = 32 / 64, 2 / 4 copies): the copies of a bin sit side by side (one / two words per bin); a lane's
+    //      increment (1 or 1 << 16) and word are constants of the lane, the read is one b32 / b64 + v_dot2_u32_u16.
+    //      Two copies share a word, so all-equal votes serialise 32 deep instead of 16 (truth votes never do).
+    // The dense scan keeps 32-bit counters, [bin][copy].
+    constexpr bool H16 = !DENSE && G == 16;
+    constexpr bool P16 = !DENSE && G > 16;
+    constexpr int S = H16 ? 1 : (P16 ? (R == 4 ? 3 : 2) : (R == 4 ? 4 : (R == 2 ? 3 : 2)));   // log2(bytes between consecutive bins)
+    constexpr int WW = (H16 || P16) ? kRegWaveWords16 : kRegWaveWords;
+    constexpr uint32_t CELLBYTES = (H16 || P16) ? (uint32_t)(kRegCopyBytes16 * R) : (uint32_t)(kRegCellBins * R * 4);
     constexpr int E = 4 * V;                  // votes per lane per batch
     constexpr uint32_t CAP = 4u * G * V;      // votes per cell slot
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_wg[];
@@ -1667,7 +1686,10 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
     const uint32_t cellbase = base + (uint32_t)sub * CELLBYTES;   // bytes
     const uint32_t KB = cellbase + (1023u << S);        // address of bin 0 (histogram index 1023), copy 0
     const uint32_t ATR = cellbase + (1024u << S);       // trash bin
-    const uint32_t copy4 = ((uint32_t)l & (R - 1)) * (H16 ? (uint32_t)kRegCopyBytes16 : 4u);   // this lane's copy, bytes
+    const uint32_t copy = (uint32_t)l & (R - 1);
+    const uint32_t copy4 = P16 ? (copy >> 1) * 4u : copy * (H16 ? (uint32_t)kRegCopyBytes16 : 4u);   // word of this lane's copy, bytes
+    const uint32_t copy_inc = 1u << (16u * (copy & 1u));                 // P16: this lane's half of that word
+    const uint32_t copy2 = copy * 2u;                                    // P16: byte offset of this lane's 16-bit counter
     const uint32_t TW = base + (uint32_t)(WW - 64) * 4u + (uint32_t)lane * 4u;   // this lane's word of the wide truth bin
     // n_valid[B] cached behind the histograms (host sizes the region; B > kMaxSortedB reads it from memory):
     // a global load here would put a dependent memory round trip in front of every batch's loads
@@ -1753,7 +1775,8 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
                 // low 5 bits of the shift: (A << 3) & 31 = 16 * bit 1).  The truth word collects both halves.
                 const uint32_t inc = __builtin_amdgcn_alignbit(1u, 1u, A << 3);
                 lds_add((A == AT ? TW : (A + copy4)) & ~3u, inc);
-            } else lds_add1(A == AT ? TW : (A | copy4));
+            } else if (P16) lds_add(A == AT ? TW : (A | copy4), copy_inc);
+            else lds_add1(A == AT ? TW : (A | copy4));
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -1768,8 +1791,8 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
             // two ds_reads in flight and the pass becomes a chain of LDS latencies: measured 48 % wave-wait)
             uint32_t cn[CH];
 #pragma unroll
-            for (int i = i0; i < i0 + CH; ++i) cn[i - i0] = H16 ? lds_count16<R>(c.v[i]) : lds_count<R>(c.v[i]);
-            __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, H16 ? CH * R : CH, 0);
+            for (int i = i0; i < i0 + CH; ++i) cn[i - i0] = H16 ? lds_count16<R>(c.v[i]) : (P16 ? lds_count_packed<R>(c.v[i]) : lds_count<R>(c.v[i]));
+            __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, CH, 0);
             __builtin_amdgcn_sched_group_barrier(0x2 /* VALU */, CH * 6, 0);
 #pragma unroll
             for (int i = i0; i < i0 + CH; ++i) {
@@ -1790,12 +1813,13 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
 #pragma unroll
         for (int i = 0; i < E; ++i) at_max += c.v[i] >= thr ? 1u : 0u;   // inactive keys have count 0: they only count when max_count == 0
         tc = *reinterpret_cast<lds_u32*>((uintptr_t)TW);            // this lane's truth votes (summed over the cell below)
-        if (H16) tc = (tc & 0xffffu) + (tc >> 16);
+        if (H16 || P16) tc = (tc & 0xffffu) + (tc >> 16);
         __builtin_amdgcn_wave_barrier();
         // pass 4: sparse clear (an inactive vote's key addresses the trash bin)
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             if (H16) *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) + copy4)) = (uint16_t)0;
+            else if (P16) *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) | copy2)) = (uint16_t)0;
             else *reinterpret_cast<lds_u32*>((uintptr_t)((c.v[i] & kKeyMask) | copy4)) = 0u;
         }
         *reinterpret_cast<lds_u32*>((uintptr_t)TW) = 0u;
