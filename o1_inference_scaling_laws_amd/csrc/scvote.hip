@@ -452,8 +452,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         else if (N <= 256) { g = 16; v = 4; }
         else if (N <= 512) { g = 32; v = 4; }
         else if (N <= 1024) { g = 64; v = 4; }
-        else if (N <= 2048) { v = 8; h = 1; }
-        else { v = 8; h = 2; }
+        else if (N <= 2048) { v = 4; h = 2; }      // 4 KiB parts: 126-136 VGPRs, 3 waves per SIMD (8 KiB parts: 200, 2 waves; measured 73 vs 79 us)
+        else { v = 4; h = 4; }
         if (ctx->reg_shape >= 1000) {
             const int fv = (ctx->reg_shape - 1000) / 10, fh = ctx->reg_shape % 10;
             if ((fv == 4 && (fh == 1 || fh == 2 || fh == 4) || fv == 8 && (fh == 1 || fh == 2)) && (int64_t)256 * fv * fh >= N) { g = 0; v = fv; h = fh; }
@@ -463,8 +463,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         }
         const int64_t cpw = h ? 1 : 64 / g;
         const int64_t nbatches = (ncells + cpw - 1) / cpw;
-        // sparse shapes count in 16 bits (8.3 KiB of LDS per wave); the dense scans keep 32-bit bins (16.4 KiB per wave)
-        const bool bins16 = h == 0 && !(g == 64 && v == 4 && ctx->reg_dense4 != 0);
+        // 16-bit bins (8.3 KiB of LDS per wave) everywhere but the A/B dense scan of scv_reg_cells (32-bit, 16.4 KiB)
+        const bool bins16 = !(h == 0 && g == 64 && v == 4 && ctx->reg_dense4 != 0);
         a.wave_lds_words = (int32_t)((bins16 ? scv::kRegWaveWords16 : scv::kRegWaveWords) + (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0));
         const RegKernel rk = h ? pick_dense_kernel(v, h, tok, vec) : pick_reg_kernel(g, v, tok, vec, ctx->reg_dense4 != 0, ctx->reg_km);
         KernelFn fn = rk.fn;

@@ -1560,9 +1560,11 @@ __device__ __forceinline__ long long cellgroup_sum_i64(long long v) {    // limb
 // key = count << kKeyShift | LDS byte address: a workgroup may hold all 160 KiB of a CU's LDS (18 address bits); counts are <= 4096 (13 bits)
 constexpr int kKeyShift = 18;
 constexpr uint32_t kKeyMask = (1u << kKeyShift) - 1u;
-constexpr int kRegCellBins = 1025;                   // 1024 bins + one trash bin that absorbs the votes of inactive lanes
+constexpr int kRegCellBins = 1025;                   // 1024 bins + one spare
 constexpr int kRegHistWords = 4 * kRegCellBins;      // per wave: C cells x 1025 bins x R copies, C * R = 4
-constexpr int kRegWaveWords = kRegHistWords + 64;    // + one word per lane: the "wide truth bin" (see below)
+constexpr int kRegLaneWords = 64 + 128;              // + per lane: one word of the "wide truth bin" (see below) and 8 bytes of trash
+                                                     // (inactive vote slots add there: a shared trash bin serialised them 32-64 deep)
+constexpr int kRegWaveWords = kRegHistWords + kRegLaneWords;
 // The waves of a workgroup are independent; a workgroup is ALL the waves a CU holds of the shape (launch bounds =
 // the occupancy the shape is meant to run at: 16 / 12 / 8 / 4 waves), so a launch is one workgroup per CU: the
 // end-of-launch counter flush then costs 256 device atomics per counter (12 ns each on one address), not 1024.
@@ -1574,12 +1576,12 @@ constexpr int reg_cells_waves() {
     return V <= 2 ? 16 : 12;
 }
 template <int V, bool TOK>
-constexpr int reg_dense_waves() { return (V == 8 && TOK) ? 4 : 8; }
+constexpr int reg_dense_waves() { return V == 4 ? (TOK ? 8 : 12) : (TOK ? 4 : 8); }
 // 16-bit counters (sparse kernels; a cell slot holds <= 1024 votes): copy c of a cell is an array of 1026 u16 bins
 // (1024 + trash + pad), so a wave's histograms take 8 KiB instead of 16 and twice the waves are resident
 constexpr int kRegCopyBytes16 = 2 * 1026;
 constexpr int kRegHist16Words = 4 * kRegCopyBytes16 / 4;
-constexpr int kRegWaveWords16 = kRegHist16Words + 64;
+constexpr int kRegWaveWords16 = kRegHist16Words + kRegLaneWords;
 
 // Per-vote state is ONE register holding the LDS byte address A of the vote's bin (all copies):
 //   A = cellbase + ((1023 - bin) << S), S = log2(4 R)   -> ds_add at A | copy*4, ds_read_b{32,64,128} at A,
@@ -1685,12 +1687,13 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
     const WgCounters wgc = wg_counters_begin(a, smem_wg + (blockDim.x >> 6) * a.wave_lds_words, (int)threadIdx.x, (int)blockDim.x);
     const uint32_t cellbase = base + (uint32_t)sub * CELLBYTES;   // bytes
     const uint32_t KB = cellbase + (1023u << S);        // address of bin 0 (histogram index 1023), copy 0
-    const uint32_t ATR = cellbase + (1024u << S);       // trash bin
+    const uint32_t LW = base + (uint32_t)(WW - kRegLaneWords) * 4u;          // first byte behind this wave's histograms
+    const uint32_t ATR = LW + 256u + (uint32_t)lane * 8u;                    // this lane's trash (above every bin address)
     const uint32_t copy = (uint32_t)l & (R - 1);
     const uint32_t copy4 = P16 ? (copy >> 1) * 4u : copy * (H16 ? (uint32_t)kRegCopyBytes16 : 4u);   // word of this lane's copy, bytes
     const uint32_t copy_inc = 1u << (16u * (copy & 1u));                 // P16: this lane's half of that word
     const uint32_t copy2 = copy * 2u;                                    // P16: byte offset of this lane's 16-bit counter
-    const uint32_t TW = base + (uint32_t)(WW - 64) * 4u + (uint32_t)lane * 4u;   // this lane's word of the wide truth bin
+    const uint32_t TW = LW + (uint32_t)lane * 4u;                            // this lane's word of the wide truth bin
     // n_valid[B] cached behind the histograms (host sizes the region; B > kMaxSortedB reads it from memory):
     // a global load here would put a dependent memory round trip in front of every batch's loads
     uint32_t* nv_lds = smem + WW;
@@ -1749,15 +1752,18 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
     uint32_t bad = 0;
     // pass 1 (o1.py:181-195): h[bin][copy] += 1; inactive votes feed the trash bin.  FULL: every lane's cell has
     // exactly CAP valid votes (wave-uniform), so no vote needs an activity predicate.
-    auto vote_pass = [&](Batch& c, auto full_tag) {
+    // EL = 4 * (live vectors): slots at or beyond the longest cell of the batch are skipped by every pass (a cell shorter
+    // than the shape's capacity, ragged n_valid) -- the cost of a batch follows its votes, not the shape's capacity.
+    auto vote_pass = [&](Batch& c, auto full_tag, auto live_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
+        constexpr int EL = 4 * decltype(live_tag)::value;
         // activity of vote i as a MASK, not a predicate (64 live SGPR pairs would spill): element(i) < n  <=>
         // const_i < nl with the lane term moved to the right-hand side; m = all ones when active
         const int32_t nl = (int32_t)c.n - (VEC ? 4 * l : l);
         // address of the truth's bin; a vote is a truth vote iff its bin address equals it (inactive slots carry ATR)
         const uint32_t AT = (c.truth >= 0 && c.truth < kBins) ? KB - ((uint32_t)c.truth << S) : 0xffffffffu;
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
+        for (int i = 0; i < EL; ++i) {
             const uint32_t v = c.v[i];
             const uint32_t vm = v < 1023u ? v : 1023u;
             uint32_t A = bin_address<S>(KB, vm);
@@ -1781,12 +1787,13 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
         __builtin_amdgcn_wave_barrier();
     };
     // passes 2-4, sparse: read back the counts of the bins this lane voted for
-    auto sparse_passes = [&](Batch& c, auto full_tag, uint32_t& gkey, uint32_t& at_max, uint32_t& tc) {
+    auto sparse_passes = [&](Batch& c, auto full_tag, auto live_tag, uint32_t& gkey, uint32_t& at_max, uint32_t& tc) {
         constexpr bool FULL = decltype(full_tag)::value;
+        constexpr int EL = 4 * decltype(live_tag)::value;
         uint32_t lmax = 0;
-        constexpr int CH = E > 16 ? 8 : E;                          // bound the registers held by reads in flight
+        constexpr int CH = EL > 16 ? 8 : EL;                          // bound the registers held by reads in flight
 #pragma unroll
-        for (int i0 = 0; i0 < E; i0 += CH) {
+        for (int i0 = 0; i0 < EL; i0 += CH) {
             // all CH reads are issued before the first count is consumed (left alone, the scheduler keeps only
             // two ds_reads in flight and the pass becomes a chain of LDS latencies: measured 48 % wave-wait)
             uint32_t cn[CH];
@@ -1798,9 +1805,9 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
             for (int i = i0; i < i0 + CH; ++i) {
                 const uint32_t A = c.v[i];
                 uint32_t key = (cn[i - i0] << kKeyShift) | A;
-                if (!FULL) {                                            // A < ATR for every real bin: inactive -> key = ATR
-                    const uint32_t m = (uint32_t)((int32_t)(A - ATR) >> 31);   // (count 0, below every real key; pass 4
-                    key = (key & m) | (ATR & ~m);                       //  then clears the trash word, never another region)
+                if (!FULL) {                                            // A < LW for every real bin: inactive -> key = ATR
+                    const uint32_t m = (uint32_t)((int32_t)(A - LW) >> 31);    // (count 0, below every real key; pass 4
+                    key = (key & m) | (ATR & ~m);                       //  then clears the lane's trash, never another region)
                 }
                 c.v[i] = key;
                 lmax = key > lmax ? key : lmax;
@@ -1811,13 +1818,13 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
         // pass 3 (statistics.py:599-601): votes at max -> number of distinct modes; h[truth]
         at_max = 0;
 #pragma unroll
-        for (int i = 0; i < E; ++i) at_max += c.v[i] >= thr ? 1u : 0u;   // inactive keys have count 0: they only count when max_count == 0
+        for (int i = 0; i < EL; ++i) at_max += c.v[i] >= thr ? 1u : 0u;   // inactive keys have count 0: they only count when max_count == 0
         tc = *reinterpret_cast<lds_u32*>((uintptr_t)TW);            // this lane's truth votes (summed over the cell below)
         if (H16 || P16) tc = (tc & 0xffffu) + (tc >> 16);
         __builtin_amdgcn_wave_barrier();
         // pass 4: sparse clear (an inactive vote's key addresses the trash bin)
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
+        for (int i = 0; i < EL; ++i) {
             if (H16) *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) + copy4)) = (uint16_t)0;
             else if (P16) *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) | copy2)) = (uint16_t)0;
             else *reinterpret_cast<lds_u32*>((uintptr_t)((c.v[i] & kKeyMask) | copy4)) = 0u;
@@ -1846,7 +1853,6 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < 16; ++j) *reinterpret_cast<lds_v4u*>((uintptr_t)(A0 + 1024u * j)) = scv_v4u{0u, 0u, 0u, 0u};
-        *reinterpret_cast<lds_u32*>((uintptr_t)(ATR | copy4)) = 0u;        // keep the trash bin from wrapping
         *reinterpret_cast<lds_u32*>((uintptr_t)TW) = 0u;
         __builtin_amdgcn_wave_barrier();
         gkey = cellgroup_max<64>(lmax);
@@ -1923,12 +1929,26 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
                 }
             }
             uint32_t gkey, at_max, tc;
+            auto partial = [&](auto live_tag) {
+                vote_pass(c, std::false_type{}, live_tag);
+                if (DENSE) dense_passes(c, gkey, at_max, tc); else sparse_passes(c, std::false_type{}, live_tag, gkey, at_max, tc);
+            };
             if (__all(n == CAP)) {
-                vote_pass(c, std::true_type{});
-                if (DENSE) dense_passes(c, gkey, at_max, tc); else sparse_passes(c, std::true_type{}, gkey, at_max, tc);
+                vote_pass(c, std::true_type{}, std::integral_constant<int, V>{});
+                if (DENSE) dense_passes(c, gkey, at_max, tc); else sparse_passes(c, std::true_type{}, std::integral_constant<int, V>{}, gkey, at_max, tc);
             } else {
-                vote_pass(c, std::false_type{});
-                if (DENSE) dense_passes(c, gkey, at_max, tc); else sparse_passes(c, std::false_type{}, gkey, at_max, tc);
+                // longest cell of the batch (wave-uniform: lane s * G holds cell slot s) -> live vectors
+                uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)n, 0);
+#pragma unroll
+                for (int sl = 1; sl < C; ++sl) {
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)n, sl * G);
+                    nmax = o > nmax ? o : nmax;
+                }
+                const uint32_t live = (nmax + 4u * G - 1u) / (4u * G);
+                if (V >= 4 && live > 3) partial(std::integral_constant<int, V >= 4 ? 4 : V>{});
+                else if (V >= 3 && live > 2) partial(std::integral_constant<int, V >= 3 ? 3 : V>{});
+                else if (V >= 2 && live > 1) partial(std::integral_constant<int, V >= 2 ? 2 : V>{});
+                else partial(std::integral_constant<int, 1>{});
             }
             finish_cell(c, gkey, at_max, tc, tsum);
         }
@@ -1953,13 +1973,14 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
 // ---- kernel 1h: register-streamed long cells (1024 < N <= 4096 and up), dense scan ----------------
 //
 // Same building blocks as scv_reg_cells with G = 64 (one wave per cell, R = 4 copies, no barrier), but a cell
-// is streamed in H parts of V vectors per lane: part s+1 is in flight while part s is voted, and since the
+// is streamed in H parts of V vectors per lane (16-bit counters, the 4 copies of a bin packed in 8 bytes: 8 KiB of
+// LDS per wave): part s+1 is in flight while part s is voted, and since the
 // dense scan never looks at the votes again only 2 x 4V registers hold votes whatever the cell length
 // (N = 4096: 64 registers instead of 128 -> 2+ waves per SIMD instead of 1).  After the last part every lane
-// scans its 16 bins (ds_read_b128 at immediate offsets), zeroes them, and the wave reduces.
+// scans its 16 bins (8 ds_read_b128 at immediate offsets, v_dot2_u32_u16 sums the copies), zeroes them, and the wave reduces.
 template <int V, int H, bool TOK, bool VEC>
 __global__ __launch_bounds__((64 * reg_dense_waves<V, TOK>())) void scv_reg_dense(const AggArgs a) {
-    constexpr int S = 4;                      // 16 bytes per bin (4 copies)
+    constexpr int S = 3;                      // 8 bytes per bin: 4 copies of a 16-bit counter (a cell holds <= 65535 votes here)
     constexpr int E = 4 * V;                  // votes per lane per part
     constexpr uint32_t PART = 256u * V;       // votes per part
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_wg[];
@@ -1968,15 +1989,16 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, TOK>())) void scv_reg_dens
     const uint32_t base = (uint32_t)(uintptr_t)(lds_u32*)smem;
     {
         uint4* h4 = reinterpret_cast<uint4*>(smem);
-        for (int i = lane; i < kRegWaveWords / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < kRegWaveWords16 / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
     }
     const WgCounters wgc = wg_counters_begin(a, smem_wg + (blockDim.x >> 6) * a.wave_lds_words, (int)threadIdx.x, (int)blockDim.x);
     const uint32_t KB = base + (1023u << S);
-    const uint32_t ATR = base + (1024u << S);
-    const uint32_t copy4 = ((uint32_t)lane & 3u) * 4u;
-    const uint32_t A0 = base + (uint32_t)lane * 16u;
-    const uint32_t TW = base + (uint32_t)kRegHistWords * 4u + (uint32_t)lane * 4u;   // this lane's word of the wide truth bin
-    uint32_t* nv_lds = smem + kRegWaveWords;
+    const uint32_t ATR = base + (uint32_t)(kRegHist16Words + 64) * 4u + (uint32_t)lane * 8u;   // this lane's trash
+    const uint32_t copy4 = (((uint32_t)lane & 3u) >> 1) * 4u;             // word of this lane's copy inside a bin
+    const uint32_t copy_inc = 1u << (16u * ((uint32_t)lane & 1u));        // ... and its half of that word
+    const uint32_t A0 = base + (uint32_t)lane * 16u;                      // scan: 16 bytes = bins (2 x, 2 x + 1), x = lane + 64 j
+    const uint32_t TW = base + (uint32_t)kRegHist16Words * 4u + (uint32_t)lane * 4u;   // this lane's word of the wide truth bin
+    uint32_t* nv_lds = smem + kRegWaveWords16;
     const bool nv_cached = a.n_valid && a.B <= kMaxSortedB;
     if (nv_cached)
         for (int i = lane; i < a.B; i += 64) nv_lds[i] = (uint32_t)valid_len(a, i);
@@ -2053,19 +2075,21 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, TOK>())) void scv_reg_dens
                 const uint32_t v = c.v[i];
                 bad |= v;
                 const uint32_t A = bin_address<S>(KB, v < 1023u ? v : 1023u);
-                lds_add1(A == AT ? TW : (A | copy4));                           // truth votes: this lane's own word
+                lds_add(A == AT ? TW : (A | copy4), copy_inc);                           // truth votes: this lane's own word
                 if (TOK) tsum += c.tk[i];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < E; ++i) {
+                // slots at or beyond the end of the cell are skipped (wave-uniform: one cell per wave)
+                if ((VEC ? (i >> 2) * 256 : i * 64) >= (int32_t)c.nrel) continue;
                 const uint32_t v = c.v[i];
                 const int32_t ci = VEC ? (i >> 2) * 256 + (i & 3) : i * 64;
                 const uint32_t m = (uint32_t)((ci - nl) >> 31);                 // all ones when the vote is valid
                 bad |= v & m;
                 uint32_t A = bin_address<S>(KB, v < 1023u ? v : 1023u);
                 A = (A & m) | (ATR & ~m);
-                lds_add1(A == AT ? TW : (A | copy4));
+                lds_add(A == AT ? TW : (A | copy4), copy_inc);
                 if (TOK) tsum += (long long)(c.tk[i] & (int32_t)m);
             }
         }
@@ -2074,23 +2098,24 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, TOK>())) void scv_reg_dens
         __builtin_amdgcn_wave_barrier();
         uint32_t key[16];
         uint32_t lmax = 0;
+        {
+            scv_v4u q[8];                                           // 8 b128 reads (32 registers) in flight
 #pragma unroll
-        for (int j0 = 0; j0 < 16; j0 += 8) {                        // 8 b128 reads (32 registers) in flight at a time
-#pragma unroll
-            for (int j = j0; j < j0 + 8; ++j) key[j] = lds_count<4>(A0 + 1024u * j);
+            for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<lds_v4u*>((uintptr_t)(A0 + 1024u * j));
             __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x2 /* VALU */, 8 * 5, 0);
 #pragma unroll
-            for (int j = j0; j < j0 + 8; ++j) {
-                key[j] = (key[j] << kKeyShift) | (A0 + 1024u * j);
-                lmax = key[j] > lmax ? key[j] : lmax;
+            for (int j = 0; j < 8; ++j) {
+                key[2 * j] = (sum_halves(q[j].x, sum_halves(q[j].y, 0u)) << kKeyShift) | (A0 + 1024u * j);
+                key[2 * j + 1] = (sum_halves(q[j].z, sum_halves(q[j].w, 0u)) << kKeyShift) | (A0 + 1024u * j + 8u);
+                lmax = key[2 * j] > lmax ? key[2 * j] : lmax;
+                lmax = key[2 * j + 1] > lmax ? key[2 * j + 1] : lmax;
             }
         }
-        const uint32_t tc_lane = *reinterpret_cast<lds_u32*>((uintptr_t)TW);   // this lane's truth votes
+        uint32_t tc_lane = *reinterpret_cast<lds_u32*>((uintptr_t)TW);   // this lane's truth votes (both halves)
+        tc_lane = (tc_lane & 0xffffu) + (tc_lane >> 16);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < 16; ++j) *reinterpret_cast<lds_v4u*>((uintptr_t)(A0 + 1024u * j)) = scv_v4u{0u, 0u, 0u, 0u};
-        *reinterpret_cast<lds_u32*>((uintptr_t)(ATR | copy4)) = 0u;        // keep the trash bin from wrapping
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<lds_v4u*>((uintptr_t)(A0 + 1024u * j)) = scv_v4u{0u, 0u, 0u, 0u};
         *reinterpret_cast<lds_u32*>((uintptr_t)TW) = 0u;
         __builtin_amdgcn_wave_barrier();
         const uint32_t gkey = cellgroup_max<64>(lmax);

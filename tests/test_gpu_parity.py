@@ -280,7 +280,7 @@ def test_register_kernels_accumulate_counters_in_lds(hip_engine, shape):
         before = hip_engine.stat("reg_lds_counters")
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
         fits = hip_engine.stat("reg_lds_counters") > before
-        assert fits == (B <= 200)                                     # B = 2000: no room for 8 classes per budget
+        assert fits == (B < 200)                                      # B >= 200 with 16 waves per CU: no room for 8 classes per budget
         got = hip_engine.aggregate(a, tr, tokens=t, n_valid=nv, want_cells=False)
         assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.truth_count_sum, want.truth_count_sum) and np.array_equal(got.token_sum, want.token_sum)
         # device mode without a cell table: nothing but the votes is read and nothing but the counters written
