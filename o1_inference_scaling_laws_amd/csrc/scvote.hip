@@ -270,8 +270,10 @@ RegKernel pick_reg_kernel(int g, int v, bool tok, bool vec, bool dense4, int km)
 // long cells: V vectors per lane per part, H parts per cell (capacity 256 * V * H votes), dense bin scan
 template <int V, int H>
 RegKernel pick_dense_vh(bool tok, bool vec) {
-    if (tok) return {vec ? (KernelFn)scv::scv_reg_dense<V, H, true, true> : (KernelFn)scv::scv_reg_dense<V, H, true, false>, scv::reg_dense_waves<V, true>()};
-    return {vec ? (KernelFn)scv::scv_reg_dense<V, H, false, true> : (KernelFn)scv::scv_reg_dense<V, H, false, false>, scv::reg_dense_waves<V, false>()};
+    if (tok) return vec ? RegKernel{(KernelFn)scv::scv_reg_dense<V, H, true, true>, scv::reg_dense_waves<V, H, true, true>()}
+                        : RegKernel{(KernelFn)scv::scv_reg_dense<V, H, true, false>, scv::reg_dense_waves<V, H, true, false>()};
+    return vec ? RegKernel{(KernelFn)scv::scv_reg_dense<V, H, false, true>, scv::reg_dense_waves<V, H, false, true>()}
+               : RegKernel{(KernelFn)scv::scv_reg_dense<V, H, false, false>, scv::reg_dense_waves<V, H, false, false>()};
 }
 RegKernel pick_dense_kernel(int v, int h, bool tok, bool vec) {
     if (v == 4) return h == 1 ? pick_dense_vh<4, 1>(tok, vec) : (h == 2 ? pick_dense_vh<4, 2>(tok, vec) : pick_dense_vh<4, 4>(tok, vec));

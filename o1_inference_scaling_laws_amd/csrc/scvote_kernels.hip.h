@@ -1575,8 +1575,12 @@ constexpr int reg_cells_waves() {
     if (G == 32) return (V <= 2 || !TOK) ? 16 : 12;
     return V <= 2 ? 16 : 12;
 }
-template <int V, bool TOK>
-constexpr int reg_dense_waves() { return V == 4 ? (TOK ? 8 : 12) : (TOK ? 4 : 8); }
+template <int V, int H, bool TOK, bool VEC>
+constexpr int reg_dense_waves() {
+    if (V == 8) return TOK ? 4 : 8;
+    if (H == 1 || !VEC) return TOK ? 8 : 12;
+    return 12;            // (126 VGPRs would allow 16 waves without tokens: measured slower, N = 4096 73 -> 82 us)
+}
 // 16-bit counters (sparse kernels; a cell slot holds <= 1024 votes): copy c of a cell is an array of 1026 u16 bins
 // (1024 + trash + pad), so a wave's histograms take 8 KiB instead of 16 and twice the waves are resident
 constexpr int kRegCopyBytes16 = 2 * 1026;
@@ -1633,6 +1637,9 @@ __device__ __forceinline__ uint32_t lds_count_packed(uint32_t A) {
     if (R == 4) { const scv_v2u q = *reinterpret_cast<lds_v2u*>((uintptr_t)A); return sum_halves(q.x, sum_halves(q.y, 0u)); }
     return sum_halves(*reinterpret_cast<lds_u32*>((uintptr_t)A), 0u);
 }
+// (Measured and dropped: one ds_wrxchg_rtn per vote that reads AND clears the bin -- no clearing pass, one key per
+// distinct bin.  Uniform votes: N = 512 51 -> 45 us; but an exchange, unlike a read, serialises on equal addresses,
+// and any popular value made it 2-4x slower: peaked 51 -> 112 us, exact ties 227 us.)
 // sum over the R copies of a 16-bit bin: R ds_read_u16 at immediate offsets (copy stride kRegCopyBytes16)
 template <int R>
 __device__ __forceinline__ uint32_t lds_count16(uint32_t A) {
@@ -1777,9 +1784,9 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
             if (!DENSE) c.v[i] = A;                                 // a truth vote keeps its bin address: that bin reads 0 later
             // a vote for the truth goes to this lane's own word instead of the (shared, contended) histogram bin
             if (H16) {
-                // the word holding the 16-bit bin, and 1 or 1 << 16 by bit 1 of its address (v_alignbit_b32 takes the
-                // low 5 bits of the shift: (A << 3) & 31 = 16 * bit 1).  The truth word collects both halves.
-                const uint32_t inc = __builtin_amdgcn_alignbit(1u, 1u, A << 3);
+                // the word holding the 16-bit bin, and 1 or 1 << 16 by bit 1 of its address (v_alignbyte_b32 shifts
+                // {1, 1} right by the low 2 bits of A in bytes: 0 or 2).  The truth word collects both halves.
+                const uint32_t inc = __builtin_amdgcn_alignbyte(1u, 1u, A);
                 lds_add((A == AT ? TW : (A + copy4)) & ~3u, inc);
             } else if (P16) lds_add(A == AT ? TW : (A | copy4), copy_inc);
             else lds_add1(A == AT ? TW : (A | copy4));
@@ -1817,18 +1824,18 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
         const uint32_t thr = gkey & ~kKeyMask;                       // max_count << kKeyShift
         // pass 3 (statistics.py:599-601): votes at max -> number of distinct modes; h[truth]
         at_max = 0;
-#pragma unroll
-        for (int i = 0; i < EL; ++i) at_max += c.v[i] >= thr ? 1u : 0u;   // inactive keys have count 0: they only count when max_count == 0
         tc = *reinterpret_cast<lds_u32*>((uintptr_t)TW);            // this lane's truth votes (summed over the cell below)
-        if (H16 || P16) tc = (tc & 0xffffu) + (tc >> 16);
-        __builtin_amdgcn_wave_barrier();
-        // pass 4: sparse clear (an inactive vote's key addresses the trash bin)
+        // ... and pass 4 in the same loop: sparse clear (an inactive vote's key addresses the lane's trash).  LDS
+        // operations of a wave execute in order, so the clears need no wait for the reads of pass 2; interleaved, the
+        // address arithmetic of the clear fills the wait state between v_cmp and the carry-in add of the count.
 #pragma unroll
         for (int i = 0; i < EL; ++i) {
+            at_max += c.v[i] >= thr ? 1u : 0u;                      // inactive keys have count 0: they only count when max_count == 0
             if (H16) *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) + copy4)) = (uint16_t)0;
             else if (P16) *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) | copy2)) = (uint16_t)0;
             else *reinterpret_cast<lds_u32*>((uintptr_t)((c.v[i] & kKeyMask) | copy4)) = 0u;
         }
+        if (H16 || P16) tc = (tc & 0xffffu) + (tc >> 16);
         *reinterpret_cast<lds_u32*>((uintptr_t)TW) = 0u;
         __builtin_amdgcn_wave_barrier();
     };
@@ -1979,7 +1986,7 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
 // (N = 4096: 64 registers instead of 128 -> 2+ waves per SIMD instead of 1).  After the last part every lane
 // scans its 16 bins (8 ds_read_b128 at immediate offsets, v_dot2_u32_u16 sums the copies), zeroes them, and the wave reduces.
 template <int V, int H, bool TOK, bool VEC>
-__global__ __launch_bounds__((64 * reg_dense_waves<V, TOK>())) void scv_reg_dense(const AggArgs a) {
+__global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_reg_dense(const AggArgs a) {
     constexpr int S = 3;                      // 8 bytes per bin: 4 copies of a 16-bit counter (a cell holds <= 65535 votes here)
     constexpr int E = 4 * V;                  // votes per lane per part
     constexpr uint32_t PART = 256u * V;       // votes per part
