@@ -111,7 +111,10 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  * default 128), "copy_threads" (default 6: threads filling the pinned bounce slots), "reg_n_max" (default 4096: 32 < N <=
  * this uses the register-resident cell kernels; 0 restores the round-1 dispatch), "reg_shape" / "reg_km" / "reg_dense4" (force a
  * register-kernel shape for A/B runs), "reg_lds_counters" (default 1: the register-resident kernels accumulate the per-budget
- * counters in LDS and flush them in the same launch; 0: cell table + scv_reduce_cells), "boot_lds" (default 1: LDS-resident bootstrap table),
+ * counters in LDS and flush them in the same launch; 0: cell table + scv_reduce_cells), "reg_wpg" (waves per workgroup of the
+ * register-resident kernels, 0 = all the waves a CU holds), "prefix_cells" (default 1: scv_aggregate_prefix_i32 on pools of N <= 4096
+ * runs on the cell kernels, each cell reading its prefix of the pool row; 0: the one-pass snapshot kernels), "prefix_lane" (default 1:
+ * pools of N <= 64 run one lane per problem, every budget out of one pass over its votes), "boot_lds" (default 1: LDS-resident bootstrap table),
  * "fused_counters_max" (cells at or below, or problem rows >= 4 MiB: per-cell atomics inside the hot
  * kernel; otherwise a separate reduction of the cell table; 0 forces the reduction), "small_reg", "pin_host" (default 0; 1: HOST-mode calls hipHostRegister caller buffers
  * of 32 MiB or more for the duration of the call -- measured no faster than pageable copies), "prefetch"
@@ -223,7 +226,8 @@ int scv_host_free(void* p);
 /* How often this ctx took a single-launch form (monotonic counters, for tests and bench lines): "boot_fused" /
  * "boot_separate" (scv_aggregate_bootstrap_i32: one launch / two), "overwrite_fused" (counters overwritten by the
  * vote kernel's last workgroup), "merge_in_launch" (split-N merged by the last-arriving segment), "reg_lds_counters"
- * (register-resident launches that produced their counters themselves). */
+ * (register-resident launches that produced their counters themselves), "prefix_cells" / "prefix_lane" (prefix calls served by the cell
+ * kernels / by the one-lane-per-problem kernel). */
 int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out);
 
 int scv_device_count(void);

@@ -148,11 +148,13 @@ struct scv_ctx {
     size_t d_tickets_words = 0;
     void* d_partial2 = nullptr;  // split-N group histograms
     size_t d_partial2_bytes = 0;
-    int64_t stat_boot_fused = 0, stat_boot_separate = 0, stat_overwrite_fused = 0, stat_merge_in_launch = 0, stat_reg_lds_counters = 0;   // scv_get_stat
+    int64_t stat_boot_fused = 0, stat_boot_separate = 0, stat_overwrite_fused = 0, stat_merge_in_launch = 0, stat_reg_lds_counters = 0, stat_prefix_cells = 0, stat_prefix_lane = 0;   // scv_get_stat
     int boot_fused = 1;      // scv_aggregate_bootstrap_i32: run the bootstrap inside the vote launch when the shape allows it
     struct BootReq { int32_t r0, r1, M; uint64_t seed; int64_t* out; bool fused; }* boot_req = nullptr;   // set for the duration of one call
     int boot_lds = 1;        // bootstrap: LDS-resident code table when it fits (0: always the global-gather kernel)
     int reg_km = 1;          // reg path: batches in flight per wave = km x 4 KiB
+    int prefix_lane = 1;     // prefix budgets over pools of N <= 64: one lane per problem, all budgets in one pass (scv_lane_prefix)
+    int prefix_cells = 1;    // prefix budgets over short pools (N <= 4096) run on the cell kernels (0: the one-pass kernels)
     int reg_wpg = 0;         // reg path: waves per workgroup (0 = the kernel's own: all the waves a CU holds)
     int reg_lds_counters = 1; // reg path: per-budget counters accumulate in LDS and are flushed by the same launch
     int reg_shape = 0;       // reg path: force a kernel shape (A/B runs), see launch_aggregate
@@ -353,12 +355,18 @@ int ensure_partial(scv_ctx* ctx, size_t bytes) {
 //   split-N   cells <= CUs/2, big N        several workgroups per cell + merge kernel   (scv_hist_argmax + scv_merge_partials)
 //   stream    everything else              one persistent workgroup streams whole cells (scv_hist_argmax)
 // plus scv_reduce_cells behind any of them when the per-budget counters are not fused.
+// lds bytes of the one-lane-per-cell kernel (tie classes 0..nv and two sums per budget)
+size_t lane_kernel_lds(int32_t B, int nv) { return (((size_t)B * (nv + 1) + 1) & ~(size_t)1) * sizeof(uint32_t) + 2 * (size_t)B * sizeof(unsigned long long); }
+
+// pool_rows: prefix budgets over one pool [P, N] through the CELL kernels (register-resident / one lane per cell):
+// cell (p, b) counts the first n_valid[b] votes of row p.  Only launch_prefix passes it, after pool_rows_eligible().
 int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
                      const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells,
-                     int64_t* cell_tokens, int64_t* tie, int64_t* tok_sum, int64_t* truth_sum) {
+                     int64_t* cell_tokens, int64_t* tie, int64_t* tok_sum, int64_t* truth_sum, bool pool_rows = false) {
     const int64_t ncells = P * (int64_t)B;
     if (ncells == 0) return SCV_OK;
     scv::AggArgs a;
+    a.pool_rows = pool_rows ? 1 : 0;
     a.answers = answers; a.tokens = tokens; a.n_valid = n_valid; a.truth = truth;
     a.ncells = ncells; a.N = N; a.B = B; a.P = P;
     a.cells = cells; a.cell_tokens = cell_tokens;
@@ -371,7 +379,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.prefetch = ctx->prefetch;
     a.tok_skew = ctx->tok_skew;
     a.sorted = ctx->sorted;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
 
@@ -527,7 +535,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         // ---- tiny cells, one lane per cell; counters accumulated in LDS and flushed by the same launch
         const int nv = N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : 32));
         const int threads = (nv == 32 || (nv == 16 && tok)) ? 512 : 1024;      // register budget: 2 x nv votes (+ tokens) per lane
-        const size_t lds = (((size_t)B * (nv + 1) + 1) & ~(size_t)1) * sizeof(uint32_t) + 2 * (size_t)B * sizeof(unsigned long long);
+        const size_t lds = lane_kernel_lds(B, nv);
         if (lds <= (size_t)60 * 1024) {
             // counters come out of this launch: undo the separate-reduction setup
             if (use_reduce) {
@@ -540,6 +548,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             a.wave_lds_words = ((N % 4 == 0) && (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0)) ? 1 : 0;   // "vec" flag
             int64_t grid = (ncells + threads - 1) / threads;
             if (grid > ctx->num_cus) grid = ctx->num_cus;            // one workgroup per CU: the flush costs one atomic per workgroup and counter
+            // grid * threads a multiple of B: every lane then sees one budget and keeps its counters in registers
+            if ((grid * threads) % B != 0 && grid > B) grid -= grid % B;
             if (ctx->grid_override > 0) grid = ctx->grid_override;
             if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
 #define SCV_LANE(NVV, TT, TOKK) hipLaunchKernelGGL((scv::scv_lane_cells<NVV, TT, TOKK>), dim3((unsigned)grid), dim3(TT), lds, ctx->stream, a)
@@ -715,12 +725,44 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
 
 // Prefix budgets over one pool [P, N]: one pass, snapshots at the boundaries (scv_prefix_hist /
 // scv_small_prefix).  Same outputs as launch_aggregate on the dense [P, B, N] expansion.
+int launch_dense(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
+                 const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells, int64_t* cell_tokens,
+                 int64_t* tie, int64_t* tok_sum, int64_t* truth_sum) {
+    return launch_aggregate(ctx, answers, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, false);
+}
+
+// Short pools (N <= 4096: the reference's own sizes) go through the cell kernels instead: the pool row is re-read
+// per budget, but out of the cache, and a cell costs what its n_valid votes cost -- the one-pass kernels below pay a
+// workgroup-wide fold per boundary (measured at P x N = 10^5 x 256, budgets 1, 2, 4 ... N: 240 -> 60 us).
+bool pool_rows_eligible(const scv_ctx* ctx, int32_t B, int64_t N) {
+    if (ctx->path != 0 || !ctx->prefix_cells || N < 1) return false;
+    if (N > ctx->tiny_n_max) return N <= ctx->reg_n_max && N <= 4096;
+    const int nv = N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : 32));
+    return N <= 32 && ctx->tiny_lane && lane_kernel_lds(B, nv) <= (size_t)60 * 1024;
+}
+
+// pools of up to 64 samples: scv_lane_prefix (tie classes 0..nv, two sums, order + sorted n_valid per budget in LDS)
+bool prefix_lane_eligible(const scv_ctx* ctx, int32_t B, int64_t N, int* nv, size_t* lds) {
+    if (ctx->path != 0 || !ctx->prefix_lane || N < 1 || N > 64 || B > scv::kMaxSortedB) return false;
+    *nv = N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : 64)));
+    *lds = ((((size_t)B * (*nv + 1) + 1) & ~(size_t)1) + 6 * (size_t)B) * sizeof(uint32_t);
+    return *lds <= (size_t)24 * 1024;   // + up to 128 KiB for the staged cell records (B <= 8)
+}
+
 int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, const int32_t* n_valid,
                   const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells, int64_t* cell_tokens,
                   int64_t* tie, int64_t* tok_sum, int64_t* truth_sum) {
     const int64_t ncells = P * (int64_t)B;
     if (ncells == 0) return SCV_OK;
+    int lane_nv = 0;
+    size_t lane_lds = 0;
+    const bool lane_ok = prefix_lane_eligible(ctx, B, N, &lane_nv, &lane_lds);
+    if (!lane_ok && pool_rows_eligible(ctx, B, N)) {
+        ctx->stat_prefix_cells += 1;
+        return launch_aggregate(ctx, pool, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, true);
+    }
     scv::AggArgs a;
+    a.pool_rows = 0;
     a.answers = pool; a.tokens = tokens; a.n_valid = n_valid; a.truth = truth;
     a.ncells = ncells; a.N = N; a.B = B; a.P = P;
     a.cells = cells; a.cell_tokens = cell_tokens;
@@ -729,11 +771,13 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
     a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.prefetch = 0; a.tok_skew = ctx->tok_skew; a.sorted = 1;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
-    const bool use_reduce = want_counters && reduce_counters_separately(ctx, ncells, B, N);
+    // pools of up to 64 samples: one lane per problem, every budget out of one pass (scv_lane_prefix); its counters
+    // come out of the same launch
+    const bool use_reduce = want_counters && !lane_ok && reduce_counters_separately(ctx, ncells, B, N);
     if (use_reduce) {
         a.tie_hits = nullptr; a.token_sum = nullptr; a.truth_sum = nullptr;
         if (!a.cells || (tok && tok_sum && !a.cell_tokens)) {
@@ -753,7 +797,33 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
     int path = ctx->path;
     if (path == 0 || path == 2) path = (N <= ctx->small_n_max) ? 3 : 1;
-    if (path == 3) {
+    if (lane_ok) {
+        // N <= 32: one 1024-thread workgroup per CU (the end-of-launch flush is one device atomic per workgroup and counter,
+        // ~12 ns each on one address).  N = 64 needs 95-151 VGPRs: 256-thread workgroups, as many as are resident (measured
+        // 64 us against 84-86 us with 768 / 1024 threads, which spill or leave a second, nearly empty round)
+        const int T = lane_nv == 64 ? 256 : 1024;
+        a.wave_lds_words = ((N % 4 == 0) && (((uintptr_t)pool & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0)) ? 1 : 0;   // "vec" flag
+        KernelFn fn;
+#define SCV_LP(NVV) (tok ? (KernelFn)scv::scv_lane_prefix<NVV, 1024, true> : (KernelFn)scv::scv_lane_prefix<NVV, 1024, false>)
+        fn = lane_nv == 4 ? SCV_LP(4) : (lane_nv == 8 ? SCV_LP(8) : (lane_nv == 16 ? SCV_LP(16) : (lane_nv == 32 ? SCV_LP(32) :
+             (tok ? (KernelFn)scv::scv_lane_prefix<64, 256, true> : (KernelFn)scv::scv_lane_prefix<64, 256, false>))));
+#undef SCV_LP
+        // cell records leave through an LDS transpose (coalesced block writes) while B KiB per wave is affordable
+        size_t lds_total = lane_lds;
+        if (a.cells && B <= 8) {
+            a.lane_stage = 1;
+            lds_total = ((lane_lds + 15) & ~(size_t)15) + (size_t)(T / 64) * 64 * B * sizeof(scv_cell);
+        }
+        SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
+        int per_cu = 0;
+        SCV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), T, lds_total));
+        if (per_cu < 1 || T == 1024) per_cu = 1;
+        int64_t grid = (P + T - 1) / T;
+        if (grid > (int64_t)ctx->num_cus * per_cu) grid = (int64_t)ctx->num_cus * per_cu;
+        if (ctx->grid_override > 0) grid = ctx->grid_override;
+        hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)T), lds_total, ctx->stream, a);
+        ctx->stat_prefix_lane += 1;
+    } else if (path == 3) {
         constexpr int T = 512, NW = T / 64;
         const size_t lds = ((size_t)NW * scv::kBins + scv::kMaxSortedB) * sizeof(uint32_t);
         int64_t grid = (P + NW - 1) / NW;
@@ -963,6 +1033,8 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "overwrite_counters")) ctx->overwrite_counters = value != 0;
     else if (!strcmp(key, "ticket_merge")) ctx->ticket_merge = value != 0;
     else if (!strcmp(key, "reg_lds_counters")) ctx->reg_lds_counters = value != 0;
+    else if (!strcmp(key, "prefix_cells")) ctx->prefix_cells = value != 0;
+    else if (!strcmp(key, "prefix_lane")) ctx->prefix_lane = value != 0;
     else if (!strcmp(key, "reg_wpg")) { if (value != 0 && value != 4 && value != 8 && value != 12 && value != 16) return fail(SCV_ERR_ARG, "reg_wpg must be 0, 4, 8, 12 or 16"); ctx->reg_wpg = (int)value; }
     else if (!strcmp(key, "reg_km")) { if (value != 1 && value != 2 && value != 4) return fail(SCV_ERR_ARG, "reg_km must be 1, 2 or 4"); ctx->reg_km = (int)value; }
     else if (!strcmp(key, "reg_shape")) { if (value < 0 || value > 9999) return fail(SCV_ERR_ARG, "reg_shape out of range"); ctx->reg_shape = (int)value; }
@@ -991,7 +1063,7 @@ namespace {
 int host_serial(scv_ctx* ctx, bool prefix, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
                 const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells_out, int64_t* cell_tokens_out,
                 int64_t* tie_class_hits_out, int64_t* token_sum_out, int64_t* truth_count_sum_out) {
-    auto launch = prefix ? launch_prefix : launch_aggregate;
+    auto launch = prefix ? launch_prefix : launch_dense;
     // ---- HOST: stage problem-chunks through HBM ------------------------------------------------
     const size_t row_bytes = (prefix ? (size_t)1 : (size_t)B) * (size_t)N * sizeof(int32_t);   // votes of one problem
     // Pageable host memory is copied through the runtime's bounce buffers at a fraction of the link
@@ -1116,7 +1188,7 @@ void add_copy_pieces(std::vector<std::function<void()>>& pieces, void* dst, cons
 int host_pipelined(scv_ctx* ctx, bool prefix, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
                    const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells_out, int64_t* cell_tokens_out,
                    int64_t* tie_class_hits_out, int64_t* token_sum_out, int64_t* truth_count_sum_out) {
-    auto launch = prefix ? launch_prefix : launch_aggregate;
+    auto launch = prefix ? launch_prefix : launch_dense;
     const size_t row_bytes = (prefix ? (size_t)1 : (size_t)B) * (size_t)N * sizeof(int32_t);   // votes of one problem
     const size_t row_elems = row_bytes / sizeof(int32_t);
     const size_t per_problem = row_bytes * (tokens ? 2 : 1) + sizeof(int32_t);
@@ -1231,7 +1303,7 @@ int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const in
     if (prefix && B > scv::kMaxSortedB) return fail(SCV_ERR_ARG, "prefix mode supports at most %d budgets", scv::kMaxSortedB);
     if (mem_kind != SCV_MEM_HOST && mem_kind != SCV_MEM_DEVICE) return fail(SCV_ERR_ARG, "bad mem_kind %d", mem_kind);
     SCV_ENTER(ctx);
-    auto launch = prefix ? launch_prefix : launch_aggregate;
+    auto launch = prefix ? launch_prefix : launch_dense;
 
     if (mem_kind == SCV_MEM_DEVICE)
         return launch(ctx, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
@@ -1401,6 +1473,8 @@ int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
     else if (!strcmp(key, "boot_separate")) *out = ctx->stat_boot_separate;
     else if (!strcmp(key, "overwrite_fused")) *out = ctx->stat_overwrite_fused;
     else if (!strcmp(key, "reg_lds_counters")) *out = ctx->stat_reg_lds_counters;
+    else if (!strcmp(key, "prefix_cells")) *out = ctx->stat_prefix_cells;
+    else if (!strcmp(key, "prefix_lane")) *out = ctx->stat_prefix_lane;
     else if (!strcmp(key, "merge_in_launch")) *out = ctx->stat_merge_in_launch;
     else return fail(SCV_ERR_ARG, "unknown stat '%s'", key);
     return SCV_OK;

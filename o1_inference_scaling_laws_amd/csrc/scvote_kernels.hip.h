@@ -68,6 +68,10 @@ struct AggArgs {
     int32_t segs;           // split-N: segments per cell (1 = whole cells)
     int64_t seg_len;        // split-N: votes per segment
     int32_t wave_lds_words; // register-resident kernels: LDS words per wave (histograms + n_valid cache)
+    int32_t pool_rows;      // cell kernels (register-resident, one-lane-per-cell): != 0 = prefix budgets over one pool: cell (p, b) reads
+                            // row p of answers / tokens [P, N] (its first n_valid[b] votes) instead of row p * B + b of [P, B, N]
+    int32_t lane_stage;     // scv_lane_prefix: != 0 = a wave's 64 x B cell records are transposed through LDS and written as one
+                            // contiguous block (a lane's own records are B * 16 bytes apart)
     int32_t acc_classes;    // register-resident kernels: > 0 = per-budget counters accumulate in LDS (this many tie classes per
                             // budget; larger classes go to memory directly) and are flushed once per workgroup
     // single-launch modes of the streaming kernel (agent-scope hand-offs inside the launch, no second kernel):
@@ -142,6 +146,8 @@ __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long lo
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+typedef unsigned short scv_v2h __attribute__((ext_vector_type(2)));
 
 template <int RL2>
 __device__ __forceinline__ void vote(uint32_t* hist, uint32_t copy, uint32_t v, uint32_t& bad) {
@@ -1283,6 +1289,13 @@ __global__ __launch_bounds__(T) void scv_lane_cells(const AggArgs a) {
     int32_t nb = (int32_t)(ncell - np * a.B);
     const int64_t dp = stride / a.B;
     const int32_t db = (int32_t)(stride - dp * a.B);
+    // stride % B == 0 (the host rounds the grid): a lane sees ONE budget, so its class-1 hits and its sums stay in
+    // registers until the end -- per-cell LDS atomics from 64 lanes on the same word are serialised 64 deep
+    const bool fixed_b = counters && db == 0;
+    const int32_t my_b = nb;
+    uint32_t h1 = 0;
+    unsigned long long tcs = 0;
+    long long toks = 0;
 
     struct Cell {
         uint32_t x[NV];
@@ -1297,7 +1310,7 @@ __global__ __launch_bounds__(T) void scv_lane_cells(const AggArgs a) {
         const bool live = ncell < a.ncells;
         c.n = live ? (uint32_t)valid_len(a, live ? nb : 0) : 0u;
         c.truth = a.truth[live ? np : 0];
-        const int64_t off = (live ? ncell : 0) * a.N;
+        const int64_t off = (live ? (a.pool_rows ? np : ncell) : 0) * a.N;
         const int32_t* row = a.answers + off;
         const int32_t* trow = TOK ? a.tokens + off : nullptr;
         if (vec) {
@@ -1416,7 +1429,12 @@ __global__ __launch_bounds__(T) void scv_lane_cells(const AggArgs a) {
                 reinterpret_cast<uint4*>(a.cells)[c.cell] = rec;
             }
             if (TOK && a.cell_tokens) a.cell_tokens[c.cell] = tok;
-            if (counters) {                                                       // o1.py:238-240 as integers, per workgroup in LDS
+            if (fixed_b) {                                                        // o1.py:238-240 as integers
+                h1 += (hit && n_modes == 1u) ? 1u : 0u;
+                if (hit && n_modes != 1u) atomicAdd(&tie[c.b * TC + (int32_t)n_modes], 1u);
+                tcs += tc;
+                if (TOK) toks += tok;
+            } else if (counters) {                                                // ... per workgroup in LDS
                 if (hit) atomicAdd(&tie[c.b * TC + (int32_t)n_modes], 1u);
                 if (tc) atomicAdd(&acc[c.b], (unsigned long long)tc);
                 if (TOK) atomicAdd(&acc[a.B + c.b], (unsigned long long)tok);
@@ -1437,6 +1455,11 @@ __global__ __launch_bounds__(T) void scv_lane_cells(const AggArgs a) {
         count(cb);
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
+    if (fixed_b) {
+        if (h1) atomicAdd(&tie[my_b * TC + 1], h1);
+        if (tcs) atomicAdd(&acc[my_b], tcs);
+        if (TOK && toks) atomicAdd(&acc[a.B + my_b], (unsigned long long)toks);
+    }
     if (counters) {
         __syncthreads();
         for (int64_t i = tid; i < (int64_t)a.B * TC; i += T) {
@@ -1503,6 +1526,179 @@ __device__ __forceinline__ void wg_counters_flush(const AggArgs& a, const WgCoun
         if (TOK && a.token_sum && w.sums[a.B + i]) atomicAdd(&a.token_sum[i], w.sums[a.B + i]);
     }
 }
+
+// ---- kernel 1f'': prefix budgets over SHORT pools, one lane per PROBLEM, online mode tracking ------
+//
+// The reference's own shape (o1.py:274-277): maj@1, 2, 4 ... N over ONE pool of N <= 64 samples per problem.  A lane
+// owns a problem and feeds its votes one at a time, in order, into a running (max_count, n_modes, min_mode, truth
+// votes): vote i of value x has count c = 1 + #{ j < i : x_j == x } (i register compares), and adding it changes the
+// mode statistics exactly one way --
+//     c >  max_count : x is the new unique mode          c == max_count : x joins the modes          else nothing
+// -- so the state after vote i IS statistics.multimode's answer for the prefix 0..i, and a budget is a snapshot of the
+// state at its boundary: every budget of a problem comes out of ONE pass over its N votes (N (N - 1) / 2 compares: 2016
+// at N = 64) instead of one count per budget.  Boundaries are visited in ascending order (rank sort of n_valid in
+// LDS; unsorted / duplicate / empty budgets allowed); the per-budget counters accumulate in LDS as in scv_lane_cells.
+template <int NV, int T, bool TOK>
+__global__ __launch_bounds__(T) void scv_lane_prefix(const AggArgs a) {
+    constexpr int TC = NV + 1;                                       // tie classes 0..NV
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* tie = lds;                                             // [B][TC]
+    const int64_t tie_words = ((int64_t)a.B * TC + 1) & ~(int64_t)1;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + tie_words);   // [B] truth sums | [B] token sums
+    int32_t* ord = reinterpret_cast<int32_t*>(lds + tie_words + 4 * (int64_t)a.B);      // [B] budgets by ascending n_valid
+    int32_t* nvs = ord + a.B;                                                            // [B] their n_valid, ascending
+    const bool stage = a.lane_stage != 0 && a.cells != nullptr;
+    // [waves][64 * B] cell records of the wave's current 64 problems, in the order they have in memory
+    uint4* stage_rec = reinterpret_cast<uint4*>(lds + ((tie_words + 6 * (int64_t)a.B + 3) & ~(int64_t)3)) + (int64_t)(threadIdx.x >> 6) * 64 * a.B;
+    const int tid = threadIdx.x;
+    for (int64_t i = tid; i < tie_words + 4 * (int64_t)a.B; i += T) lds[i] = 0;
+    for (int b = tid; b < a.B; b += T) {
+        const int64_t nb = valid_len(a, b);
+        int rank = 0;
+        for (int c = 0; c < a.B; ++c) {
+            const int64_t nc = valid_len(a, c);
+            rank += (nc < nb) || (nc == nb && c < b);
+        }
+        ord[rank] = b;
+        nvs[rank] = (int32_t)nb;
+    }
+    __syncthreads();
+    const bool vec = a.wave_lds_words != 0;                          // host: N % 4 == 0 and 16-byte aligned bases
+    const int32_t N = (int32_t)a.N;
+    const int32_t B = a.B;
+    uint32_t bad = 0;
+    const int64_t stride = (int64_t)gridDim.x * T;
+    const int64_t first = (int64_t)blockIdx.x * T + tid - (tid & 63);   // lanes of a wave run the same number of steps
+    for (int64_t p0 = first; p0 < a.P; p0 += stride) {
+        const int64_t p = p0 + (tid & 63);
+        const bool live = p < a.P;
+        const int64_t off = (live ? p : 0) * a.N;
+        const int32_t* row = a.answers + off;
+        const int32_t* trow = TOK ? a.tokens + off : nullptr;
+        uint32_t x[NV];
+        if (vec) {
+#pragma unroll
+            for (int k = 0; k < NV / 4; ++k) {
+                int4 q = make_int4(0, 0, 0, 0);
+                if (4 * k < N) q = stream_load(reinterpret_cast<const int4*>(row) + k);
+                x[4 * k] = (uint32_t)q.x; x[4 * k + 1] = (uint32_t)q.y; x[4 * k + 2] = (uint32_t)q.z; x[4 * k + 3] = (uint32_t)q.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                x[i] = 0;
+                if (i < N) x[i] = (uint32_t)__builtin_nontemporal_load(row + i);
+            }
+        }
+        const int32_t truth = a.truth[live ? p : 0];
+        const uint32_t tcmp = (truth >= 0 && truth < kBins) ? (uint32_t)truth : 0xffffffffu;
+        uint32_t maxc = 0, n_modes = 0, min_mode = 0xffffu, tc = 0;
+        long long tok = 0;
+        int k = 0;                                                   // next boundary (wave-uniform)
+        // Every lane of the wave takes part (inactive lanes contribute nothing): the counters of a budget are reduced over
+        // the wave first -- 64 lanes adding to the same LDS word would be serialised 64 deep, three times per budget.
+        auto emit = [&](int32_t b) {
+            const bool any = maxc > 0;
+            const uint32_t hit = (live && any && tc == maxc) ? 1u : 0u;     // o1.py:206
+            if (live) {
+                uint4 rec;
+                rec.x = maxc;
+                rec.y = tc;
+                rec.z = (n_modes & 0xffffu) | ((any ? (min_mode & 0xffffu) : 0xffffu) << 16);
+                rec.w = hit;
+                if (stage) stage_rec[(tid & 63) * B + b] = rec;
+                else if (a.cells) reinterpret_cast<uint4*>(a.cells)[p * B + b] = rec;
+                if (TOK && a.cell_tokens) a.cell_tokens[p * B + b] = tok;
+            }
+            const unsigned long long m1 = __ballot(hit != 0u && n_modes == 1u);       // o1.py:238-240 as integers
+            if (hit && n_modes != 1u) atomicAdd(&tie[b * TC + (int32_t)n_modes], 1u);
+            const uint32_t tcs = wave_sum_u32(live ? tc : 0u);
+            long long toks = 0;
+            if (TOK) toks = wave_sum_i64(live ? tok : 0ll);
+            if ((tid & 63) == 0) {
+                if (m1) atomicAdd(&tie[b * TC + 1], (uint32_t)__popcll(m1));
+                if (tcs) atomicAdd(&acc[b], (unsigned long long)tcs);
+                if (TOK) atomicAdd(&acc[B + b], (unsigned long long)toks);
+            }
+        };
+        // next boundary in a scalar register: the per-vote test is then one s_cmp (an LDS read per vote otherwise)
+        auto boundary = [&](int kk) -> int32_t { return kk < B ? __builtin_amdgcn_readfirstlane(nvs[kk]) : -1; };
+        int32_t next_n = boundary(0);
+        while (next_n == 0) { emit(__builtin_amdgcn_readfirstlane(ord[k])); next_n = boundary(++k); }
+        // votes packed two per register (values <= 1023): one xor + one saturating packed subtract + one dot product
+        // compare TWO earlier votes with vote i and add the matches -- no carry chain through VCC (v_cmp + v_addc
+        // costs two wait states per compare on gfx950)
+        uint32_t xp[NV / 2];
+#pragma unroll
+        for (int m = 0; m < NV / 2; ++m) {
+            if (2 * m < N) bad |= x[2 * m];
+            if (2 * m + 1 < N) bad |= x[2 * m + 1];
+            const uint32_t lo = x[2 * m] < 1023u ? x[2 * m] : 1023u, hi = x[2 * m + 1] < 1023u ? x[2 * m + 1] : 1023u;
+            xp[m] = lo | (hi << 16);
+        }
+        // tokens are loaded after the votes are packed (64 + 64 live registers spilled at NV = 64)
+        int32_t tk[TOK ? NV : 1];
+        if (TOK) {
+            if (vec) {
+#pragma unroll
+                for (int k = 0; k < NV / 4; ++k) {
+                    int4 y = make_int4(0, 0, 0, 0);
+                    if (4 * k < N) y = stream_load(reinterpret_cast<const int4*>(trow) + k);
+                    tk[4 * k] = y.x; tk[4 * k + 1] = y.y; tk[4 * k + 2] = y.z; tk[4 * k + 3] = y.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    tk[i] = 0;
+                    if (i < N) tk[i] = __builtin_nontemporal_load(trow + i);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (i < N) {                                             // uniform
+                const uint32_t xi = (i & 1) ? (xp[i >> 1] >> 16) : (xp[i >> 1] & 0xffffu);
+                const uint32_t xi2 = xi | (xi << 16);
+                // pairs 0 .. (i + 1) / 2 - 1 hold votes j <= i (i odd, itself included) or j < i (i even: itself adds 1)
+                uint32_t c = (i & 1) ? 0u : 1u;
+#pragma unroll
+                for (int m = 0; m < (i + 1) / 2; ++m) {
+                    const scv_v2h e = __builtin_elementwise_sub_sat(scv_v2h{1, 1}, __builtin_bit_cast(scv_v2h, xp[m] ^ xi2));   // 1 where equal
+                    c = __builtin_amdgcn_udot2(e, scv_v2h{1, 1}, c, false);
+                }
+                const bool gt = c > maxc, eq = c == maxc;
+                n_modes = gt ? 1u : n_modes + (eq ? 1u : 0u);
+                min_mode = gt ? xi : ((eq && xi < min_mode) ? xi : min_mode);
+                maxc = gt ? c : maxc;
+                tc += xi == tcmp ? 1u : 0u;
+                if (TOK) tok += (long long)tk[i];
+                while (next_n == i + 1) { emit(__builtin_amdgcn_readfirstlane(ord[k])); next_n = boundary(++k); }
+            }
+        }
+        if (stage) {
+            // the wave's block: cells[p0 * B .. (p0 + 64) * B), contiguous; LDS operations of a wave are in order
+            __builtin_amdgcn_wave_barrier();
+            const int64_t nrec = (a.P - p0 < 64 ? a.P - p0 : 64) * B;
+            uint4* out = reinterpret_cast<uint4*>(a.cells) + p0 * B;
+            for (int64_t r = tid & 63; r < nrec; r += 64) out[r] = stage_rec[r];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+    __syncthreads();
+    for (int64_t i = tid; i < (int64_t)a.B * TC; i += T) {
+        const uint32_t v = tie[i];
+        if (v && a.tie_hits) {
+            const int64_t b = i / TC;
+            atomicAdd(&a.tie_hits[b * SCV_TIE_CLASSES + (i - b * TC)], (unsigned long long)v);
+        }
+    }
+    for (int i = tid; i < a.B; i += T) {
+        if (a.truth_sum && acc[i]) atomicAdd(&a.truth_sum[i], acc[i]);
+        if (TOK && a.token_sum && acc[a.B + i]) atomicAdd(&a.token_sum[i], acc[a.B + i]);
+    }
+}
+
 
 // ---- kernel 1g: register-resident cells (32 < N <= 4096), no barrier, no fold ---------------------
 //
@@ -1627,7 +1823,6 @@ __device__ __forceinline__ void lds_add(uint32_t addr, uint32_t inc) {
     __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>((uintptr_t)addr), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
-typedef unsigned short scv_v2h __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t sum_halves(uint32_t w, uint32_t acc) {      // acc + w.lo + w.hi: v_dot2_u32_u16
     return __builtin_amdgcn_udot2(__builtin_bit_cast(scv_v2h, w), scv_v2h{1, 1}, acc, false);
 }
@@ -1711,7 +1906,7 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
 
     struct Batch {
         uint32_t v[E];        // votes (loaded) -> bin address A (pass 1) -> key (pass 2)
-        int64_t cell;
+        int64_t cell, rowi;   // cell index; row of answers / tokens it reads (the problem's, for prefix budgets over a pool)
         int32_t b, truth;
         uint32_t n;           // valid votes of this lane's cell (0 when the slot is past the last cell)
     };
@@ -1737,7 +1932,8 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
         const int32_t bb = live ? nb : 0;
         t.n = live ? (nv_cached ? nv_lds[bb] : (uint32_t)valid_len(a, bb)) : 0u;
         t.truth = a.truth[live ? np : 0];
-        const int32_t* row = a.answers + (live ? ncell : 0) * a.N;
+        t.rowi = live ? (a.pool_rows ? np : ncell) : 0;
+        const int32_t* row = a.answers + t.rowi * a.N;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             if (VEC) {
@@ -1917,7 +2113,7 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
             // tokens of the current batch: issued now, consumed after the LDS passes (only the sum is needed)
             long long tsum = 0;
             if (TOK) {
-                const int32_t* trow = a.tokens + (c.cell < a.ncells ? c.cell : 0) * a.N;
+                const int32_t* trow = a.tokens + c.rowi * a.N;
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     if (VEC) {
@@ -2036,7 +2232,7 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_
     // unconditional loads (constant count per part -> counted vmcnt waits), clamped to element 0 of the row
     auto load_part = [&](Part& t) {
         const bool live = ncell < a.ncells;
-        const int64_t rowoff = (live ? ncell : 0) * a.N + (int64_t)lpart * PART;
+        const int64_t rowoff = (live ? (a.pool_rows ? np : ncell) : 0) * a.N + (int64_t)lpart * PART;
         const int32_t nrel = (int32_t)ln - (int32_t)(lpart * PART);
         t.nrel = (uint32_t)nrel;
         const int32_t* row = a.answers + rowoff;

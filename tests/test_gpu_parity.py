@@ -208,7 +208,7 @@ def _with_options(eng, opts):
         def __exit__(self_, *exc):
             for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
                          ("small_n_max", 512), ("tiny_n_max", 32), ("small_reg", 1), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096),
-                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_lds_counters", 1)):
+                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1)):
                 eng.set_option(k, v)
     return _Ctx()
 
@@ -568,6 +568,44 @@ def test_prefix_mode_equals_dense_oracle(hip_engine, case):
             assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
         with _with_options(hip_engine, {"path": 3}):
             assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+        with _with_options(hip_engine, {"prefix_cells": 0, "prefix_lane": 0}):   # the one-pass snapshot kernels
+            assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+
+
+@pytest.mark.parametrize("dist", [0, 1, 3])
+@pytest.mark.parametrize("shape", [(700, 1), (500, 5), (333, 8), (400, 16), (90, 31), (300, 32), (250, 33), (200, 64), (150, 100), (120, 256),
+                                   (60, 600), (40, 1024), (30, 1027), (20, 2048), (12, 3001), (9, 4096)], ids=lambda s: f"P{s[0]}_N{s[1]}")
+def test_prefix_budgets_over_short_pools_run_on_the_cell_kernels(hip_engine, dist, shape):
+    """The reference's own shape (o1.py:274-277: maj@1, 2, 4 ... N over ONE pool of N samples per problem): for pools
+    of up to 4096 samples scv_aggregate_prefix_i32 runs on the cell kernels with pool-row addressing (cell (p, b)
+    = the first n_valid[b] votes of row p).  Equal to the oracle on the dense expansion, with tokens, with unsorted /
+    duplicate / empty budgets, from HOST and DEVICE memory; scv_get_stat says which path ran."""
+    import torch
+    P, N = shape
+    a, t, tr = coracle.synth_fill(P, 1, N, 77 + N, dist, want_tokens=True)
+    pool, tpool = a[:, 0, :], t[:, 0, :]
+    for nv in ([1 << k for k in range(N.bit_length()) if (1 << k) <= N] + [N], [N, 0, 1, max(1, N // 3), N, max(0, N - 1)]):
+        nv = np.array(nv, dtype=np.int32)
+        want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
+        stat = "prefix_lane" if N <= 64 else "prefix_cells"          # one lane per problem / cell kernels on pool rows
+        before = hip_engine.stat(stat)
+        assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+        assert hip_engine.stat(stat) == before + 1
+        assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
+        if N <= 64:
+            with _with_options(hip_engine, {"prefix_lane": 0}):
+                before = hip_engine.stat("prefix_cells")
+                assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+                assert hip_engine.stat("prefix_cells") == before + 1
+            with _with_options(hip_engine, {"grid": 3}):               # many problems per lane
+                assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+        dev = torch.device("cuda:0")
+        c, cells, _ = hip_engine.aggregate_prefix_device(torch.from_numpy(pool.copy()).to(dev), torch.from_numpy(tr).to(dev), torch.from_numpy(nv).to(dev))
+        hip_engine.sync()
+        from o1_inference_scaling_laws_amd.engine import CELL_DTYPE, AggregateResult
+        r = AggregateResult.from_counters(c.cpu().numpy(), P, len(nv))
+        assert np.array_equal(r.tie_class_hits, want.tie_class_hits) and np.array_equal(r.truth_count_sum, want.truth_count_sum)
+        assert np.array_equal(cells.cpu().numpy().view(CELL_DTYPE).reshape(P, len(nv))["max_count"], want.cells["max_count"])
 
 
 def test_prefix_mode_device_and_errors(hip_engine):

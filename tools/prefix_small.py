@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Prefix budgets over SHORT pools (the reference's own shape: N = 8 ... 4096 samples per problem, budgets 1, 2, 4 ... N):
+scv_aggregate_prefix_i32 on pool[P, N] against the dense ragged expansion [P, B, N] + n_valid."""
+import json
+import os
+import statistics as st
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine, counters_size
+    eng = Engine(device=0, timing=True)
+    for kv in sys.argv[1:]:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
+    dev = torch.device("cuda:0")
+    out = []
+    for (P, N) in [(400000, 16), (200000, 64), (100000, 256), (50000, 1024), (20000, 4096), (4000, 16384)]:
+        nv = [1 << k for k in range(N.bit_length()) if (1 << k) <= N]
+        B = len(nv)
+        pool = torch.empty((P, 1, N), dtype=torch.int32, device=dev)
+        tr = torch.empty((P,), dtype=torch.int32, device=dev)
+        eng.synth_fill_device(pool, None, tr, P=P, B=1, N=N, seed=4, dist=1)
+        nvt = torch.tensor(nv, dtype=torch.int32, device=dev)
+        counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
+        cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
+        res = {"shape": [P, B, N], "n_valid": "1,2,4..N"}
+        for mode in ("prefix", "dense"):
+            if mode == "dense":
+                if P * B * N * 4 > 6e9:
+                    continue
+                dense = pool.expand(P, B, N).contiguous()
+            eng.sync(); eng.drain_kernel_ns()
+            ts = []
+            for r in range(6):
+                counters.zero_()
+                if mode == "prefix":
+                    eng.aggregate_prefix_device(pool.view(P, N), tr, nvt, counters=counters, cells=cells)
+                else:
+                    eng.aggregate_device(dense, tr, n_valid=nvt, counters=counters, cells=cells)
+                eng.sync()
+                ns, n = eng.drain_kernel_ns()
+                if r:
+                    ts.append(ns / n)
+            if mode == "prefix":
+                ref = counters.clone()
+            else:
+                assert torch.equal(ref, counters), "prefix and dense counters differ"
+                del dense
+            res[mode + "_us"] = st.median(ts) / 1e3
+        res["pool_GBps"] = P * N * 4 / (res["prefix_us"] * 1e3)
+        res["votes_per_s"] = P * sum(nv) / (res["prefix_us"] * 1e-6)
+        out.append(res)
+        print(json.dumps(res), flush=True)
+        del pool
+        torch.cuda.empty_cache()
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "prefix_small.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

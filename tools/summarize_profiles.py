@@ -41,9 +41,15 @@ for sub in ("prof_fetch", "prof_write", "prof_lds"):
     f = newest(f"{sub}/*/*_counter_collection.csv")
     if not f:
         continue
-    for r in csv.DictReader(open(f)):
-        if "scv_hist_argmax" in r["Kernel_Name"]:
-            pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # one file per process of the profiled command (bench.py and the read-ceiling probe it spawns): take every file of
+    # the newest run
+    t = os.path.getmtime(f)
+    for g in glob.glob(os.path.join(G, f"{sub}/*/*_counter_collection.csv")):
+        if os.path.getmtime(g) < t - 120:
+            continue
+        for r in csv.DictReader(open(g)):
+            if "scv_hist_argmax" in r["Kernel_Name"]:
+                pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 if pmc:
     avg = {k: sum(v) / len(v) for k, v in pmc.items()}
     lines += ["## PMC (separate --pmc passes, per launch of scv_hist_argmax, averaged)", "", "| counter | value |", "|---|---|"]
