@@ -118,7 +118,12 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  * "fused_counters_max" (cells at or below, or problem rows >= 4 MiB: per-cell atomics inside the hot
  * kernel; otherwise a separate reduction of the cell table; 0 forces the reduction), "small_reg", "pin_host" (default 0; 1: HOST-mode calls hipHostRegister caller buffers
  * of 32 MiB or more for the duration of the call -- measured no faster than pageable copies), "prefetch"
- * (default 1: cross-item prefetch in the streaming kernel), "stagger_vecs", "plain_loads". */
+ * (default 1: cross-item prefetch in the streaming kernel), "stagger_vecs", "plain_loads", "tok_skew" (default 0; 1: the tokens
+ * row is read rotated by half a row against the votes row), "tiny_lane" (default 1: N <= 32 runs one lane per cell; 0: the
+ * several-lanes-per-cell kernel), "overwrite_counters" (default 0; 1: the per-budget counters are OVERWRITTEN, not accumulated
+ * into -- with few long cells the streaming kernel's last workgroup does it and the call is one launch, otherwise a memset
+ * precedes the launch), "ticket_merge" (default 0; 1: split-N cells are merged inside the launch by the last-arriving segment
+ * instead of by a merge kernel -- measured 0-9 % slower). */
 int scv_set_option(scv_ctx* ctx, const char* key, int64_t value);
 
 /*

@@ -72,3 +72,17 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "libscv_oracle" not in text and "scv_oracle.c" not in text, f
     _ = np
+
+
+def test_every_option_and_stat_key_is_documented_in_the_header():
+    """scv_set_option / scv_get_stat accept string keys: each key the library compares against must be named in the
+    header's documentation of that entry point (the keys are part of the boundary)."""
+    src = open(os.path.join(REPO, "o1_inference_scaling_laws_amd", "csrc", "scvote.hip")).read()
+    hdr = open(os.path.join(REPO, "include", "scvote.h")).read()
+    for fn in ("scv_set_option", "scv_get_stat"):
+        body = src[src.index(f"int {fn}("):]
+        body = body[: body.index("\n}\n")]
+        keys = re.findall(r'!strcmp\(key, "([a-z0-9_]+)"\)', body)
+        assert len(keys) >= 5, fn
+        missing = [k for k in keys if f'"{k}"' not in hdr]
+        assert not missing, f"{fn}: keys not documented in include/scvote.h: {missing}"
