@@ -114,7 +114,8 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  * counters in LDS and flush them in the same launch; 0: cell table + scv_reduce_cells), "reg_wpg" (waves per workgroup of the
  * register-resident kernels, 0 = all the waves a CU holds), "prefix_cells" (default 1: scv_aggregate_prefix_i32 on pools of N <= 4096
  * runs on the cell kernels, each cell reading its prefix of the pool row; 0: the one-pass snapshot kernels), "prefix_lane" (default 1:
- * pools of N <= 64 run one lane per problem, every budget out of one pass over its votes), "boot_lds" (default 1: LDS-resident bootstrap table),
+ * pools of N <= 64 run one lane per problem, every budget out of one pass over its votes), "prefix_stage" (default 1: that kernel
+ * keeps its per-boundary snapshots in LDS when they fit; 0: reductions at every boundary), "boot_lds" (default 1: LDS-resident bootstrap table),
  * "fused_counters_max" (cells at or below, or problem rows >= 4 MiB: per-cell atomics inside the hot
  * kernel; otherwise a separate reduction of the cell table; 0 forces the reduction), "small_reg", "pin_host" (default 0; 1: HOST-mode calls hipHostRegister caller buffers
  * of 32 MiB or more for the duration of the call -- measured no faster than pageable copies), "prefetch"

@@ -153,6 +153,7 @@ struct scv_ctx {
     struct BootReq { int32_t r0, r1, M; uint64_t seed; int64_t* out; bool fused; }* boot_req = nullptr;   // set for the duration of one call
     int boot_lds = 1;        // bootstrap: LDS-resident code table when it fits (0: always the global-gather kernel)
     int reg_km = 1;          // reg path: batches in flight per wave = km x 4 KiB
+    int prefix_stage = 1;    // scv_lane_prefix: snapshots staged in LDS when they fit (0: reductions at every boundary)
     int prefix_lane = 1;     // prefix budgets over pools of N <= 64: one lane per problem, all budgets in one pass (scv_lane_prefix)
     int prefix_cells = 1;    // prefix budgets over short pools (N <= 4096) run on the cell kernels (0: the one-pass kernels)
     int reg_wpg = 0;         // reg path: waves per workgroup (0 = the kernel's own: all the waves a CU holds)
@@ -798,22 +799,27 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     int path = ctx->path;
     if (path == 0 || path == 2) path = (N <= ctx->small_n_max) ? 3 : 1;
     if (lane_ok) {
-        // N <= 32: one 1024-thread workgroup per CU (the end-of-launch flush is one device atomic per workgroup and counter,
-        // ~12 ns each on one address).  N = 64 needs 95-151 VGPRs: 256-thread workgroups, as many as are resident (measured
-        // 64 us against 84-86 us with 768 / 1024 threads, which spill or leave a second, nearly empty round)
-        const int T = lane_nv == 64 ? 256 : 1024;
         a.wave_lds_words = ((N % 4 == 0) && (((uintptr_t)pool & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0)) ? 1 : 0;   // "vec" flag
-        KernelFn fn;
-#define SCV_LP(NVV) (tok ? (KernelFn)scv::scv_lane_prefix<NVV, 1024, true> : (KernelFn)scv::scv_lane_prefix<NVV, 1024, false>)
-        fn = lane_nv == 4 ? SCV_LP(4) : (lane_nv == 8 ? SCV_LP(8) : (lane_nv == 16 ? SCV_LP(16) : (lane_nv == 32 ? SCV_LP(32) :
-             (tok ? (KernelFn)scv::scv_lane_prefix<64, 256, true> : (KernelFn)scv::scv_lane_prefix<64, 256, false>))));
-#undef SCV_LP
-        // cell records leave through an LDS transpose (coalesced block writes) while B KiB per wave is affordable
-        size_t lds_total = lane_lds;
-        if (a.cells && B <= 8) {
-            a.lane_stage = 1;
-            lds_total = ((lane_lds + 15) & ~(size_t)15) + (size_t)(T / 64) * 64 * B * sizeof(scv_cell);
+        // Workgroup size.  N <= 32: 1024 threads, one workgroup per CU (the end-of-launch flush is one device atomic per
+        // workgroup and counter, ~12 ns each on one address).  N = 64 needs 95-151 VGPRs: 256 threads, as many workgroups
+        // as are resident (measured 61-64 us against 84-86 us with 768 / 1024 threads, which spill or leave a second, nearly
+        // empty round).  Snapshots are staged in LDS (24 bytes x 64 x B per wave with tokens) when that fits, in
+        // smaller workgroups if need be; with many budgets the reductions run at every boundary instead.
+        const size_t counters_bytes = (lane_lds + 15) & ~(size_t)15;
+        const size_t per_wave = (size_t)64 * B * (sizeof(scv_cell) + (tok ? sizeof(int64_t) : 0));
+        int T = lane_nv == 64 ? 256 : 1024;
+        bool staged = false;
+        for (int t = T; t >= 256; t >>= 1) {
+            if (counters_bytes + (size_t)(t / 64) * per_wave + 1024 <= (size_t)ctx->lds_max) { T = t; staged = true; break; }
         }
+        if (!ctx->prefix_stage) { staged = false; T = lane_nv == 64 ? 256 : 1024; }
+        const size_t lds_total = staged ? counters_bytes + (size_t)(T / 64) * per_wave : lane_lds;
+        a.lane_stage = staged ? 1 : 0;
+        KernelFn fn;
+#define SCV_LP2(NVV, TBB) (tok ? (staged ? (KernelFn)scv::scv_lane_prefix<NVV, TBB, true, true> : (KernelFn)scv::scv_lane_prefix<NVV, TBB, true, false>) \
+                              : (staged ? (KernelFn)scv::scv_lane_prefix<NVV, TBB, false, true> : (KernelFn)scv::scv_lane_prefix<NVV, TBB, false, false>))
+        fn = lane_nv == 4 ? SCV_LP2(4, 1024) : (lane_nv == 8 ? SCV_LP2(8, 1024) : (lane_nv == 16 ? SCV_LP2(16, 1024) : (lane_nv == 32 ? SCV_LP2(32, 1024) : SCV_LP2(64, 256))));
+#undef SCV_LP2
         SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
         int per_cu = 0;
         SCV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), T, lds_total));
@@ -1035,6 +1041,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "reg_lds_counters")) ctx->reg_lds_counters = value != 0;
     else if (!strcmp(key, "prefix_cells")) ctx->prefix_cells = value != 0;
     else if (!strcmp(key, "prefix_lane")) ctx->prefix_lane = value != 0;
+    else if (!strcmp(key, "prefix_stage")) ctx->prefix_stage = value != 0;
     else if (!strcmp(key, "reg_wpg")) { if (value != 0 && value != 4 && value != 8 && value != 12 && value != 16) return fail(SCV_ERR_ARG, "reg_wpg must be 0, 4, 8, 12 or 16"); ctx->reg_wpg = (int)value; }
     else if (!strcmp(key, "reg_km")) { if (value != 1 && value != 2 && value != 4) return fail(SCV_ERR_ARG, "reg_km must be 1, 2 or 4"); ctx->reg_km = (int)value; }
     else if (!strcmp(key, "reg_shape")) { if (value < 0 || value > 9999) return fail(SCV_ERR_ARG, "reg_shape out of range"); ctx->reg_shape = (int)value; }

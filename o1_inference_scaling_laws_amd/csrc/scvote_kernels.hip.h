@@ -1538,19 +1538,27 @@ __device__ __forceinline__ void wg_counters_flush(const AggArgs& a, const WgCoun
 // state at its boundary: every budget of a problem comes out of ONE pass over its N votes (N (N - 1) / 2 compares: 2016
 // at N = 64) instead of one count per budget.  Boundaries are visited in ascending order (rank sort of n_valid in
 // LDS; unsorted / duplicate / empty budgets allowed); the per-budget counters accumulate in LDS as in scv_lane_cells.
-template <int NV, int T, bool TOK>
-__global__ __launch_bounds__(T) void scv_lane_prefix(const AggArgs a) {
+// TB: launch bound (the block may be smaller); STAGE: a boundary only stores the lane's snapshot (16-byte cell record,
+// token sum) in LDS, and the counters of all B budgets are taken from the snapshots after the last vote, then the wave's
+// 64 x B records leave as one contiguous block -- the unrolled vote loop then carries 64 tiny snapshot sites instead of 64
+// copies of the reductions (with tokens the latter did not fully unroll and put the token registers in scratch: 230 us).
+// !STAGE (many budgets: 24 B x 64 x B per wave do not fit): reductions at the boundary, records written directly.
+template <int NV, int TB, bool TOK, bool STAGE>
+__global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
     constexpr int TC = NV + 1;                                       // tie classes 0..NV
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int T = (int)blockDim.x;
     uint32_t* tie = lds;                                             // [B][TC]
     const int64_t tie_words = ((int64_t)a.B * TC + 1) & ~(int64_t)1;
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + tie_words);   // [B] truth sums | [B] token sums
     int32_t* ord = reinterpret_cast<int32_t*>(lds + tie_words + 4 * (int64_t)a.B);      // [B] budgets by ascending n_valid
     int32_t* nvs = ord + a.B;                                                            // [B] their n_valid, ascending
-    const bool stage = a.lane_stage != 0 && a.cells != nullptr;
-    // [waves][64 * B] cell records of the wave's current 64 problems, in the order they have in memory
-    uint4* stage_rec = reinterpret_cast<uint4*>(lds + ((tie_words + 6 * (int64_t)a.B + 3) & ~(int64_t)3)) + (int64_t)(threadIdx.x >> 6) * 64 * a.B;
+    // [waves][64 * B] snapshots of the wave's current 64 problems, in the order the cells have in memory
+    uint4* stage_base = reinterpret_cast<uint4*>(lds + ((tie_words + 6 * (int64_t)a.B + 3) & ~(int64_t)3));
+    uint4* stage_rec = stage_base + (int64_t)(threadIdx.x >> 6) * 64 * a.B;
+    long long* stage_tok = reinterpret_cast<long long*>(stage_base + (int64_t)(T >> 6) * 64 * a.B) + (int64_t)(threadIdx.x >> 6) * 64 * a.B;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     for (int64_t i = tid; i < tie_words + 4 * (int64_t)a.B; i += T) lds[i] = 0;
     for (int b = tid; b < a.B; b += T) {
         const int64_t nb = valid_len(a, b);
@@ -1567,10 +1575,24 @@ __global__ __launch_bounds__(T) void scv_lane_prefix(const AggArgs a) {
     const int32_t N = (int32_t)a.N;
     const int32_t B = a.B;
     uint32_t bad = 0;
+    // the counters of budget b from every lane's (hit, n_modes, truth votes, tokens), reduced over the wave first: 64 lanes
+    // adding to the same LDS word would be serialised 64 deep, three times per budget
+    auto count_budget = [&](int32_t b, uint32_t hit, uint32_t n_modes, uint32_t tc, long long tok) {
+        const unsigned long long m1 = __ballot(hit != 0u && n_modes == 1u);       // o1.py:238-240 as integers
+        if (hit && n_modes != 1u) atomicAdd(&tie[b * TC + (int32_t)n_modes], 1u);
+        const uint32_t tcs = wave_sum_u32(tc);
+        long long toks = 0;
+        if (TOK) toks = wave_sum_i64(tok);
+        if (lane == 0) {
+            if (m1) atomicAdd(&tie[b * TC + 1], (uint32_t)__popcll(m1));
+            if (tcs) atomicAdd(&acc[b], (unsigned long long)tcs);
+            if (TOK) atomicAdd(&acc[B + b], (unsigned long long)toks);
+        }
+    };
     const int64_t stride = (int64_t)gridDim.x * T;
-    const int64_t first = (int64_t)blockIdx.x * T + tid - (tid & 63);   // lanes of a wave run the same number of steps
+    const int64_t first = (int64_t)blockIdx.x * T + tid - lane;     // lanes of a wave run the same number of steps
     for (int64_t p0 = first; p0 < a.P; p0 += stride) {
-        const int64_t p = p0 + (tid & 63);
+        const int64_t p = p0 + lane;
         const bool live = p < a.P;
         const int64_t off = (live ? p : 0) * a.N;
         const int32_t* row = a.answers + off;
@@ -1595,30 +1617,23 @@ __global__ __launch_bounds__(T) void scv_lane_prefix(const AggArgs a) {
         uint32_t maxc = 0, n_modes = 0, min_mode = 0xffffu, tc = 0;
         long long tok = 0;
         int k = 0;                                                   // next boundary (wave-uniform)
-        // Every lane of the wave takes part (inactive lanes contribute nothing): the counters of a budget are reduced over
-        // the wave first -- 64 lanes adding to the same LDS word would be serialised 64 deep, three times per budget.
         auto emit = [&](int32_t b) {
             const bool any = maxc > 0;
             const uint32_t hit = (live && any && tc == maxc) ? 1u : 0u;     // o1.py:206
-            if (live) {
-                uint4 rec;
-                rec.x = maxc;
-                rec.y = tc;
-                rec.z = (n_modes & 0xffffu) | ((any ? (min_mode & 0xffffu) : 0xffffu) << 16);
-                rec.w = hit;
-                if (stage) stage_rec[(tid & 63) * B + b] = rec;
-                else if (a.cells) reinterpret_cast<uint4*>(a.cells)[p * B + b] = rec;
-                if (TOK && a.cell_tokens) a.cell_tokens[p * B + b] = tok;
-            }
-            const unsigned long long m1 = __ballot(hit != 0u && n_modes == 1u);       // o1.py:238-240 as integers
-            if (hit && n_modes != 1u) atomicAdd(&tie[b * TC + (int32_t)n_modes], 1u);
-            const uint32_t tcs = wave_sum_u32(live ? tc : 0u);
-            long long toks = 0;
-            if (TOK) toks = wave_sum_i64(live ? tok : 0ll);
-            if ((tid & 63) == 0) {
-                if (m1) atomicAdd(&tie[b * TC + 1], (uint32_t)__popcll(m1));
-                if (tcs) atomicAdd(&acc[b], (unsigned long long)tcs);
-                if (TOK) atomicAdd(&acc[B + b], (unsigned long long)toks);
+            uint4 rec;
+            rec.x = maxc;
+            rec.y = tc;
+            rec.z = (n_modes & 0xffffu) | ((any ? (min_mode & 0xffffu) : 0xffffu) << 16);
+            rec.w = hit;
+            if (STAGE) {
+                stage_rec[lane * B + b] = rec;                       // (an inactive lane's slot is never copied out or counted)
+                if (TOK) stage_tok[lane * B + b] = tok;
+            } else {
+                if (live) {
+                    if (a.cells) reinterpret_cast<uint4*>(a.cells)[p * B + b] = rec;
+                    if (TOK && a.cell_tokens) a.cell_tokens[p * B + b] = tok;
+                }
+                count_budget(b, hit, n_modes, live ? tc : 0u, live ? tok : 0ll);
             }
         };
         // next boundary in a scalar register: the per-vote test is then one s_cmp (an LDS read per vote otherwise)
@@ -1636,15 +1651,15 @@ __global__ __launch_bounds__(T) void scv_lane_prefix(const AggArgs a) {
             const uint32_t lo = x[2 * m] < 1023u ? x[2 * m] : 1023u, hi = x[2 * m + 1] < 1023u ? x[2 * m + 1] : 1023u;
             xp[m] = lo | (hi << 16);
         }
-        // tokens are loaded after the votes are packed (64 + 64 live registers spilled at NV = 64)
+        // tokens are loaded after the votes are packed (64 + 64 live registers would spill at NV = 64)
         int32_t tk[TOK ? NV : 1];
         if (TOK) {
             if (vec) {
 #pragma unroll
-                for (int k = 0; k < NV / 4; ++k) {
+                for (int kq = 0; kq < NV / 4; ++kq) {
                     int4 y = make_int4(0, 0, 0, 0);
-                    if (4 * k < N) y = stream_load(reinterpret_cast<const int4*>(trow) + k);
-                    tk[4 * k] = y.x; tk[4 * k + 1] = y.y; tk[4 * k + 2] = y.z; tk[4 * k + 3] = y.w;
+                    if (4 * kq < N) y = stream_load(reinterpret_cast<const int4*>(trow) + kq);
+                    tk[4 * kq] = y.x; tk[4 * kq + 1] = y.y; tk[4 * kq + 2] = y.z; tk[4 * kq + 3] = y.w;
                 }
             } else {
 #pragma unroll
@@ -1675,12 +1690,25 @@ __global__ __launch_bounds__(T) void scv_lane_prefix(const AggArgs a) {
                 while (next_n == i + 1) { emit(__builtin_amdgcn_readfirstlane(ord[k])); next_n = boundary(++k); }
             }
         }
-        if (stage) {
-            // the wave's block: cells[p0 * B .. (p0 + 64) * B), contiguous; LDS operations of a wave are in order
+        if (STAGE) {
+            // LDS operations of a wave are in order: the snapshots are complete here
             __builtin_amdgcn_wave_barrier();
+            for (int32_t b = 0; b < B; ++b) {
+                const uint4 rec = stage_rec[lane * B + b];
+                long long tv = 0;
+                if (TOK) tv = stage_tok[lane * B + b];
+                count_budget(b, live ? rec.w : 0u, rec.z & 0xffffu, live ? rec.y : 0u, live ? tv : 0ll);
+            }
+            // the wave's block: cells[p0 * B .. (p0 + 64) * B), contiguous
             const int64_t nrec = (a.P - p0 < 64 ? a.P - p0 : 64) * B;
-            uint4* out = reinterpret_cast<uint4*>(a.cells) + p0 * B;
-            for (int64_t r = tid & 63; r < nrec; r += 64) out[r] = stage_rec[r];
+            if (a.cells) {
+                uint4* out = reinterpret_cast<uint4*>(a.cells) + p0 * B;
+                for (int64_t r = lane; r < nrec; r += 64) out[r] = stage_rec[r];
+            }
+            if (TOK && a.cell_tokens) {
+                long long* out = reinterpret_cast<long long*>(a.cell_tokens) + p0 * B;
+                for (int64_t r = lane; r < nrec; r += 64) out[r] = stage_tok[r];
+            }
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -1698,7 +1726,6 @@ __global__ __launch_bounds__(T) void scv_lane_prefix(const AggArgs a) {
         if (TOK && a.token_sum && acc[a.B + i]) atomicAdd(&a.token_sum[i], acc[a.B + i]);
     }
 }
-
 
 // ---- kernel 1g: register-resident cells (32 < N <= 4096), no barrier, no fold ---------------------
 //

@@ -208,7 +208,7 @@ def _with_options(eng, opts):
         def __exit__(self_, *exc):
             for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
                          ("small_n_max", 512), ("tiny_n_max", 32), ("small_reg", 1), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096),
-                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1)):
+                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1)):
                 eng.set_option(k, v)
     return _Ctx()
 
@@ -599,6 +599,12 @@ def test_prefix_budgets_over_short_pools_run_on_the_cell_kernels(hip_engine, dis
                 assert hip_engine.stat("prefix_cells") == before + 1
             with _with_options(hip_engine, {"grid": 3}):               # many problems per lane
                 assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+            with _with_options(hip_engine, {"prefix_stage": 0, "grid": 5}):   # reductions at every boundary, direct cell writes
+                assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+                got = hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool, want_cells=False)
+                assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum)
+            got = hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool, want_cells=False)     # staged, no cell table
+            assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum) and np.array_equal(got.truth_count_sum, want.truth_count_sum)
         dev = torch.device("cuda:0")
         c, cells, _ = hip_engine.aggregate_prefix_device(torch.from_numpy(pool.copy()).to(dev), torch.from_numpy(tr).to(dev), torch.from_numpy(nv).to(dev))
         hip_engine.sync()
@@ -606,6 +612,20 @@ def test_prefix_budgets_over_short_pools_run_on_the_cell_kernels(hip_engine, dis
         r = AggregateResult.from_counters(c.cpu().numpy(), P, len(nv))
         assert np.array_equal(r.tie_class_hits, want.tie_class_hits) and np.array_equal(r.truth_count_sum, want.truth_count_sum)
         assert np.array_equal(cells.cpu().numpy().view(CELL_DTYPE).reshape(P, len(nv))["max_count"], want.cells["max_count"])
+
+
+@pytest.mark.parametrize("P,N,B", [(300, 16, 200), (130, 64, 40), (70, 8, 512), (1000, 33, 12)])
+def test_prefix_lane_kernel_with_many_budgets(hip_engine, P, N, B):
+    """Many budgets over a short pool: the snapshots of 64 x B cells per wave no longer fit the LDS (or only in smaller
+    workgroups), so the kernel reduces at every boundary / runs in 256-thread groups; budgets repeat, are unsorted,
+    include 0 and values beyond N (clamped)."""
+    rng = np.random.default_rng(B)
+    a, t, tr = coracle.synth_fill(P, 1, N, 31 + B, 1, want_tokens=True)
+    pool, tpool = a[:, 0, :], t[:, 0, :]
+    nv = rng.integers(0, N + 3, size=B).astype(np.int32)
+    want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
+    assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+    assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
 
 
 def test_prefix_mode_device_and_errors(hip_engine):

@@ -1,7 +1,11 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "prefix or golden or tiny" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "prefix or golden" 2>&1 | tail -3
 timeout 600 env SCV_FUZZ_SEEDS=500 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -3
-python tools/prefix_small.py 2>&1 | grep -v amdgpu
-SHAPES="200000:4:64 100000:4:256 50000:4:1024 40000:4:2048 20000:8:4096" bash tools/prof_regimes.sh reg4 > gpurun_out/prof_reg4.log 2>&1
+run() { python tools/one_case.py "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.readlines()[-1]); print('%-22s %-40s %8.1f us %8.1f GB/s' % (r['shape'], r['opts'], r['median_us'], r['GBps']))"; }
+for n in 8 16 32 64; do
+run --prefix --P 200000 --N $n
+run --prefix --P 200000 --N $n --tokens
+run --prefix --P 200000 --N $n --tokens --opt prefix_stage=0
+done
