@@ -1737,18 +1737,20 @@ __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
 // Here a cell lives in REGISTERS: it occupies G = 16 / 32 / 64 adjacent lanes (C = 64/G cells per wave)
 // and every lane holds V 16-byte vectors of it (capacity 4*G*V votes); the vectors of the NEXT batch of
 // cells are loaded into a second register set before the current batch is counted, so a wave always
-// has a whole batch (up to 16 KiB) in flight and never waits on memory with nothing to do.  Workgroups
-// are single waves: no barrier exists in the kernel.  Every cell slot of the wave owns a private
-// histogram in LDS, 1024 bins x R copies with R = G/16 (16 KiB per wave whatever G; a vote goes to copy
-// lane % R, so all-equal votes are at most 16-way same-address -- above the HBM rate, see DESIGN), and
-// only the bins a cell votes for are ever touched (sparse read-back, sparse clear):
-//   pass 1  h[bin][copy] += 1                                (ds_add_u32; inactive votes go to a trash word)
-//   pass 2  key = (sum over copies of h[bin]) << 10 | (1023 - bin), in place of the vote; running max
+// has a whole batch (4 KiB) in flight and never waits on memory with nothing to do.  The waves of a
+// workgroup are independent: no barrier exists in the loop.  Every cell slot of the wave owns a private
+// histogram in LDS, 1024 bins x R copies with R = G/16, 16-bit counters (8 KiB per wave whatever G: the
+// layouts are described at the kernel; a vote goes to copy lane % R), and only the bins a cell votes for
+// are ever touched (sparse read-back, sparse clear):
+//   pass 1  h[bin][copy] += 1                                (ds_add_u32 on the word holding the 16-bit counter;
+//                                                             inactive vote slots add to per-lane trash words)
+//   pass 2  key = (sum over copies of h[bin]) << 18 | address of the bin, in place of the vote; running max
 //           -> one group reduction gives max_count AND the smallest modal bin
-//   pass 3  #keys >= max_count << 10, divided by max_count = len(statistics.multimode); h[truth]
-//   pass 4  h[bin][copy] = 0 for every vote
+//   pass 3  #keys >= max_count << 18, divided by max_count = len(statistics.multimode); truth votes
+//   pass 4  h[bin][copy] = 0 for every vote (same loop as pass 3)
 // LDS operations of one wave execute in order, so the passes need no waits between them.  The
-// histogram is indexed by 1023 - bin so that the key's low bits are the histogram index.
+// histogram is indexed by 1023 - bin (a smaller bin has the larger address), so the maximum key is the
+// smallest modal bin.
 
 template <int G>
 __device__ __forceinline__ uint32_t cellgroup_max(uint32_t v) {
@@ -1811,10 +1813,10 @@ constexpr int kRegHist16Words = 4 * kRegCopyBytes16 / 4;
 constexpr int kRegWaveWords16 = kRegHist16Words + kRegLaneWords;
 
 // Per-vote state is ONE register holding the LDS byte address A of the vote's bin (all copies):
-//   A = cellbase + ((1023 - bin) << S), S = log2(4 R)   -> ds_add at A | copy*4, ds_read_b{32,64,128} at A,
-//   key = count << 18 | A                                 -> ds_write at (key & 0x3ffff) | copy*4
-// so a full cell costs ~13 instructions per vote: or (domain) . min . mad . or . ds_add | ds_read . 2 add .
-// lshl_or . max | cmp . addc | and_or . ds_write.  A is < 2^18 (160 KiB of LDS), counts are <= 4096 < 2^13.
+//   A = cellbase + ((1023 - bin) << S), S = log2(bytes between bins)  -> ds_add on the word of A (+ copy), reads at A,
+//   key = count << 18 | A                                              -> clear at (key & 0x3ffff) (+ copy)
+// so a full cell costs ~11.5 VALU per vote: or3 (domain, half) . min . mad . alignbyte . cmp . cndmask . and . ds_add |
+// ds_read . lshl_or . max3 (half) | cmp . addc . and . ds_write.  A is < 2^18 (160 KiB of LDS), counts are <= 4096 < 2^13.
 // LDS is addressed through address_space(3) pointers built from integers, so constant parts of an address
 // land in the instruction's offset field instead of a VALU add.
 //
@@ -1829,8 +1831,9 @@ constexpr int kRegWaveWords16 = kRegHist16Words + kRegLaneWords;
 //
 // DENSE (G = 64, long cells): after pass 1 the votes are dead; every lane scans its 16 bins (x = lane + 64 j:
 // consecutive lanes read consecutive 16-byte slots, conflict-free ds_read_b128 with immediate offsets), so the
-// per-vote cost is pass 1 alone (~5 instructions) and the rest is a fixed ~110 instructions per cell --
+// per-vote cost is pass 1 alone (~6 instructions) and the rest is a fixed ~110 instructions per cell --
 // cheaper than the sparse read-back from ~24 votes per lane up; len(multimode) is then a count of BINS.
+// (scv_reg_cells keeps this as an A/B variant with 32-bit bins; the production dense scan is scv_reg_dense.)
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef uint32_t scv_v2u __attribute__((ext_vector_type(2)));
 typedef uint32_t scv_v4u __attribute__((ext_vector_type(4)));
