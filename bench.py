@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--seed", type=int, default=20240914)
+    ap.add_argument("--graph-steps", type=int, default=1,
+                    help="with --graph: consecutive steps captured into ONE graph (the launch-bound inner loop of C2 as a single "
+                         "graph launch); --steps and --warmup are rounded up to multiples of it")
     ap.add_argument("--graph", action="store_true",
                     help="single GPU: capture memset + hot-path launch of every resident chunk into a hipGraph and replay it "
                          "(launch-bound workloads such as --workload c2); kernel time is then taken from the wall clock")
@@ -305,23 +308,32 @@ def main():
         return pipe.publish(i)               # async all-reduce (no-op with one rank)
 
     graphs = {}
+    gs = max(1, args.graph_steps) if use_graph else 1
     if use_graph:
+        args.steps = -(-args.steps // gs) * gs
+        args.warmup = -(-args.warmup // gs) * gs
         side = torch.cuda.Stream(device=dev)
-        # one graph per (slot, counter buffer) pair that the step sequence visits
+        # the step sequence repeats with period lcm(R, 2) (slot, counter buffer); one graph per group of gs consecutive
+        # steps, as many groups as it takes for the group sequence to repeat
         period = R if R % 2 == 0 else 2 * R
+        import math
+        ngroups = period // math.gcd(period, gs)
         with torch.cuda.stream(side):
             for i in range(period):                       # warm-up on the capture stream: scratch sized, attributes set
                 step(i)
         torch.cuda.synchronize(dev)
-        for i in range(period):
+        eager_step = step
+        for j in range(ngroups):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
-                step(i)
-            graphs[i] = g
+                for i in range(j * gs, (j + 1) * gs):
+                    eager_step(i)
+            graphs[j] = g
         eng.use_torch_stream()
 
         def step(i):                                      # noqa: F811 - replay instead of launching
-            graphs[i % period].replay()
+            if i % gs == 0:                               # the group's graph runs all gs steps; the other calls are no-ops
+                graphs[(i // gs) % ngroups].replay()
             return pipe.buffers[i % 2]
 
     def fence():
@@ -335,7 +347,7 @@ def main():
     step(0)
     fence()
     first_cells = cells_from_torch(cells) if rank == 0 else None
-    first_off = slots[0][3]
+    first_off = slots[(gs - 1) % R][3]                    # (a graph of gs steps leaves the cells of its last step)
     if rank == 0:
         c = first_cells
         ok = ((c["truth_count"] <= c["max_count"]).all() and (c["max_count"] <= N).all()
@@ -419,7 +431,7 @@ def main():
             "tokens_stream": bool(args.tokens),
             "parallelism": f"problems sharded over {world} GPU(s), one int64 all-reduce of {counters_size(B)} counters per step",
             "seed": args.seed,
-            "launch": "hipGraph replay (memset + kernels captured per resident chunk)" if use_graph else "eager",
+            "launch": (f"hipGraph replay ({gs} step(s) per graph launch)" if use_graph else "eager"),
             "backend": args.backend if (world > 1 or force) else None,
             "collectives_forced_on_one_rank": bool(force),
             "rccl_ranks": rccl_ranks,

@@ -10,11 +10,12 @@ echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 |
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee gpurun_out/smoke.log
 echo "== bench"; timeout 900 python bench.py 2> gpurun_out/bench.err | tee gpurun_out/bench.json | cut -c1-600; tail -2 gpurun_out/bench.err
 echo "== bench c5"; timeout 900 python bench.py --workload c5 --steps 5 --warmup 2 2> gpurun_out/bench_c5.err > gpurun_out/bench_c5.json; cut -c1-400 gpurun_out/bench_c5.json
-echo "== bench c2 (eager / graph)"; timeout 600 python bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null > gpurun_out/bench_c2.json; timeout 600 python bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline --graph 2>/dev/null > gpurun_out/bench_c2_graph.json; cut -c1-300 gpurun_out/bench_c2.json gpurun_out/bench_c2_graph.json
+echo "== bench c2 (eager / graph)"; timeout 600 python bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null > gpurun_out/bench_c2.json; timeout 600 python bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline --graph 2>/dev/null > gpurun_out/bench_c2_graph.json; timeout 600 python bench.py --workload c2 --steps 200 --warmup 20 --cpu-baseline-seconds 0.2 --graph --graph-steps 10 2>/dev/null > gpurun_out/bench_c2_graph10.json; cut -c1-300 gpurun_out/bench_c2.json gpurun_out/bench_c2_graph.json gpurun_out/bench_c2_graph10.json
 echo "== bench dists"; for d in 0 2 3; do timeout 600 python bench.py --dist $d --no-cpu-baseline --steps 6 2>/dev/null; done > gpurun_out/bench_dists.jsonl; cut -c1-200 gpurun_out/bench_dists.jsonl
 echo "== bench tokens"; timeout 600 python bench.py --tokens --problems-per-step 625 --no-cpu-baseline --steps 6 2>/dev/null > gpurun_out/bench_tokens.json; cut -c1-300 gpurun_out/bench_tokens.json
 echo "== probe"; timeout 300 ./tools/hbm_probe.bin 10000 2>&1 | tee gpurun_out/hbm_probe.log | tail -4
 echo "== regimes"; timeout 900 python tools/regimes.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/regimes.log | tail -30
+echo "== prefix budgets over short pools"; timeout 600 python tools/prefix_small.py 2>&1 | grep -v amdgpu.ids | tail -14
 echo "== host mode"; timeout 600 python tools/host_mode_bench.py 2>&1 | grep -v amdgpu | tee gpurun_out/host_mode.log | tail -12
 echo "== rocprof kernel-trace"; cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_trace.log 2>&1; tail -2 $R/gpurun_out/prof_trace.log | cut -c1-300
 echo "== rocprof pmc FETCH_SIZE"; timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_fetch.log 2>&1; tail -1 $R/gpurun_out/prof_fetch.log | cut -c1-200
