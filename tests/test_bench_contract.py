@@ -112,3 +112,14 @@ def test_rccl_calls_execute_on_one_rank(tmp_path):
     for k in ("counters", "cells", "boot"):
         assert np.array_equal(a[k], b[k]), k
     assert _last_json(out.stdout)["c5"]["pass_at_k"] == plain5["c5"]["pass_at_k"]
+
+
+def test_c2_steps_captured_in_one_graph_launch():
+    """C2 (30 x 8 x 2^17, one kernel launch per evaluation): --graph --graph-steps K replays K evaluations per graph
+    launch; steps round up to a multiple of K, the line keeps the contract and the cells of the last timed step are
+    checked against the oracle inside bench.py."""
+    d = _bench(["--workload", "c2", "--steps", "10", "--warmup", "3", "--graph", "--graph-steps", "4", "--cpu-baseline-seconds", "0.2"])
+    assert KEYS <= set(d) and d["steps"] == 12 and d["warmup"] == 4
+    assert d["config"]["launch"] == "hipGraph replay (4 step(s) per graph launch)"
+    assert d["parity"].startswith("bit-exact: 30 problems x 8 budgets x 131072 votes of the last TIMED chunk")
+    assert abs(d["value"] - 30 * 8 * (1 << 17) * 12 / (d["ms_per_step"] * 12e-3)) / d["value"] < 1e-9
