@@ -830,6 +830,73 @@ def test_hot_path_is_hipgraph_capturable():
             assert rc == 0 and np.array_equal(boot.cpu().numpy(), wb)
 
 
+@pytest.mark.parametrize("P,B,N", [(300, 4, 1024), (500, 3, 200), (90, 2, 4096), (700, 4, 16)])
+def test_cell_kernels_are_hipgraph_capturable(P, B, N):
+    """The register-resident kernels (counters accumulated in the launch) and the one-lane-per-cell kernel replay from a
+    hipGraph: their host side queries occupancy and sets function attributes, but enqueues nothing but the launch."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine
+    dev = torch.device("cuda:0")
+    with Engine(device=0) as eng:
+        ans = torch.empty((P, B, N), dtype=torch.int32, device=dev)
+        tr = torch.empty((P,), dtype=torch.int32, device=dev)
+        counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
+        cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
+        eng.synth_fill_device(ans, None, tr, P=P, B=B, N=N, seed=1, dist=1)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            counters.zero_()
+            eng.aggregate_device(ans, tr, counters=counters, cells=cells)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            counters.zero_()
+            eng.aggregate_device(ans, tr, counters=counters, cells=cells)
+        for seed in (2, 3):
+            eng.use_torch_stream()
+            eng.synth_fill_device(ans, None, tr, P=P, B=B, N=N, seed=seed, dist=1)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            a, _, trc = coracle.synth_fill(P, B, N, seed, 1)
+            got = AggregateResult.from_counters(counters.cpu().numpy(), P, B, cells_from_torch(cells))
+            assert_results_equal(got, oracle(a, trc), check_tokens=False)
+
+
+def test_prefix_lane_kernel_is_hipgraph_capturable():
+    """maj@1, 2, 4 ... 64 over one pool per problem, captured once and replayed on new pools."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine
+    dev = torch.device("cuda:0")
+    P, N = 3000, 64
+    nvl = [1, 2, 4, 8, 16, 32, 64]
+    with Engine(device=0) as eng:
+        pool = torch.empty((P, 1, N), dtype=torch.int32, device=dev)
+        tr = torch.empty((P,), dtype=torch.int32, device=dev)
+        nv = torch.tensor(nvl, dtype=torch.int32, device=dev)
+        counters = torch.zeros(counters_size(len(nvl)), dtype=torch.int64, device=dev)
+        cells = torch.empty((P, len(nvl), 16), dtype=torch.uint8, device=dev)
+        eng.synth_fill_device(pool, None, tr, P=P, B=1, N=N, seed=1, dist=1)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            counters.zero_()
+            eng.aggregate_prefix_device(pool.view(P, N), tr, nv, counters=counters, cells=cells)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            counters.zero_()
+            eng.aggregate_prefix_device(pool.view(P, N), tr, nv, counters=counters, cells=cells)
+        eng.use_torch_stream()
+        eng.synth_fill_device(pool, None, tr, P=P, B=1, N=N, seed=9, dist=1)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        a, _, trc = coracle.synth_fill(P, 1, N, 9, 1)
+        want = OracleEngine().aggregate_prefix(a[:, 0, :], trc, np.array(nvl, dtype=np.int32))
+        got = AggregateResult.from_counters(counters.cpu().numpy(), P, len(nvl), cells_from_torch(cells))
+        assert_results_equal(got, want, check_tokens=False)
+
+
 def test_permutation_invariance(hip_engine):
     import torch
     ans, _, tr, counters, cells, _ = _device_run(hip_engine, 12, 4, 50000, 77, 3)
