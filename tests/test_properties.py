@@ -74,3 +74,50 @@ def test_accuracy_float_is_the_rational_rounded(hits, P):
     assert abs(Fraction(scoring.accuracy_from_tie_classes(tie, P)) - exact) <= Fraction(1, 10 ** 13) * max(1, exact)
     if all(m & (m - 1) == 0 for m, _ in hits):                 # dyadic tie sizes: exactly representable sums
         assert scoring.accuracy_from_tie_classes(tie, P) == float(sum(Fraction(int(tie[m]), m) for m in range(1, 1025))) / P
+
+
+def _online_prefix_modes(votes, truth):
+    """Python model of scv_lane_prefix (csrc/scvote_kernels.hip.h): votes enter in order; vote i of value x has count
+    c = #{ j <= i : x_j == x }, and adding it changes the mode statistics exactly one way.  Yields the state after
+    every vote: (max_count, n_modes, min_mode, truth_count)."""
+    maxc = n_modes = tc = 0
+    min_mode = None
+    for i, x in enumerate(votes):
+        c = sum(1 for j in range(i + 1) if votes[j] == x)           # the kernel: packed compares with the earlier votes
+        if c > maxc:
+            maxc, n_modes, min_mode = c, 1, x
+        elif c == maxc:
+            n_modes, min_mode = n_modes + 1, min(min_mode, x)
+        tc += x == truth
+        yield maxc, n_modes, min_mode, tc
+
+
+@settings(max_examples=300, deadline=None)
+@given(st.lists(st.integers(min_value=0, max_value=12), min_size=1, max_size=64), st.integers(min_value=0, max_value=12))
+def test_online_mode_tracking_equals_multimode_on_every_prefix(votes, truth):
+    """The one-pass prefix kernel's invariant: the running state after vote i IS statistics.multimode's answer for the
+    prefix 0..i (o1.py:202-213 applied to samples[:i+1]) -- so a budget is a snapshot, whatever its boundary."""
+    for i, (maxc, n_modes, min_mode, tc) in enumerate(_online_prefix_modes(votes, truth)):
+        modes = statistics.multimode(votes[: i + 1])
+        assert n_modes == len(modes) and min_mode == min(modes) and maxc == votes[: i + 1].count(modes[0])
+        assert tc == votes[: i + 1].count(truth)
+        assert (tc == maxc and maxc > 0) == (truth in modes)                     # the kernel's `hit`
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.lists(st.integers(min_value=0, max_value=1023), min_size=1, max_size=200))
+def test_sixteen_bit_bin_packing_of_the_register_kernels(votes):
+    """Python model of the 16-bit histogram of scv_reg_cells (G = 16): bin b lives at byte address A = KB - 2 b; a vote adds
+    `alignbyte(1, 1, A)` = 1 << 16 * (bit 1 of A) to the 32-bit WORD at A & ~3, a count is read back as the 16-bit value
+    at A.  Counts stay below 2^16, so the two bins of a word never disturb each other."""
+    KB = 2 * 1023 + 4096                                     # any 4-byte aligned base works
+    words = {}
+    for v in votes:
+        A = KB - 2 * v
+        inc = ((1 << 32 | 1) >> (8 * (A & 3))) & 0xFFFFFFFF  # v_alignbyte_b32 D = ({hi = 1, lo = 1} >> 8 * S2[1:0])
+        assert inc == (1 << (16 * ((A >> 1) & 1)))
+        words[A & ~3] = (words.get(A & ~3, 0) + inc) & 0xFFFFFFFF
+    for b in set(votes):
+        A = KB - 2 * b
+        w = words[A & ~3]
+        assert (w >> (8 * (A & 3))) & 0xFFFF == votes.count(b)                   # ds_read_u16 at A (little endian)
