@@ -1597,6 +1597,40 @@ __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
         const int64_t off = (live ? p : 0) * a.N;
         const int32_t* row = a.answers + off;
         const int32_t* trow = TOK ? a.tokens + off : nullptr;
+        // next boundary in a scalar register: the per-vote test is then one s_cmp (an LDS read per vote otherwise)
+        auto boundary = [&](int kk) -> int32_t { return kk < B ? __builtin_amdgcn_readfirstlane(nvs[kk]) : -1; };
+        if (TOK && STAGE) {
+            // Token sums of the budgets in a pass of their own, BEFORE the votes are loaded: 64 token registers next to
+            // 64 votes + 32 packed pairs meant 226 VGPRs (2 waves per SIMD); the running sum is snapshot into the staged
+            // slots at the same boundaries the vote pass will visit.
+            int32_t tkv[NV];
+            if (vec) {
+#pragma unroll
+                for (int kq = 0; kq < NV / 4; ++kq) {
+                    int4 y = make_int4(0, 0, 0, 0);
+                    if (4 * kq < N) y = stream_load(reinterpret_cast<const int4*>(trow) + kq);
+                    tkv[4 * kq] = y.x; tkv[4 * kq + 1] = y.y; tkv[4 * kq + 2] = y.z; tkv[4 * kq + 3] = y.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    tkv[i] = 0;
+                    if (i < N) tkv[i] = __builtin_nontemporal_load(trow + i);
+                }
+            }
+            long long ts = 0;
+            int kt = 0;
+            int32_t nn = boundary(0);
+            while (nn == 0) { stage_tok[lane * B + __builtin_amdgcn_readfirstlane(ord[kt])] = 0; nn = boundary(++kt); }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                if (i < N) {
+                    ts += (long long)tkv[i];
+                    while (nn == i + 1) { stage_tok[lane * B + __builtin_amdgcn_readfirstlane(ord[kt])] = ts; nn = boundary(++kt); }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                       // the vote loads start after the token registers are dead
+        }
         uint32_t x[NV];
         if (vec) {
 #pragma unroll
@@ -1626,8 +1660,8 @@ __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
             rec.z = (n_modes & 0xffffu) | ((any ? (min_mode & 0xffffu) : 0xffffu) << 16);
             rec.w = hit;
             if (STAGE) {
-                stage_rec[lane * B + b] = rec;                       // (an inactive lane's slot is never copied out or counted)
-                if (TOK) stage_tok[lane * B + b] = tok;
+                stage_rec[lane * B + b] = rec;                       // (an inactive lane's slot is never copied out or counted;
+                                                                     //  its token sum was staged by the token pass)
             } else {
                 if (live) {
                     if (a.cells) reinterpret_cast<uint4*>(a.cells)[p * B + b] = rec;
@@ -1636,8 +1670,6 @@ __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
                 count_budget(b, hit, n_modes, live ? tc : 0u, live ? tok : 0ll);
             }
         };
-        // next boundary in a scalar register: the per-vote test is then one s_cmp (an LDS read per vote otherwise)
-        auto boundary = [&](int kk) -> int32_t { return kk < B ? __builtin_amdgcn_readfirstlane(nvs[kk]) : -1; };
         int32_t next_n = boundary(0);
         while (next_n == 0) { emit(__builtin_amdgcn_readfirstlane(ord[k])); next_n = boundary(++k); }
         // votes packed two per register (values <= 1023): one xor + one saturating packed subtract + one dot product
@@ -1652,8 +1684,8 @@ __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
             xp[m] = lo | (hi << 16);
         }
         // tokens are loaded after the votes are packed (64 + 64 live registers would spill at NV = 64)
-        int32_t tk[TOK ? NV : 1];
-        if (TOK) {
+        int32_t tk[(TOK && !STAGE) ? NV : 1];
+        if (TOK && !STAGE) {
             if (vec) {
 #pragma unroll
                 for (int kq = 0; kq < NV / 4; ++kq) {
@@ -1686,7 +1718,7 @@ __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
                 min_mode = gt ? xi : ((eq && xi < min_mode) ? xi : min_mode);
                 maxc = gt ? c : maxc;
                 tc += xi == tcmp ? 1u : 0u;
-                if (TOK) tok += (long long)tk[i];
+                if (TOK && !STAGE) tok += (long long)tk[i];
                 while (next_n == i + 1) { emit(__builtin_amdgcn_readfirstlane(ord[k])); next_n = boundary(++k); }
             }
         }
