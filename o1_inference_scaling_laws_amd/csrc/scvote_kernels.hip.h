@@ -1828,9 +1828,11 @@ constexpr int kRegWaveWords = kRegHistWords + kRegLaneWords;
 template <int G, int V, bool TOK, bool DENSE>
 constexpr int reg_cells_waves() {
     if (DENSE) return 8;
-    if (G == 16) return (V <= 2 || !TOK) ? 16 : 12;
-    if (G == 32) return (V <= 2 || !TOK) ? 16 : 12;
-    return V <= 2 ? 16 : 12;
+    // (with tokens the one-vector shapes run K = 4 batches per iteration, each with its token loads in flight: they
+    // spill at 128 VGPRs -- tools/kernel_resources.py -- and get 12 waves = 168 VGPRs like the four-vector shapes)
+    if (TOK && (V == 1 || V == 4)) return 12;
+    if (G == 64 && V == 2 && TOK) return 12;
+    return (V <= 2 || G < 64) ? 16 : 12;
 }
 template <int V, int H, bool TOK, bool VEC>
 constexpr int reg_dense_waves() {
