@@ -67,7 +67,7 @@ def all_gather_cells(cells_local, P: int, group=None):
 
 
 def aggregate_sharded(engine, answers_local, truth_local, num_problems: int, tokens_local=None, n_valid=None,
-                      group=None, want_cells=True):
+                      group=None, want_cells=True, prefix=False):
     """One sharded evaluation: this rank's contiguous block of problems goes through
     ``engine.aggregate_device`` (any object with that method: the HIP engine in production), the packed
     int64 counters are summed over the ranks with ONE all-reduce, and the reference's floats are taken
@@ -77,16 +77,30 @@ def aggregate_sharded(engine, answers_local, truth_local, num_problems: int, tok
     Data errors are collective: the device error word of every rank (SCV_ERR_DOMAIN: a vote outside bins
     0..1023, which makes the counters invalid) rides in one extra word of the same all-reduce, and EVERY rank
     raises ``DomainError`` when any rank saw one -- no rank returns counters the ABI documents as invalid, and
-    no rank is left waiting in a collective the others skipped."""
+    no rank is left waiting in a collective the others skipped.
+
+    ``prefix=True``: ``answers_local`` / ``tokens_local`` are this rank's block of ONE sample pool per problem,
+    ``[P_local, N]``, and budget b votes over its first ``n_valid[b]`` samples (the reference's shape, o1.py:274-277);
+    the block goes through ``engine.aggregate_prefix_device`` and everything else is the same."""
     import torch
     from ._lib import ERR_DOMAIN, DomainError
     from .engine import AggregateResult, cells_from_torch, counters_size
-    P_local, B = int(answers_local.shape[0]), int(answers_local.shape[1])
+    if prefix:
+        if n_valid is None:
+            raise ValueError("prefix=True needs n_valid[B]")
+        P_local, B = int(answers_local.shape[0]), int(n_valid.shape[0])
+    else:
+        P_local, B = int(answers_local.shape[0]), int(answers_local.shape[1])
     ncount = counters_size(B)
     packed = torch.zeros(ncount + 1, dtype=torch.int64, device=answers_local.device)     # counters | error word
-    _, cells, cell_tokens = engine.aggregate_device(
-        answers_local, truth_local, tokens=tokens_local, n_valid=n_valid, counters=packed[:ncount],
-        cells=None if want_cells else False)
+    if prefix:
+        _, cells, cell_tokens = engine.aggregate_prefix_device(
+            answers_local, truth_local, n_valid, tokens=tokens_local, counters=packed[:ncount],
+            cells=None if want_cells else False)
+    else:
+        _, cells, cell_tokens = engine.aggregate_device(
+            answers_local, truth_local, tokens=tokens_local, n_valid=n_valid, counters=packed[:ncount],
+            cells=None if want_cells else False)
     local_error = None
     if hasattr(engine, "sync"):
         try:

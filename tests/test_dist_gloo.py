@@ -61,6 +61,13 @@ class _CpuDeviceEngine:
         self.rc = out["rc"]
         return cnt, (None if cells is False else c), (torch.from_numpy(out["cell_tokens"]) if tokens is not None else None)
 
+    def aggregate_prefix_device(self, pool, truth, n_valid, tokens=None, counters=None, cells=None, cell_tokens=None):
+        # the oracle on the dense expansion answers[p, b, :] = pool[p, :] (what the prefix entry point is defined as)
+        B = int(n_valid.shape[0])
+        dense = pool.unsqueeze(1).expand(pool.shape[0], B, pool.shape[1]).contiguous()
+        dtok = None if tokens is None else tokens.unsqueeze(1).expand(pool.shape[0], B, pool.shape[1]).contiguous()
+        return self.aggregate_device(dense, truth, tokens=dtok, n_valid=n_valid, counters=counters, cells=cells)
+
     def sync(self):
         from o1_inference_scaling_laws_amd._lib import ERR_DOMAIN, DomainError
         if getattr(self, "rc", 0) == ERR_DOMAIN:
@@ -135,6 +142,51 @@ def test_aggregate_sharded_api_three_ranks():
     whole = AggregateResult.from_counters(_pack(coracle.aggregate(a, tr, tokens=t)), P, B)
     assert acc == [whole.accuracy(b) for b in range(B)]
     assert avg == [float(whole.avg_tokens_used(b)) for b in range(B)]
+
+
+PREFIX_NV = [1, 2, 4, 8, 16, 32, 64, 96, 0, 50]
+
+
+def _worker_prefix(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = scv_dist.shard_bounds(P, rank, world)
+        a, t, tr = coracle.synth_fill(hi - lo, 1, N, SEED, 1, p_offset=lo, want_tokens=True)
+        nv = torch.tensor(PREFIX_NV, dtype=torch.int32)
+        res = scv_dist.aggregate_sharded(_CpuDeviceEngine(), torch.from_numpy(a[:, 0, :].copy()), torch.from_numpy(tr), P,
+                                         tokens_local=torch.from_numpy(t[:, 0, :].copy()), n_valid=nv, prefix=True)
+        assert res.cells.shape == (hi - lo, len(PREFIX_NV))
+        if rank == 0:
+            q.put(([res.accuracy(b) for b in range(len(PREFIX_NV))], [float(res.avg_tokens_used(b)) for b in range(len(PREFIX_NV))],
+                   res.tie_class_hits.copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prefix_budgets_sharded_over_two_ranks():
+    """The reference's shape (one sample pool per problem, budgets = prefixes: o1.py:274-277) sharded by problem: two
+    ranks + one all-reduce reproduce the unsharded dense evaluation bit for bit, floats included."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_prefix, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    acc, avg, tie = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a, t, tr = coracle.synth_fill(P, 1, N, SEED, 1, want_tokens=True)
+    nb = len(PREFIX_NV)
+    dense = np.ascontiguousarray(np.broadcast_to(a, (P, nb, N)))
+    dtok = np.ascontiguousarray(np.broadcast_to(t, (P, nb, N)))
+    whole = AggregateResult.from_counters(_pack(coracle.aggregate(dense, tr, tokens=dtok, n_valid=np.array(PREFIX_NV, dtype=np.int32))), P, nb)
+    assert np.array_equal(tie, whole.tie_class_hits)
+    assert acc == [whole.accuracy(b) for b in range(nb)]
+    assert avg == [float(whole.avg_tokens_used(b)) for b in range(nb)]
 
 
 def _worker_pipeline(rank, world, port, q):

@@ -901,6 +901,24 @@ def test_prefix_lane_kernel_is_hipgraph_capturable():
         assert_results_equal(got, want, check_tokens=False)
 
 
+def test_aggregate_sharded_with_the_real_engine_single_rank(hip_engine):
+    """dist.aggregate_sharded on the HIP engine without a process group: dense [P, B, N] and the reference's
+    prefix shape (one pool per problem), counters taken from a slice of the packed buffer that carries the error word."""
+    import torch
+    from o1_inference_scaling_laws_amd import dist as scv_dist
+    dev = torch.device("cuda:0")
+    P, B, N = 700, 3, 64
+    a, t, tr = coracle.synth_fill(P, B, N, 77, 1, want_tokens=True)
+    res = scv_dist.aggregate_sharded(hip_engine, torch.from_numpy(a).to(dev), torch.from_numpy(tr).to(dev), P,
+                                     tokens_local=torch.from_numpy(t).to(dev))
+    assert_results_equal(res, oracle(a, tr, tokens=t))
+    nvl = np.array([1, 2, 4, 8, 16, 32, 64], dtype=np.int32)
+    pool, tpool = np.ascontiguousarray(a[:, 0, :]), np.ascontiguousarray(t[:, 0, :])
+    res = scv_dist.aggregate_sharded(hip_engine, torch.from_numpy(pool).to(dev), torch.from_numpy(tr).to(dev), P,
+                                     tokens_local=torch.from_numpy(tpool).to(dev), n_valid=torch.from_numpy(nvl).to(dev), prefix=True)
+    assert_results_equal(res, OracleEngine().aggregate_prefix(pool, tr, nvl, tokens=tpool))
+
+
 def test_permutation_invariance(hip_engine):
     import torch
     ans, _, tr, counters, cells, _ = _device_run(hip_engine, 12, 4, 50000, 77, 3)
