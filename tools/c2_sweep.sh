@@ -1,7 +1,6 @@
 #!/bin/bash
 # Geometry sweep for the few-huge-cell shapes (C2 30x8x2^17, 30x2^20, 1x2^24): default vs 8 loads in flight per lane vs two
 # 512-thread workgroups per CU on half-cells.  Result (dead ends): the defaults are the fastest.
-#!/bin/bash
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 run() { python tools/one_case.py "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.readlines()[-1]); print('%-22s %-40s %8.1f us %8.1f GB/s' % (r['shape'], r.get('opts'), r['median_us'], r['GBps']))"; }
 for shape in "30 8 131072" "30 1 1048576" "1 1 16777216"; do
