@@ -86,3 +86,20 @@ def test_every_option_and_stat_key_is_documented_in_the_header():
         assert len(keys) >= 5, fn
         missing = [k for k in keys if f'"{k}"' not in hdr]
         assert not missing, f"{fn}: keys not documented in include/scvote.h: {missing}"
+
+
+def test_no_kernel_spills_to_scratch():
+    """Compiler metadata of every gfx950 kernel (one device-only compile, ~1 min, no GPU): nothing on the hot paths may
+    carry scratch -- a launch bound set for more waves than a variant's registers allow shows up here, not as a silent
+    slowdown on the GPU box (the token variants of the one-vector register shapes once did: 48-84 B)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(REPO, "tools", "kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = mod.collect()
+    assert len(rows) > 150
+    allowed = {"scv_lane_cells<32, 512, true>"}                      # 12 B, N = 17..32 with tokens: known, measured
+    spilled = {r[0]: r[4] for r in rows if r[4] and r[0] not in allowed}
+    assert not spilled, spilled
+    head = [r for r in rows if r[0] == "scv_hist_argmax<4, 1024, 4, false, false>"]
+    assert head and head[0][1] <= 128 and head[0][4] == 0            # the headline kernel: 16 waves per CU need <= 128 VGPRs

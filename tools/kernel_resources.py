@@ -8,29 +8,43 @@ import sys
 import tempfile
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(R, "o1_inference_scaling_laws_amd", "csrc", "scvote.hip")
-with tempfile.TemporaryDirectory() as d:
-    asm = os.path.join(d, "scvote.s")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", asm, src],
-                   check=True, stderr=subprocess.DEVNULL)
-    s = open(asm).read()
-demangle = subprocess.run(["c++filt"], input="\n".join(re.findall(r"\.amdhsa_kernel (\S+)", s)),
-                          capture_output=True, text=True).stdout.splitlines()
-rows = []
-for mangled, name in zip(re.findall(r"\.amdhsa_kernel (\S+)", s), demangle):
-    i = s.find("; -- End function", s.find("\n" + mangled + ":"))
-    info = s[i:i + 2000]
-    g = lambda k: int(re.search(k + r": (\d+)", info).group(1))   # noqa: E731
-    short = re.sub(r"\(scv::AggArgs\)|\(.*\)$", "", name).replace("void ", "").replace("scv::", "")
-    rows.append((short, g("NumVgprs"), g("NumAgprs"), g("NumSgprs"), g("ScratchSize"), g("Occupancy"), g("LDSByteSize")))
-rows.sort()
-out = ["# Kernel resources (gfx950, hipcc -O3; compiler metadata, `tools/kernel_resources.py`)", "",
-       f"{len(rows)} kernels; `occupancy` = waves per SIMD the register count allows (LDS may allow fewer: dynamic LDS is sized by the host).", "",
-       "| kernel | VGPR | AGPR | SGPR | scratch B | occupancy | static LDS B |", "|---|---|---|---|---|---|---|"]
-out += [f"| `{n}` | {v} | {a} | {sg} | {sc} | {oc} | {l} |" for n, v, a, sg, sc, oc, l in rows]
-spill = [r for r in rows if r[4]]
-out += ["", f"Kernels with scratch: {len(spill)}" + (": " + ", ".join(f"`{r[0]}` ({r[4]} B)" for r in spill) if spill else "") + "."]
-text = "\n".join(out) + "\n"
-if len(sys.argv) > 1:
-    open(sys.argv[1], "w").write(text)
-print(text)
+CSRC = os.path.join(R, "o1_inference_scaling_laws_amd", "csrc")
+
+
+def collect():
+    """[(kernel, vgpr, agpr, sgpr, scratch_bytes, occupancy, static_lds_bytes)], sorted by name."""
+    src = os.path.join(CSRC, "scvote.hip")
+    with tempfile.TemporaryDirectory() as d:
+        asm = os.path.join(d, "scvote.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", asm, src],
+                       check=True, stderr=subprocess.DEVNULL)
+        s = open(asm).read()
+    mangled_names = re.findall(r"\.amdhsa_kernel (\S+)", s)
+    demangled = subprocess.run(["c++filt"], input="\n".join(mangled_names), capture_output=True, text=True).stdout.splitlines()
+    rows = []
+    for mangled, name in zip(mangled_names, demangled):
+        i = s.find("; -- End function", s.find("\n" + mangled + ":"))
+        info = s[i:i + 2000]
+        g = lambda k: int(re.search(k + r": (\d+)", info).group(1))   # noqa: E731
+        short = re.sub(r"\(scv::AggArgs\)|\(.*\)$", "", name).replace("void ", "").replace("scv::", "")
+        rows.append((short, g("NumVgprs"), g("NumAgprs"), g("NumSgprs"), g("ScratchSize"), g("Occupancy"), g("LDSByteSize")))
+    rows.sort()
+    return rows
+
+
+def main():
+    rows = collect()
+    out = ["# Kernel resources (gfx950, hipcc -O3; compiler metadata, `tools/kernel_resources.py`)", "",
+           f"{len(rows)} kernels; `occupancy` = waves per SIMD the register count allows (LDS may allow fewer: dynamic LDS is sized by the host).", "",
+           "| kernel | VGPR | AGPR | SGPR | scratch B | occupancy | static LDS B |", "|---|---|---|---|---|---|---|"]
+    out += [f"| `{n}` | {v} | {a} | {sg} | {sc} | {oc} | {l} |" for n, v, a, sg, sc, oc, l in rows]
+    spill = [r for r in rows if r[4]]
+    out += ["", f"Kernels with scratch: {len(spill)}" + (": " + ", ".join(f"`{r[0]}` ({r[4]} B)" for r in spill) if spill else "") + "."]
+    text = "\n".join(out) + "\n"
+    if len(sys.argv) > 1:
+        open(sys.argv[1], "w").write(text)
+    print(text)
+
+
+if __name__ == "__main__":
+    main()
