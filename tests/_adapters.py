@@ -80,3 +80,24 @@ def assert_results_equal(got: AggregateResult, want: AggregateResult, check_toke
         assert np.array_equal(got.token_sum, want.token_sum)
         if want.cell_tokens is not None:
             assert np.array_equal(got.cell_tokens, want.cell_tokens)
+
+
+def assert_golden_case_via_prefix(engine, case, vt):
+    """The reference's result for budget N of a golden case, obtained through the PREFIX entry point: the case's samples
+    as one pool per problem, budgets {1, 2, N // 2, N} over it (the last one is the golden's).  ``engine`` is anything
+    with ``aggregate_prefix`` (the HIP engine; the oracle adapter on CPU, which checks this helper itself)."""
+    from fractions import Fraction
+    pool = np.ascontiguousarray(vt.answers[:, 0, :])
+    tpool = np.ascontiguousarray(vt.tokens[:, 0, :])
+    N = pool.shape[1]
+    nv = np.array(sorted({1, min(2, N), max(1, N // 2), N}), dtype=np.int32)
+    res = engine.aggregate_prefix(pool, vt.truth, nv, tokens=tpool)
+    b = len(nv) - 1                                                  # n_valid[b] == N
+    for p, (num, den, tok) in enumerate(case["per_problem"]):
+        cell = res.cells[p, b]
+        assert (Fraction(1, int(cell["n_modes"])) if cell["hit"] else Fraction(0)) == Fraction(num, den), (case["name"], p)
+        assert int(res.cell_tokens[p, b]) == tok, (case["name"], p)
+    assert res.exact_accuracy(b) == Fraction(*case["accuracy_exact"]), case["name"]
+    # budget 1 = the first sample alone: one mode, hit iff it is the truth (o1.py:202-206 on a single vote)
+    first_is_truth = (pool[:, 0] == vt.truth)
+    assert np.array_equal(res.cells["hit"][:, 0].astype(bool), first_is_truth) and (res.cells["n_modes"][:, 0] == 1).all()

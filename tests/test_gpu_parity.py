@@ -13,8 +13,8 @@ from o1_inference_scaling_laws_amd import _lib, o1_dropin, synth
 from o1_inference_scaling_laws_amd.engine import (AggregateResult, cells_from_torch, counters_size)
 from o1_inference_scaling_laws_amd.extract import build_vote_tensors
 from oracle import coracle
-from tests._adapters import (TEST_MODEL, TEST_PROMPT, OracleEngine, assert_results_equal, build_cache,
-                             make_dataset)
+from tests._adapters import (TEST_MODEL, TEST_PROMPT, OracleEngine, assert_golden_case_via_prefix, assert_results_equal,
+                             build_cache, make_dataset)
 
 pytestmark = pytest.mark.gpu
 
@@ -668,6 +668,9 @@ def test_golden_fixtures_through_the_gpu(hip_engine, golden, tmp_path):
             assert (Fraction(1, int(cell["n_modes"])) if cell["hit"] else Fraction(0)) == Fraction(num, den)
             assert int(res.cell_tokens[p, 0]) == tok
         assert res.exact_accuracy(0) == Fraction(*case["accuracy_exact"])
+        # the same reference result through the prefix entry point (one lane per problem up to N = 64, cell kernels on
+        # pool rows up to 4096, the streaming snapshot kernel beyond)
+        assert_golden_case_via_prefix(hip_engine, case, vt)
         acc, avg = o1_dropin.run_experiments(cfg, ds, cache, case["token_limit"], case["N"])
         assert abs(acc - float(case["accuracy_live"])) < 1e-12 and repr(float(avg)) == case["avg_tokens_used"]
     pipe = golden["pipeline"]
