@@ -155,7 +155,10 @@ int scv_aggregate_i32(scv_ctx* ctx,
  * o1.py:85-88).  pool / tokens are int32 [P, N]; cell (p, b) votes over pool[p, 0:n_valid[b]]
  * (n_valid required, any order, B <= 512).  Outputs and conventions are exactly those of
  * scv_aggregate_i32 called on the dense expansion answers[p, b, :] = pool[p, :], but the pool is
- * streamed once: 4 * max_b n_valid[b] algorithmic bytes per problem instead of 4 * sum_b n_valid[b].
+ * read from HBM once: 4 * max_b n_valid[b] algorithmic bytes per problem instead of 4 * sum_b n_valid[b].
+ * Dispatch by pool length: N <= 64 (the reference's pools) one lane per problem, every budget a snapshot of one
+ * pass over its votes; N <= 4096 the cell kernels, each cell reading its prefix of the problem's row; longer pools
+ * the streaming kernel with a snapshot of the histogram at every boundary.
  */
 int scv_aggregate_prefix_i32(scv_ctx* ctx,
                              const int32_t* pool, const int32_t* tokens,
