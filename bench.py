@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- sample-votes/s of the self-consistency aggregation path on MI355X.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1 under torch.distributed.run)
-prints ONE JSON line on rank 0.
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+prints ONE JSON line on rank 0.  N > 1: either the driver launches the ranks itself (python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N ...: RANK / WORLD_SIZE are then in the environment), or -- like the reference,
+whose run_experiments fans its problems out itself (o1.py:232-240) -- a plain `python bench.py --gpus N` starts its
+own N ranks (one process per GPU through torch.distributed.run on 127.0.0.1) and relays rank 0's line.  With fewer
+visible GPUs than ranks the line is {"error": ...} and the exit status is non-zero.
 
 Default workload = BASELINE.json config C3, "synthetic int32 answers P=10k x B=8 x N=2^20" (335.5 GB, does
 not fit 288 GB of HBM), streamed in problem-chunks: a STEP is one pass of the hot path over one
@@ -18,17 +22,20 @@ distinct tensors cycled so the 256 MiB Infinity Cache cannot serve reruns) and -
 1000-resample bootstrap, pass@k sweep on the host; o1_inference_scaling_laws_amd/passk.py).
 
 Inputs are generated ON DEVICE (closed-form integer generator, include/scvote.h) and are resident
-in HBM before the timed region; `--resident` distinct chunks are cycled (each is 41.9 GB >> the
-256 MiB Infinity Cache, so every step streams from HBM).  Distribution D1 (peaked/realistic) is
+in HBM before the timed region; `--resident` distinct chunks are cycled (default: as many of C3's 8 chunks as
+fit in free HBM -- 7 on a 288 GB part -- each 41.9 GB >> the 256 MiB Infinity Cache, so every step streams
+from HBM; the line reports `chunks_distinct`).  Distribution D1 (peaked/realistic) is
 the headline; --dist 0/2/3 select uniform/degenerate/tie.
 
 The timed region is bracketed by barrier + torch.cuda.synchronize() on both sides; the kernel's own
 duration is taken from hipEvents recorded by the library on the launch stream (scv_drain_kernel_ns).
 
-cpu_baseline (rank 0, N=1): the reference's own arithmetic -- statistics.multimode + o1.py:204-213 scoring on
-Python int lists (oracle/pybaseline.py, run as a subprocess) -- on one host core and on a process pool over the
-host cores, on a bounded sample of the same workload; the C restatement (oracle/scv_oracle.c) is a secondary
-field.  The same leg is the checker: GPU cells of a timed chunk vs the C oracle (>= 256 problems x 8 budgets x
+cpu_baseline (rank 0, N=1): `value` is the UNMODIFIED reference loop -- o1.run_experiments (o1.py:216-247) imported
+from the bytecode __graft_entry__.build() compiled into oracle/_ref (oracle/make_ref.py; kind "reference") -- timed on
+this box's host at P = 30, N in {2^8, 2^11} on votes of the workload's generator (oracle/refbaseline.py, a subprocess).
+Beside it: the reference's arithmetic without its thread pools and cache lookups -- statistics.multimode +
+o1.py:204-213 scoring on Python int lists (oracle/pybaseline.py) -- on one host core and on a process pool, and the C
+restatement (oracle/scv_oracle.c).  The same leg is the checker: GPU cells of a timed chunk vs the C oracle (>= 256 problems x 8 budgets x
 2^20 votes) and vs the Python reference arithmetic.  It is the ONLY place bench.py touches oracle/.
 """
 from __future__ import annotations
@@ -40,8 +47,8 @@ import subprocess
 import sys
 import time
 
-# the host driver only supports dmabuf IPC: RCCL across processes needs this (set before torch loads)
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+HSA_IPC_NOTE = {"value": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "source": "inherited from the environment"
+                if "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ else "unset"}
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -64,7 +71,8 @@ def parse():
     ap.add_argument("--budgets", type=int, default=8)
     ap.add_argument("--samples", type=int, default=1 << 20)
     ap.add_argument("--dist", type=int, default=1, help="0 uniform, 1 peaked (headline), 2 degenerate, 3 tie")
-    ap.add_argument("--resident", type=int, default=2, help="distinct chunks kept in HBM and cycled")
+    ap.add_argument("--resident", type=int, default=0,
+                    help="distinct chunks kept in HBM and cycled (0 = auto: c3 as many of its 8 chunks as fit in free HBM)")
     ap.add_argument("--tokens", action="store_true", help="also stream the tokens tensor (8 B/vote)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-read-ceiling", action="store_true", help="skip the pure-read probe after the timed region")
@@ -162,23 +170,128 @@ def cpu_baseline(args, B, N, gpu_first_cells, first_off, gpu_last_cells, last_of
               f"sanity pass vs oracle/scv_oracle.c ({t_check:.1f} s); {checked_py} problems x {B} cells also vs statistics.multimode "
               f"(score = hit / n_modes, o1.py:202-210)")
     ps, pa = py["single"], py.get("all_cores")
-    base = {
+    arithmetic = {
         "value": ps["votes_per_s"], "unit": "sample-votes/s", "cores": 1, "kind": "port",
-        "what": "the reference's arithmetic: statistics.multimode(answers) + o1.py:204-213 scoring on Python int lists "
-                "(oracle/pyoracle.py, line-by-line restatement of o1.py:181-213; the unmodified reference cannot travel to the GPU box)",
+        "what": "the reference's arithmetic without its thread pools and cache lookups: statistics.multimode(answers) + o1.py:204-213 "
+                "scoring on Python int lists (oracle/pyoracle.py, line-by-line restatement of o1.py:181-213)",
         "sample": f"{ps['problems']} problems x {B} budgets x {N} samples of the workload's generator (dist {args.dist}), "
                   f"{ps['timed_s']:.1f} s on 1 of {cores} host cores",
         "all_cores": None if pa is None else {
             "value": pa["votes_per_s"], "processes": pa["procs"], "host_cores": cores,
             "sample": f"{pa['problems']} problems x {B} x {N}, one problem per process (multiprocessing), wall {pa['wall_s']:.2f} s"},
-        "c_port": {"value": votes / dt, "cores": 1, "what": "oracle/scv_oracle.c (C restatement, the bit-exactness comparator)",
-                   "sample": f"{P1} problems x {B} x {N}, {votes // a.size} passes, {dt:.1f} s",
-                   "all_cores": {"value": mt_rate, "threads": threads, "sample": f"{Pm} problems x {B} x {N}, {passes} passes, OpenMP over problems"}},
     }
+    c_port = {"value": votes / dt, "cores": 1, "kind": "port", "what": "oracle/scv_oracle.c (C restatement, the bit-exactness comparator)",
+              "sample": f"{P1} problems x {B} x {N}, {votes // a.size} passes, {dt:.1f} s",
+              "all_cores": {"value": mt_rate, "threads": threads, "sample": f"{Pm} problems x {B} x {N}, {passes} passes, OpenMP over problems"}}
+    # (4) the UNMODIFIED reference loop on this box's host: o1.run_experiments from oracle/_ref (a subprocess)
+    ref = reference_loop(args)
+    if ref is not None:
+        big = ref["results"][-1]
+        base = {
+            "value": big["votes_per_s"], "unit": "sample-votes/s", "cores": 1, "kind": "reference",
+            "what": "the UNMODIFIED reference loop o1.run_experiments (o1.py:216-247: nested thread pools, per-sample cache-key lookups, "
+                    f"statistics.multimode, completion-order float sum) imported from {ref['reference']} "
+                    "(oracle/_ref = py_compile of /root/reference, oracle/make_ref.py), warm in-memory synthetic cache, save_cache no-op'd; "
+                    "its ~300 threads share the GIL: one core does the work",
+            "sample": "; ".join(f"P={r['P']} x N={r['N']}: {r['seconds']:.2f} s = {r['votes_per_s']:.0f} votes/s" for r in ref["results"])
+                      + f" (votes of the workload's generator, dist {args.dist}; accuracy equal to the restatement's: "
+                      + str(all(r["accuracy_matches_restatement"] for r in ref["results"])) + f"); {cores} host cores",
+            "reference_loop": ref["results"],
+            "arithmetic": arithmetic,
+            "c_port": c_port,
+        }
+    else:
+        base = dict(arithmetic, c_port=c_port, reference_loop=None,
+                    note="oracle/_ref is absent (build() did not run where /root/reference exists): the restatement is the baseline")
     return parity, base
 
 
+def reference_loop(args):
+    """oracle/refbaseline.py as a subprocess: the unmodified o1.run_experiments at P = 30, N = 2^8 and 2^11 (SURVEY 8d "R0").
+    None when oracle/_ref is not there."""
+    cmd = [sys.executable, "-m", "oracle.refbaseline", "--N", "256", "2048", "--seed", str(args.seed), "--dist", str(args.dist)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, timeout=300, env=dict(os.environ, MPLBACKEND="Agg"))
+    except subprocess.TimeoutExpired:
+        return None
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if out.returncode != 0 or not lines:
+        sys.exit("reference loop baseline failed: " + out.stderr[-2000:])
+    ref = json.loads(lines[-1])
+    return ref if ref.get("available") else None
+
+
 # ---- helpers -------------------------------------------------------------------------------------------------
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def probe_ipc_mode():
+    """RCCL between processes shares device memory through hipIpcGetMemHandle.  Hosts whose driver only supports dmabuf
+    IPC need HSA_ENABLE_IPC_MODE_LEGACY=0 (read when the HSA runtime starts, so it has to be in the environment before
+    the ranks import torch).  When the variable is already set it is left alone; when it is not, a throw-away process
+    asks the runtime for an IPC handle in its default mode and the variable is set to 0 only if that fails."""
+    if "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ:
+        return
+    code = ("import ctypes,sys\n"
+            "h=ctypes.CDLL('libamdhip64.so')\n"
+            "p=ctypes.c_void_p()\n"
+            "sys.exit(3) if h.hipMalloc(ctypes.byref(p),ctypes.c_size_t(1<<20)) else None\n"
+            "b=(ctypes.c_char*64)()\n"
+            "sys.exit(0 if h.hipIpcGetMemHandle(ctypes.byref(b),p)==0 else 4)\n")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    try:
+        rc = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=120).returncode
+    except (OSError, subprocess.TimeoutExpired):
+        rc = -1
+    if rc == 4:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        HSA_IPC_NOTE.update(value="0", source="set by bench.py: hipIpcGetMemHandle failed in the runtime's default IPC mode (probe process)")
+    else:
+        HSA_IPC_NOTE.update(source=f"unset: probe process rc={rc} (0 = hipIpcGetMemHandle works in the default mode)")
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves -- the fan-out is the callee's
+    job in the reference too (o1.py:232-240) -- one process per GPU, rendezvous on 127.0.0.1, and relay rank 0's line."""
+    n = args.gpus
+    visible = -1
+    if not args.share_device:
+        try:
+            import ctypes
+            visible = int(ctypes.CDLL(os.path.join(REPO, "o1_inference_scaling_laws_amd", "csrc", "libscvote.so")).scv_device_count())
+        except OSError as e:
+            print(json.dumps({"error": f"libscvote.so is not built: {e}", "n_gpus": n}), flush=True)
+            return 2
+        if visible < n:
+            print(json.dumps({"error": f"bench.py --gpus {n}: only {visible} HIP device(s) visible; one rank per GPU is required "
+                                       f"(--share-device exists for the 1-GPU test box only)",
+                              "metric": "sample-votes/sec (problems x samples)", "value": None, "n_gpus": n,
+                              "hip_devices_visible": visible}), flush=True)
+            return 2
+    if args.backend == "nccl":
+        probe_ipc_mode()
+    env = dict(os.environ, SCV_BENCH_SPAWNED="1", SCV_HSA_IPC_NOTE=json.dumps(HSA_IPC_NOTE))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    rest = [l for l in proc.stdout.splitlines() if not l.startswith("{")]
+    if rest:
+        print("\n".join(rest), file=sys.stderr)
+    if proc.returncode != 0 or len(lines) != 1:
+        print(json.dumps({"error": f"{n}-rank run failed (rc {proc.returncode}, {len(lines)} JSON lines)", "n_gpus": n,
+                          "lines": lines[-2:]}), flush=True)
+        return proc.returncode or 1
+    print(lines[0], flush=True)
+    return 0
+
 
 def measure_read_ceiling(cells: int):
     """Pure-read ceiling of THIS box, measured right after the timed region by tools/hbm_probe.bin --quick (a separate
@@ -219,6 +332,12 @@ def committed_evidence():
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("SCV_FORCE_COLLECTIVES") == "1"):
+        sys.exit(spawn_ranks(args))             # plain `python bench.py --gpus N`: start the ranks ourselves
+    if "SCV_HSA_IPC_NOTE" in os.environ:
+        HSA_IPC_NOTE.update(json.loads(os.environ["SCV_HSA_IPC_NOTE"]))
+    elif int(os.environ.get("WORLD_SIZE", "1")) > 1 and args.backend == "nccl":
+        probe_ipc_mode()                        # ranks started by the driver's own torch.distributed.run (before torch loads HIP)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -227,15 +346,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world                       # under a launcher the launcher's world size wins
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     ndev = torch.cuda.device_count()
     # preflight for N > 1: one GPU per rank, or say loudly why not (the 1-GPU test box shares cuda:0 on purpose)
     if world > 1 and not args.share_device and ndev < world:
-        sys.exit(f"bench.py --gpus {world}: only {ndev} HIP device(s) visible; one rank per GPU is required "
-                 f"(--share-device exists for the 1-GPU test box only)")
+        if rank == 0:
+            print(json.dumps({"error": f"bench.py --gpus {world}: only {ndev} HIP device(s) visible; one rank per GPU is required "
+                                       f"(--share-device exists for the 1-GPU test box only)",
+                              "metric": "sample-votes/sec (problems x samples)", "value": None, "n_gpus": world,
+                              "hip_devices_visible": ndev}), flush=True)
+        sys.exit(2)
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -249,6 +370,7 @@ def main():
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             rccl_ranks = dist.get_world_size()
+            assert rccl_ranks == world, f"RCCL communicator has {rccl_ranks} ranks, expected {world}"
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
@@ -270,19 +392,31 @@ def main():
     eng.set_tuning(args.copies, args.threads, args.wg_per_cu, args.unroll)
 
     # ---- resident inputs: `resident` distinct chunks, generated on device ------------------------
-    R = max(1, min(args.resident, args.steps + args.warmup)) if args.workload == "c3" else args.resident
+    # c3 default: as many DISTINCT chunks of C3's 8 as free HBM holds (7 of 41.94 GB on a 288 GB part; the 8th would need
+    # 335.5 GB), never more than the run has steps; an explicit --resident is honoured as far as memory allows
+    want_R = args.resident if args.resident > 0 else (8 if args.workload == "c3" else 1)
+    R = max(1, min(want_R, args.steps + args.warmup)) if args.workload == "c3" else max(1, want_R)
     chunk_bytes = Pc * B * N * 4 * (2 if args.tokens else 1)
     free_b, _total_b = torch.cuda.mem_get_info(dev)
-    while R > 1 and R * chunk_bytes > 0.85 * free_b:
+    usable = (free_b // (world if args.share_device else 1)) - (3 << 30)        # headroom: cell table, counters, library scratch, RCCL
+    while R > 1 and R * chunk_bytes > usable:
         R -= 1
-    if chunk_bytes > 0.85 * free_b:
+    if chunk_bytes > usable:
         sys.exit(f"one chunk ({chunk_bytes / 1e9:.1f} GB) does not fit in free HBM ({free_b / 1e9:.1f} GB)")
     slots = []
     for s in range(R):
         # global problem index of this rank's block: chunk s of a weak-scaling run, or the rank's shard of C5
         p_off = shard_bounds(args.problems, rank, world)[0] if c5 else (s * world + rank) * Pc
-        ans = torch.empty((Pc, B, N), dtype=torch.int32, device=dev)
-        tok = torch.empty((Pc, B, N), dtype=torch.int32, device=dev) if args.tokens else None
+        try:
+            ans = torch.empty((Pc, B, N), dtype=torch.int32, device=dev)
+            tok = torch.empty((Pc, B, N), dtype=torch.int32, device=dev) if args.tokens else None
+        except torch.OutOfMemoryError:
+            if not slots:
+                raise
+            ans = tok = None
+            torch.cuda.empty_cache()
+            R = len(slots)                      # fewer distinct chunks than planned: reported as chunks_distinct
+            break
         tr = torch.empty((Pc,), dtype=torch.int32, device=dev)
         eng.synth_fill_device(ans, tok, tr, P=Pc, B=B, N=N, seed=args.seed, dist=args.dist, p_offset=p_off)
         slots.append((ans, tok, tr, p_off))
@@ -386,6 +520,7 @@ def main():
     last_slot = slots[(args.warmup + args.steps - 1) % R] if args.steps > 0 else slots[0]
     last_cells = cells_from_torch(cells) if rank == 0 else None
 
+    slots_span = f"{min(sl[3] for sl in slots)}..{max(sl[3] for sl in slots) + Pc - 1}" + (" interleaved over the ranks" if world > 1 else "")
     votes_per_step_per_gpu = Pc * B * N
     total_votes = (args.problems * B * N if c5 else votes_per_step_per_gpu * world) * args.steps
     value = total_votes / elapsed
@@ -394,6 +529,11 @@ def main():
     ev = committed_evidence() if (Pc, B, N, args.tokens, args.workload) == (1250, 8, 1 << 20, False, "c3") else {}
     # the read ceiling of THIS box, measured now (rank 0 of a single-GPU default run; the probe allocates its own 41.9 GB)
     if rank == 0 and world == 1 and ev and not args.no_read_ceiling:
+        last_off_kept = last_slot[3]
+        slots.clear()                           # the probe allocates its own 41.9 GB: hand the resident chunks back first
+        last_slot = (None, None, None, last_off_kept)
+        ans = tok = tr = None                   # (the allocation loop's last references)
+        torch.cuda.empty_cache()
         live = measure_read_ceiling(chunk_bytes // (4 << 20))
         if live:
             ev["read_ceiling_gbs"] = live
@@ -428,6 +568,9 @@ def main():
             "workload": workload,
             "distribution": DISTS[args.dist],
             "resident_chunks": R,
+            "chunks_distinct": R,
+            "chunks_note": (f"{R} distinct 1250-problem chunks of C3's 8 are resident and cycled (global problems "
+                            f"{slots_span}); the 8th does not fit: 8 x 41.94 GB = 335.5 GB > HBM") if args.workload == "c3" else None,
             "tokens_stream": bool(args.tokens),
             "parallelism": f"problems sharded over {world} GPU(s), one int64 all-reduce of {counters_size(B)} counters per step",
             "seed": args.seed,
@@ -436,6 +579,9 @@ def main():
             "collectives_forced_on_one_rank": bool(force),
             "rccl_ranks": rccl_ranks,
             "hip_devices_visible": ndev,
+            "ranks_started_by": ("bench.py itself (torch.distributed.run child)" if os.environ.get("SCV_BENCH_SPAWNED") == "1"
+                                 else ("external launcher" if "RANK" in os.environ else None)),
+            "hsa_enable_ipc_mode_legacy": dict(HSA_IPC_NOTE),
             "devices_shared_by_ranks": bool(args.share_device),
         },
         "roofline": {

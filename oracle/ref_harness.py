@@ -1,11 +1,15 @@
 """TEST INFRASTRUCTURE -- run the UNMODIFIED reference (/root/reference/o1.py) under stub modules.
 
-Works only where /root/reference exists (the build container).  Used by
-tests/golden/make_golden.py to generate the committed fixtures and by the optional
-``tests/test_reference_live.py`` (skipped when the reference is absent).  Recipe: SURVEY.md 8c.
+Where /root/reference exists (the build container) the reference is imported from there.  On the GPU
+box it does not exist: there the harness imports the sourceless bytecode ``oracle/make_ref.py`` compiled
+from it into the git-ignored ``oracle/_ref/`` (the same code objects CPython would execute from the
+sources).  Used by tests/golden/make_golden.py to generate the committed fixtures, by
+``tests/test_reference_live.py`` (CPU: oracle adapter as the engine; ``-m gpu``: the HIP engine) and by
+``bench.py``'s ``cpu_baseline.reference_loop``.  Recipe: SURVEY.md 8c.
 
-Nothing of the reference is copied: O1_MODEL / PROMPT are read out of o1.py at run time (ast)
-because they are part of the cache-key scheme (o1.py:85-88).
+No reference source is copied into the repository: O1_MODEL / PROMPT are read out of o1.py at run time
+(ast) -- or out of oracle/_ref/manifest.json, where the build recorded them -- because they are part of
+the cache-key scheme (o1.py:85-88).
 """
 from __future__ import annotations
 
@@ -19,16 +23,37 @@ import sys
 import tempfile
 import types
 
-REFERENCE_ROOT = "/root/reference"
+REFERENCE_SOURCES = "/root/reference"
+
+
+def _sources_present() -> bool:
+    return os.path.isfile(os.path.join(REFERENCE_SOURCES, "o1.py"))
+
+
+def reference_root() -> str | None:
+    """Directory ``import o1`` is resolved from: the read-only sources, else the compiled copy in oracle/_ref."""
+    if _sources_present():
+        return REFERENCE_SOURCES
+    from oracle import make_ref
+    return make_ref.REF_OUT if make_ref.available() else None
+
+
+def reference_kind() -> str | None:
+    """"sources" | "bytecode" | None -- for the result files that quote a reference timing."""
+    root = reference_root()
+    return None if root is None else ("sources" if root == REFERENCE_SOURCES else "bytecode")
 
 
 def reference_available() -> bool:
-    return os.path.isfile(os.path.join(REFERENCE_ROOT, "o1.py"))
+    return reference_root() is not None
 
 
 def reference_constants() -> dict:
     """O1_MODEL, PROMPT, RESPONSE_CACHE_FILENAME as assigned at o1.py:17,20,21-30."""
-    with open(os.path.join(REFERENCE_ROOT, "o1.py")) as f:
+    if not _sources_present():
+        from oracle import make_ref
+        return dict(make_ref.manifest()["constants"])
+    with open(os.path.join(REFERENCE_SOURCES, "o1.py")) as f:
         tree = ast.parse(f.read())
     out = {}
     for node in tree.body:
@@ -115,7 +140,8 @@ def imported_reference(dataset, import_cache):
     """Import the unmodified o1.py (which RUNS the whole pipeline at import, o1.py:312-315) in a
     scratch cwd holding helpers/response_cache.json = import_cache.  Yields (module, workdir);
     workdir/helpers/results_log_*.json are the files the import-time run wrote."""
-    assert reference_available(), "/root/reference is not present (GPU box?)"
+    root = reference_root()
+    assert root is not None, "neither /root/reference nor oracle/_ref (python -m oracle.make_ref) is present"
     import logging
     old_cwd = os.getcwd()
     old_env = {k: os.environ.get(k) for k in ("OPENAI_API_KEY", "MPLBACKEND")}
@@ -127,7 +153,7 @@ def imported_reference(dataset, import_cache):
         json.dump(import_cache, f)
     os.environ["OPENAI_API_KEY"] = "stub"
     os.environ["MPLBACKEND"] = "Agg"
-    sys.path.insert(0, REFERENCE_ROOT)
+    sys.path.insert(0, root)
     for m in [k for k in sys.modules if k == "o1" or k == "helpers" or k.startswith("helpers.")]:
         del sys.modules[m]
     os.chdir(workdir)
@@ -141,7 +167,7 @@ def imported_reference(dataset, import_cache):
     finally:
         logging.getLogger().setLevel(root_level)
         os.chdir(old_cwd)
-        sys.path.remove(REFERENCE_ROOT)
+        sys.path.remove(root)
         for m in [k for k in sys.modules if k == "o1" or k == "helpers" or k.startswith("helpers.")]:
             del sys.modules[m]
         for k, v in saved_mods.items():

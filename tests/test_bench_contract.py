@@ -23,9 +23,12 @@ def _last_json(text):
     return json.loads(lines[0])
 
 
-def _bench(extra, ranks=1, timeout=900):
-    if ranks == 1:
+def _bench(extra, ranks=1, timeout=900, self_spawn=False, env=None):
+    if ranks == 1 and not self_spawn:
         cmd = [sys.executable, os.path.join(REPO, "bench.py"), *extra]
+    elif self_spawn:
+        # the driver's own form: plain `python bench.py --gpus N ...`, no launcher -- bench.py starts its ranks itself
+        cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(ranks), *extra]
     else:
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
@@ -33,7 +36,7 @@ def _bench(extra, ranks=1, timeout=900):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(ranks), *extra,
                "--backend", "gloo", "--share-device"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=REPO)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=REPO, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     return _last_json(out.stdout)
 
@@ -50,8 +53,13 @@ def test_single_gpu_line_has_the_contract_fields():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
     assert r["traffic"] is None and r["traffic_measured_in_this_run"] is None     # not the default workload: nothing injected
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c and "statistics.multimode" in c["what"]
-    assert c["all_cores"]["value"] > 0 and c["c_port"]["value"] > c["value"]      # C port beats the Python loop
+    # value = the UNMODIFIED reference loop (o1.run_experiments from oracle/_ref), timed on this box's host
+    assert c["kind"] == "reference" and c["cores"] == 1 and c["value"] > 0 and "sample" in c and "o1.run_experiments" in c["what"]
+    assert [r["N"] for r in c["reference_loop"]] == [256, 2048] and all(r["accuracy_matches_restatement"] for r in c["reference_loop"])
+    a = c["arithmetic"]
+    assert a["kind"] == "port" and "statistics.multimode" in a["what"] and a["value"] > c["value"]   # without pools and key lookups
+    assert a["all_cores"]["value"] > 0 and c["c_port"]["value"] > a["value"]      # C port beats the Python loop
+    assert d["config"]["chunks_distinct"] == d["config"]["resident_chunks"] == 4  # min(8 chunks of C3, steps + warmup)
     assert d["parity"].startswith("bit-exact") and "statistics.multimode" in d["parity"] and "bit-exact" in d["metric"]
     assert abs(d["value"] - 48 * 8 * (1 << 16) * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-9
 
@@ -123,3 +131,44 @@ def test_c2_steps_captured_in_one_graph_launch():
     assert d["config"]["launch"] == "hipGraph replay (4 step(s) per graph launch)"
     assert d["parity"].startswith("bit-exact: 30 problems x 8 budgets x 131072 votes of the last TIMED chunk")
     assert abs(d["value"] - 30 * 8 * (1 << 17) * 12 / (d["ms_per_step"] * 12e-3)) / d["value"] < 1e-9
+
+
+def test_plain_python_bench_gpus_2_starts_its_own_ranks(tmp_path):
+    """The driver's multi-GPU form is the single-GPU command with another number: `python bench.py --gpus N`, no
+    torch.distributed.run in front.  bench.py then starts N ranks itself (the reference's run_experiments fans out
+    itself too, o1.py:232-240) and relays exactly one JSON line.  Two self-started ranks (gloo, sharing cuda:0) must
+    give the 1-rank run's counters word for word."""
+    common = ["--samples", str(1 << 15), "--steps", "3", "--warmup", "1", "--resident", "4"]
+    two = _bench(["--problems-per-step", "48", *common, "--backend", "gloo", "--share-device", "--dump", str(tmp_path / "two.npz")],
+                 ranks=2, self_spawn=True)
+    one = _bench(["--problems-per-step", "96", *common, "--dump", str(tmp_path / "one.npz"), "--no-cpu-baseline"])
+    assert two["n_gpus"] == 2 and two["steps"] == 3 and two["config"]["ranks_started_by"].startswith("bench.py itself")
+    assert two["config"]["backend"] == "gloo" and two["config"]["rccl_ranks"] is None
+    a, b = np.load(tmp_path / "two.npz")["counters"], np.load(tmp_path / "one.npz")["counters"]
+    assert a.shape == (8 * 1027,) and np.array_equal(a, b) and a.sum() > 0
+    assert two["accuracy_last_step"] == one["accuracy_last_step"]
+
+
+def test_plain_python_bench_runs_rccl_on_a_self_started_rank(tmp_path):
+    """Same entry, backend nccl: with SCV_FORCE_COLLECTIVES=1 the self-started (single) rank builds a real RCCL
+    communicator and every collective of the N > 1 path executes; rccl_ranks equals the world size (asserted inside
+    bench.py too) and the counters equal the plain run's."""
+    c3 = ["--problems-per-step", "48", "--samples", str(1 << 15), "--steps", "3", "--warmup", "1", "--resident", "4", "--no-cpu-baseline"]
+    d = _bench([*c3, "--backend", "nccl", "--dump", str(tmp_path / "rccl.npz")], ranks=1, self_spawn=True,
+               env=dict(os.environ, SCV_FORCE_COLLECTIVES="1"))
+    assert d["config"]["rccl_ranks"] == 1 == d["n_gpus"] and d["config"]["collectives_forced_on_one_rank"] is True
+    assert d["config"]["ranks_started_by"].startswith("bench.py itself")
+    assert d["config"]["hsa_enable_ipc_mode_legacy"]["source"]                   # inherited, probed, or left unset: always said
+    plain = _bench([*c3, "--dump", str(tmp_path / "plain.npz")])
+    assert np.array_equal(np.load(tmp_path / "rccl.npz")["counters"], np.load(tmp_path / "plain.npz")["counters"])
+
+
+def test_more_ranks_than_gpus_is_one_json_error_line():
+    """`python bench.py --gpus 8` on a 1-GPU box: exit status != 0 and ONE JSON line that says why."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert out.returncode != 0
+    d = _last_json(out.stdout)
+    assert "error" in d and f"--gpus {n}" in d["error"] and d["n_gpus"] == n and d["value"] is None

@@ -1,7 +1,13 @@
-"""Integration against the LIVE, unmodified reference (build container only; skipped on the GPU
-box where /root/reference does not exist).  Installs the drop-in into the imported o1 module (with
-the oracle adapter as the engine -- CPU) and checks the reference's own drivers + plot/log writers
-produce byte-identical results_log_*.json."""
+"""Integration against the LIVE, unmodified reference.  Installs the drop-in into the imported o1 module
+and checks that the reference's own drivers + plot/log writers produce byte-identical results_log_*.json
+and pixel-identical PNGs.
+
+* CPU tests (build container): the oracle adapter is the engine; the reference is imported from
+  /root/reference, and once more from the compiled copy in oracle/_ref (oracle/make_ref.py) to show that
+  both are the same program.
+* ``-m gpu`` tests (GPU box, where /root/reference does not exist): the HIP ``Engine`` is the engine and the
+  reference is the bytecode in oracle/_ref that ``__graft_entry__.build()`` compiled from the unmodified
+  sources -- the unmodified reference and the HIP engine in ONE process.  Missing bytecode FAILS there."""
 import os
 import random
 
@@ -9,7 +15,7 @@ import pytest
 
 from oracle import ref_harness as rh
 
-pytestmark = pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present")
+needs_reference = pytest.mark.skipif(not rh.reference_available(), reason="neither /root/reference nor oracle/_ref present")
 
 
 PNGS = ("accuracy_vs_tokens_no_shade_regions.png", "token_limit_vs_actual.png", "just_ask_nicely_tokens.png")
@@ -38,8 +44,7 @@ def _pipeline_inputs(seed=99):
     return truths, samples
 
 
-@pytest.mark.parametrize("batched", [True, False])
-def test_installed_dropin_reproduces_reference_logs(batched, oracle_engine):
+def _check_installed_dropin_reproduces_reference_logs(batched, engine):
     from o1_inference_scaling_laws_amd import o1_dropin
     consts = rh.reference_constants()
     truths, samples = _pipeline_inputs()
@@ -56,7 +61,7 @@ def test_installed_dropin_reproduces_reference_logs(batched, oracle_engine):
         for n in PNGS:
             os.remove(os.path.join(workdir, "graphs", n))
         import contextlib, io
-        o1_dropin.install(o1, engine=oracle_engine, batched=batched)
+        o1_dropin.install(o1, engine=engine, batched=batched)
         with contextlib.redirect_stdout(io.StringIO()):
             o1.run_majority_vote_inference_experiments(ds, cache)
             o1.run_just_ask_nicely_experiments(ds, cache)
@@ -66,7 +71,7 @@ def test_installed_dropin_reproduces_reference_logs(batched, oracle_engine):
             assert _image_hash(os.path.join(workdir, "graphs", n)) == h, f"{n}: rendered pixels differ"
 
 
-def test_shade_regions_and_full_range_records_match(oracle_engine):
+def _check_shade_regions_and_full_range_records_match(engine):
     """The reference's non-default driver modes: shade_regions=True (o1.py:266-267: budgets up to 2^18,
     N up to 128 from the 2048 pool) and run_full_range=True (o1.py:298-299: 2^0..2^19, N = 1).  The
     records each driver hands to its plot function are captured for the unmodified module and for the
@@ -97,7 +102,7 @@ def test_shade_regions_and_full_range_records_match(oracle_engine):
             o1.run_just_ask_nicely_experiments(ds, cache, run_full_range=True)
         want = dict(captured)
         captured.clear()
-        o1_dropin.install(o1, engine=oracle_engine, batched=True)
+        o1_dropin.install(o1, engine=engine, batched=True)
         o1.run_majority_vote_inference_experiments(ds, cache, shade_regions=True)
         o1.run_just_ask_nicely_experiments(ds, cache, run_full_range=True)
         got = dict(captured)
@@ -112,3 +117,71 @@ def test_shade_regions_and_full_range_records_match(oracle_engine):
             assert abs(g["accuracy"] - w["accuracy"]) < 1e-12          # o1.py:239 accumulates in completion order
             assert repr(float(g["avg_tokens_used"])) == repr(float(w["avg_tokens_used"]))
             assert type(g["avg_tokens_used"]) is type(w["avg_tokens_used"])
+
+
+# ---- CPU: oracle adapter as the engine ------------------------------------------------------------------------
+
+@needs_reference
+@pytest.mark.parametrize("batched", [True, False])
+def test_installed_dropin_reproduces_reference_logs(batched, oracle_engine):
+    _check_installed_dropin_reproduces_reference_logs(batched, oracle_engine)
+
+
+@needs_reference
+def test_shade_regions_and_full_range_records_match(oracle_engine):
+    _check_shade_regions_and_full_range_records_match(oracle_engine)
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/o1.py"), reason="/root/reference not present")
+def test_compiled_reference_in_oracle_ref_is_the_same_program(oracle_engine, monkeypatch):
+    """oracle/make_ref.py: the bytecode under oracle/_ref is built from the sources whose hashes its manifest
+    records, carries the same constants, and -- imported sourceless, as on the GPU box -- reproduces the logs and
+    PNGs the drop-in is compared with."""
+    import hashlib
+    from oracle import make_ref
+    assert make_ref.build() == make_ref.REF_OUT and make_ref.available()
+    m = make_ref.manifest()
+    for f, h in m["sha256"].items():
+        assert hashlib.sha256(open(os.path.join("/root/reference", f), "rb").read()).hexdigest() == h
+    assert m["constants"] == rh.reference_constants()
+    assert not any(n.endswith(".py") for _, _, names in os.walk(make_ref.REF_OUT) for n in names), "sources must not be copied"
+    monkeypatch.setattr(rh, "REFERENCE_SOURCES", "/nonexistent")
+    assert rh.reference_kind() == "bytecode" and rh.reference_constants() == m["constants"]
+    _check_installed_dropin_reproduces_reference_logs(True, oracle_engine)
+
+
+# ---- GPU: the unmodified reference and the HIP engine in one process -------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batched", [True, False])
+def test_gpu_installed_dropin_reproduces_reference_logs(batched, hip_engine):
+    assert rh.reference_available(), "oracle/_ref is missing on the GPU box: __graft_entry__.build() must run where /root/reference exists"
+    _check_installed_dropin_reproduces_reference_logs(batched, hip_engine)
+
+
+@pytest.mark.gpu
+def test_gpu_shade_regions_and_full_range_records_match(hip_engine):
+    assert rh.reference_available(), "oracle/_ref is missing on the GPU box"
+    _check_shade_regions_and_full_range_records_match(hip_engine)
+
+
+@pytest.mark.gpu
+def test_gpu_default_engine_installed_without_arguments(hip_engine):
+    """INTEGRATION.md section 1 verbatim: ``install(o1)`` with no engine argument creates the process-wide HIP engine;
+    the reference's own ``run_experiments`` call sites (o1.py:277, :302) then reach the GPU."""
+    from o1_inference_scaling_laws_amd import o1_dropin
+    assert rh.reference_available()
+    consts = rh.reference_constants()
+    truths, samples = _pipeline_inputs(seed=7)
+    ds = rh.make_dataset([str(t) for t in truths])
+    cache = rh.build_cache(consts, ds, samples)
+    with rh.imported_reference(ds, cache) as (o1, _workdir):
+        want = [o1.run_experiments(ds, cache, 2048, n) for n in (1, 2, 4, 8)]
+        want_one = o1.process_single_example(ds[3], 2048, cache, 8)
+        cfg = o1_dropin.install(o1)
+        assert type(cfg.get_engine()).__name__ == "Engine"
+        got = [o1.run_experiments(ds, cache, 2048, n) for n in (1, 2, 4, 8)]
+        got_one = o1.process_single_example(ds[3], 2048, cache, 8)
+    for (ga, gt), (wa, wt) in zip(got, want):
+        assert ga == wa and repr(gt) == repr(wt) and type(gt) is type(wt)     # dyadic tie sizes: accuracy is exact
+    assert got_one == want_one and type(got_one[0]) is type(want_one[0])
