@@ -421,7 +421,7 @@ def main():
         eng.synth_fill_device(ans, tok, tr, P=Pc, B=B, N=N, seed=args.seed, dist=args.dist, p_offset=p_off)
         slots.append((ans, tok, tr, p_off))
     # two counter buffers: the all-reduce of step i (RCCL's own stream) overlaps the kernel of step i+1
-    pipe = CounterPipeline([torch.zeros(counters_size(B), dtype=torch.int64, device=dev) for _ in range(2)])
+    pipe = CounterPipeline([torch.zeros(counters_size(B) + (1 if c5 else 0), dtype=torch.int64, device=dev) for _ in range(2)])   # c5: + the collective error word
     cells = torch.empty((Pc, B, 16), dtype=torch.uint8, device=dev)
     ctok = torch.empty((Pc, B), dtype=torch.int64, device=dev) if args.tokens else None
     eng.sync()
@@ -623,7 +623,7 @@ def main():
     # ---- C5 epilogue (outside the timed region): gather the bootstrap slices, host floats, oracle check ----------
     if c5:
         d = c5_state["last"]
-        boot_all = passk.gather_bootstrap(d, args.resamples)
+        boot_all = passk.gather_bootstrap(d, args.resamples, engine=eng)      # raises on every rank if any rank's device error word is set
         if rank == 0:
             all_cells = cells_from_torch(d.cells)
             t1 = time.perf_counter()

@@ -124,7 +124,9 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  * several-lanes-per-cell kernel), "overwrite_counters" (default 0; 1: the per-budget counters are OVERWRITTEN, not accumulated
  * into -- with few long cells the streaming kernel's last workgroup does it and the call is one launch, otherwise a memset
  * precedes the launch), "ticket_merge" (default 0; 1: split-N cells are merged inside the launch by the last-arriving segment
- * instead of by a merge kernel -- measured 0-9 % slower). */
+ * instead of by a merge kernel -- measured 0-9 % slower), "boot_fused" (default 1: scv_aggregate_bootstrap_i32 runs the bootstrap
+ * inside the vote launch when the shape allows it), "boot_cooperative" (default 1: that launch is a cooperative launch), "boot_spin_limit"
+ * (default 2^20: polls at the grid barrier before a workgroup gives up and leaves the bootstrap to scv_sync; tests set 1). */
 int scv_set_option(scv_ctx* ctx, const char* key, int64_t value);
 
 /*
@@ -185,8 +187,14 @@ int scv_bootstrap(scv_ctx* ctx, const scv_cell* cells, int64_t P, int32_t B,
  * allows it (whole-cell streaming kernel, the [P, B] code table fits the workgroup's LDS, the persistent grid is
  * resident at once) both run in ONE kernel launch: all workgroups meet at a grid barrier after their last cell and
  * then share the resamples.  Otherwise (or with option "boot_fused" = 0) the bootstrap kernel is queued behind the
- * vote kernel on the same stream.  cells_out and counts_out are required.  Asynchronous like every DEVICE-mode call;
- * a grid barrier that times out (the grid was not co-resident after all) is reported by scv_sync as an error.
+ * vote kernel on the same stream.  cells_out and counts_out are required.  Asynchronous like every DEVICE-mode call.
+ * Co-tenancy cannot make a valid call fail: the one-launch form is started with hipLaunchCooperativeKernel (the
+ * runtime starts it only when the whole grid is resident, whatever other streams, RCCL or other processes run; a
+ * refused cooperative launch becomes two launches; option "boot_cooperative" = 0 uses an ordinary launch, as does a
+ * call made while the stream is being captured into a hipGraph).  Under an ordinary launch a workgroup gives up at the
+ * barrier after "boot_spin_limit" polls; the vote outputs are complete by then, and the next scv_sync resets the
+ * barrier, runs scv_bootstrap over cells_out as a separate launch and returns its status (stat "boot_recovered").
+ * Until that scv_sync counts_out is undefined -- as after any asynchronous call that has not been synchronised.
  */
 int scv_aggregate_bootstrap_i32(scv_ctx* ctx,
                                 const int32_t* answers, const int32_t* tokens,
@@ -216,6 +224,16 @@ int scv_synth_fill_i32(scv_ctx* ctx, int32_t* answers, int32_t* tokens, int32_t*
                        int64_t P, int32_t B, int64_t N, int64_t p_offset,
                        uint64_t seed, int dist);
 
+/*
+ * The device error word (bit 0: a vote outside bins 0..1023, bit 1: a drawn bootstrap hit had n_modes >= M), widened to
+ * int64 and written to *dst_device IN STREAM ORDER behind everything queued so far; it is not cleared (scv_sync does
+ * that).  For multi-GPU callers: the reference sums scores over problems in one process (o1.py:236-245); when the
+ * problems are sharded over ranks, the word goes into one extra element behind the packed counters so that the ONE
+ * all-reduce of the evaluation also tells every rank whether any rank's counters are invalid -- no host round trip,
+ * no rank left waiting in a collective (o1_inference_scaling_laws_amd/passk.py, dist.py).
+ */
+int scv_export_error_word(scv_ctx* ctx, int64_t* dst_device);
+
 /* Duration of the most recent aggregation kernel launch on this ctx, from hipEvents recorded on
  * the launch stream (needs SCV_FLAG_TIMING).  Blocks until that launch has finished. */
 int scv_last_kernel_ns(scv_ctx* ctx, uint64_t* ns_out);
@@ -233,7 +251,8 @@ int scv_host_alloc(void** out, size_t bytes);
 int scv_host_free(void* p);
 
 /* How often this ctx took a single-launch form (monotonic counters, for tests and bench lines): "boot_fused" /
- * "boot_separate" (scv_aggregate_bootstrap_i32: one launch / two), "overwrite_fused" (counters overwritten by the
+ * "boot_separate" (scv_aggregate_bootstrap_i32: one launch / two), "boot_cooperative" (one-launch forms started as cooperative
+ * launches), "boot_recovered" (grid-barrier timeouts repaired by scv_sync with a separate bootstrap launch), "overwrite_fused" (counters overwritten by the
  * vote kernel's last workgroup), "merge_in_launch" (split-N merged by the last-arriving segment), "reg_lds_counters"
  * (register-resident launches that produced their counters themselves), "prefix_cells" / "prefix_lane" (prefix calls served by the cell
  * kernels / by the one-lane-per-problem kernel). */

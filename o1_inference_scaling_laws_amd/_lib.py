@@ -52,6 +52,7 @@ def load():
     L.scv_bootstrap.argtypes = [p, p, i64, i32, i32, i32, u64, i32, C.c_int, p]
     L.scv_aggregate_bootstrap_i32.argtypes = [p, p, p, p, p, i64, i32, i64, p, p, p, p, p, i32, i32, u64, i32, p]
     L.scv_synth_fill_i32.argtypes = [p, p, p, p, i64, i32, i64, i64, u64, C.c_int]
+    L.scv_export_error_word.argtypes = [p, p]
     L.scv_last_kernel_ns.argtypes = [p, C.POINTER(u64)]
     L.scv_drain_kernel_ns.argtypes = [p, C.POINTER(u64), C.POINTER(u64)]
     L.scv_get_stat.argtypes = [p, C.c_char_p, C.POINTER(i64)]
@@ -65,7 +66,7 @@ def load():
     L.scv_version.restype = C.c_char_p
     for name in ("scv_create", "scv_destroy", "scv_set_stream", "scv_sync", "scv_set_tuning", "scv_set_option", "scv_aggregate_i32", "scv_aggregate_prefix_i32",
                  "scv_bootstrap", "scv_aggregate_bootstrap_i32", "scv_synth_fill_i32", "scv_last_kernel_ns", "scv_drain_kernel_ns",
-                 "scv_device_count", "scv_device_info", "scv_host_alloc", "scv_host_free", "scv_get_stat"):
+                 "scv_device_count", "scv_device_info", "scv_host_alloc", "scv_host_free", "scv_get_stat", "scv_export_error_word"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

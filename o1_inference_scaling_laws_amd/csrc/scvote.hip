@@ -151,6 +151,11 @@ struct scv_ctx {
     int64_t stat_boot_fused = 0, stat_boot_separate = 0, stat_overwrite_fused = 0, stat_merge_in_launch = 0, stat_reg_lds_counters = 0, stat_prefix_cells = 0, stat_prefix_lane = 0;   // scv_get_stat
     int boot_fused = 1;      // scv_aggregate_bootstrap_i32: run the bootstrap inside the vote launch when the shape allows it
     struct BootReq { int32_t r0, r1, M; uint64_t seed; int64_t* out; bool fused; }* boot_req = nullptr;   // set for the duration of one call
+    // the last fused request, kept so that a grid-barrier timeout can be repaired at scv_sync by a separate bootstrap launch
+    struct BootLast { const scv_cell* cells = nullptr; int64_t P = 0; int32_t B = 0, r0 = 0, r1 = 0, M = 0; uint64_t seed = 0; int64_t* out = nullptr; bool valid = false; } boot_last;
+    int64_t stat_boot_recovered = 0, stat_boot_cooperative = 0;
+    int boot_spin_limit = 1 << 20;   // polls (x s_sleep 8) a workgroup waits at the grid barrier before giving up (option, tests force 1)
+    int boot_cooperative = 1;        // fused form is launched with hipLaunchCooperativeKernel (0: ordinary launch; A/B + tests)
     int boot_lds = 1;        // bootstrap: LDS-resident code table when it fits (0: always the global-gather kernel)
     int reg_km = 1;          // reg path: batches in flight per wave = km x 4 KiB
     int prefix_stage = 1;    // scv_lane_prefix: snapshots staged in LDS when they fit (0: reductions at every boundary)
@@ -321,13 +326,23 @@ int ensure_cells(scv_ctx* ctx, size_t bytes) {
 }
 
 // Arrival counters: zero when allocated, and every counter is reset by the workgroup that completes it, so the
-// buffer is all-zero again whenever no launch is in flight.
+// buffer is all-zero again whenever no launch is in flight.  scv_create allocates kTicketWordsAtCreate words (zeroed
+// synchronously), which covers the fixed-size users (overwrite mode, fused bootstrap: 4 words) -- those never allocate
+// on the launch path, so they are legal inside hipGraph capture and independent of later scv_set_stream calls.  Only
+// split-N cells merged inside the launch (option "ticket_merge") can outgrow it; growing synchronises, frees and
+// allocates, which is refused with a clear error while the stream is being captured.
+constexpr size_t kTicketWordsAtCreate = 4096;
 int ensure_tickets(scv_ctx* ctx, size_t words) {
     if (words <= ctx->d_tickets_words) return SCV_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone)
+        return fail(SCV_ERR_ARG, "ticket buffer must grow to %zu words while the stream is being captured: run this shape once outside the capture first", words);
     if (ctx->d_tickets) { SCV_HIP(hipStreamSynchronize(ctx->stream)); SCV_HIP(hipFree(ctx->d_tickets)); ctx->d_tickets = nullptr; ctx->d_tickets_words = 0; }
     words = (words + 1023) & ~(size_t)1023;
     SCV_HIP(hipMalloc(&ctx->d_tickets, words * sizeof(uint32_t)));
-    SCV_HIP(hipMemsetAsync(ctx->d_tickets, 0, words * sizeof(uint32_t), ctx->stream));
+    SCV_HIP(hipMemset(ctx->d_tickets, 0, words * sizeof(uint32_t)));      // synchronous: ordered before anything on any stream
+    SCV_HIP(hipDeviceSynchronize());
     ctx->d_tickets_words = words;
     return SCV_OK;
 }
@@ -381,7 +396,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.tok_skew = ctx->tok_skew;
     a.sorted = ctx->sorted;
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0;
-    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
+    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
 
     // per-budget counters: fused per-cell atomics for few cells, a separate reduction of the cell
@@ -428,7 +443,6 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     if (ctx->overwrite_counters && want_counters) {
         if (stream_path && ncells <= 8192 && B <= 64) {
             overwrite_fused = true;
-            ctx->stat_overwrite_fused += 1;
             use_reduce = false;
             if (int rc = need_cell_scratch()) return rc;
             if (int rc = ensure_tickets(ctx, 4)) return rc;
@@ -670,6 +684,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         // split cells finished by the merge KERNEL: the main launch's last workgroup would read an unfinished cell
         // table.  Overwrite = memset node + accumulate here.
         a.overwrite = 0;
+        overwrite_fused = false;
         a.ow_tie = a.ow_tok = a.ow_truth = nullptr;
         a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
         a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
@@ -679,6 +694,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         if (truth_sum) SCV_HIP(hipMemsetAsync(truth_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
     }
     if (a.overwrite || a.ticket_merge) a.tickets = static_cast<uint32_t*>(ctx->d_tickets);   // (the buffer may have grown)
+    if (overwrite_fused) ctx->stat_overwrite_fused += 1;                                     // counted once the form is final
     const int64_t nitems = ncells * S;
     int64_t grid = slots;
     if (ctx->grid_override > 0) grid = ctx->grid_override;
@@ -704,16 +720,43 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             if (int rc = ensure_tickets(ctx, 4)) return rc;
             a.boot = 1;
             a.boot_r0 = rq.r0; a.boot_r1 = rq.r1; a.boot_M = rq.M; a.boot_seed = rq.seed;
+            a.boot_spins = (uint32_t)(ctx->boot_spin_limit > 0 ? ctx->boot_spin_limit : 1);
             a.boot_out = reinterpret_cast<unsigned long long*>(rq.out);
             a.tickets = static_cast<uint32_t*>(ctx->d_tickets);
-            ctx->boot_req->fused = true;
-            ctx->stat_boot_fused += 1;
         }
     }
     KernelFn fn = pick_kernel(copies, threads, unroll, tok, a.overwrite != 0 || a.ticket_merge != 0 || a.boot != 0);
     SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)threads), lds, ctx->stream, a);
+    bool launched = false;
+    if (a.boot) {
+        // The workgroups meet at a grid barrier: ask the runtime for a COOPERATIVE launch, which only starts when the
+        // whole grid can be resident at once whatever else (other streams, RCCL's kernels, another process) is on the
+        // device.  Not available while the stream is being captured into a graph: there the ordinary launch is used and
+        // the bounded spin + the repair in scv_sync cover a grid that turned out not to be co-resident.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        if (ctx->boot_cooperative && cap == hipStreamCaptureStatusNone) {
+            void* kargs[] = {const_cast<scv::AggArgs*>(&a)};
+            const hipError_t ce = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3((unsigned)grid), dim3((unsigned)threads), kargs, (unsigned)lds, ctx->stream);
+            if (ce == hipSuccess) { launched = true; ctx->stat_boot_cooperative += 1; }
+            else {
+                // refused (grid too large for a cooperative launch right now, or no support): two kernels instead
+                (void)hipGetLastError();
+                a.boot = 0; a.boot_out = nullptr;
+                fn = pick_kernel(copies, threads, unroll, tok, a.overwrite != 0 || a.ticket_merge != 0);
+                SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+        }
+        if (a.boot) {
+            const scv_ctx::BootReq& rq = *ctx->boot_req;
+            ctx->boot_req->fused = true;
+            ctx->stat_boot_fused += 1;
+            ctx->boot_last.cells = a.cells; ctx->boot_last.P = P; ctx->boot_last.B = B; ctx->boot_last.r0 = rq.r0; ctx->boot_last.r1 = rq.r1;
+            ctx->boot_last.M = rq.M; ctx->boot_last.seed = rq.seed; ctx->boot_last.out = rq.out; ctx->boot_last.valid = true;
+        }
+    }
+    if (!launched) hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)threads), lds, ctx->stream, a);
     SCV_HIP(hipGetLastError());
     if (S > 1 && !merge_in_launch) {
         int64_t mgrid = ncells < (int64_t)ctx->num_cus * 8 ? ncells : (int64_t)ctx->num_cus * 8;
@@ -773,7 +816,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     a.err_flag = ctx->d_err;
     a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.prefetch = 0; a.tok_skew = ctx->tok_skew; a.sorted = 1;
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0;
-    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
+    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
     // pools of up to 64 samples: one lane per problem, every budget out of one pass (scv_lane_prefix); its counters
@@ -882,15 +925,33 @@ int fetch_err(scv_ctx* ctx, uint32_t* out, bool force = false) {
     return SCV_OK;
 }
 
+int recover_fused_bootstrap(scv_ctx* ctx, uint32_t* w);
+
 int check_err_word(scv_ctx* ctx, uint32_t w) {
+    if (w & 4u) {
+        // A workgroup of the fused vote + bootstrap launch gave up at the grid barrier (the grid was not co-resident:
+        // only possible for the non-cooperative form, e.g. inside a captured graph).  The vote part is complete -- every
+        // workgroup writes its cells and counters BEFORE it arrives at the barrier -- so the evaluation is repaired here:
+        // barrier state reset, the whole bootstrap re-run as a separate launch over the same cell table, bit cleared.
+        if (int rc = recover_fused_bootstrap(ctx, &w)) return rc;
+    }
     if ((w & 1u) && !(ctx->flags & SCV_FLAG_CLAMP_TO_INVALID_BIN))
         return fail(SCV_ERR_DOMAIN, "a vote outside bins 0..1023 was seen; results are invalid");
-    if (w & 4u) {
-        // the fused bootstrap's grid barrier timed out (the grid was not co-resident): its state is undefined now
-        if (ctx->d_tickets) (void)hipMemsetAsync(ctx->d_tickets, 0, 4 * sizeof(uint32_t), ctx->stream);
-        return fail(SCV_ERR_ARG, "fused bootstrap: grid barrier timed out; rerun with option boot_fused = 0");
-    }
     if (w & 2u) return fail(SCV_ERR_ARG, "bootstrap: a drawn hit had n_modes >= M");
+    return SCV_OK;
+}
+
+int recover_fused_bootstrap(scv_ctx* ctx, uint32_t* w) {
+    SCV_HIP(hipMemsetAsync(ctx->d_tickets, 0, 4 * sizeof(uint32_t), ctx->stream));      // arrivals / generation: a clean barrier again
+    if (!ctx->boot_last.valid)
+        return fail(SCV_ERR_ARG, "fused bootstrap: grid barrier timed out and the request is not known any more (graph replay of an older capture?); use option boot_fused = 0");
+    const scv_ctx::BootLast q = ctx->boot_last;
+    *w &= ~(4u | 2u);                            // bit 2 (class overflow) is re-derived by the re-run over the complete table
+    if (int rc = scv_bootstrap(ctx, q.cells, q.P, q.B, q.r0, q.r1, q.seed, q.M, SCV_MEM_DEVICE, q.out)) return rc;
+    uint32_t again = 0;
+    if (int rc = fetch_err(ctx, &again, true)) return rc;        // synchronises the stream
+    *w |= again & ~4u;
+    ctx->stat_boot_recovered += 1;
     return SCV_OK;
 }
 
@@ -935,8 +996,13 @@ int scv_create(scv_ctx** out, int device, uint32_t flags) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) { ctx->own_stream = true; e = hipMalloc((void**)&ctx->d_err, 256); }
     if (e == hipSuccess) e = hipMemset(ctx->d_err, 0, 256);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_tickets, kTicketWordsAtCreate * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(ctx->d_tickets, 0, kTicketWordsAtCreate * sizeof(uint32_t));
+    if (e == hipSuccess) { ctx->d_tickets_words = kTicketWordsAtCreate; e = hipDeviceSynchronize(); }
     if (e != hipSuccess) {
         int code = fail(-(int)e, "scv_create: %s", hipGetErrorString(e));
+        if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
+        if (ctx->d_err) (void)hipFree(ctx->d_err);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return code;
@@ -1036,6 +1102,8 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "tiny_lane")) ctx->tiny_lane = value != 0;
     else if (!strcmp(key, "tok_skew")) ctx->tok_skew = value != 0;
     else if (!strcmp(key, "boot_fused")) ctx->boot_fused = value != 0;
+    else if (!strcmp(key, "boot_cooperative")) ctx->boot_cooperative = value != 0;
+    else if (!strcmp(key, "boot_spin_limit")) { if (value < 1 || value > (1 << 30)) return fail(SCV_ERR_ARG, "boot_spin_limit out of range"); ctx->boot_spin_limit = (int)value; }
     else if (!strcmp(key, "overwrite_counters")) ctx->overwrite_counters = value != 0;
     else if (!strcmp(key, "ticket_merge")) ctx->ticket_merge = value != 0;
     else if (!strcmp(key, "reg_lds_counters")) ctx->reg_lds_counters = value != 0;
@@ -1430,6 +1498,14 @@ int scv_synth_fill_i32(scv_ctx* ctx, int32_t* answers, int32_t* tokens, int32_t*
     return SCV_OK;
 }
 
+int scv_export_error_word(scv_ctx* ctx, int64_t* dst_device) {
+    if (!ctx || !dst_device) return fail(SCV_ERR_ARG, "NULL argument");
+    SCV_ENTER(ctx);
+    hipLaunchKernelGGL(scv::scv_export_err_k, dim3(1), dim3(1), 0, ctx->stream, ctx->d_err, reinterpret_cast<long long*>(dst_device));
+    SCV_HIP(hipGetLastError());
+    return SCV_OK;
+}
+
 int scv_last_kernel_ns(scv_ctx* ctx, uint64_t* ns_out) {
     if (!ctx || !ns_out) return fail(SCV_ERR_ARG, "NULL argument");
     if (!(ctx->flags & SCV_FLAG_TIMING) || ctx->events_used == 0)
@@ -1478,6 +1554,8 @@ int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
     if (!ctx || !key || !out) return fail(SCV_ERR_ARG, "NULL argument");
     if (!strcmp(key, "boot_fused")) *out = ctx->stat_boot_fused;
     else if (!strcmp(key, "boot_separate")) *out = ctx->stat_boot_separate;
+    else if (!strcmp(key, "boot_recovered")) *out = ctx->stat_boot_recovered;
+    else if (!strcmp(key, "boot_cooperative")) *out = ctx->stat_boot_cooperative;
     else if (!strcmp(key, "overwrite_fused")) *out = ctx->stat_overwrite_fused;
     else if (!strcmp(key, "reg_lds_counters")) *out = ctx->stat_reg_lds_counters;
     else if (!strcmp(key, "prefix_cells")) *out = ctx->stat_prefix_cells;

@@ -83,6 +83,8 @@ struct AggArgs {
     unsigned long long* ow_truth;
     int32_t boot;           // != 0: after the vote, ALL workgroups meet at a grid barrier and run the bootstrap (one launch)
     int32_t boot_r0, boot_r1, boot_M;
+    uint32_t boot_spins;    // grid barrier: polls before a waiting workgroup gives up (error bit 4; the host then runs the bootstrap
+                            // as a separate launch at the next scv_sync)
     uint64_t boot_seed;
     unsigned long long* boot_out;   // [r1 - r0][B][M]
     int32_t ticket_merge;   // != 0: split-N cells are merged by the last segment to arrive (2-level tree, fan-in 16)
@@ -516,8 +518,11 @@ __device__ __forceinline__ void overwrite_counters_from_cells(const AggArgs& a, 
 
 // (c) Bootstrap in the SAME launch as the vote (north_star: "fused in the same launch").  The problem-
 //     level bootstrap needs every cell of the launch, so all workgroups meet at a grid barrier after their last
-//     cell (one arrival counter + a generation word; the grid is sized to be co-resident by the host and the spin is
-//     bounded: a timeout raises error bit 4 and the host falls back to the separate launch).  Then every workgroup
+//     cell (one arrival counter + a generation word).  Co-residency is the runtime's promise: the host launches this
+//     form with hipLaunchCooperativeKernel (grid <= the occupancy query; refused launches fall back to two kernels).
+//     Belt and braces: the spin is bounded (a.boot_spins polls); a workgroup that gives up raises error bit 4, skips
+//     its resamples, and the host re-runs the WHOLE bootstrap as a separate launch at the next scv_sync and clears the
+//     bit (csrc/scvote.hip: recover_fused_bootstrap) -- a valid call never fails because of co-tenancy.  Then every workgroup
 //     stages the write-through cell table as 2-byte codes in the LDS that held its histogram and runs its share of
 //     the resamples exactly as scv_bootstrap_lds_k does.
 template <int T>
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
                 uint32_t spins = 0;
                 while (ld_agent(a.tickets + 2) == g0) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 20)) { ok = 0; break; }  // not co-resident after all: give up loudly
+                    if (++spins > a.boot_spins) { ok = 0; break; }  // not co-resident after all: give up; scv_sync re-runs the bootstrap
                 }
             }
             red[51] = ok;
@@ -2641,6 +2646,10 @@ __global__ __launch_bounds__(256) void scv_synth_fill_k(int32_t* answers, int32_
         for (int64_t pl = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; pl < P; pl += (int64_t)gridDim.x * blockDim.x)
             truth[pl] = (int32_t)problem_params(seed, p_offset + pl).truth;
 }
+
+// The device error word as an int64 in caller memory, in stream order (scv_export_error_word): lets a multi-rank
+// caller put it behind the counters of the SAME all-reduce without a host round trip.
+__global__ void scv_export_err_k(const uint32_t* err_flag, long long* dst) { *dst = (long long)*err_flag; }
 
 // ---- problem-level bootstrap --------------------------------------------------------------------
 

@@ -74,16 +74,17 @@ def aggregate_sharded(engine, answers_local, truth_local, num_problems: int, tok
     over the GLOBAL number of problems.  Returns an ``AggregateResult`` whose counters are global and
     whose cell table is this rank's block.
 
-    Data errors are collective: the device error word of every rank (SCV_ERR_DOMAIN: a vote outside bins
-    0..1023, which makes the counters invalid) rides in one extra word of the same all-reduce, and EVERY rank
-    raises ``DomainError`` when any rank saw one -- no rank returns counters the ABI documents as invalid, and
-    no rank is left waiting in a collective the others skipped.
+    Errors are collective: whatever ``engine.sync()`` raises on a rank (SCV_ERR_DOMAIN: a vote outside bins
+    0..1023, which makes the counters invalid; a HIP error; any other ``ScvError``) is held back, its code rides in
+    one extra word of the same all-reduce, and EVERY rank raises when any rank saw one -- the rank itself with its own
+    exception, the others with a ``DomainError`` / ``ScvError`` that says so.  No rank returns counters the ABI
+    documents as invalid, and no rank is left waiting in a collective the others skipped.
 
     ``prefix=True``: ``answers_local`` / ``tokens_local`` are this rank's block of ONE sample pool per problem,
     ``[P_local, N]``, and budget b votes over its first ``n_valid[b]`` samples (the reference's shape, o1.py:274-277);
     the block goes through ``engine.aggregate_prefix_device`` and everything else is the same."""
     import torch
-    from ._lib import ERR_DOMAIN, DomainError
+    from ._lib import ERR_DOMAIN, DomainError, ScvError
     from .engine import AggregateResult, cells_from_torch, counters_size
     if prefix:
         if n_valid is None:
@@ -104,15 +105,17 @@ def aggregate_sharded(engine, answers_local, truth_local, num_problems: int, tok
     local_error = None
     if hasattr(engine, "sync"):
         try:
-            engine.sync()                       # DEVICE mode reports SCV_ERR_DOMAIN here and only here
-        except DomainError as e:
+            engine.sync()                       # DEVICE mode reports its errors here and only here
+        except ScvError as e:                   # DomainError, HIP errors, barrier / bootstrap errors: all collective
             local_error = e
-            packed[ncount] = 1
+            packed[ncount] = 1 if isinstance(e, DomainError) else (1 << 20)
     all_reduce_counters(packed, group)
     host = packed.cpu().numpy()
     if host[ncount] != 0:
         if local_error is not None:
             raise local_error
+        if int(host[ncount]) >> 20:
+            raise ScvError(int(-2001), "another rank failed in the engine; the all-reduced counters are invalid")
         raise DomainError(ERR_DOMAIN, "another rank saw a vote outside bins 0..1023; the all-reduced counters are invalid")
     host_cells = cells_from_torch(cells) if cells is not None else None
     host_ctok = cell_tokens.cpu().numpy() if cell_tokens is not None else None

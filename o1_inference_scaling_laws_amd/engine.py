@@ -346,6 +346,17 @@ class Engine:
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
         check(self._L.scv_synth_fill_i32(self._ctx, ptr(answers), ptr(tokens), ptr(truth), P, B, N, p_offset, seed, dist))
 
+    def export_error_word(self, dst):
+        """dst: int64 cuda tensor (>= 1 element, on the engine's device).  dst[0] = the device error word, written in
+        stream order behind everything queued so far; not cleared (``sync`` does that).  No host round trip: the word
+        can ride behind the packed counters in the evaluation's one all-reduce (scv_export_error_word)."""
+        import torch
+        if not (dst.is_cuda and dst.dtype == torch.int64 and dst.numel() >= 1):
+            raise ValueError("dst must be an int64 CUDA tensor")
+        self._check_device(dst, "dst")
+        self.use_torch_stream()
+        check(self._L.scv_export_error_word(self._ctx, C.c_void_p(dst.data_ptr())))
+
     def bootstrap_device(self, cells, r_begin: int, r_end: int, seed: int, M: int, out=None):
         """cells uint8 cuda [P,B,16] -> int64 cuda [r_end-r_begin, B, M] (asynchronous)."""
         import torch

@@ -14,6 +14,12 @@ Device pipeline per rank, all on torch's current stream, no host round trip of p
 With one rank steps 2-3 are no-ops and vote + bootstrap are ONE kernel launch (the workgroups meet at a grid
 barrier after their last cell and share the resamples; scv_aggregate_bootstrap_i32), or two launches back to back
 when the shape does not allow the fused form.
+
+Errors are collective and cost no host round trip.  The device error word of the engine (an out-of-domain vote makes
+the counters invalid; a drawn hit with n_modes >= M makes the resample table invalid) is copied ON DEVICE into one
+extra word behind the packed counters (scv_export_error_word) and rides in the counters' all-reduce; ``check`` -- or
+``gather_bootstrap``, which exchanges the word once more after the bootstrap launch -- raises on EVERY rank when any
+rank saw one.  No rank feeds invalid counters into host floats and none is left waiting in a collective.
 """
 from __future__ import annotations
 
@@ -35,6 +41,13 @@ class C5Device:
     r0: int
     r1: int
     M: int
+    flag: object = None     # int64 [1]: sum over the ranks of the device error words after the vote (0 = clean)
+
+
+def packed_size(B: int) -> int:
+    """int64 words of a counters buffer that also carries the collective error word: counters_size(B) + 1."""
+    from .engine import counters_size
+    return counters_size(B) + 1
 
 
 def class_bound(counters, B: int) -> int:
@@ -49,35 +62,91 @@ def evaluate_device(engine, answers_local, truth_local, num_problems: int, resam
                     M: int | None = None, tokens_local=None, n_valid=None, group=None, counters=None,
                     cells_local=None, boot_out=None, fused: bool = True) -> C5Device:
     """Steps 1-4 for this rank.  ``M=None`` derives the class bound from the counters (host sync); with one rank
-    and a known M the vote and the bootstrap are one call (``fused=False`` keeps them as two launches)."""
+    and a known M the vote and the bootstrap are one call (``fused=False`` keeps them as two launches).
+
+    ``counters``: int64 [packed_size(B)] = counters | error word (allocated when None; zeroed here).  A buffer of
+    counters_size(B) words is accepted too; the error word then travels in a one-word all-reduce of its own.
+    Nothing here synchronises the host: call ``check`` (or ``gather_bootstrap(..., engine=engine)``) before trusting
+    the numbers."""
+    import torch
     import torch.distributed as dist
+    from .engine import counters_size
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank(group) if world > 1 else 0
     B = int(answers_local.shape[1])
-    if counters is not None:
+    ncount = counters_size(B)
+    if counters is None:
+        counters = torch.zeros(ncount + 1, dtype=torch.int64, device=answers_local.device)
+    else:
         counters.zero_()
+    packed = counters.numel() == ncount + 1
+    flag = counters[ncount:] if packed else torch.zeros(1, dtype=torch.int64, device=answers_local.device)
+    cnt = counters[:ncount]
+    export = getattr(engine, "export_error_word", None)
     if world == 1 and M is not None and fused and not scv_dist.collectives_active(group) and hasattr(engine, "aggregate_bootstrap_device"):
         # one rank: the cell table is complete after the vote, so vote + bootstrap go down as ONE call -- one kernel
         # launch when the shape allows it (scv_aggregate_bootstrap_i32)
-        counters, cells, _, boot = engine.aggregate_bootstrap_device(
-            answers_local, truth_local, 0, resamples, seed, M, tokens=tokens_local, n_valid=n_valid, counters=counters,
+        _, cells, _, boot = engine.aggregate_bootstrap_device(
+            answers_local, truth_local, 0, resamples, seed, M, tokens=tokens_local, n_valid=n_valid, counters=cnt,
             cells=cells_local, out=boot_out)
-        return C5Device(counters, cells, boot, 0, resamples, M)
-    counters, cells, _ = engine.aggregate_device(answers_local, truth_local, tokens=tokens_local, n_valid=n_valid,
-                                                 counters=counters, cells=cells_local)
-    scv_dist.all_reduce_counters(counters, group)
+        if export is not None:
+            export(flag)
+        return C5Device(cnt, cells, boot, 0, resamples, M, flag)
+    _, cells, _ = engine.aggregate_device(answers_local, truth_local, tokens=tokens_local, n_valid=n_valid,
+                                          counters=cnt, cells=cells_local)
+    if export is not None:
+        export(flag)                            # device -> device, on the launch stream: no host round trip
+    scv_dist.all_reduce_counters(counters, group)            # counters (+ the error word when packed): ONE all-reduce
+    if not packed:
+        scv_dist.all_reduce_counters(flag, group)
     all_cells = scv_dist.all_gather_cells(cells, num_problems, group)
     if M is None:
-        M = class_bound(counters, B)
+        M = class_bound(cnt, B)
     r0, r1 = (rank * resamples) // world, ((rank + 1) * resamples) // world
     boot = engine.bootstrap_device(all_cells, r0, r1, seed, M, out=boot_out)
-    return C5Device(counters, all_cells, boot, r0, r1, M)
+    return C5Device(cnt, all_cells, boot, r0, r1, M, flag)
 
 
-def gather_bootstrap(dev: C5Device, resamples: int, group=None):
-    """All ranks' resample slices -> int64 [R, B, M] on every rank (step 5's exchange)."""
+def _raise_collectively(global_word: int, engine, what: str):
+    """Every rank raises when the all-reduced error word is non-zero: the rank(s) that saw the error with the
+    engine's own exception (``engine.sync()`` reads and clears the local word), the others with a remote notice."""
+    from ._lib import ERR_DOMAIN, DomainError, ScvError
+    if global_word == 0:
+        return                                  # the branch is taken on the EXCHANGED word only: all ranks agree
+    local = None
+    if engine is not None and hasattr(engine, "sync"):
+        try:
+            engine.sync()
+        except ScvError as e:
+            local = e
+    if local is not None:
+        raise local
+    raise DomainError(ERR_DOMAIN, f"another rank reported a device error during {what}; the exchanged results are invalid")
+
+
+def check(dev: C5Device, engine=None, group=None):
+    """Host side of the collective error word after the VOTE (one host sync; every rank takes the same branch because
+    the word was summed over the ranks inside the counters' all-reduce).  Call before ``finish_host``."""
+    word = int(dev.flag.cpu()[0]) if dev.flag is not None else 0
+    _raise_collectively(word, engine, "the vote")
+
+
+def gather_bootstrap(dev: C5Device, resamples: int, group=None, engine=None):
+    """All ranks' resample slices -> int64 [R, B, M] on every rank (step 5's exchange).  With ``engine`` the device
+    error word is exchanged once more first (it now also covers the bootstrap launch: a drawn hit with n_modes >= M),
+    and every rank raises instead of gathering an invalid table."""
     import torch
     import torch.distributed as dist
+    if engine is not None:
+        word = torch.zeros(1, dtype=torch.int64, device=dev.boot.device)
+        if dev.flag is not None:
+            word += dev.flag
+        if hasattr(engine, "export_error_word"):
+            after = torch.zeros(1, dtype=torch.int64, device=dev.boot.device)
+            engine.export_error_word(after)
+            word += after
+        scv_dist.all_reduce_counters(word, group)
+        _raise_collectively(int(word.cpu()[0]), engine, "the vote or the bootstrap")
     if not scv_dist.collectives_active(group):
         return dev.boot
     world = dist.get_world_size(group)

@@ -69,9 +69,23 @@ class _CpuDeviceEngine:
         return self.aggregate_device(dense, truth, tokens=dtok, n_valid=n_valid, counters=counters, cells=cells)
 
     def sync(self):
-        from o1_inference_scaling_laws_amd._lib import ERR_DOMAIN, DomainError
-        if getattr(self, "rc", 0) == ERR_DOMAIN:
+        from o1_inference_scaling_laws_amd._lib import ERR_DOMAIN, DomainError, ScvError
+        rc, self.rc = getattr(self, "rc", 0), 0                   # like scv_sync: report and clear
+        if rc == ERR_DOMAIN:
             raise DomainError(ERR_DOMAIN, "a vote outside bins 0..1023 was seen; results are invalid")
+        if rc != 0:
+            raise ScvError(rc, "engine failure (test double)")
+
+    def export_error_word(self, dst):
+        """scv_export_error_word: the (device) error word into caller memory, not cleared."""
+        dst[0] = 0 if getattr(self, "rc", 0) == 0 else 1
+
+    def bootstrap_device(self, cells, r_begin, r_end, seed, M, out=None):
+        c = np.ascontiguousarray(cells.numpy()).view(coracle.CELL_DTYPE).reshape(cells.shape[0], cells.shape[1])
+        rc, boot = coracle.bootstrap(c, r_begin, r_end, seed, M)
+        if rc != 0:
+            self.rc = -2001
+        return torch.from_numpy(boot)
 
 
 def _worker_api(rank, world, port, q):
@@ -253,3 +267,59 @@ def test_two_rank_all_reduce_equals_unsharded():
     res = AggregateResult.from_counters(counters, P, B)
     assert res.accuracy(0) == AggregateResult.from_counters(_pack(whole), P, B).accuracy(0)
     assert res.tie_class_hits[:, 2:4].sum() > 0      # the tie classes really were exercised
+
+
+def _worker_c5_error(rank, world, port, q, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from o1_inference_scaling_laws_amd import passk
+        from o1_inference_scaling_laws_amd._lib import DomainError, ScvError
+        lo, hi = scv_dist.shard_bounds(P, rank, world)
+        a, _, tr = coracle.synth_fill(hi - lo, 1, N, SEED, 3, p_offset=lo)
+        if mode == "domain" and rank == 1:
+            a[2, 0, 5] = 7777                    # only rank 1 holds an out-of-domain vote
+        eng = _CpuDeviceEngine()
+        M = 1 if mode == "overflow" else None    # D3 has 2-/3-way ties: M = 1 overflows in the bootstrap (on every rank that draws one)
+        try:
+            d = passk.evaluate_device(eng, torch.from_numpy(a), torch.from_numpy(tr), P, 40, 9, M=M)
+            passk.check(d, eng)                  # after the vote
+            boot = passk.gather_bootstrap(d, 40, engine=eng)
+            q.put((rank, "ok", tuple(boot.shape)))
+        except DomainError as e:
+            q.put((rank, "domain-local" if "was seen" in str(e) else "domain-remote", None))
+        except ScvError as e:
+            q.put((rank, "scv", None))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_c5(mode, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c5_error, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, what, shape = q.get(timeout=180)
+        got[r] = (what, shape)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_c5_pipeline_errors_are_collective():
+    """passk.evaluate_device on two ranks.  One bad vote on rank 1 makes EVERY rank raise in
+    passk.check (the error word rode in the counters' all-reduce: rank 1 with its own error, rank 0 with the remote
+    notice) instead of feeding invalid counters into accuracy / CI / pass@k while a peer sits in gather_bootstrap; a
+    class bound that overflows in the bootstrap is caught by gather_bootstrap's exchange of the word on every rank;
+    a clean run returns the whole table on both."""
+    assert _run_c5("clean") == {0: ("ok", (40, 1, 4)), 1: ("ok", (40, 1, 4))}
+    assert _run_c5("domain") == {0: ("domain-remote", None), 1: ("domain-local", None)}
+    got = _run_c5("overflow")
+    assert {v[0] for v in got.values()} <= {"scv", "domain-remote"} and len(got) == 2 and "ok" not in {v[0] for v in got.values()}

@@ -1149,3 +1149,148 @@ def test_kernel_timing_is_reported(hip_engine):
     hip_engine.aggregate(a, tr)
     total, n = hip_engine.drain_kernel_ns()
     assert n == 1 and 0 < total < 10 ** 9
+
+
+# ---- round 3: a valid fused vote + bootstrap call never fails because of co-tenancy ------------------------------------
+
+def _boot_case(hip_engine, P=3000, B=1, N=70000, dist=3, seed=321):
+    import torch
+    dev = torch.device("cuda:0")
+    ans = torch.empty((P, B, N), dtype=torch.int32, device=dev)
+    tr = torch.empty((P,), dtype=torch.int32, device=dev)
+    hip_engine.synth_fill_device(ans, None, tr, P=P, B=B, N=N, seed=seed, dist=dist)
+    a, _, trc = coracle.synth_fill(P, B, N, seed, dist)
+    want = coracle.aggregate_mt(a, trc, 16)
+    M = int(want["cells"]["n_modes"][want["cells"]["hit"] == 1].max(initial=0)) + 1
+    rc, want_boot = coracle.bootstrap(want["cells"], 0, 150, 77, M)
+    assert rc == 0
+    return ans, tr, want, M, want_boot
+
+
+def test_fused_bootstrap_is_a_cooperative_launch(hip_engine):
+    """The one-launch form meets at a grid barrier, so it is started with hipLaunchCooperativeKernel: co-residency is
+    the runtime's guarantee, not an occupancy estimate (stat "boot_cooperative" counts them)."""
+    ans, tr, want, M, want_boot = _boot_case(hip_engine)
+    c0, f0, r0 = hip_engine.stat("boot_cooperative"), hip_engine.stat("boot_fused"), hip_engine.stat("boot_recovered")
+    counters, cells, _, boot = hip_engine.aggregate_bootstrap_device(ans, tr, 0, 150, 77, M)
+    hip_engine.sync()
+    assert np.array_equal(boot.cpu().numpy(), want_boot)
+    assert hip_engine.stat("boot_fused") - f0 == 1 and hip_engine.stat("boot_cooperative") - c0 == 1
+    assert hip_engine.stat("boot_recovered") == r0
+
+
+def test_fused_bootstrap_barrier_timeout_is_repaired_not_reported(hip_engine):
+    """ADVICE r2 / VERDICT r2 #7.  Force what a non-co-resident grid would cause: ordinary launch, every waiting workgroup
+    gives up at the grid barrier after ONE poll.  The call must still deliver the oracle's counters, cells and the whole
+    resample table: scv_sync resets the barrier, re-runs the bootstrap as a separate launch and clears the error bit.
+    Afterwards the fused form works again (barrier state clean), and a too-small class bound is still reported."""
+    ans, tr, want, M, want_boot = _boot_case(hip_engine)
+    hip_engine.set_option("boot_cooperative", 0)
+    hip_engine.set_option("boot_spin_limit", 1)
+    try:
+        r0 = hip_engine.stat("boot_recovered")
+        for _ in range(3):
+            counters, cells, _, boot = hip_engine.aggregate_bootstrap_device(ans, tr, 0, 150, 77, M)
+            hip_engine.sync()                                   # no exception: repaired
+            assert np.array_equal(boot.cpu().numpy(), want_boot)
+            gc = cells_from_torch(cells)
+            for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+                assert np.array_equal(gc[f], want["cells"][f]), f
+            got = AggregateResult.from_counters(counters.cpu().numpy(), ans.shape[0], ans.shape[1])
+            assert np.array_equal(got.tie_class_hits, want["tie_class_hits"])
+        recovered = hip_engine.stat("boot_recovered") - r0
+        assert recovered >= 1, "a 1-poll barrier on a 256-workgroup grid must time out at least once in three calls"
+        if M > 1:                                               # the repair re-derives the overflow bit
+            hip_engine.aggregate_bootstrap_device(ans, tr, 0, 40, 77, M - 1)
+            with pytest.raises(_lib.ScvError):
+                hip_engine.sync()
+    finally:
+        hip_engine.set_option("boot_spin_limit", 1 << 20)
+        hip_engine.set_option("boot_cooperative", 1)
+    counters, cells, _, boot = hip_engine.aggregate_bootstrap_device(ans, tr, 0, 150, 77, M)
+    hip_engine.sync()
+    assert np.array_equal(boot.cpu().numpy(), want_boot)
+
+
+@pytest.mark.parametrize("cooperative", [1, 0])
+def test_fused_bootstrap_with_a_competing_kernel_on_another_stream(hip_engine, cooperative):
+    """A long elementwise workload keeps the CUs' wave slots busy from a side stream while the fused call is made (the
+    co-tenancy the occupancy query cannot see: RCCL kernels, torch side streams).  Whatever the runtime does --
+    cooperative launch waits for residency, ordinary launch may time out at the barrier and be repaired at sync -- the
+    result is the oracle's table and no error."""
+    import torch
+    ans, tr, want, M, want_boot = _boot_case(hip_engine, P=2500, N=1 << 16, dist=1, seed=99)
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(device=dev)
+    x = torch.ones(1 << 28, dtype=torch.float32, device=dev)              # 1 GiB
+    hip_engine.set_option("boot_cooperative", cooperative)
+    try:
+        for _ in range(2):
+            with torch.cuda.stream(side):
+                for _k in range(40):
+                    x.mul_(1.0000001).add_(1e-9)                            # ~80 launches x 2 GiB of traffic
+            counters, cells, _, boot = hip_engine.aggregate_bootstrap_device(ans, tr, 0, 150, 77, M)
+            hip_engine.sync()
+            assert np.array_equal(boot.cpu().numpy(), want_boot)
+            assert np.array_equal(cells_from_torch(cells)["n_modes"], want["cells"]["n_modes"])
+            side.synchronize()
+    finally:
+        hip_engine.set_option("boot_cooperative", 1)
+        torch.cuda.synchronize()
+
+
+def test_export_error_word_in_stream_order(hip_engine):
+    """scv_export_error_word: the device error word lands in caller memory behind the launches queued so far, without a
+    host sync, and is NOT cleared by the export (scv_sync reports and clears it)."""
+    import torch
+    dev = torch.device("cuda:0")
+    a, _, tr = coracle.synth_fill(20, 2, 5000, 3, 1)
+    ans, trd = torch.from_numpy(a).to(dev), torch.from_numpy(tr).to(dev)
+    flag = torch.full((3,), -7, dtype=torch.int64, device=dev)
+    hip_engine.aggregate_device(ans, trd)
+    hip_engine.export_error_word(flag)
+    hip_engine.sync()
+    assert flag.tolist() == [0, -7, -7]
+    ans[7, 1, 123] = 4000                                      # out of domain
+    hip_engine.aggregate_device(ans, trd)
+    hip_engine.export_error_word(flag[1:])
+    torch.cuda.synchronize()
+    assert flag.tolist() == [0, 1, -7]
+    hip_engine.export_error_word(flag[2:])                     # still set: the export does not clear
+    torch.cuda.synchronize()
+    assert flag.tolist() == [0, 1, 1]
+    with pytest.raises(_lib.DomainError):
+        hip_engine.sync()
+    hip_engine.export_error_word(flag)
+    hip_engine.sync()
+    assert flag.tolist()[0] == 0
+
+
+def test_c5_pipeline_reports_device_errors(hip_engine):
+    """passk.evaluate_device must not hand invalid counters to the host floats.  An out-of-domain
+    vote (and, separately, a class bound M that is too small for the bootstrap) surfaces in passk.check /
+    gather_bootstrap as an exception; a clean run passes both."""
+    import torch
+    from o1_inference_scaling_laws_amd import passk
+    dev = torch.device("cuda:0")
+    P, N = 400, 9000
+    a, _, tr = coracle.synth_fill(P, 1, N, 11, 3)
+    ans, trd = torch.from_numpy(a).to(dev), torch.from_numpy(tr).to(dev)
+    d = passk.evaluate_device(hip_engine, ans, trd, P, 64, 5)                     # M derived: host sync inside
+    passk.check(d, hip_engine)
+    boot = passk.gather_bootstrap(d, 64, engine=hip_engine)
+    assert boot.shape == (64, 1, d.M) and d.flag.numel() == 1 and int(d.flag.cpu()[0]) == 0
+    for fused in (True, False):
+        d2 = passk.evaluate_device(hip_engine, ans, trd, P, 64, 5, M=max(1, d.M - 1), fused=fused)     # bound too small
+        passk.check(d2, hip_engine) if not fused else None      # (fused: the overflow bit is already in the exported word)
+        with pytest.raises(_lib.ScvError):
+            passk.gather_bootstrap(d2, 64, engine=hip_engine)
+    bad = ans.clone()
+    bad[17, 0, 4321] = 1 << 20
+    for fused in (True, False):
+        d3 = passk.evaluate_device(hip_engine, bad, trd, P, 64, 5, M=d.M, fused=fused)
+        with pytest.raises(_lib.DomainError):
+            passk.check(d3, hip_engine)
+    d4 = passk.evaluate_device(hip_engine, ans, trd, P, 64, 5, M=d.M)             # and the engine is clean again
+    passk.check(d4, hip_engine)
+    assert np.array_equal(passk.gather_bootstrap(d4, 64, engine=hip_engine).cpu().numpy(), boot.cpu().numpy())
