@@ -32,7 +32,7 @@ duration is taken from hipEvents recorded by the library on the launch stream (s
 
 cpu_baseline (rank 0, N=1): `value` is the UNMODIFIED reference loop -- o1.run_experiments (o1.py:216-247) imported
 from the bytecode __graft_entry__.build() compiled into oracle/_ref (oracle/make_ref.py; kind "reference") -- timed on
-this box's host at P = 30, N in {2^8, 2^11} on votes of the workload's generator (oracle/refbaseline.py, a subprocess).
+this box's host at P = 30, N in {2^8, 2^11, 2^13} on votes of the workload's generator (oracle/refbaseline.py, a subprocess).
 Beside it: the reference's arithmetic without its thread pools and cache lookups -- statistics.multimode +
 o1.py:204-213 scoring on Python int lists (oracle/pybaseline.py) -- on one host core and on a process pool, and the C
 restatement (oracle/scv_oracle.c).  The same leg is the checker: GPU cells of a timed chunk vs the C oracle (>= 256 problems x 8 budgets x
@@ -168,7 +168,9 @@ def cpu_baseline(args, B, N, gpu_first_cells, first_off, gpu_last_cells, last_of
     mt_rate = passes * am.size / (time.perf_counter() - t2)
     parity = (f"bit-exact: {nwide} problems x {B} budgets x {N} votes of {'the last TIMED' if last_is_timed else 'a'} chunk + {n16} of the "
               f"sanity pass vs oracle/scv_oracle.c ({t_check:.1f} s); {checked_py} problems x {B} cells also vs statistics.multimode "
-              f"(score = hit / n_modes, o1.py:202-210)")
+              f"(score = hit / n_modes, o1.py:202-210); integers only -- the reference's float accuracy accumulates in thread-completion order "
+              f"(o1.py:236-239), so floats are derived from the integer tie classes in one canonical order: equal to the reference's when every "
+              f"tie size is a power of two, within 1e-12 otherwise")
     ps, pa = py["single"], py.get("all_cores")
     arithmetic = {
         "value": ps["votes_per_s"], "unit": "sample-votes/s", "cores": 1, "kind": "port",
@@ -207,9 +209,9 @@ def cpu_baseline(args, B, N, gpu_first_cells, first_off, gpu_last_cells, last_of
 
 
 def reference_loop(args):
-    """oracle/refbaseline.py as a subprocess: the unmodified o1.run_experiments at P = 30, N = 2^8 and 2^11 (SURVEY 8d "R0").
+    """oracle/refbaseline.py as a subprocess: the unmodified o1.run_experiments at P = 30, N = 2^8, 2^11, 2^13 (SURVEY 8d "R0"; ~10 s).
     None when oracle/_ref is not there."""
-    cmd = [sys.executable, "-m", "oracle.refbaseline", "--N", "256", "2048", "--seed", str(args.seed), "--dist", str(args.dist)]
+    cmd = [sys.executable, "-m", "oracle.refbaseline", "--N", "256", "2048", "8192", "--seed", str(args.seed), "--dist", str(args.dist)]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, timeout=300, env=dict(os.environ, MPLBACKEND="Agg"))
     except subprocess.TimeoutExpired:

@@ -60,7 +60,7 @@ def run(ns, seed: int, dist: int, repeats: int = 1):
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--N", type=int, nargs="+", default=[256, 2048])
+    ap.add_argument("--N", type=int, nargs="+", default=[256, 2048, 8192])
     ap.add_argument("--seed", type=int, default=20240914)
     ap.add_argument("--dist", type=int, default=1)
     ap.add_argument("--repeats", type=int, default=1)

@@ -55,7 +55,7 @@ def test_single_gpu_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     # value = the UNMODIFIED reference loop (o1.run_experiments from oracle/_ref), timed on this box's host
     assert c["kind"] == "reference" and c["cores"] == 1 and c["value"] > 0 and "sample" in c and "o1.run_experiments" in c["what"]
-    assert [r["N"] for r in c["reference_loop"]] == [256, 2048] and all(r["accuracy_matches_restatement"] for r in c["reference_loop"])
+    assert [r["N"] for r in c["reference_loop"]] == [256, 2048, 8192] and all(r["accuracy_matches_restatement"] for r in c["reference_loop"])
     a = c["arithmetic"]
     assert a["kind"] == "port" and "statistics.multimode" in a["what"] and a["value"] > c["value"]   # without pools and key lookups
     assert a["all_cores"]["value"] > 0 and c["c_port"]["value"] > a["value"]      # C port beats the Python loop
