@@ -1,33 +1,63 @@
-"""Build recipe for the HIP extension: hipcc cross-compiles gfx950 without a GPU (seconds)."""
+"""Build recipe for the HIP extension: hipcc cross-compiles gfx950 without a GPU.
+
+The ~200 kernel instantiations are spread over several translation units (csrc/scvote_dispatch.h); each is compiled
+to an object file under csrc/build/ by its own hipcc process (in parallel, skipped when the object is newer than its
+sources) and the objects are linked into csrc/libscvote.so, in-tree, so that it travels to the GPU box."""
 from __future__ import annotations
 
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJDIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(CSRC, "libscvote.so")
-SOURCES = ["scvote.hip", "scvote_kernels.hip.h"]
-HEADER = os.path.join(os.path.dirname(HERE), "include", "scvote.h")
+UNITS = ["scvote.hip", "scvote_stream_c4.hip", "scvote_stream_c8.hip", "scvote_stream_c16.hip", "scvote_stream_c32.hip",
+         "scvote_reg_g16.hip", "scvote_reg_g32.hip", "scvote_reg_g64.hip", "scvote_dense.hip"]
+HEADERS = [os.path.join(CSRC, "scvote_kernels.hip.h"), os.path.join(CSRC, "scvote_dispatch.h"),
+           os.path.join(os.path.dirname(HERE), "include", "scvote.h")]
+SOURCES = UNITS + ["scvote_kernels.hip.h", "scvote_dispatch.h"]          # (tools/kernel_resources.py lists them)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+def _hipcc() -> str:
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _obj(unit: str) -> str:
+    return os.path.join(OBJDIR, unit.replace(".hip", ".o"))
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> csrc/libscvote.so (in-tree, so it travels to the GPU box)."""
+def needs_build() -> bool:
+    return _stale(LIB_PATH, [os.path.join(CSRC, u) for u in UNITS] + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
+    """hipcc --offload-arch=gfx950: one object per translation unit (parallel) -> csrc/libscvote.so."""
     if not force and not needs_build():
         return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB_PATH, os.path.join(CSRC, "scvote.hip")]
+    os.makedirs(OBJDIR, exist_ok=True)
+    todo = [u for u in UNITS if force or _stale(_obj(u), [os.path.join(CSRC, u)] + HEADERS)]
+
+    def compile_unit(unit):
+        cmd = [_hipcc(), *FLAGS, "-c", "-o", _obj(unit), os.path.join(CSRC, unit)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(UNITS), os.cpu_count() or 4)) as pool:
+        list(pool.map(compile_unit, todo))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *[_obj(u) for u in UNITS]]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB_PATH
 

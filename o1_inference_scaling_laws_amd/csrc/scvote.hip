@@ -4,7 +4,9 @@
 // the CU count), variant dispatch for A/B tuning, hipEvent timing on the launch stream, and the
 // HOST-memory staging path.  No C++ exception crosses the ABI; every entry returns 0 or a
 // negative code and sets a thread-local message.
+#define SCV_TU_MAIN 1   // the non-template kernels are emitted by this translation unit only
 #include "scvote_kernels.hip.h"
+#include "scvote_dispatch.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -219,74 +221,13 @@ bool valid_copies(int c) { return c == 4 || c == 8 || c == 16 || c == 32; }
 bool valid_threads(int t) { return t == 256 || t == 512 || t == 1024; }
 bool valid_unroll(int u) { return u == 2 || u == 4 || u == 8; }
 
-using KernelFn = void (*)(const scv::AggArgs);
-
-template <int RL2, int T, int U>
-KernelFn pick_tok(bool tok) {
-    return tok ? (KernelFn)scv::scv_hist_argmax<RL2, T, U, true> : (KernelFn)scv::scv_hist_argmax<RL2, T, U, false>;
-}
-template <int RL2, int T>
-KernelFn pick_u(int u, bool tok) {
-    switch (u) {
-    case 2: return pick_tok<RL2, T, 2>(tok);
-    case 8: return pick_tok<RL2, T, 8>(tok);
-    default: return pick_tok<RL2, T, 4>(tok);
-    }
-}
-// variants with the single-launch epilogues compiled in (XTRA): unroll 4 only
-template <int RL2, int T>
-KernelFn pick_xtra(bool tok) {
-    return tok ? (KernelFn)scv::scv_hist_argmax<RL2, T, 4, true, true> : (KernelFn)scv::scv_hist_argmax<RL2, T, 4, false, true>;
-}
-template <int RL2>
-KernelFn pick_t(int t, int u, bool tok, bool xtra) {
-    switch (t) {
-    case 256: return xtra ? pick_xtra<RL2, 256>(tok) : pick_u<RL2, 256>(u, tok);
-    case 1024: return xtra ? pick_xtra<RL2, 1024>(tok) : pick_u<RL2, 1024>(u, tok);
-    default: return xtra ? pick_xtra<RL2, 512>(tok) : pick_u<RL2, 512>(u, tok);
-    }
-}
-KernelFn pick_kernel(int copies, int t, int u, bool tok, bool xtra) {
-    switch (copies) {
-    case 4: return pick_t<2>(t, u, tok, xtra);
-    case 8: return pick_t<3>(t, u, tok, xtra);
-    case 32: return pick_t<5>(t, u, tok, xtra);
-    default: return pick_t<4>(t, u, tok, xtra);
-    }
-}
-
-struct RegKernel { KernelFn fn; int waves; };   // + the workgroup size (waves) the kernel was compiled for
-template <int G, int V, int K, bool DENSE>
-RegKernel pick_reg_gv(bool tok, bool vec) {
-    if (tok) return {vec ? (KernelFn)scv::scv_reg_cells<G, V, K, true, true, DENSE> : (KernelFn)scv::scv_reg_cells<G, V, K, true, false, DENSE>, scv::reg_cells_waves<G, V, true, DENSE>()};
-    return {vec ? (KernelFn)scv::scv_reg_cells<G, V, K, false, true, DENSE> : (KernelFn)scv::scv_reg_cells<G, V, K, false, false, DENSE>, scv::reg_cells_waves<G, V, false, DENSE>()};
-}
-// lanes per cell g, 16-byte vectors per lane v (capacity 4*g*v votes); short cells run K = 4 / v batches per
-// iteration (4 KiB of votes in flight per wave behind the batch being counted -- measured: 8 KiB is slower, the
-// waves wait on LDS, not on memory).
-template <int KM>
-RegKernel pick_reg_km(int g, int v, bool tok, bool vec) {
-    if (g == 16) return v == 1 ? pick_reg_gv<16, 1, 4 * KM, false>(tok, vec) : (v == 2 ? pick_reg_gv<16, 2, 2 * KM, false>(tok, vec) : pick_reg_gv<16, 4, KM, false>(tok, vec));
-    if (g == 32) return v == 1 ? pick_reg_gv<32, 1, 4 * KM, false>(tok, vec) : (v == 2 ? pick_reg_gv<32, 2, 2 * KM, false>(tok, vec) : pick_reg_gv<32, 4, KM, false>(tok, vec));
-    return v == 1 ? pick_reg_gv<64, 1, 4 * KM, false>(tok, vec) : (v == 2 ? pick_reg_gv<64, 2, 2 * KM, false>(tok, vec) : pick_reg_gv<64, 4, KM, false>(tok, vec));
-}
-RegKernel pick_reg_kernel(int g, int v, bool tok, bool vec, bool dense4, int km) {
-    if (g == 64 && v == 4 && dense4) return pick_reg_gv<64, 4, 1, true>(tok, vec);
-    (void)km;   // 8 and 16 KiB in flight per wave (KM = 2, 4) were measured equal / slower (profiles/r02 notes): not instantiated
-    return pick_reg_km<1>(g, v, tok, vec);
-}
-// long cells: V vectors per lane per part, H parts per cell (capacity 256 * V * H votes), dense bin scan
-template <int V, int H>
-RegKernel pick_dense_vh(bool tok, bool vec) {
-    if (tok) return vec ? RegKernel{(KernelFn)scv::scv_reg_dense<V, H, true, true>, scv::reg_dense_waves<V, H, true, true>()}
-                        : RegKernel{(KernelFn)scv::scv_reg_dense<V, H, true, false>, scv::reg_dense_waves<V, H, true, false>()};
-    return vec ? RegKernel{(KernelFn)scv::scv_reg_dense<V, H, false, true>, scv::reg_dense_waves<V, H, false, true>()}
-               : RegKernel{(KernelFn)scv::scv_reg_dense<V, H, false, false>, scv::reg_dense_waves<V, H, false, false>()};
-}
-RegKernel pick_dense_kernel(int v, int h, bool tok, bool vec) {
-    if (v == 4) return h == 1 ? pick_dense_vh<4, 1>(tok, vec) : (h == 2 ? pick_dense_vh<4, 2>(tok, vec) : pick_dense_vh<4, 4>(tok, vec));
-    return h == 1 ? pick_dense_vh<8, 1>(tok, vec) : pick_dense_vh<8, 2>(tok, vec);
-}
+// Kernel variant tables live in their own translation units (scvote_stream_*.hip, scvote_reg.hip, scvote_dense.hip):
+// the template instantiations are compiled in parallel and only the table that changed is rebuilt (csrc/scvote_dispatch.h).
+using scv::KernelFn;
+using scv::RegKernel;
+using scv::pick_kernel;
+using scv::pick_reg_kernel;
+using scv::pick_dense_kernel;
 
 // Every entry point runs on the ctx device and leaves the caller's current HIP device as it found it
 // (a process driving several GPUs from one thread -- MultiDeviceEngine -- must not have torch's
@@ -1575,3 +1516,22 @@ int scv_device_info(scv_ctx* ctx, int64_t info_out[4]) {
 }
 
 }  // extern "C"
+
+// ---- kernel tables: the per-translation-unit tables behind one switch each (scvote_dispatch.h) ----------------------
+namespace scv {
+KernelFn pick_kernel(int copies, int t, int u, bool tok, bool xtra) {
+    switch (copies) {
+    case 4: return pick_stream_c4(t, u, tok, xtra);
+    case 8: return pick_stream_c8(t, u, tok, xtra);
+    case 32: return pick_stream_c32(t, u, tok, xtra);
+    default: return pick_stream_c16(t, u, tok, xtra);
+    }
+}
+RegKernel pick_reg_kernel(int g, int v, bool tok, bool vec, bool dense4, int km) {
+    (void)km;   // 8 and 16 KiB in flight per wave (KM = 2, 4) were measured equal / slower (profiles/r02 notes): not instantiated
+    if (g == 16) return pick_reg_g16(v, tok, vec);
+    if (g == 32) return pick_reg_g32(v, tok, vec);
+    return pick_reg_g64(v, tok, vec, dense4);
+}
+}  // namespace scv
+

@@ -2602,6 +2602,7 @@ __device__ __forceinline__ ProblemParams problem_params(uint64_t seed, int64_t p
     return r;
 }
 
+#ifdef SCV_TU_MAIN   // non-template kernels: emitted once, by csrc/scvote.hip (the header is shared by several translation units)
 __global__ __launch_bounds__(256) void scv_synth_fill_k(int32_t* answers, int32_t* tokens, int32_t* truth,
                                                         int64_t P, int32_t B, int64_t N, int64_t p_offset,
                                                         uint64_t seed, int dist) {
@@ -2734,5 +2735,6 @@ __global__ __launch_bounds__(1024) void scv_bootstrap_lds_k(const scv_cell* cell
     }
     if (overflow) atomicOr(err_flag, 2u);
 }
+#endif  // SCV_TU_MAIN
 
 }  // namespace scv

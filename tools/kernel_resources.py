@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Register / LDS / scratch usage of every gfx950 kernel in csrc/scvote.hip, from the compiler's own metadata
-(hipcc --cuda-device-only -S; no GPU needed).  Usage: kernel_resources.py [out.md]"""
+"""Register / LDS / scratch usage of every gfx950 kernel of the library (all translation units of csrc/, compiled in
+parallel), from the compiler's own metadata (hipcc --cuda-device-only -S; no GPU needed).  Usage: kernel_resources.py [out.md]"""
 import os
 import re
 import subprocess
@@ -13,12 +13,16 @@ CSRC = os.path.join(R, "o1_inference_scaling_laws_amd", "csrc")
 
 def collect():
     """[(kernel, vgpr, agpr, sgpr, scratch_bytes, occupancy, static_lds_bytes)], sorted by name."""
-    src = os.path.join(CSRC, "scvote.hip")
+    from concurrent.futures import ThreadPoolExecutor
+    units = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     with tempfile.TemporaryDirectory() as d:
-        asm = os.path.join(d, "scvote.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", asm, src],
-                       check=True, stderr=subprocess.DEVNULL)
-        s = open(asm).read()
+        def one(unit):
+            asm = os.path.join(d, unit + ".s")
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", asm,
+                            os.path.join(CSRC, unit)], check=True, stderr=subprocess.DEVNULL)
+            return open(asm).read()
+        with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as pool:
+            s = "\n".join(pool.map(one, units))
     mangled_names = re.findall(r"\.amdhsa_kernel (\S+)", s)
     demangled = subprocess.run(["c++filt"], input="\n".join(mangled_names), capture_output=True, text=True).stdout.splitlines()
     rows = []
