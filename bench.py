@@ -25,7 +25,7 @@ Inputs are generated ON DEVICE (closed-form integer generator, include/scvote.h)
 in HBM before the timed region; `--resident` distinct chunks are cycled (default: as many of C3's 8 chunks as
 fit in free HBM -- 7 on a 288 GB part -- each 41.9 GB >> the 256 MiB Infinity Cache, so every step streams
 from HBM; the line reports `chunks_distinct`).  Distribution D1 (peaked/realistic) is
-the headline; --dist 0/2/3 select uniform/degenerate/tie.
+the headline; --dist 0/2/3/4/5 select uniform / degenerate / tie / peaked on a wrong value / degenerate-wrong.
 
 The timed region is bracketed by barrier + torch.cuda.synchronize() on both sides; the kernel's own
 duration is taken from hipEvents recorded by the library on the launch stream (scv_drain_kernel_ns).
@@ -56,7 +56,7 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_VOTE = 4             # one int32 read per sample-vote, nothing written per vote
-DISTS = {0: "D0 uniform", 1: "D1 peaked", 2: "D2 degenerate", 3: "D3 tie"}
+DISTS = {0: "D0 uniform", 1: "D1 peaked", 2: "D2 degenerate", 3: "D3 tie", 4: "D4 peaked on a wrong value", 5: "D5 degenerate-wrong"}
 
 
 def parse():
@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--resamples", type=int, default=1000, help="c5: bootstrap resamples (split over the ranks)")
     ap.add_argument("--budgets", type=int, default=8)
     ap.add_argument("--samples", type=int, default=1 << 20)
-    ap.add_argument("--dist", type=int, default=1, help="0 uniform, 1 peaked (headline), 2 degenerate, 3 tie")
+    ap.add_argument("--dist", type=int, default=1, help="0 uniform, 1 peaked (headline), 2 degenerate, 3 tie, 4 peaked on a wrong value, 5 degenerate-wrong")
     ap.add_argument("--resident", type=int, default=0,
                     help="distinct chunks kept in HBM and cycled (0 = auto: c3 as many of its 8 chunks as fit in free HBM)")
     ap.add_argument("--tokens", action="store_true", help="also stream the tokens tensor (8 B/vote)")

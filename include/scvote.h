@@ -51,6 +51,9 @@ extern "C" {
 #define SCV_DIST_PEAKED 1         /* D1: truth w.p. q_p in {.1...7}, 4 distractors at .05, rest uniform */
 #define SCV_DIST_DEGENERATE 2     /* D2: every vote == truth[p]                                 */
 #define SCV_DIST_TIE 3            /* D3: exact 2-/3-way ties, with and without truth among them */
+#define SCV_DIST_PEAKED_WRONG 4   /* D4: D1 with the roles swapped: a WRONG value w.p. q_p, truth at .05 -- a confidently
+                                     wrong majority, an ordinary outcome of the reference (o1.py:204-213 scores it 0)    */
+#define SCV_DIST_DEGENERATE_WRONG 5 /* D5: every vote == one wrong value (truth + 500) % 1000                            */
 
 /* error codes: 0 ok; -(hipError_t) for HIP failures; the following for argument/data errors. */
 #define SCV_OK 0
@@ -110,7 +113,8 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  * "host_pipeline" (default 1; 0: the serial round-1 staging loop), "stage_mb" (HOST-mode chunk size,
  * default 128), "copy_threads" (default 6: threads filling the pinned bounce slots), "reg_n_max" (default 4096: 32 < N <=
  * this uses the register-resident cell kernels; 0 restores the round-1 dispatch), "reg_shape" / "reg_km" / "reg_dense4" (force a
- * register-kernel shape for A/B runs), "reg_lds_counters" (default 1: the register-resident kernels accumulate the per-budget
+ * register-kernel shape for A/B runs), "reg_pivots" (register-resident kernels: a lane adds the votes equal to its first and second
+ * vote to words of its own instead of the contended histogram bins; 1 switches the second pivot off for A/B runs, default 0), "reg_lds_counters" (default 1: the register-resident kernels accumulate the per-budget
  * counters in LDS and flush them in the same launch; 0: cell table + scv_reduce_cells), "reg_wpg" (waves per workgroup of the
  * register-resident kernels, 0 = all the waves a CU holds), "prefix_cells" (default 1: scv_aggregate_prefix_i32 on pools of N <= 4096
  * runs on the cell kernels, each cell reading its prefix of the pool row; 0: the one-pass snapshot kernels), "prefix_lane" (default 1:
@@ -217,6 +221,9 @@ int scv_aggregate_bootstrap_i32(scv_ctx* ctx,
  *   D0: uv.  D1: x = hi32(u); x < q_num*429496729 -> truth; else (x - that) < 4*214748364 -> d_[(x-that)/214748364]; else uv.
  *   D2: truth.  D3: m = 2 + (p & 1); base = ((p >> 1) & 1) ? (truth + 500) % 1000 : truth;
  *       i < (N / m) * m -> (base + 37 * (i % m)) % 1000, else (base + 999) % 1000.
+ *   D4: D1 with hot = (d_0 == truth ? (truth + 500) % 1000 : d_0) in the truth's place and truth in d_0's:
+ *       x < q_num*429496729 -> hot; else j = (x-that)/214748364 < 4 -> (j == 0 ? truth : d_j); else uv.
+ *   D5: (truth + 500) % 1000.
  *   tokens: 100 + mulhi32(hi32(mix64(u ^ G)), 11901)                       (100..12000)
  * All pointers are DEVICE pointers (any may be NULL); async on the ctx stream.
  */

@@ -11,7 +11,7 @@ _lib = None
 # include/scvote.h constants
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_TIMING, FLAG_CLAMP = 0x1, 0x2
-DIST_UNIFORM, DIST_PEAKED, DIST_DEGENERATE, DIST_TIE = 0, 1, 2, 3
+DIST_UNIFORM, DIST_PEAKED, DIST_DEGENERATE, DIST_TIE, DIST_PEAKED_WRONG, DIST_DEGENERATE_WRONG = 0, 1, 2, 3, 4, 5
 NUM_BINS, TIE_CLASSES = 1024, 1025
 OK, ERR_ARG, ERR_DOMAIN, ERR_NO_DEVICE, ERR_NOT_TIMED, ERR_ALLOC = 0, -2001, -2002, -2003, -2004, -2005
 

@@ -166,6 +166,7 @@ struct scv_ctx {
     int reg_wpg = 0;         // reg path: waves per workgroup (0 = the kernel's own: all the waves a CU holds)
     int reg_lds_counters = 1; // reg path: per-budget counters accumulate in LDS and are flushed by the same launch
     int reg_shape = 0;       // reg path: force a kernel shape (A/B runs), see launch_aggregate
+    int reg_pivots = 0;      // reg path: pivots per lane (votes equal to a pivot are counted in registers): 0 = per batch (2 when it shows two hot values), 1, 2
     int reg_dense4 = 0;      // reg path, 512 < N <= 1024: 1 = dense bin scan instead of the sparse read-back (A/B option)
     int reg_n_max = 4096;    // auto: 32 < N <= this -> register-resident cells kernel (scv_reg_cells); 0 = off (round-1 dispatch)
     bool user_tuned = false; // set_tuning called: auto geometry off
@@ -336,7 +337,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.prefetch = ctx->prefetch;
     a.tok_skew = ctx->tok_skew;
     a.sorted = ctx->sorted;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0; a.reg_pivots = ctx->reg_pivots;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
 
@@ -402,30 +403,33 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         if (N > ctx->tiny_n_max && N <= ctx->reg_n_max) path = 4;
         else path = (N <= ctx->small_n_max) ? 3 : 1;
     }
-    if (path == 4 && (N > 4096 || N < 1)) path = (N <= ctx->small_n_max) ? 3 : 1;   // forced reg path outside its range
+    // register-resident kernels: rows that are not all 16-byte aligned are read as their aligned supersets (up to 3 slots more)
+    const bool reg_vec = (N % 4 == 0) && (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0);
+    const int64_t Nreg = reg_vec ? N : N + 3;
+    if (path == 4 && (Nreg > 4096 || N < 1)) path = (N <= ctx->small_n_max) ? 3 : 1;   // (forced) reg path outside its range
 
     EventPair* ev = nullptr;
     if (int rc = next_event_pair(ctx, &ev)) return rc;
 
     if (path == 4) {
         // ---- register-resident cells: single-wave workgroups, 16 KiB of LDS each, 8 per CU
-        const bool vec = (N % 4 == 0) && (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0);
-        // shape of the kernel from N; the "reg_shape" option forces one for A/B runs:
-        // g*100 + v (sparse: g lanes per cell, v vectors per lane) or 1000 + v*10 + h (dense: h parts of v vectors)
+        const bool vec = reg_vec;
+        // shape of the kernel from the slots a row needs (N, or N + 3 for unaligned rows); the "reg_shape" option forces one for
+        // A/B runs: g*100 + v (sparse: g lanes per cell, v vectors per lane) or 1000 + v*10 + h (dense: h parts of v vectors)
         int g = 0, v = 0, h = 0;
-        if (N <= 64) { g = 16; v = 1; }
-        else if (N <= 128) { g = 16; v = 2; }
-        else if (N <= 256) { g = 16; v = 4; }
-        else if (N <= 512) { g = 32; v = 4; }
-        else if (N <= 1024) { g = 64; v = 4; }
-        else if (N <= 2048) { v = 4; h = 2; }      // 4 KiB parts: 126-136 VGPRs, 3 waves per SIMD (8 KiB parts: 200, 2 waves; measured 73 vs 79 us)
+        if (Nreg <= 64) { g = 16; v = 1; }
+        else if (Nreg <= 128) { g = 16; v = 2; }
+        else if (Nreg <= 256) { g = 16; v = 4; }
+        else if (Nreg <= 512) { g = 32; v = 4; }
+        else if (Nreg <= 1024) { g = 64; v = 4; }
+        else if (Nreg <= 2048) { v = 4; h = 2; }      // 4 KiB parts: 126-136 VGPRs, 3 waves per SIMD (8 KiB parts: 200, 2 waves; measured 73 vs 79 us)
         else { v = 4; h = 4; }
         if (ctx->reg_shape >= 1000) {
             const int fv = (ctx->reg_shape - 1000) / 10, fh = ctx->reg_shape % 10;
-            if ((fv == 4 && (fh == 1 || fh == 2 || fh == 4) || fv == 8 && (fh == 1 || fh == 2)) && (int64_t)256 * fv * fh >= N) { g = 0; v = fv; h = fh; }
+            if (fv == 4 && (fh == 1 || fh == 2 || fh == 4) && (int64_t)256 * fv * fh >= Nreg) { g = 0; v = fv; h = fh; }
         } else if (ctx->reg_shape > 0) {
             const int fg = ctx->reg_shape / 100, fv = ctx->reg_shape % 100;
-            if ((fg == 16 || fg == 32 || fg == 64) && (fv == 1 || fv == 2 || fv == 4) && (int64_t)4 * fg * fv >= N) { g = fg; v = fv; h = 0; }
+            if ((fg == 16 || fg == 32 || fg == 64) && (fv == 1 || fv == 2 || fv == 4) && (int64_t)4 * fg * fv >= Nreg) { g = fg; v = fv; h = 0; }
         }
         const int64_t cpw = h ? 1 : 64 / g;
         const int64_t nbatches = (ncells + cpw - 1) / cpw;
@@ -719,9 +723,9 @@ int launch_dense(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens, co
 // Short pools (N <= 4096: the reference's own sizes) go through the cell kernels instead: the pool row is re-read
 // per budget, but out of the cache, and a cell costs what its n_valid votes cost -- the one-pass kernels below pay a
 // workgroup-wide fold per boundary (measured at P x N = 10^5 x 256, budgets 1, 2, 4 ... N: 240 -> 60 us).
-bool pool_rows_eligible(const scv_ctx* ctx, int32_t B, int64_t N) {
+bool pool_rows_eligible(const scv_ctx* ctx, int32_t B, int64_t N, bool rows_aligned) {
     if (ctx->path != 0 || !ctx->prefix_cells || N < 1) return false;
-    if (N > ctx->tiny_n_max) return N <= ctx->reg_n_max && N <= 4096;
+    if (N > ctx->tiny_n_max) return N <= ctx->reg_n_max && N + (rows_aligned ? 0 : 3) <= 4096;   // (+ 3: an unaligned pool row is read as its aligned superset)
     const int nv = N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : 32));
     return N <= 32 && ctx->tiny_lane && lane_kernel_lds(B, nv) <= (size_t)60 * 1024;
 }
@@ -742,7 +746,8 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     int lane_nv = 0;
     size_t lane_lds = 0;
     const bool lane_ok = prefix_lane_eligible(ctx, B, N, &lane_nv, &lane_lds);
-    if (!lane_ok && pool_rows_eligible(ctx, B, N)) {
+    const bool rows_aligned = (N % 4 == 0) && (((uintptr_t)pool & 15u) == 0) && (!tokens || ((uintptr_t)tokens & 15u) == 0);
+    if (!lane_ok && pool_rows_eligible(ctx, B, N, rows_aligned)) {
         ctx->stat_prefix_cells += 1;
         return launch_aggregate(ctx, pool, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, true);
     }
@@ -756,7 +761,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
     a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.prefetch = 0; a.tok_skew = ctx->tok_skew; a.sorted = 1;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0; a.reg_pivots = ctx->reg_pivots;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
@@ -1039,6 +1044,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "prefetch")) ctx->prefetch = value != 0;
     else if (!strcmp(key, "path")) { if (value < 0 || value > 4) return fail(SCV_ERR_ARG, "path must be 0..4"); ctx->path = (int)value; }
     else if (!strcmp(key, "reg_dense4")) ctx->reg_dense4 = value != 0;
+    else if (!strcmp(key, "reg_pivots")) { if (value < 0 || value > 2) return fail(SCV_ERR_ARG, "reg_pivots must be 0, 1 or 2"); ctx->reg_pivots = (int)value; }
     else if (!strcmp(key, "boot_lds")) ctx->boot_lds = value != 0;
     else if (!strcmp(key, "tiny_lane")) ctx->tiny_lane = value != 0;
     else if (!strcmp(key, "tok_skew")) ctx->tok_skew = value != 0;
@@ -1425,7 +1431,7 @@ int scv_synth_fill_i32(scv_ctx* ctx, int32_t* answers, int32_t* tokens, int32_t*
                        int64_t N, int64_t p_offset, uint64_t seed, int dist) {
     if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
     if (P < 0 || B < 0 || N < 0 || p_offset < 0) return fail(SCV_ERR_ARG, "synth_fill: negative shape");
-    if (dist < SCV_DIST_UNIFORM || dist > SCV_DIST_TIE) return fail(SCV_ERR_ARG, "synth_fill: unknown dist %d", dist);
+    if (dist < SCV_DIST_UNIFORM || dist > SCV_DIST_DEGENERATE_WRONG) return fail(SCV_ERR_ARG, "synth_fill: unknown dist %d", dist);
     SCV_ENTER(ctx);
     if (P == 0) return SCV_OK;
     int64_t grid = P * (int64_t)B;

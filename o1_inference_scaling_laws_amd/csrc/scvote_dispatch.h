@@ -56,8 +56,10 @@ inline KernelFn stream_t(int t, int u, bool tok, bool xtra) {
 }
 template <int G, int V, int K, bool DENSE>
 inline RegKernel reg_gv(bool tok, bool vec) {
-    if (tok) return {vec ? (KernelFn)scv_reg_cells<G, V, K, true, true, DENSE> : (KernelFn)scv_reg_cells<G, V, K, true, false, DENSE>, reg_cells_waves<G, V, true, DENSE>()};
-    return {vec ? (KernelFn)scv_reg_cells<G, V, K, false, true, DENSE> : (KernelFn)scv_reg_cells<G, V, K, false, false, DENSE>, reg_cells_waves<G, V, false, DENSE>()};
+    if (tok) return vec ? RegKernel{(KernelFn)scv_reg_cells<G, V, K, true, true, DENSE>, reg_cells_waves<G, V, true, DENSE, true>()}
+                        : RegKernel{(KernelFn)scv_reg_cells<G, V, K, true, false, DENSE>, reg_cells_waves<G, V, true, DENSE, false>()};
+    return vec ? RegKernel{(KernelFn)scv_reg_cells<G, V, K, false, true, DENSE>, reg_cells_waves<G, V, false, DENSE, true>()}
+               : RegKernel{(KernelFn)scv_reg_cells<G, V, K, false, false, DENSE>, reg_cells_waves<G, V, false, DENSE, false>()};
 }
 // lanes per cell g, 16-byte vectors per lane v (capacity 4*g*v votes); short cells run K = 4 / v batches per
 // iteration (4 KiB of votes in flight per wave behind the batch being counted -- measured: 8 KiB is slower, the

@@ -72,6 +72,7 @@ struct AggArgs {
                             // row p of answers / tokens [P, N] (its first n_valid[b] votes) instead of row p * B + b of [P, B, N]
     int32_t lane_stage;     // scv_lane_prefix: != 0 = a wave's 64 x B cell records are transposed through LDS and written as one
                             // contiguous block (a lane's own records are B * 16 bytes apart)
+    int32_t reg_pivots;     // register-resident kernels: 1 = the lanes' second pivot is switched off (A/B runs); otherwise two pivots per lane
     int32_t acc_classes;    // register-resident kernels: > 0 = per-budget counters accumulate in LDS (this many tie classes per
                             // budget; larger classes go to memory directly) and are flushed once per workgroup
     // single-launch modes of the streaming kernel (agent-scope hand-offs inside the launch, no second kernel):
@@ -335,6 +336,33 @@ __device__ __forceinline__ void finalize_cell(const AggArgs& a, uint32_t* red, c
         if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
         if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
         if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
+    }
+}
+
+// votes + tokens, 16-byte vectors [lo, hi) of a run whose token row is 16-byte congruent with its vote row: UT loads of each
+// stream in flight per lane
+template <int RL2, int T, int UT>
+__device__ __forceinline__ void stream_votes_tokens(uint32_t* hist, uint32_t copy, const int4* v4, const int4* t4, int64_t lo, int64_t hi,
+                                                    int tid, uint32_t& bad, long long& tsum) {
+    int64_t i = lo + tid;
+    for (; i + (int64_t)(UT - 1) * T < hi; i += (int64_t)UT * T) {
+        int4 x[UT], y[UT];
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            x[u] = stream_load(v4 + i + (int64_t)u * T);
+            y[u] = stream_load(t4 + i + (int64_t)u * T);
+        }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            vote4<RL2>(hist, copy, x[u], bad);
+            tsum += (long long)y[u].x + (long long)y[u].y + (long long)y[u].z + (long long)y[u].w;
+        }
+    }
+    for (; i < hi; i += T) {
+        const int4 x = stream_load(v4 + i);
+        const int4 y = stream_load(t4 + i);
+        vote4<RL2>(hist, copy, x, bad);
+        tsum += (long long)y.x + (long long)y.y + (long long)y.z + (long long)y.w;
     }
 }
 
@@ -693,6 +721,16 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
     // registers before the current item's epilogue (B1 / fold / reductions), so a short cell's load
     // latency overlaps the previous cell's epilogue instead of following it.
     const bool pf = !TOK && a.prefetch && a.stagger_vecs == 0 && !a.plain_loads;
+    // ... and with the tokens stream: the first UT vectors of BOTH rows of the next item (round 2 had no prefetch here: 6.4-6.6
+    // against 6.9-7.1 TB/s votes-only).  Items whose token row is not 16-byte congruent with the vote row take stream_row.
+    constexpr int UT = U > 1 ? U / 2 : 1;
+    const bool pft = TOK && !(U == 8 && T == 1024) /* (that A/B variant has no registers to spare) */ && a.prefetch && a.stagger_vecs == 0 && !a.plain_loads && !a.tok_skew;
+    int4 pret[TOK ? UT : 1];
+    const int4* cur_t4 = nullptr;             // first aligned vector of the current item's token row (NULL: not congruent)
+    auto token_vectors = [&](const StreamItem& it, int64_t lo) -> const int4* {
+        const int32_t* t = a.tokens + it.cell * a.N + lo + it.head;
+        return (((uintptr_t)t) & 15u) == 0 ? reinterpret_cast<const int4*>(t) : nullptr;
+    };
     int4 pre[U];
     StreamItem cur;
     int64_t cur_lo = 0;
@@ -703,6 +741,17 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
             for (int u = 0; u < U; ++u) {
                 const int64_t idx = tid + (int64_t)u * T;
                 pre[u] = idx < cur.nvec ? stream_load(cur.v4 + idx) : make_int4(0, 0, 0, 0);
+            }
+        }
+        if (TOK && pft) {
+            cur_t4 = token_vectors(cur, cur_lo);
+            if (cur_t4) {
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+                    const int64_t idx = tid + (int64_t)u * T;
+                    pre[u] = idx < cur.nvec ? stream_load(cur.v4 + idx) : make_int4(0, 0, 0, 0);
+                    pret[u] = idx < cur.nvec ? stream_load(cur_t4 + idx) : make_int4(0, 0, 0, 0);
+                }
             }
         }
     }
@@ -719,6 +768,19 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
             if (cur.nvec > (int64_t)U * T) stream_votes<RL2, T, U, true>(hist, copy, cur.v4, (int64_t)U * T, cur.nvec, tid, bad);
             const int64_t t0 = cur.head + (cur.nvec << 2);
             if (tid < cur.n - t0) vote<RL2>(hist, copy, (uint32_t)cur.row[t0 + tid], bad);
+        } else if (TOK && pft && cur_t4) {
+            // votes + tokens with the first tile of both rows already in registers
+            const int32_t* trow = a.tokens + cell * a.N + cur_lo;
+            if (tid < cur.head) { vote<RL2>(hist, copy, (uint32_t)cur.row[tid], bad); tsum += trow[tid]; }
+#pragma unroll
+            for (int u = 0; u < UT; ++u)
+                if (tid + (int64_t)u * T < cur.nvec) {
+                    vote4<RL2>(hist, copy, pre[u], bad);
+                    tsum += (long long)pret[u].x + (long long)pret[u].y + (long long)pret[u].z + (long long)pret[u].w;
+                }
+            if (cur.nvec > (int64_t)UT * T) stream_votes_tokens<RL2, T, UT>(hist, copy, cur.v4, cur_t4, (int64_t)UT * T, cur.nvec, tid, bad, tsum);
+            const int64_t t0 = cur.head + (cur.nvec << 2);
+            if (tid < cur.n - t0) { vote<RL2>(hist, copy, (uint32_t)cur.row[t0 + tid], bad); tsum += trow[t0 + tid]; }
         } else {
             const int32_t* trow = TOK ? a.tokens + cell * a.N + cur_lo : nullptr;
             stream_row<RL2, T, U, TOK>(a, hist, copy, cur.row, trow, cur.n, tid, bad, tsum);   // o1.py:181-195
@@ -726,6 +788,7 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
         const bool more = item + gridDim.x < nitems;
         StreamItem nxt = cur;
         int64_t nxt_lo = 0;
+        const int4* nxt_t4 = nullptr;
         if (more) {
             describe_item(a, use_ord, ord, item + gridDim.x, nxt, nxt_lo);
             if (pf) {
@@ -733,6 +796,17 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
                 for (int u = 0; u < U; ++u) {
                     const int64_t idx = tid + (int64_t)u * T;
                     pre[u] = idx < nxt.nvec ? stream_load(nxt.v4 + idx) : make_int4(0, 0, 0, 0);
+                }
+            }
+            if (TOK && pft) {
+                nxt_t4 = token_vectors(nxt, nxt_lo);
+                if (nxt_t4) {
+#pragma unroll
+                    for (int u = 0; u < UT; ++u) {
+                        const int64_t idx = tid + (int64_t)u * T;
+                        pre[u] = idx < nxt.nvec ? stream_load(nxt.v4 + idx) : make_int4(0, 0, 0, 0);
+                        pret[u] = idx < nxt.nvec ? stream_load(nxt_t4 + idx) : make_int4(0, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -775,6 +849,7 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
         }
         cur = nxt;
         cur_lo = nxt_lo;
+        cur_t4 = nxt_t4;
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
     if (XTRA && a.overwrite) {
@@ -1824,15 +1899,16 @@ constexpr int kKeyShift = 18;
 constexpr uint32_t kKeyMask = (1u << kKeyShift) - 1u;
 constexpr int kRegCellBins = 1025;                   // 1024 bins + one spare
 constexpr int kRegHistWords = 4 * kRegCellBins;      // per wave: C cells x 1025 bins x R copies, C * R = 4
-constexpr int kRegLaneWords = 64 + 128;              // + per lane: one word of the "wide truth bin" (see below) and 8 bytes of trash
-                                                     // (inactive vote slots add there: a shared trash bin serialised them 32-64 deep)
+constexpr int kRegLaneWords = 64 + 128 + 64;         // + per lane: the first pivot's word, 8 bytes of trash (inactive vote slots add there: a
+                                                     // shared trash bin serialised them 32-64 deep), the second pivot's word
 constexpr int kRegWaveWords = kRegHistWords + kRegLaneWords;
 // The waves of a workgroup are independent; a workgroup is ALL the waves a CU holds of the shape (launch bounds =
 // the occupancy the shape is meant to run at: 16 / 12 / 8 / 4 waves), so a launch is one workgroup per CU: the
 // end-of-launch counter flush then costs 256 device atomics per counter (12 ns each on one address), not 1024.
-template <int G, int V, bool TOK, bool DENSE>
+template <int G, int V, bool TOK, bool DENSE, bool VEC = true>
 constexpr int reg_cells_waves() {
     if (DENSE) return 8;
+    if (!VEC && V == 1) return 12;             // unaligned rows, K = 4 batches in flight: 12-28 B of scratch at 128 VGPRs
     // (with tokens the one-vector shapes run K = 4 batches per iteration, each with its token loads in flight: they
     // spill at 128 VGPRs -- tools/kernel_resources.py -- and get 12 waves = 168 VGPRs like the four-vector shapes)
     if (TOK && (V == 1 || V == 4)) return 12;
@@ -1841,7 +1917,7 @@ constexpr int reg_cells_waves() {
 }
 template <int V, int H, bool TOK, bool VEC>
 constexpr int reg_dense_waves() {
-    if (V == 8) return TOK ? 4 : 8;
+    if (V == 8) return TOK ? 4 : 8;   // (not instantiated any more)
     if (H == 1 || !VEC) return TOK ? 8 : 12;
     return 12;            // (126 VGPRs would allow 16 waves without tokens: measured slower, N = 4096 73 -> 82 us)
 }
@@ -1920,11 +1996,48 @@ __device__ __forceinline__ uint32_t bin_address(uint32_t KB, uint32_t vm) {
     return A;
 }
 
+// W = (A == ap0) ? tw : ((A == ap1) ? tw2 : A | c4): the pivot selection of one vote, hand-scheduled.  gfx950 wants two
+// instructions between a VALU compare and the v_cndmask that reads its mask; left alone the compiler chains compare / s_nop /
+// cndmask through VCC (seen in the ISA: 3 s_nop per vote, 4 idle cycles of ~36).  Here both compares are issued first -- one
+// into an SGPR pair, one into VCC -- and an instruction the vote needs anyway (the address OR / the 16-bit increment) fills the gap.
+__device__ __forceinline__ uint32_t pivot_select(uint32_t A, uint32_t c4, uint32_t ap0, uint32_t ap1, uint32_t tw, uint32_t tw2) {
+    uint32_t W;
+    unsigned long long m1;
+    asm("v_cmp_eq_u32_e64 %[m1], %[a], %[p1]\n\t"
+        "v_cmp_eq_u32_e32 vcc, %[a], %[p0]\n\t"
+        "v_or_b32_e32 %[w], %[a], %[c]\n\t"
+        "v_cndmask_b32_e64 %[w], %[w], %[t2], %[m1]\n\t"
+        "v_cndmask_b32_e32 %[w], %[w], %[t1], vcc"
+        : [w] "=&v"(W), [m1] "=&s"(m1)
+        : [a] "v"(A), [c] "v"(c4), [p0] "v"(ap0), [p1] "v"(ap1), [t1] "v"(tw), [t2] "v"(tw2)
+        : "vcc");
+    return W;
+}
+// 16-bit bins, one copy (G = 16): the word that holds the bin (A & ~3) and the increment 1 or 1 << 16 by bit 1 of A
+// (v_alignbyte_b32 shifts {1, 1} right by the low 2 bits of A in bytes: 0 or 2); a pivot's word collects the same increments.
+__device__ __forceinline__ uint32_t pivot_select_h16(uint32_t A, uint32_t ap0, uint32_t ap1, uint32_t tw, uint32_t tw2, uint32_t& inc) {
+    uint32_t W;
+    unsigned long long m1;
+    asm("v_cmp_eq_u32_e64 %[m1], %[a], %[p1]\n\t"
+        "v_cmp_eq_u32_e32 vcc, %[a], %[p0]\n\t"
+        "v_alignbyte_b32 %[i], 1, 1, %[a]\n\t"
+        "v_cndmask_b32_e64 %[w], %[a], %[t2], %[m1]\n\t"
+        "v_cndmask_b32_e32 %[w], %[w], %[t1], vcc\n\t"
+        "v_and_b32_e32 %[w], -4, %[w]"
+        : [w] "=&v"(W), [i] "=&v"(inc), [m1] "=&s"(m1)
+        : [a] "v"(A), [p0] "v"(ap0), [p1] "v"(ap1), [t1] "v"(tw), [t2] "v"(tw2)
+        : "vcc");
+    return W;
+}
+
 // G lanes per cell, V 16-byte vectors per lane, K batches of C cells per loop iteration (short cells: more
-// bytes in flight per wave), TOK tokens stream, VEC rows are 16-byte aligned (N % 4 == 0 and aligned bases:
-// dwordx4 loads); !VEC takes dword loads with a lane-contiguous element order.
+// bytes in flight per wave), TOK tokens stream.  VEC: every row is 16-byte aligned (N % 4 == 0 and aligned bases).  !VEC: rows
+// start anywhere (the reference's N is arbitrary, o1.py:276): a cell reads the 16-byte-aligned SUPERSET of its row with the same
+// dwordx4 loads -- vector 0 starts `sh` = 0..3 elements before the row -- and masks both ends (votes are order-independent, so
+// the shift only moves the validity window: slot e of the superset is vote e - sh).  The superset of n votes has up to n + 3
+// slots; the host sizes the shape for N + 3.  (Round 2 used dword loads here: 3.45 vs 4.72 TB/s at N = 1001 / 1024.)
 template <int G, int V, int K, bool TOK, bool VEC, bool DENSE>
-__global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void scv_reg_cells(const AggArgs a) {
+__global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE, VEC>())) void scv_reg_cells(const AggArgs a) {
     static_assert(!DENSE || G == 64, "the dense scan owns a whole wave per cell");
     constexpr int C = 64 / G;                 // cells per wave per batch
     constexpr int R = G / 16;                 // histogram copies per cell
@@ -1964,7 +2077,8 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
     const uint32_t copy4 = P16 ? (copy >> 1) * 4u : copy * (H16 ? (uint32_t)kRegCopyBytes16 : 4u);   // word of this lane's copy, bytes
     const uint32_t copy_inc = 1u << (16u * (copy & 1u));                 // P16: this lane's half of that word
     const uint32_t copy2 = copy * 2u;                                    // P16: byte offset of this lane's 16-bit counter
-    const uint32_t TW = LW + (uint32_t)lane * 4u;                            // this lane's word of the wide truth bin
+    const uint32_t TW = LW + (uint32_t)lane * 4u;                            // this lane's pivot words (first / second pivot)
+    const uint32_t TW2 = LW + 768u + (uint32_t)lane * 4u;
     // n_valid[B] cached behind the histograms (host sizes the region; B > kMaxSortedB reads it from memory):
     // a global load here would put a dependent memory round trip in front of every batch's loads
     uint32_t* nv_lds = smem + WW;
@@ -1978,6 +2092,7 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
         int64_t cell, rowi;   // cell index; row of answers / tokens it reads (the problem's, for prefix budgets over a pool)
         int32_t b, truth;
         uint32_t n;           // valid votes of this lane's cell (0 when the slot is past the last cell)
+        uint32_t sh;          // !VEC: elements between the aligned start of the superset and the row (0..3); VEC: 0
     };
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1988,8 +2103,8 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
     const int64_t dp = stride / a.B;
     const int32_t db = (int32_t)(stride - dp * a.B);
 
-    auto element = [&](int k, int j) -> uint32_t {                  // index of vote (k, j) of this lane inside its cell
-        return VEC ? (uint32_t)((k * G + l) * 4 + j) : (uint32_t)((k * 4 + j) * G + l);
+    auto element = [&](int k, int j) -> uint32_t {                  // slot (k, j) of this lane inside its cell's (superset) row
+        return (uint32_t)((k * G + l) * 4 + j);
     };
     // Loads are UNCONDITIONAL (a vote past the valid prefix re-reads element 0 of the row; a slot past the last
     // cell reads cell 0): the number of loads per batch is then a compile-time constant, so the compiler can
@@ -2003,19 +2118,13 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
         t.truth = a.truth[live ? np : 0];
         t.rowi = live ? (a.pool_rows ? np : ncell) : 0;
         const int32_t* row = a.answers + t.rowi * a.N;
+        t.sh = VEC ? 0u : ((uint32_t)(uintptr_t)row & 15u) >> 2;
+        const int4* row4 = reinterpret_cast<const int4*>(row - t.sh);          // 16-byte aligned (a vector never crosses a page)
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            if (VEC) {
-                const uint32_t vi = element(k, 0) < t.n ? (uint32_t)(k * G + l) : 0u;
-                const int4 x = stream_load(reinterpret_cast<const int4*>(row) + vi);
-                t.v[4 * k] = (uint32_t)x.x; t.v[4 * k + 1] = (uint32_t)x.y; t.v[4 * k + 2] = (uint32_t)x.z; t.v[4 * k + 3] = (uint32_t)x.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t e = element(k, j);
-                    t.v[4 * k + j] = (uint32_t)__builtin_nontemporal_load(row + (e < t.n ? e : 0u));
-                }
-            }
+            const uint32_t vi = element(k, 0) < t.n + t.sh ? (uint32_t)(k * G + l) : 0u;
+            const int4 x = stream_load(row4 + vi);
+            t.v[4 * k] = (uint32_t)x.x; t.v[4 * k + 1] = (uint32_t)x.y; t.v[4 * k + 2] = (uint32_t)x.z; t.v[4 * k + 3] = (uint32_t)x.w;
         }
         ncell += stride; np += dp; nb += db;
         if (nb >= a.B) { nb -= a.B; np += 1; }
@@ -2026,44 +2135,105 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
     // exactly CAP valid votes (wave-uniform), so no vote needs an activity predicate.
     // EL = 4 * (live vectors): slots at or beyond the longest cell of the batch are skipped by every pass (a cell shorter
     // than the shape's capacity, ragged n_valid) -- the cost of a batch follows its votes, not the shape's capacity.
-    auto vote_pass = [&](Batch& c, auto full_tag, auto live_tag) {
+    // FULL: every slot of every lane is a vote (wave-uniform).  Otherwise the slots that are NOT votes -- beyond a cell's valid
+    // prefix, or (unaligned rows) in front of the row -- are first replaced by a per-lane sentinel value whose bin address is the
+    // lane's trash (SENT below), vector by vector and only in the vectors that can hold such slots: every lane's vectors
+    // [first unaligned ? 1 : 0, kfull) are all votes (kfull: wave-uniform, from the shortest cell of the batch).  After that the
+    // passes run unmasked: a cell of 1001 votes costs what its 1001 votes cost, not 1024 masked ones.
+    auto vote_pass = [&](Batch& c, auto full_tag, auto live_tag, int kfull) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr int EL = 4 * decltype(live_tag)::value;
         // activity of vote i as a MASK, not a predicate (64 live SGPR pairs would spill): element(i) < n  <=>
         // const_i < nl with the lane term moved to the right-hand side; m = all ones when active
-        const int32_t nl = (int32_t)c.n - (VEC ? 4 * l : l);
-        // address of the truth's bin; a vote is a truth vote iff its bin address equals it (inactive slots carry ATR)
-        const uint32_t AT = (c.truth >= 0 && c.truth < kBins) ? KB - ((uint32_t)c.truth << S) : 0xffffffffu;
+        const int32_t nl = (int32_t)(c.n + c.sh) - 4 * l;
+        // PIVOTS (see the kernel comment): this lane's first (and second) vote.  A vote equal to a pivot is added to a word of
+        // the lane's own (TW / TW2: conflict-free) instead of its -- shared, contended -- histogram bin; after the last vote
+        // the word is moved into the pivot's bin: one read-and-clear + one add per lane and pivot instead of one add per vote.
+        // Two pivots per lane: exact 2-way ties (and a wrong majority next to the truth) are as cheap as one peaked value.
+        // (One code path: selecting a one-pivot variant per batch cost 20 VGPRs -- spills at 16 waves -- for 2 VALU per vote.)
+        // Domain check of the whole batch up front (o1.py:140 int(extracted_answer) is unbounded; the extractor maps it into
+        // bins 0..1023): the per-vote clamp runs only in the -- wave-uniform, rare -- case that some slot holds a larger value.
+        {
+            uint32_t orv = 0;
+#pragma unroll
+            for (int i = 0; i < EL; ++i) orv |= c.v[i];
+            if (__any(orv > 1023u)) {
+#pragma unroll
+                for (int i = 0; i < EL; ++i) {
+                    const uint32_t v = c.v[i];
+                    uint32_t m = 0xffffffffu;
+                    if (!FULL) {
+                        m = (uint32_t)(((i >> 2) * G * 4 + (i & 3) - nl) >> 31);
+                        if (!VEC && i < 3) m &= ~(uint32_t)((int32_t)(4 * l + i - (int32_t)c.sh) >> 31);
+                    }
+                    bad |= v & m;                                   // (an inactive slot holds a re-read of vector 0 / the row's neighbours)
+                    c.v[i] = v < 1023u ? v : 1023u;
+                }
+            }
+        }
+        if (!FULL) {
+            // SENT: the (negative) "vote" whose bin address KB - (SENT << S) is ATR, the lane's trash.  KB - ATR is a multiple of the
+            // bin stride in every 16-bit layout (regions are 8-byte multiples); the 32-bit dense variant (16 bytes per bin, votes
+            // dead after this pass) rounds the trash address down to its stride.
+            const uint32_t SENT = (uint32_t)((int32_t)(KB - (DENSE ? (ATR & ~15u) : ATR)) >> S);
+#pragma unroll
+            for (int k = 0; k < EL / 4; ++k) {
+                if (k < kfull && (VEC || k > 0)) continue;          // (wave-uniform) every slot of this vector is a vote in every lane
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * k + j;
+                    bool ok = k * G * 4 + j < nl;
+                    if (!VEC && i < 3) ok = ok && (4 * l + i >= (int32_t)c.sh);     // the <= 3 slots before the row
+                    c.v[i] = ok ? c.v[i] : SENT;
+                }
+            }
+        }
+        // bin addresses of all votes (a sentinel's: the lane's trash address), then the pivots: the lane's first vote, and the
+        // first of its next three votes that differs from it
+        uint32_t A[EL];
 #pragma unroll
         for (int i = 0; i < EL; ++i) {
-            const uint32_t v = c.v[i];
-            const uint32_t vm = v < 1023u ? v : 1023u;
-            uint32_t A = bin_address<S>(KB, vm);
-            if (FULL) bad |= v;
-            else {
-                const int32_t ci = VEC ? (i >> 2) * G * 4 + (i & 3) : i * G;
-                const uint32_t m = (uint32_t)((ci - nl) >> 31);
-                bad |= v & m;                                       // an inactive slot holds a re-read of element 0
-                A = (A & m) | (ATR & ~m);
-            }
-            if (!DENSE) c.v[i] = A;                                 // a truth vote keeps its bin address: that bin reads 0 later
-            // a vote for the truth goes to this lane's own word instead of the (shared, contended) histogram bin
-            if (H16) {
-                // the word holding the 16-bit bin, and 1 or 1 << 16 by bit 1 of its address (v_alignbyte_b32 shifts
-                // {1, 1} right by the low 2 bits of A in bytes: 0 or 2).  The truth word collects both halves.
-                const uint32_t inc = __builtin_amdgcn_alignbyte(1u, 1u, A);
-                lds_add((A == AT ? TW : (A + copy4)) & ~3u, inc);
-            } else if (P16) lds_add(A == AT ? TW : (A | copy4), copy_inc);
-            else lds_add1(A == AT ? TW : (A | copy4));
+            A[i] = bin_address<S>(KB, c.v[i]);
+            if (!DENSE) c.v[i] = A[i];                              // (a pivot vote keeps its bin address: the bin holds the total when it is read)
         }
+        const uint32_t ap0 = A[0];                                  // an inactive lane's pivot is its trash address
+        uint32_t ap1 = A[1] != ap0 ? A[1] : (A[2] != ap0 ? A[2] : A[3]);
+        if (a.reg_pivots == 1) ap1 = ap0;                           // (second pivot off: never selected, the first test wins)
+#pragma unroll
+        for (int i = 0; i < EL; ++i) {
+            if (H16) {
+                uint32_t inc, W;
+                if (i == 0) { W = TW; inc = __builtin_amdgcn_alignbyte(1u, 1u, A[0]); }
+                else W = pivot_select_h16(A[i], ap0, ap1, TW, TW2, inc);
+                lds_add(W, inc);
+            } else {
+                const uint32_t W = i == 0 ? TW : pivot_select(A[i], copy4, ap0, ap1, TW, TW2);
+                if (P16) lds_add(W, copy_inc); else lds_add1(W);
+            }
+        }
+        // move the pivot words into the pivots' bins (LDS operations of a wave execute in order: the reads of pass 2 see them)
+        {
+            const uint32_t w0 = __hip_atomic_exchange(reinterpret_cast<lds_u32*>((uintptr_t)TW), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t w1 = __hip_atomic_exchange(reinterpret_cast<lds_u32*>((uintptr_t)TW2), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_add(H16 ? (ap0 + copy4) & ~3u : (ap0 | copy4), w0);
+            // (a second pivot that collected nothing -- it equals the first, or is off -- adds its zero to the lane's trash: a zero
+            //  added to a hot bin still queues behind the other lanes' adds to that word)
+            const uint32_t t1 = w1 ? ap1 : ATR;
+            lds_add(H16 ? (t1 + copy4) & ~3u : (t1 | copy4), w1);
+        }
+        // the lane's trash has collected the non-votes (and empty pivots): zero it, so that pass 2 reads count 0 there and needs no masks
+        if (!FULL && !DENSE) *reinterpret_cast<lds_v2u*>((uintptr_t)ATR) = scv_v2u{0u, 0u};
         __builtin_amdgcn_wave_barrier();
     };
     // passes 2-4, sparse: read back the counts of the bins this lane voted for
-    auto sparse_passes = [&](Batch& c, auto full_tag, auto live_tag, uint32_t& gkey, uint32_t& at_max, uint32_t& tc) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    auto sparse_passes = [&](Batch& c, auto live_tag, uint32_t& gkey, uint32_t& at_max, uint32_t& tc) {
         constexpr int EL = 4 * decltype(live_tag)::value;
         uint32_t lmax = 0;
         constexpr int CH = EL > 16 ? 8 : EL;                          // bound the registers held by reads in flight
+        // h[truth] (o1.py:206): every lane of the cell reads the truth's bin (same address: a broadcast).  Issued first, so it
+        // has returned when the counts of pass 2 have (LDS answers in order); pinned before the clears of pass 4 below.
+        const uint32_t ATt = (c.truth >= 0 && c.truth < kBins) ? KB - ((uint32_t)c.truth << S) : ATR;   // no such bin: the lane's trash
+        tc = H16 ? lds_count16<R>(ATt) : (P16 ? lds_count_packed<R>(ATt) : lds_count<R>(ATt));
 #pragma unroll
         for (int i0 = 0; i0 < EL; i0 += CH) {
             // all CH reads are issued before the first count is consumed (left alone, the scheduler keeps only
@@ -2077,19 +2247,19 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
             for (int i = i0; i < i0 + CH; ++i) {
                 const uint32_t A = c.v[i];
                 uint32_t key = (cn[i - i0] << kKeyShift) | A;
-                if (!FULL) {                                            // A < LW for every real bin: inactive -> key = ATR
-                    const uint32_t m = (uint32_t)((int32_t)(A - LW) >> 31);    // (count 0, below every real key; pass 4
-                    key = (key & m) | (ATR & ~m);                       //  then clears the lane's trash, never another region)
-                }
-                c.v[i] = key;
+                c.v[i] = key;                                           // (a non-vote reads its lane's trash, zeroed after pass 1: count 0, below
+                                                                        //  every real key; pass 4 then clears the trash again, never another region)
                 lmax = key > lmax ? key : lmax;
             }
         }
         gkey = cellgroup_max<G>(lmax);                              // every lane of the cell gets it
         const uint32_t thr = gkey & ~kKeyMask;                       // max_count << kKeyShift
-        // pass 3 (statistics.py:599-601): votes at max -> number of distinct modes; h[truth]
+        // pass 3 (statistics.py:599-601): votes at max -> number of distinct modes
         at_max = 0;
-        tc = *reinterpret_cast<lds_u32*>((uintptr_t)TW);            // this lane's truth votes (summed over the cell below)
+        // The truth's count is consumed here: the compiler may not sink its load below the 16-bit clears that follow (the load
+        // is a 32- / 64-bit access: type-based alias analysis would let it).
+        asm volatile("" : "+v"(tc) : : "memory");
+        if (ATt == ATR) tc = 0u;
         // ... and pass 4 in the same loop: sparse clear (an inactive vote's key addresses the lane's trash).  LDS
         // operations of a wave execute in order, so the clears need no wait for the reads of pass 2; interleaved, the
         // address arithmetic of the clear fills the wait state between v_cmp and the carry-in add of the count.
@@ -2100,8 +2270,6 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
             else if (P16) *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) | copy2)) = (uint16_t)0;
             else *reinterpret_cast<lds_u32*>((uintptr_t)((c.v[i] & kKeyMask) | copy4)) = 0u;
         }
-        if (H16 || P16) tc = (tc & 0xffffu) + (tc >> 16);
-        *reinterpret_cast<lds_u32*>((uintptr_t)TW) = 0u;
         __builtin_amdgcn_wave_barrier();
     };
     // passes 2-4, dense (G = 64): lane scans histogram indices x = lane + 64 j
@@ -2121,11 +2289,11 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
                 lmax = key[j] > lmax ? key[j] : lmax;
             }
         }
-        tc = *reinterpret_cast<lds_u32*>((uintptr_t)TW);
+        tc = (c.truth >= 0 && c.truth < kBins) ? lds_count<4>(KB - ((uint32_t)c.truth << S)) : 0u;     // h[truth], before the zeroing
+        asm volatile("" : "+v"(tc) : : "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < 16; ++j) *reinterpret_cast<lds_v4u*>((uintptr_t)(A0 + 1024u * j)) = scv_v4u{0u, 0u, 0u, 0u};
-        *reinterpret_cast<lds_u32*>((uintptr_t)TW) = 0u;
         __builtin_amdgcn_wave_barrier();
         gkey = cellgroup_max<64>(lmax);
         const uint32_t thr = gkey & ~kKeyMask;
@@ -2134,23 +2302,17 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
         for (int j = 0; j < 16; ++j) at_max += key[j] >= thr ? 1u : 0u;    // BINS at max (all 1024 when the cell is empty)
     };
 
-    auto finish_cell = [&](const Batch& c, uint32_t gkey, uint32_t at_max, uint32_t tc_lane, long long tsum) {
-        const uint32_t hmax = gkey >> kKeyShift;                            // max count over every value but the truth
-        // (at_max, truth votes) summed over the cell in one reduction: both are <= 4096
-        const uint32_t sums = cellgroup_sum<G>(at_max | (tc_lane << 16));
-        const uint32_t sum_at_max = sums & 0xffffu, tc = sums >> 16;
+    auto finish_cell = [&](const Batch& c, uint32_t gkey, uint32_t at_max, uint32_t tc, long long tsum) {
+        const uint32_t maxc = gkey >> kKeyShift;                            // max count over every value of the cell
+        const uint32_t sum_at_max = cellgroup_sum<G>(at_max);               // votes (dense: bins) at the maximum, over the cell
         long long tok = 0;
         if (TOK) tok = cellgroup_sum_i64<G>(tsum);
         if (l == 0 && c.cell < a.ncells) {
-            // merge (statistics.multimode over histogram values + the truth value): o1.py:202-206
-            const uint32_t maxc = tc > hmax ? tc : hmax;
+            // statistics.multimode + o1.py:202-206
             const bool any = maxc > 0;
-            const uint32_t h_modes = hmax > 0 ? (DENSE ? sum_at_max : exact_quotient(sum_at_max, hmax)) : 0u;
-            const uint32_t h_min = 1023u - (((gkey & kKeyMask) - cellbase) >> S);
+            const uint32_t n_modes = any ? (DENSE ? sum_at_max : exact_quotient(sum_at_max, maxc)) : 0u;
+            const uint32_t mm = 1023u - (((gkey & kKeyMask) - cellbase) >> S);
             const uint32_t hit = (any && tc == maxc) ? 1u : 0u;             // o1.py:206
-            const uint32_t n_modes = any ? (tc > hmax ? 1u : h_modes + hit) : 0u;
-            const uint32_t tv = (uint32_t)c.truth;                          // hit implies 0 <= truth < 1024
-            const uint32_t mm = tc > hmax ? tv : (hit && tv < h_min ? tv : h_min);
             if (a.cells) {
                 uint4 rec;
                 rec.x = maxc;
@@ -2182,40 +2344,41 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE>())) void sc
             // tokens of the current batch: issued now, consumed after the LDS passes (only the sum is needed)
             long long tsum = 0;
             if (TOK) {
+                // the token row has its own alignment (its base may differ from the votes'): same superset trick, only the sum is needed
                 const int32_t* trow = a.tokens + c.rowi * a.N;
+                const uint32_t tsh = VEC ? 0u : ((uint32_t)(uintptr_t)trow & 15u) >> 2;
+                const int4* trow4 = reinterpret_cast<const int4*>(trow - tsh);
+                const uint32_t hi = n + tsh;
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    if (VEC) {
-                        const uint32_t vi = element(k, 0) < n ? (uint32_t)(k * G + l) : 0u;
-                        const int4 y = stream_load(reinterpret_cast<const int4*>(trow) + vi);
-                        tsum += (element(k, 0) < n ? (long long)y.x : 0) + (element(k, 1) < n ? (long long)y.y : 0)
-                              + (element(k, 2) < n ? (long long)y.z : 0) + (element(k, 3) < n ? (long long)y.w : 0);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const uint32_t e = element(k, q);
-                            const int32_t y = __builtin_nontemporal_load(trow + (e < n ? e : 0u));
-                            tsum += e < n ? (long long)y : 0;
-                        }
-                    }
+                    const uint32_t vi = element(k, 0) < hi ? (uint32_t)(k * G + l) : 0u;
+                    const int4 y = stream_load(trow4 + vi);
+                    // slot e is token e - tsh: valid iff tsh <= e < n + tsh (unsigned: e - tsh < n)
+                    tsum += (element(k, 0) - tsh < n ? (long long)y.x : 0) + (element(k, 1) - tsh < n ? (long long)y.y : 0)
+                          + (element(k, 2) - tsh < n ? (long long)y.z : 0) + (element(k, 3) - tsh < n ? (long long)y.w : 0);
                 }
             }
             uint32_t gkey, at_max, tc;
+            int kfull = 0;
             auto partial = [&](auto live_tag) {
-                vote_pass(c, std::false_type{}, live_tag);
-                if (DENSE) dense_passes(c, gkey, at_max, tc); else sparse_passes(c, std::false_type{}, live_tag, gkey, at_max, tc);
+                vote_pass(c, std::false_type{}, live_tag, kfull);
+                if (DENSE) dense_passes(c, gkey, at_max, tc); else sparse_passes(c, live_tag, gkey, at_max, tc);
             };
-            if (__all(n == CAP)) {
-                vote_pass(c, std::true_type{}, std::integral_constant<int, V>{});
-                if (DENSE) dense_passes(c, gkey, at_max, tc); else sparse_passes(c, std::true_type{}, std::integral_constant<int, V>{}, gkey, at_max, tc);
+            if (__all(n == CAP && (VEC || c.sh == 0u))) {
+                vote_pass(c, std::true_type{}, std::integral_constant<int, V>{}, V);
+                if (DENSE) dense_passes(c, gkey, at_max, tc); else sparse_passes(c, std::integral_constant<int, V>{}, gkey, at_max, tc);
             } else {
-                // longest cell of the batch (wave-uniform: lane s * G holds cell slot s) -> live vectors
-                uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)n, 0);
+                // longest and shortest cell of the batch (wave-uniform: lane s * G holds cell slot s) -> live vectors, and the
+                // vectors [0, kfull) whose every slot is a vote in every lane
+                const uint32_t nsh = n + c.sh;                     // slots of the (superset) row in use
+                uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)nsh, 0), nmin = nmax;
 #pragma unroll
                 for (int sl = 1; sl < C; ++sl) {
-                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)n, sl * G);
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)nsh, sl * G);
                     nmax = o > nmax ? o : nmax;
+                    nmin = o < nmin ? o : nmin;
                 }
+                kfull = (int)(nmin / (4u * G));
                 const uint32_t live = (nmax + 4u * G - 1u) / (4u * G);
                 if (V >= 4 && live > 3) partial(std::integral_constant<int, V >= 4 ? 4 : V>{});
                 else if (V >= 3 && live > 2) partial(std::integral_constant<int, V >= 3 ? 3 : V>{});
@@ -2279,7 +2442,9 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_
     struct Part {
         uint32_t v[E];
         int32_t tk[TOK ? E : 1];
-        uint32_t nrel;        // valid votes of the cell minus the votes before this part (may be <= 0 as int)
+        uint32_t nrel;        // slots of the cell's (superset) row in use, minus the slots before this part (may be <= 0 as int)
+        uint32_t sh;          // !VEC: elements between the aligned start of the superset and the row (0..3); VEC: 0
+        uint32_t tnrel, tsh;  // !VEC && TOK: the same for the token row (its base may be aligned differently)
     };
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -2295,38 +2460,34 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_
         const int32_t bb = live ? nb : 0;
         ln = live ? (nv_cached ? nv_lds[bb] : (uint32_t)valid_len(a, bb)) : 0u;
     };
-    auto element = [&](int k, int j) -> uint32_t {                  // index inside the part
-        return VEC ? (uint32_t)((k * 64 + lane) * 4 + j) : (uint32_t)((k * 4 + j) * 64 + lane);
-    };
-    // unconditional loads (constant count per part -> counted vmcnt waits), clamped to element 0 of the row
+    // unconditional loads (constant count per part -> counted vmcnt waits), clamped to vector 0 of the row.  !VEC: the row's
+    // 16-byte-aligned superset is read (see scv_reg_cells): slot e of the superset is vote e - sh.
     auto load_part = [&](Part& t) {
         const bool live = ncell < a.ncells;
-        const int64_t rowoff = (live ? (a.pool_rows ? np : ncell) : 0) * a.N + (int64_t)lpart * PART;
-        const int32_t nrel = (int32_t)ln - (int32_t)(lpart * PART);
-        t.nrel = (uint32_t)nrel;
+        const int64_t rowoff = (live ? (a.pool_rows ? np : ncell) : 0) * a.N;
         const int32_t* row = a.answers + rowoff;
-        const int32_t* trow = TOK ? a.tokens + rowoff : nullptr;
-        const int64_t back = (int64_t)lpart * PART;                  // clamp target: element 0 of the row
+        t.sh = VEC ? 0u : ((uint32_t)(uintptr_t)row & 15u) >> 2;
+        const int4* row4 = reinterpret_cast<const int4*>(row - t.sh);
+        const int32_t nrel = (int32_t)(ln + t.sh) - (int32_t)(lpart * PART);
+        t.nrel = (uint32_t)nrel;
+        const int4* trow4 = nullptr;
+        int32_t tnrel = nrel;
+        t.tsh = t.sh;
+        if (TOK) {
+            const int32_t* trow = a.tokens + rowoff;
+            t.tsh = VEC ? 0u : ((uint32_t)(uintptr_t)trow & 15u) >> 2;
+            trow4 = reinterpret_cast<const int4*>(trow - t.tsh);
+            tnrel = (int32_t)(ln + t.tsh) - (int32_t)(lpart * PART);
+        }
+        t.tnrel = (uint32_t)tnrel;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            if (VEC) {
-                const bool in = (int32_t)element(k, 0) < nrel;
-                const int4* src = in ? reinterpret_cast<const int4*>(row) + (k * 64 + lane) : reinterpret_cast<const int4*>(row - back);
-                const int4 x = stream_load(src);
-                t.v[4 * k] = (uint32_t)x.x; t.v[4 * k + 1] = (uint32_t)x.y; t.v[4 * k + 2] = (uint32_t)x.z; t.v[4 * k + 3] = (uint32_t)x.w;
-                if (TOK) {
-                    const int4* ts = in ? reinterpret_cast<const int4*>(trow) + (k * 64 + lane) : reinterpret_cast<const int4*>(trow - back);
-                    const int4 y = stream_load(ts);
-                    t.tk[4 * k] = y.x; t.tk[4 * k + 1] = y.y; t.tk[4 * k + 2] = y.z; t.tk[4 * k + 3] = y.w;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int32_t e = (int32_t)element(k, j);
-                    const int64_t off = e < nrel ? (int64_t)e : -back;
-                    t.v[4 * k + j] = (uint32_t)__builtin_nontemporal_load(row + off);
-                    if (TOK) t.tk[4 * k + j] = __builtin_nontemporal_load(trow + off);
-                }
+            const int32_t e0 = (k * 64 + lane) * 4;                  // first slot of this lane's vector inside the part
+            const int4 x = stream_load(e0 < nrel ? row4 + (int64_t)lpart * (PART / 4) + (k * 64 + lane) : row4);
+            t.v[4 * k] = (uint32_t)x.x; t.v[4 * k + 1] = (uint32_t)x.y; t.v[4 * k + 2] = (uint32_t)x.z; t.v[4 * k + 3] = (uint32_t)x.w;
+            if (TOK) {
+                const int4 y = stream_load(e0 < tnrel ? trow4 + (int64_t)lpart * (PART / 4) + (k * 64 + lane) : trow4);
+                t.tk[4 * k] = y.x; t.tk[4 * k + 1] = y.y; t.tk[4 * k + 2] = y.z; t.tk[4 * k + 3] = y.w;
             }
         }
         if (++lpart == H) {
@@ -2339,34 +2500,84 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_
 
     uint32_t bad = 0;
     long long tsum = 0;
-    auto vote_part = [&](const Part& c, uint32_t AT) {                 // AT: address of the truth's bin (or no address)
-        const int32_t nl = (int32_t)c.nrel - (VEC ? 4 * lane : lane);
-        if (__all((int32_t)c.nrel >= (int32_t)PART)) {
+    // PIVOTS (as in scv_reg_cells): the lane's first (and, when the cell shows two hot values, second) vote of the CELL; votes
+    // equal to a pivot go to the lane's own words TW / TW2 across all parts and join their bins once, before the scan.
+    uint32_t ap0 = 0xffffffffu, ap1 = 0xffffffffu;
+    const uint32_t TW2 = base + (uint32_t)(kRegHist16Words + 192) * 4u + (uint32_t)lane * 4u;
+    auto vote_part = [&](const Part& c, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;         // first part of a cell: slots 0 (and 1) set the pivots
+        const int32_t nl = (int32_t)c.nrel - 4 * lane;
+        const int32_t tnl = (int32_t)c.tnrel - 4 * lane;              // (tokens: their own window when !VEC)
+        auto one = [&](int i, uint32_t A) {
+            lds_add(pivot_select(A, copy4, ap0, ap1, TW, TW2), copy_inc);
+        };
+        if (FIRST) {
+            // the cell's pivots: the lane's first vote and the first of its next three that differs (an inactive slot: the trash address)
+            uint32_t A4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t m = (uint32_t)(((i & 3) - nl) >> 31) & ~(VEC ? 0u : (uint32_t)((int32_t)(4 * lane + i - (int32_t)c.sh) >> 31));
+                const uint32_t v = c.v[i];
+                A4[i] = (bin_address<S>(KB, v < 1023u ? v : 1023u) & m) | (ATR & ~m);
+            }
+            ap0 = A4[0];
+            ap1 = A4[1] != ap0 ? A4[1] : (A4[2] != ap0 ? A4[2] : A4[3]);
+            if (a.reg_pivots == 1) ap1 = ap0;
+        }
+        // a part is FULL when every slot of it is a vote (and a token): no masks
+        bool full = (int32_t)c.nrel >= (int32_t)PART;
+        if (!VEC) full = full && (!TOK || (int32_t)c.tnrel >= (int32_t)PART) && (!FIRST || (c.sh == 0u && c.tsh == 0u));
+        // domain check of the whole part up front: the per-vote clamp only runs in the (wave-uniform, rare) case that some slot
+        // -- a vote, or a neighbour of the row that is masked out below -- holds a value above 1023
+        uint32_t orv = 0;
+#pragma unroll
+        for (int i = 0; i < E; ++i) orv |= c.v[i];
+        const bool clamp = __any(orv > 1023u);
+        if (__all(full)) {
+            if (clamp) bad |= orv;
 #pragma unroll
             for (int i = 0; i < E; ++i) {
                 const uint32_t v = c.v[i];
-                bad |= v;
-                const uint32_t A = bin_address<S>(KB, v < 1023u ? v : 1023u);
-                lds_add(A == AT ? TW : (A | copy4), copy_inc);                           // truth votes: this lane's own word
+                one(i, bin_address<S>(KB, clamp ? (v < 1023u ? v : 1023u) : v));
                 if (TOK) tsum += c.tk[i];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                // slots at or beyond the end of the cell are skipped (wave-uniform: one cell per wave)
-                if ((VEC ? (i >> 2) * 256 : i * 64) >= (int32_t)c.nrel) continue;
+                // slots at or beyond the end of the cell are skipped (wave-uniform: one cell per wave) -- except the pivot
+                // slots of a first part, which must define the pivots (an inactive one becomes the lane's trash address)
+                const int32_t beyond = (TOK && !VEC && (int32_t)c.tnrel > (int32_t)c.nrel) ? (int32_t)c.tnrel : (int32_t)c.nrel;
+                if ((i >> 2) * 256 >= beyond) continue;
                 const uint32_t v = c.v[i];
-                const int32_t ci = VEC ? (i >> 2) * 256 + (i & 3) : i * 64;
-                const uint32_t m = (uint32_t)((ci - nl) >> 31);                 // all ones when the vote is valid
-                bad |= v & m;
-                uint32_t A = bin_address<S>(KB, v < 1023u ? v : 1023u);
+                const int32_t ci = (i >> 2) * 256 + (i & 3);
+                uint32_t m = (uint32_t)((ci - nl) >> 31);                       // all ones when the vote is valid
+                if (!VEC && FIRST && i < 3) m &= ~(uint32_t)((int32_t)(4 * lane + i - (int32_t)c.sh) >> 31);   // the <= 3 slots before the row
+                if (clamp) bad |= v & m;
+                uint32_t A = bin_address<S>(KB, clamp ? (v < 1023u ? v : 1023u) : v);
                 A = (A & m) | (ATR & ~m);
-                lds_add(A == AT ? TW : (A | copy4), copy_inc);
-                if (TOK) tsum += (long long)(c.tk[i] & (int32_t)m);
+                one(i, A);
+                if (TOK) {
+                    uint32_t mt = m;
+                    if (!VEC) {
+                        mt = (uint32_t)((ci - tnl) >> 31);
+                        if (FIRST && i < 3) mt &= ~(uint32_t)((int32_t)(4 * lane + i - (int32_t)c.tsh) >> 31);
+                    }
+                    tsum += (long long)(c.tk[i] & (int32_t)mt);
+                }
             }
         }
     };
     auto finish_cell = [&](int64_t cell, int32_t b, int32_t truth) {
+        // the pivot words join the pivots' bins (read-and-clear, then one add per lane and pivot)
+        {
+            const uint32_t w0 = __hip_atomic_exchange(reinterpret_cast<lds_u32*>((uintptr_t)TW), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_add(ap0 | copy4, w0);
+            const uint32_t w1 = __hip_atomic_exchange(reinterpret_cast<lds_u32*>((uintptr_t)TW2), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_add((w1 ? ap1 : ATR) | copy4, w1);                     // (a pivot that collected nothing adds its zero to the lane's trash)
+        }
+        // h[truth] (o1.py:206): the four 16-bit copies of the truth's bin, read before the scan zeroes them
+        uint32_t tc = 0;
+        if (truth >= 0 && truth < kBins) tc = lds_count_packed<4>(KB - ((uint32_t)truth << S));
         __builtin_amdgcn_wave_barrier();
         uint32_t key[16];
         uint32_t lmax = 0;
@@ -2383,12 +2594,10 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_
                 lmax = key[2 * j + 1] > lmax ? key[2 * j + 1] : lmax;
             }
         }
-        uint32_t tc_lane = *reinterpret_cast<lds_u32*>((uintptr_t)TW);   // this lane's truth votes (both halves)
-        tc_lane = (tc_lane & 0xffffu) + (tc_lane >> 16);
+        asm volatile("" : "+v"(tc) : : "memory");                    // h[truth] has returned with the scan's reads: pinned before the zeroing stores
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < 8; ++j) *reinterpret_cast<lds_v4u*>((uintptr_t)(A0 + 1024u * j)) = scv_v4u{0u, 0u, 0u, 0u};
-        *reinterpret_cast<lds_u32*>((uintptr_t)TW) = 0u;
         __builtin_amdgcn_wave_barrier();
         const uint32_t gkey = cellgroup_max<64>(lmax);
         const uint32_t thr = gkey & ~kKeyMask;
@@ -2396,20 +2605,16 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_
 #pragma unroll
         for (int j = 0; j < 16; ++j) at_max += key[j] >= thr ? 1u : 0u;    // BINS at max (<= 16 per lane)
         const uint32_t bins_at_max = cellgroup_sum<64>(at_max);
-        const uint32_t tc = cellgroup_sum<64>(tc_lane);
         long long tok = 0;
         if (TOK) tok = cellgroup_sum_i64<64>(tsum);
         tsum = 0;
         if (lane == 0) {
-            // merge (statistics.multimode over histogram values + the truth value): o1.py:202-206
-            const uint32_t hmax = gkey >> kKeyShift;
-            const uint32_t maxc = tc > hmax ? tc : hmax;
+            // statistics.multimode + o1.py:202-206
+            const uint32_t maxc = gkey >> kKeyShift;
             const bool any = maxc > 0;
-            const uint32_t h_min = 1023u - (((gkey & kKeyMask) - base) >> S);
+            const uint32_t mm = 1023u - (((gkey & kKeyMask) - base) >> S);
             const uint32_t hit = (any && tc == maxc) ? 1u : 0u;             // o1.py:206
-            const uint32_t n_modes = any ? (tc > hmax ? 1u : (hmax > 0 ? bins_at_max : 0u) + hit) : 0u;
-            const uint32_t tv = (uint32_t)truth;                            // hit implies 0 <= truth < 1024
-            const uint32_t mm = tc > hmax ? tv : (hit && tv < h_min ? tv : h_min);
+            const uint32_t n_modes = any ? bins_at_max : 0u;
             if (a.cells) {
                 uint4 rec;
                 rec.x = maxc;
@@ -2437,7 +2642,8 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_
     int cpart = 0;
     int32_t ctruth = my_cells > 0 ? a.truth[cp] : 0;
     auto count_part = [&](const Part& c) {
-        vote_part(c, (ctruth >= 0 && ctruth < kBins) ? KB - ((uint32_t)ctruth << S) : 0xffffffffu);
+        if (cpart == 0) vote_part(c, std::true_type{});
+        else vote_part(c, std::false_type{});
         if (++cpart == H) {
             cpart = 0;
             finish_cell(ccell, cb, ctruth);
@@ -2636,6 +2842,15 @@ __global__ __launch_bounds__(256) void scv_synth_fill_k(int32_t* answers, int32_
                         v = (x < 4u * T5) ? pp.d[j] : uv;
                     }
                 } else if (dist == SCV_DIST_DEGENERATE) v = pp.truth;
+                else if (dist == SCV_DIST_PEAKED_WRONG) {
+                    const uint32_t hot = pp.d[0] == pp.truth ? (pp.truth + 500u) % 1000u : pp.d[0];
+                    if (hi < t0) v = hot;
+                    else {
+                        const uint32_t x = hi - t0;
+                        const uint32_t j = (x >= T5) + (x >= 2u * T5) + (x >= 3u * T5);
+                        v = (x < 4u * T5) ? (j == 0 ? pp.truth : pp.d[j]) : uv;
+                    }
+                } else if (dist == SCV_DIST_DEGENERATE_WRONG) v = (pp.truth + 500u) % 1000u;
                 else v = (i < full) ? (base + 37u * (uint32_t)(i % m)) % 1000u : (base + 999u) % 1000u;
                 arow[i] = (int32_t)v;
             }

@@ -73,6 +73,16 @@ def fill(P: int, B: int, N: int, seed: int, dist: int, p_offset: int = 0, want_t
                     full = (N // m) * m
                     v = np.where(i < np.uint64(full), (np.uint64(base) + np.uint64(37) * (i % np.uint64(m))) % np.uint64(1000),
                                  np.uint64((base + 999) % 1000))
+                elif dist == 4:
+                    hot = (int(tr[pl]) + 500) % 1000 if int(d[pl][0]) == int(tr[pl]) else int(d[pl][0])
+                    t0 = np.uint64((int(q_num[pl]) * 429496729) & 0xFFFFFFFF)
+                    x = (hi - t0) & _MASK32
+                    j = np.minimum(x // T5, np.uint64(3)).astype(np.int64)
+                    dj = d[pl].astype(np.uint64).copy()
+                    dj[0] = np.uint64(tr[pl])
+                    v = np.where(hi < t0, np.uint64(hot), np.where(x < np.uint64(4) * T5, dj[j], uv))
+                elif dist == 5:
+                    v = np.full(N, (int(tr[pl]) + 500) % 1000, dtype=np.uint64)
                 else:
                     raise ValueError(f"unknown dist {dist}")
                 answers[pl, b] = v.astype(np.int32)

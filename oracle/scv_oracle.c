@@ -67,7 +67,7 @@ static scvo_pparam problem_params(uint64_t seed, int64_t p) {
 int scvo_synth_fill_i32(int32_t* answers, int32_t* tokens, int32_t* truth,
                         int64_t P, int32_t B, int64_t N, int64_t p_offset,
                         uint64_t seed, int dist) {
-    if (P < 0 || B < 0 || N < 0 || dist < 0 || dist > 3) return -1;
+    if (P < 0 || B < 0 || N < 0 || dist < 0 || dist > 5) return -1;
     /* problems are independent (closed form per element): spread them over the host cores so that the
      * bench's wide parity check (hundreds of problems x 2^20 samples) does not wait on one core */
 #ifdef _OPENMP
@@ -99,6 +99,12 @@ int scvo_synth_fill_i32(int32_t* answers, int32_t* tokens, int32_t* truth,
                         else { uint32_t x = hi - t0; v = (x < 4u * T5) ? pp.d[x / T5] : uv; }
                     } break;
                     case 2: v = pp.truth; break;
+                    case 4: {   /* D4: D1 with a wrong value in the truth's place and the truth in d_0's */
+                        const uint32_t hot = pp.d[0] == pp.truth ? (pp.truth + 500u) % 1000u : pp.d[0];
+                        if (hi < t0) v = hot;
+                        else { uint32_t x = hi - t0; uint32_t j = x / T5; v = (x < 4u * T5) ? (j == 0 ? pp.truth : pp.d[j]) : uv; }
+                    } break;
+                    case 5: v = (pp.truth + 500u) % 1000u; break;
                     default: v = (i < full) ? (base + 37u * (uint32_t)(i % m)) % 1000u
                                             : (base + 999u) % 1000u;
                     }

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1), ("small_n_max", 512),
             ("tiny_n_max", 32), ("small_reg", 1), ("prefetch", 1), ("stagger_vecs", 0), ("plain_loads", 0),
-            ("fused_counters_max", 4096), ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1),
+            ("fused_counters_max", 4096), ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_pivots", 0),
             ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1))
 
 
@@ -81,6 +81,8 @@ def _draw(rng):
         opts["prefix_lane"] = 0                                   # prefix mode on pools of <= 64: cell kernels / one-pass kernels
     if rng.random() < 0.3:
         opts["prefix_stage"] = 0                                  # one-lane-per-problem kernel without the LDS snapshots
+    if rng.random() < 0.4:
+        opts["reg_pivots"] = int(rng.integers(1, 3))              # register kernels: one / two pivots per lane forced (default: per batch)
     return P, B, N, dist, narrow, tokens, nv, opts, tuning, prefix
 
 

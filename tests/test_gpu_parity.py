@@ -30,7 +30,7 @@ SHAPES = [  # (P, B, N): aligned, unaligned rows (N % 4 != 0), tiny, one vote, m
 ]
 
 
-@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_host_mode_bit_exact_vs_oracle(hip_engine, dist, shape):
     P, B, N = shape
@@ -208,7 +208,7 @@ def _with_options(eng, opts):
         def __exit__(self_, *exc):
             for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
                          ("small_n_max", 512), ("tiny_n_max", 32), ("small_reg", 1), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096),
-                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1)):
+                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1), ("reg_pivots", 0)):
                 eng.set_option(k, v)
     return _Ctx()
 
@@ -218,7 +218,7 @@ REG_SHAPES = [(700, 3, 33), (1200, 2, 64), (500, 4, 65), (301, 3, 100), (900, 2,
               (100, 2, 2048), (20, 2, 2049), (19, 3, 3000), (17, 2, 4095), (60, 2, 4096)]
 
 
-@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("shape", REG_SHAPES, ids=lambda s: "x".join(map(str, s)))
 def test_register_resident_cells_path(hip_engine, dist, shape):
     """scv_reg_cells: every (lanes per cell, vectors per lane, batches per iteration) variant, 16-byte aligned
@@ -231,8 +231,8 @@ def test_register_resident_cells_path(hip_engine, dist, shape):
     shapes = [g * 100 + v for g in (16, 32, 64) for v in (1, 2, 4) if 4 * g * v >= N]
     shapes += [1000 + 10 * v + h for v, h in ((4, 1), (4, 2), (4, 4), (8, 1), (8, 2)) if 256 * v * h >= N]
     pick = [shapes[(P + dist + i * 3) % len(shapes)] for i in range(3)]
-    for opts in ({"path": 4}, {"path": 4, "grid": 7, "fused_counters_max": 0, "reg_shape": pick[0], "reg_lds_counters": 0},
-                 {"path": 4, "grid": 64, "fused_counters_max": 1 << 30, "reg_shape": pick[1], "reg_lds_counters": 0},
+    for opts in ({"path": 4}, {"path": 4, "grid": 7, "fused_counters_max": 0, "reg_shape": pick[0], "reg_lds_counters": 0, "reg_pivots": 2},
+                 {"path": 4, "grid": 64, "fused_counters_max": 1 << 30, "reg_shape": pick[1], "reg_lds_counters": 0, "reg_pivots": 1},
                  {"path": 4, "reg_shape": pick[2], "reg_dense4": 1, "grid": 5}):
         with _with_options(hip_engine, opts):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
@@ -297,7 +297,7 @@ def test_register_kernels_accumulate_counters_in_lds(hip_engine, shape):
         assert np.array_equal(r.tie_class_hits, want.tie_class_hits) and np.array_equal(r.truth_count_sum, want.truth_count_sum)
 
 
-@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("shape", [(50, 3, 1), (40, 2, 2), (33, 4, 3), (70, 8, 64), (20, 3, 100), (900, 2, 128), (9, 2, 257),
                                    (300, 3, 512), (5, 11, 2048), (3, 2, 5001), (2000, 2, 17), (4000, 1, 33)])
 def test_small_n_wave_per_cell_path(hip_engine, dist, shape):
@@ -311,7 +311,7 @@ def test_small_n_wave_per_cell_path(hip_engine, dist, shape):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
 
 
-@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("shape", [(1, 1, 1), (50, 3, 1), (41, 11, 8), (333, 5, 7), (64, 8, 9), (100, 3, 16), (77, 2, 17),
                                    (30, 7, 32), (5000, 3, 4), (3, 1, 0)])
 def test_tiny_cells_register_path(hip_engine, dist, shape):
@@ -329,7 +329,7 @@ def test_tiny_cells_register_path(hip_engine, dist, shape):
             assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
 
 
-@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("shape", [(1, 1, 1), (700, 3, 1), (41, 11, 8), (3333, 5, 7), (6400, 8, 4), (1000, 3, 16), (777, 2, 17), (300, 7, 32),
                                    (50000, 3, 4), (20000, 2, 12), (9000, 1, 31), (100, 200, 8)])
 def test_tiny_cells_one_lane_per_cell(hip_engine, dist, shape):
@@ -576,7 +576,7 @@ def test_prefix_mode_equals_dense_oracle(hip_engine, case):
             assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
 
 
-@pytest.mark.parametrize("dist", [0, 1, 3])
+@pytest.mark.parametrize("dist", [0, 1, 3, 4, 5])
 @pytest.mark.parametrize("shape", [(700, 1), (500, 5), (333, 8), (400, 16), (90, 31), (300, 32), (250, 33), (200, 64), (150, 100), (120, 256),
                                    (60, 600), (40, 1024), (30, 1027), (20, 2048), (12, 3001), (9, 4096)], ids=lambda s: f"P{s[0]}_N{s[1]}")
 def test_prefix_budgets_over_short_pools_run_on_the_cell_kernels(hip_engine, dist, shape):
@@ -697,7 +697,7 @@ def _device_run(hip_engine, P, B, N, seed, dist, with_tokens=False, n_valid=None
     return ans, tok, tr, counters, cells, ctok
 
 
-@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
 def test_device_generator_equals_cpu_mirror(hip_engine, dist):
     P, B, N = 6, 3, 1037
     ans, tok, tr, *_ = _device_run(hip_engine, P, B, N, 0xC0FFEE, dist, with_tokens=True, p_offset=12345)
@@ -706,7 +706,7 @@ def test_device_generator_equals_cpu_mirror(hip_engine, dist):
     assert np.array_equal(tr.cpu().numpy(), trc)
 
 
-@pytest.mark.parametrize("dist", [0, 1, 3])
+@pytest.mark.parametrize("dist", [0, 1, 3, 4, 5])
 def test_config_C2_full_size_bit_exact(hip_engine, dist):
     """BASELINE config 2: P=30 x B=8 x N=2^17 synthetic int32, bit-exact vs the CPU loop."""
     P, B, N = 30, 8, 1 << 17

@@ -126,7 +126,7 @@ def test_pass_at_k_matches_combinatorial_definition():
     assert abs(sweep[1][0] - (0 + 4 / 16 + 1) / 3) < 1e-12 and abs(sweep[8][1] - (1 + 1 + 0) / 3) < 1e-12
 
 
-@pytest.mark.parametrize("dist", [0, 1, 2, 3])
+@pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
 def test_numpy_generator_equals_c_generator(dist):
     for (P, B, N, off) in [(5, 3, 257, 0), (3, 2, 64, 10 ** 6), (2, 1, 5, 9999)]:
         a, t, tr = synth.fill(P, B, N, 0xC0FFEE, dist, off, want_tokens=True)
@@ -147,6 +147,19 @@ def test_generator_distributions_have_the_intended_shape():
     out = coracle.aggregate(a, tr)
     assert out["cells"]["n_modes"][::2, 0].tolist() == [2] * 4 and out["cells"]["n_modes"][1::2, 0].tolist() == [3] * 4
     assert out["cells"]["hit"][:, 0].tolist() == [1, 1, 0, 0, 1, 1, 0, 0]
+    # D4: a confidently WRONG majority (the hot value is never the truth; the truth gets ~5 %) -- o1.py:204-213 scores it 0
+    a, _, tr = coracle.synth_fill(8, 1, 1 << 14, 11, 4)
+    out = coracle.aggregate(a, tr)
+    for p in range(8):
+        counts = np.bincount(a[p, 0], minlength=1000)
+        assert counts.argmax() != tr[p] and counts.max() > 0.08 * (1 << 14)
+        assert 0.03 * (1 << 14) < counts[tr[p]] < 0.07 * (1 << 14)
+    assert out["cells"]["hit"].sum() == 0 and (out["cells"]["n_modes"] == 1).all()
+    # D5: every vote is the same wrong value
+    a, _, tr = coracle.synth_fill(8, 2, 4096, 11, 5)
+    assert all((a[p] == (tr[p] + 500) % 1000).all() for p in range(8))
+    out = coracle.aggregate(a, tr)
+    assert out["cells"]["hit"].sum() == 0 and (out["cells"]["max_count"] == 4096).all() and (out["cells"]["truth_count"] == 0).all()
 
 
 def test_generator_is_shard_consistent():

@@ -28,7 +28,7 @@ def collect():
     rows = []
     for mangled, name in zip(mangled_names, demangled):
         i = s.find("; -- End function", s.find("\n" + mangled + ":"))
-        info = s[i:i + 2000]
+        info = s[i:i + 8000]
         g = lambda k: int(re.search(k + r": (\d+)", info).group(1))   # noqa: E731
         short = re.sub(r"\(scv::AggArgs\)|\(.*\)$", "", name).replace("void ", "").replace("scv::", "")
         rows.append((short, g("NumVgprs"), g("NumAgprs"), g("NumSgprs"), g("ScratchSize"), g("Occupancy"), g("LDSByteSize")))

@@ -11,7 +11,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(eng, torch, P, B, N, tokens, dist=1, nbuf=None, rounds=6, n_valid=None):
+def run(eng, torch, P, B, N, tokens, dist=1, nbuf=None, rounds=6, n_valid=None, want_cells=True):
     from o1_inference_scaling_laws_amd.engine import counters_size
     dev = torch.device("cuda:0")
     per = P * B * N * 4 * (2 if tokens else 1)
@@ -26,7 +26,7 @@ def run(eng, torch, P, B, N, tokens, dist=1, nbuf=None, rounds=6, n_valid=None):
         bufs.append((a, t, tr))
     nv = None if n_valid is None else torch.tensor(n_valid, dtype=torch.int32, device=dev)
     counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
-    cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
+    cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev) if want_cells else False   # False: counters only, no cell table
     eng.sync(); eng.drain_kernel_ns()
     times = []
     for r in range(rounds + 1):
@@ -39,7 +39,7 @@ def run(eng, torch, P, B, N, tokens, dist=1, nbuf=None, rounds=6, n_valid=None):
                 times.append(ns / n)
     med = statistics.median(times)
     votes = P * B * N if n_valid is None else P * sum(min(v, N) for v in n_valid)
-    return {"shape": [P, B, N], "tokens": tokens, "buffers": nbuf, "median_us": med / 1e3, "min_us": min(times) / 1e3,
+    return {"shape": [P, B, N], "tokens": tokens, "dist": dist, "cell_table": bool(want_cells), "buffers": nbuf, "median_us": med / 1e3, "min_us": min(times) / 1e3,
             "GBps": votes * 4 * (2 if tokens else 1) / med, "votes_per_s": votes / (med * 1e-9)}
 
 
@@ -72,10 +72,28 @@ def main():
         ("tiny N=16 P=400000", 400000, 4, 16, False, None),
         ("tiny N=8 P=400000", 400000, 4, 8, False, None),
         ("reference family 30x11x8", 30, 11, 8, True, [1] * 8 + [2, 4, 8]),
+        # rows that are not 16-byte aligned (the reference's N is arbitrary, o1.py:276): aligned supersets, not dword loads
+        ("N=1000 (aligned, cells not full)", 50000, 4, 1000, False, None),
+        ("N=1001 (unaligned rows)", 50000, 4, 1001, False, None),
+        ("N=1001 + tokens (unaligned)", 50000, 4, 1001, True, None),
+        ("N=253 (unaligned rows)", 100000, 4, 253, False, None),
+        ("N=4093 (unaligned rows)", 20000, 8, 4093, False, None),
+        ("N=4501 (streaming, unaligned)", 18000, 8, 4501, False, None),
+        ("N=4608 (streaming, aligned)", 18000, 8, 4608, False, None),
+        # counters only (no cell table written): what the drop-in's run_experiments needs
+        ("tiny N=8 counters only", 400000, 4, 8, False, None, 1, False),
+        ("tiny N=16 counters only", 400000, 4, 16, False, None, 1, False),
+        ("tiny N=32 counters only", 400000, 4, 32, False, None, 1, False),
+        ("small N=64 counters only", 200000, 4, 64, False, None, 1, False),
+        ("small N=256 counters only", 100000, 4, 256, False, None, 1, False),
     ]
+    # the hot value is NOT the truth (D3 exact ties, D4 a confidently wrong majority, D5 all votes one wrong value) and D0
+    for (P, B, N) in ((100000, 4, 256), (50000, 4, 1024), (20000, 8, 4096)):
+        for d, nm in ((0, "D0 uniform"), (3, "D3 tie"), (4, "D4 wrong majority"), (5, "D5 degenerate-wrong")):
+            cases.append((f"N={N} {nm}", P, B, N, False, None, d))
     for case in cases:
         name, P, B, N, tok, nv = case[:6]
-        r = run(eng, torch, P, B, N, tok, n_valid=nv, dist=case[6] if len(case) > 6 else 1)
+        r = run(eng, torch, P, B, N, tok, n_valid=nv, dist=case[6] if len(case) > 6 else 1, want_cells=case[7] if len(case) > 7 else True)
         r["name"] = name
         out.append(r)
         print(f"{name:28s} {str(r['shape']):22s} tok={int(tok)}  {r['median_us']:10.1f} us  {r['GBps']:8.1f} GB/s  {r['votes_per_s']:.3e} votes/s", flush=True)
