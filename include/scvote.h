@@ -241,6 +241,37 @@ int scv_synth_fill_i32(scv_ctx* ctx, int32_t* answers, int32_t* tokens, int32_t*
  */
 int scv_export_error_word(scv_ctx* ctx, int64_t* dst_device);
 
+/*
+ * Several GPUs from ONE process (the reference is one process, o1.py:312-315): a communicator owns one scv_ctx per device and
+ * the exchange step of the path -- the sum over problems of o1.py:236-245, which becomes ONE all-reduce of the packed int64
+ * per-budget counters when the problems are sharded by contiguous block over the devices.  No launcher, no
+ * torch.distributed: a ctypes / C caller shards its problems, calls scv_aggregate_i32 (DEVICE mode) on every rank's ctx, then
+ * scv_allreduce_counters, then scv_comm_sync.
+ *
+ *   devices      HIP device index of every rank (NULL or n == 0: all visible devices, rank r = device r); an index may
+ *                repeat (several contexts on one GPU: how a 1-GPU box exercises the path); at most 16 ranks
+ *   ctx_flags    SCV_FLAG_* for every rank's context
+ *   comm_flags   SCV_COMM_PEER (default): one-shot all-reduce over xGMI peer access, pure HIP -- every rank's kernel reads the
+ *                other ranks' buffers directly, sums them into a staging buffer, and the sums replace the buffers when every
+ *                rank has finished reading; the devices' streams are ordered by events, the host never blocks.
+ *                SCV_COMM_RCCL: ncclCommInitAll + grouped ncclAllReduce(ncclInt64, ncclSum); librccl is resolved at run time
+ *                (the copy the process already holds, else /opt/rocm's); distinct devices only.
+ *
+ * scv_allreduce_counters: buffers[r] is a DEVICE pointer on rank r's device (count int64 each, e.g. the packed counters
+ * tie_class_hits | token_sum | truth_count_sum, optionally one more word from scv_export_error_word); in place, SUM, ordered
+ * behind everything queued on the ranks' ctx streams, asynchronous.  Integer sums => the same bits at any device count.
+ * scv_comm_sync = scv_sync on every rank (first error wins).
+ */
+typedef struct scv_comm scv_comm;
+#define SCV_COMM_PEER 0x0u
+#define SCV_COMM_RCCL 0x1u
+int scv_comm_create(scv_comm** out, const int* devices, int n, uint32_t ctx_flags, uint32_t comm_flags);
+int scv_comm_destroy(scv_comm* comm);
+int scv_comm_size(const scv_comm* comm);
+scv_ctx* scv_comm_ctx(scv_comm* comm, int rank);       /* owned by the communicator: do not scv_destroy it */
+int scv_allreduce_counters(scv_comm* comm, int64_t* const* buffers, int64_t count);
+int scv_comm_sync(scv_comm* comm);
+
 /* Duration of the most recent aggregation kernel launch on this ctx, from hipEvents recorded on
  * the launch stream (needs SCV_FLAG_TIMING).  Blocks until that launch has finished. */
 int scv_last_kernel_ns(scv_ctx* ctx, uint64_t* ns_out);

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(CSRC, "libscvote.so")
 UNITS = ["scvote.hip", "scvote_stream_c4.hip", "scvote_stream_c8.hip", "scvote_stream_c16.hip", "scvote_stream_c32.hip",
-         "scvote_reg_g16.hip", "scvote_reg_g32.hip", "scvote_reg_g64.hip", "scvote_dense.hip"]
+         "scvote_reg_g16.hip", "scvote_reg_g32.hip", "scvote_reg_g64.hip", "scvote_dense.hip", "scvote_comm.hip"]
 HEADERS = [os.path.join(CSRC, "scvote_kernels.hip.h"), os.path.join(CSRC, "scvote_dispatch.h"),
            os.path.join(os.path.dirname(HERE), "include", "scvote.h")]
 SOURCES = UNITS + ["scvote_kernels.hip.h", "scvote_dispatch.h"]          # (tools/kernel_resources.py lists them)
@@ -55,7 +55,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
 
     with ThreadPoolExecutor(max_workers=jobs or min(len(UNITS), os.cpu_count() or 4)) as pool:
         list(pool.map(compile_unit, todo))
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *[_obj(u) for u in UNITS]]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *[_obj(u) for u in UNITS], "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -11,6 +11,7 @@ _lib = None
 # include/scvote.h constants
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_TIMING, FLAG_CLAMP = 0x1, 0x2
+COMM_PEER, COMM_RCCL = 0x0, 0x1
 DIST_UNIFORM, DIST_PEAKED, DIST_DEGENERATE, DIST_TIE, DIST_PEAKED_WRONG, DIST_DEGENERATE_WRONG = 0, 1, 2, 3, 4, 5
 NUM_BINS, TIE_CLASSES = 1024, 1025
 OK, ERR_ARG, ERR_DOMAIN, ERR_NO_DEVICE, ERR_NOT_TIMED, ERR_ALLOC = 0, -2001, -2002, -2003, -2004, -2005
@@ -53,6 +54,13 @@ def load():
     L.scv_aggregate_bootstrap_i32.argtypes = [p, p, p, p, p, i64, i32, i64, p, p, p, p, p, i32, i32, u64, i32, p]
     L.scv_synth_fill_i32.argtypes = [p, p, p, p, i64, i32, i64, i64, u64, C.c_int]
     L.scv_export_error_word.argtypes = [p, p]
+    L.scv_comm_create.argtypes = [C.POINTER(p), C.POINTER(C.c_int), C.c_int, u32, u32]
+    L.scv_comm_destroy.argtypes = [p]
+    L.scv_comm_size.argtypes = [p]
+    L.scv_comm_ctx.argtypes = [p, C.c_int]
+    L.scv_comm_ctx.restype = p
+    L.scv_allreduce_counters.argtypes = [p, C.POINTER(p), i64]
+    L.scv_comm_sync.argtypes = [p]
     L.scv_last_kernel_ns.argtypes = [p, C.POINTER(u64)]
     L.scv_drain_kernel_ns.argtypes = [p, C.POINTER(u64), C.POINTER(u64)]
     L.scv_get_stat.argtypes = [p, C.c_char_p, C.POINTER(i64)]
@@ -66,7 +74,8 @@ def load():
     L.scv_version.restype = C.c_char_p
     for name in ("scv_create", "scv_destroy", "scv_set_stream", "scv_sync", "scv_set_tuning", "scv_set_option", "scv_aggregate_i32", "scv_aggregate_prefix_i32",
                  "scv_bootstrap", "scv_aggregate_bootstrap_i32", "scv_synth_fill_i32", "scv_last_kernel_ns", "scv_drain_kernel_ns",
-                 "scv_device_count", "scv_device_info", "scv_host_alloc", "scv_host_free", "scv_get_stat", "scv_export_error_word"):
+                 "scv_device_count", "scv_device_info", "scv_host_alloc", "scv_host_free", "scv_get_stat", "scv_export_error_word",
+                 "scv_comm_create", "scv_comm_destroy", "scv_comm_size", "scv_allreduce_counters", "scv_comm_sync"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

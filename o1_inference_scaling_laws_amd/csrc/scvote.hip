@@ -1523,6 +1523,19 @@ int scv_device_info(scv_ctx* ctx, int64_t info_out[4]) {
 
 }  // extern "C"
 
+// ---- what csrc/scvote_comm.hip needs of the opaque context -----------------------------------------------------------
+namespace scv {
+hipStream_t ctx_stream(scv_ctx* ctx) { return ctx->stream; }
+int ctx_device(scv_ctx* ctx) { return ctx->device; }
+int comm_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace scv
+
 // ---- kernel tables: the per-translation-unit tables behind one switch each (scvote_dispatch.h) ----------------------
 namespace scv {
 KernelFn pick_kernel(int copies, int t, int u, bool tok, bool xtra) {

@@ -1522,17 +1522,31 @@ __global__ __launch_bounds__(T) void scv_lane_cells(const AggArgs a) {
         }
     };
 
-    Cell ca, cb;
+    // KC cells per lane and step: KC row loads are in flight behind the KC cells being counted.  With one cell per step a wave of
+    // the N = 8 shape had 2 KiB in flight and ~6 dependent memory round trips per launch: latency, not the ~100 VALU instructions
+    // per 64 cells, set its time (PMC, profiles/r03_lane_cells_pmc.md).
+    constexpr int KC = NV <= 4 ? (TOK ? 2 : 4) : (NV == 8 && !TOK ? 2 : 1);      // (more would spill at the shapes' 128-VGPR bounds)
+    Cell ca[KC], cb[KC];
     const int64_t last = a.ncells;                                   // lanes of a wave run the same number of steps
     const int64_t first = (int64_t)blockIdx.x * T + tid - (tid & 63);
-    load(ca);
-    for (int64_t c0 = first; c0 < last; c0 += 2 * stride) {
-        const bool more = c0 + stride < last;
-        if (more) load(cb);
-        count(ca);
+    const int64_t kstride = (int64_t)KC * stride;                    // cells a step of the whole grid covers
+#pragma unroll
+    for (int k = 0; k < KC; ++k) load(ca[k]);
+    for (int64_t c0 = first; c0 < last; c0 += 2 * kstride) {
+        const bool more = c0 + kstride < last;
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < KC; ++k) load(cb[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) count(ca[k]);
         if (!more) break;
-        if (c0 + 2 * stride < last) load(ca);
-        count(cb);
+        if (c0 + 2 * kstride < last) {
+#pragma unroll
+            for (int k = 0; k < KC; ++k) load(ca[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) count(cb[k]);
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
     if (fixed_b) {

@@ -88,7 +88,7 @@ def pinned_empty(shape, dtype=np.int32) -> np.ndarray:
 class Engine:
     """One context per GPU per process (one process per GPU under torch.distributed)."""
 
-    def __init__(self, device: int | None = None, timing: bool = False, clamp_to_invalid_bin: bool = False):
+    def __init__(self, device: int | None = None, timing: bool = False, clamp_to_invalid_bin: bool = False, _adopt=None):
         self._L = _lib.load()            # raises ImportError when csrc/libscvote.so is missing
         self._ctx = C.c_void_p()
         flags = (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_CLAMP if clamp_to_invalid_bin else 0)
@@ -96,7 +96,11 @@ class Engine:
             import torch
             device = torch.cuda.current_device() if torch.cuda.is_available() else -1
         self.device = int(device)
-        check(self._L.scv_create(C.byref(self._ctx), self.device, flags))
+        self._owns_ctx = _adopt is None
+        if _adopt is None:
+            check(self._L.scv_create(C.byref(self._ctx), self.device, flags))
+        else:                            # a context owned by a communicator (scv_comm_ctx): never destroyed from here
+            self._ctx = C.c_void_p(_adopt)
         info = (C.c_int64 * 4)()
         check(self._L.scv_device_info(self._ctx, C.byref(info)))
         self.num_cus, self.lds_bytes, self.clock_khz, self.hbm_bytes = (int(x) for x in info)
@@ -106,7 +110,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx:
-            self._L.scv_destroy(self._ctx)
+            if self._owns_ctx:
+                self._L.scv_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
     def __del__(self):
@@ -379,25 +384,59 @@ class MultiDeviceEngine:
 
     ``devices``: list of HIP device indices (default: all visible).  The same index may appear twice
     (two contexts on one GPU), which is how the 1-GPU test box exercises this class.
+
+    The contexts belong to ONE communicator of the library (``scv_comm_create``): DEVICE-mode evaluations finish with
+    ``scv_allreduce_counters`` -- the exchange step behind the C ABI, no torch.distributed and no torch collective:
+    a one-shot all-reduce over xGMI peer access (default), or RCCL single-process (``rccl=True``; distinct devices).
     """
 
-    def __init__(self, devices=None, **engine_kwargs):
+    def __init__(self, devices=None, rccl: bool = False, timing: bool = False, clamp_to_invalid_bin: bool = False):
+        L = _lib.load()
         if devices is None:
-            n = _lib.load().scv_device_count()
+            n = L.scv_device_count()
             if n <= 0:
                 raise _lib.ScvError(_lib.ERR_NO_DEVICE, "no HIP device visible")
             devices = list(range(n))
-        self.engines = [Engine(device=d, **engine_kwargs) for d in devices]
+        devices = [int(d) for d in devices]
+        self._L = L
+        self._comm = C.c_void_p()
+        flags = (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_CLAMP if clamp_to_invalid_bin else 0)
+        arr = (C.c_int * len(devices))(*devices)
+        check(L.scv_comm_create(C.byref(self._comm), arr, len(devices), flags, _lib.COMM_RCCL if rccl else _lib.COMM_PEER))
+        self.rccl = bool(rccl)
+        self.engines = [Engine(device=d, timing=timing, clamp_to_invalid_bin=clamp_to_invalid_bin, _adopt=L.scv_comm_ctx(self._comm, r))
+                        for r, d in enumerate(devices)]
 
     def close(self):
-        for e in self.engines:
-            e.close()
+        for e in getattr(self, "engines", []):
+            e.close()                           # (adopted contexts: only forgets the pointer)
+        if getattr(self, "_comm", None) is not None and self._comm:
+            self._L.scv_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
         self.close()
+
+    def all_reduce_counters(self, counters):
+        """``counters[g]``: int64 CUDA tensor on engine g's device (equal lengths).  In-place SUM over the engines through the
+        library's communicator (scv_allreduce_counters), ordered behind the engines' queued work; asynchronous."""
+        n = int(counters[0].numel())
+        for e, c in zip(self.engines, counters):
+            if int(c.numel()) != n or not c.is_contiguous():
+                raise ValueError("counters must be contiguous int64 tensors of one length")
+            e._check_device(c, "counters")
+        ptrs = (C.c_void_p * len(counters))(*[c.data_ptr() for c in counters])
+        check(self._L.scv_allreduce_counters(self._comm, ptrs, n))
+        return counters
 
     def _run(self, fn_name, rows, truth, per_shard_kwargs, shared_kwargs):
         from concurrent.futures import ThreadPoolExecutor
@@ -449,10 +488,10 @@ class MultiDeviceEngine:
         """Single-process, several GPUs, data resident: ``shards[g] = (answers_g, truth_g, tokens_g | None)`` are torch
         tensors on engine g's device (any split of the problems; ``scatter`` makes block shards).  Every engine launches
         on its own device's current stream (asynchronously, from this one thread), then the packed int64 counters
-        (65.7 KB at B = 8) are summed onto ``destination`` (default: the first engine's device) with
-        ``torch.cuda.comm.reduce_add`` -- single-process RCCL over xGMI when the shards sit on distinct GPUs, plain
-        copies + adds when contexts share a GPU (the 1-GPU test box).  Integer sums: bit-exact, order-independent
-        (SURVEY 8e).  Returns (counters on destination, [cells_g], [cell_tokens_g]); does not synchronise the host.
+        (65.7 KB at B = 8) are all-reduced in place by the library's communicator (``scv_allreduce_counters``: one-shot over
+        xGMI peer access, or RCCL) -- every engine's buffer ends up holding the sum; the one on ``destination`` (default:
+        the first engine's device) is returned.  Integer sums: bit-exact, order-independent.
+        Returns (counters, [cells_g], [cell_tokens_g]); does not synchronise the host.
         ``n_valid``: host int array [B] (copied to every device) or None."""
         import torch
         if len(shards) != len(self.engines):
@@ -463,14 +502,13 @@ class MultiDeviceEngine:
             with torch.cuda.device(dev):
                 nv = None if n_valid is None else torch.as_tensor(np.asarray(n_valid, dtype=np.int32), device=dev)
                 outs.append(e.aggregate_device(ans, tr, tokens=tok, n_valid=nv, cells=None if want_cells else False))
-        dest = torch.device("cuda", self.engines[0].device) if destination is None else torch.device(destination)
         counters = [o[0] for o in outs]
-        if len({c.device for c in counters}) == len(counters) and len(counters) > 1:
-            total = torch.cuda.comm.reduce_add(counters, destination=dest.index)
-        else:                                   # contexts sharing a GPU: same algebra without the collective
-            total = counters[0].to(dest, copy=True)
-            for c in counters[1:]:
-                total += c.to(dest)
+        self.all_reduce_counters(counters)          # every engine's buffer now holds the sum (scv_allreduce_counters)
+        total = counters[0]
+        if destination is not None:
+            dest = torch.device(destination)
+            match = [c for c in counters if c.device == dest]
+            total = match[0] if match else counters[0].to(dest)
         return total, [o[1] for o in outs], [o[2] for o in outs]
 
     def sync(self):

@@ -103,3 +103,15 @@ def test_no_kernel_spills_to_scratch():
     assert not spilled, spilled
     head = [r for r in rows if r[0] == "scv_hist_argmax<4, 1024, 4, false, false>"]
     assert head and head[0][1] <= 128 and head[0][4] == 0            # the headline kernel: 16 waves per CU need <= 128 VGPRs
+
+
+def test_communicator_refuses_without_a_device():
+    """scv_comm_create on a box without a GPU: SCV_ERR_NO_DEVICE, no communicator, no crash (and no RCCL needed to say so)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = _lib.load()
+    comm = ctypes.c_void_p()
+    for flags in (_lib.COMM_PEER, _lib.COMM_RCCL):
+        assert L.scv_comm_create(ctypes.byref(comm), None, 0, 0, flags) == _lib.ERR_NO_DEVICE and not comm.value
+    assert b"no HIP device" in L.scv_last_error()

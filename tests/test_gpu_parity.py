@@ -932,9 +932,15 @@ def test_permutation_invariance(hip_engine):
 
 
 @pytest.mark.parametrize("off_a,off_t", [(1, 1), (1, 2), (3, 0), (0, 3)])
-@pytest.mark.parametrize("shape", [(37, 3, 4099), (9, 2, 40000), (400, 2, 100), (500, 3, 7)])
+@pytest.mark.parametrize("shape", [(37, 3, 4099), (9, 2, 40000), (400, 2, 100), (500, 3, 7),
+                                   # every register-resident shape, rows of every alignment class (N % 4 = 0..3), capacity edges
+                                   (300, 3, 61), (300, 2, 64), (200, 3, 125), (150, 3, 253), (150, 2, 256), (100, 3, 509), (80, 3, 1001),
+                                   (80, 2, 1021), (60, 2, 1024), (40, 3, 2045), (30, 3, 3001), (24, 3, 4093), (24, 2, 4096)])
 def test_device_pointers_not_16_byte_aligned(hip_engine, off_a, off_t, shape):
-    """Views into larger device buffers: vote and token bases misaligned (differently) w.r.t. 16 bytes."""
+    """Views into larger device buffers: vote and token bases misaligned (differently) w.r.t. 16 bytes -- and rows whose length
+    is not a multiple of four votes (the reference's N is arbitrary, o1.py:276).  The register-resident kernels read the
+    16-byte-aligned superset of every row (dwordx4 loads, both ends masked); N + 3 slots decide the kernel shape, so a shape's
+    last three lengths move up one shape (or to the streaming kernel at 4094..4096) when the rows are unaligned."""
     import torch
     P, B, N = shape
     a, t, tr = coracle.synth_fill(P, B, N, 17, 1, want_tokens=True)
@@ -947,12 +953,18 @@ def test_device_pointers_not_16_byte_aligned(hip_engine, off_a, off_t, shape):
     vt.copy_(torch.from_numpy(t))
     assert va.data_ptr() % 16 == (4 * off_a) % 16 and va.is_contiguous()
     want = oracle(a, tr, tokens=t)
-    for path in (0, 1, 3):
+    nv = np.array([N, max(0, N - 5), N // 3][:B], dtype=np.int32)
+    want_nv = oracle(a, tr, n_valid=nv)
+    for path in (0, 1, 3, 4):
         with _with_options(hip_engine, {"path": path}):
             counters, cells, ctok = hip_engine.aggregate_device(va, torch.from_numpy(tr).to(dev), tokens=vt)
             hip_engine.sync()
             got = AggregateResult.from_counters(counters.cpu().numpy(), P, B, cells_from_torch(cells), ctok.cpu().numpy())
             assert_results_equal(got, want)
+            counters, cells, _ = hip_engine.aggregate_device(va, torch.from_numpy(tr).to(dev), n_valid=torch.from_numpy(nv).to(dev))   # votes only, ragged
+            hip_engine.sync()
+            got = AggregateResult.from_counters(counters.cpu().numpy(), P, B, cells_from_torch(cells))
+            assert_results_equal(got, want_nv, check_tokens=False)
 
 
 def test_device_mode_domain_error_surfaces_at_sync(hip_engine):
@@ -1120,9 +1132,8 @@ def test_multi_device_engine_single_process(golden, tmp_path):
 
 def test_multi_device_engine_device_mode_single_process():
     """single-process DEVICE-mode sharding -- every context launches on its own stream from one
-    thread, counters summed on the destination device (torch.cuda.comm.reduce_add = single-process RCCL when the
-    contexts sit on distinct GPUs; here three contexts share cuda:0, which exercises the control flow and the
-    algebra).  Counters and cell tables equal the single-engine / oracle result; the caller's current device and
+    thread, counters all-reduced by the library's communicator (scv_allreduce_counters: one-shot over peer access;
+    here three contexts share cuda:0, which exercises the control flow and the algebra).  Counters and cell tables equal the single-engine / oracle result; the caller's current device and
     stream are untouched."""
     import torch
     from o1_inference_scaling_laws_amd.engine import MultiDeviceEngine
@@ -1294,3 +1305,104 @@ def test_c5_pipeline_reports_device_errors(hip_engine):
     d4 = passk.evaluate_device(hip_engine, ans, trd, P, 64, 5, M=d.M)             # and the engine is clean again
     passk.check(d4, hip_engine)
     assert np.array_equal(passk.gather_bootstrap(d4, 64, engine=hip_engine).cpu().numpy(), boot.cpu().numpy())
+
+
+# ---- round 3: the exchange step behind the C ABI (scv_comm_*, scv_allreduce_counters) -------------------------------------
+
+def _comm_run(devices, comm_flags, P=97, B=3, N=6000, dist=3, seed=31, reps=2):
+    """Raw C-ABI calls, the way a C / ctypes caller without torch.distributed would make them: one communicator, problems
+    sharded by contiguous block over its ranks, scv_aggregate_i32 (DEVICE mode) per rank, ONE scv_allreduce_counters,
+    scv_comm_sync.  Returns the per-rank counters (all must hold the sum) and the concatenated cell table."""
+    import ctypes as C
+    import torch
+    from o1_inference_scaling_laws_amd.dist import shard_bounds
+    L = _lib.load()
+    comm = C.c_void_p()
+    arr = (C.c_int * len(devices))(*devices)
+    _lib.check(L.scv_comm_create(C.byref(comm), arr, len(devices), 0, comm_flags))
+    try:
+        G = L.scv_comm_size(comm)
+        assert G == len(devices)
+        a, _, tr = coracle.synth_fill(P, B, N, seed, dist)
+        ncount = counters_size(B)
+        shards, outs = [], []
+        for r in range(G):
+            lo, hi = shard_bounds(P, r, G)
+            dev = torch.device("cuda", devices[r])
+            shards.append((torch.from_numpy(a[lo:hi]).to(dev), torch.from_numpy(tr[lo:hi]).to(dev)))
+        torch.cuda.synchronize()
+        for rep in range(reps):
+            bufs, cells = [], []
+            for r in range(G):
+                ans, trd = shards[r]
+                cnt = torch.zeros(ncount + 1, dtype=torch.int64, device=ans.device)       # + the error word
+                cl = torch.empty((ans.shape[0], B, 16), dtype=torch.uint8, device=ans.device)
+                torch.cuda.synchronize()
+                ctx = L.scv_comm_ctx(comm, r)
+                base = cnt.data_ptr()
+                _lib.check(L.scv_aggregate_i32(ctx, C.c_void_p(ans.data_ptr()), None, None, C.c_void_p(trd.data_ptr()), ans.shape[0], B, N,
+                                               _lib.MEM_DEVICE, C.c_void_p(cl.data_ptr()), None, C.c_void_p(base),
+                                               C.c_void_p(base + 8 * B * _lib.TIE_CLASSES), C.c_void_p(base + 8 * (B * _lib.TIE_CLASSES + B))))
+                _lib.check(L.scv_export_error_word(ctx, C.c_void_p(base + 8 * ncount)))
+                bufs.append(cnt)
+                cells.append(cl)
+            ptrs = (C.c_void_p * G)(*[b.data_ptr() for b in bufs])
+            _lib.check(L.scv_allreduce_counters(comm, ptrs, ncount + 1))
+            _lib.check(L.scv_comm_sync(comm))
+            outs = ([b.cpu().numpy() for b in bufs], np.concatenate([cells_from_torch(c) for c in cells], axis=0))
+        return outs, oracle(a, tr)
+    finally:
+        L.scv_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0]])
+def test_c_abi_communicator_peer_all_reduce(devices):
+    """SCV_COMM_PEER: the one-shot all-reduce (every rank's kernel reads all ranks' buffers, staging, copy back; streams ordered
+    by events).  1, 2 and 5 ranks on cuda:0 (the box has one GPU: contexts share it, the control flow and the algebra are
+    those of 8 GPUs).  Every rank's buffer holds the sum == the unsharded oracle; the error word (last element) sums to 0."""
+    (bufs, cells), want = _comm_run(devices, _lib.COMM_PEER)
+    P, B = want.cells.shape
+    for b in bufs:
+        assert np.array_equal(b, bufs[0])
+        got = AggregateResult.from_counters(b[:-1], P, B, cells)
+        assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.truth_count_sum, want.truth_count_sum)
+        assert b[-1] == 0
+    for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+        assert np.array_equal(cells[f], want.cells[f]), f
+
+
+def test_c_abi_communicator_rccl_on_one_device():
+    """SCV_COMM_RCCL: librccl resolved at run time, ncclCommInitAll over the communicator's devices (here: one), the
+    all-reduce call path of the library; equal to the plain run."""
+    (bufs, cells), want = _comm_run([0], _lib.COMM_RCCL)
+    P, B = want.cells.shape
+    got = AggregateResult.from_counters(bufs[0][:-1], P, B, cells)
+    assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and bufs[0][-1] == 0
+
+
+def test_c_abi_communicator_argument_errors():
+    import ctypes as C
+    L = _lib.load()
+    comm = C.c_void_p()
+    arr = (C.c_int * 2)(0, 99)
+    assert L.scv_comm_create(C.byref(comm), arr, 2, 0, 0) == _lib.ERR_ARG and not comm.value
+    arr17 = (C.c_int * 17)(*([0] * 17))
+    assert L.scv_comm_create(C.byref(comm), arr17, 17, 0, 0) == _lib.ERR_ARG
+    assert L.scv_comm_size(None) == 0 and L.scv_comm_destroy(None) == 0
+    _lib.check(L.scv_comm_create(C.byref(comm), None, 0, 0, 0))          # NULL / 0: all visible devices
+    import torch
+    assert L.scv_comm_size(comm) == torch.cuda.device_count() and L.scv_comm_ctx(comm, 0) and not L.scv_comm_ctx(comm, 99)
+    assert L.scv_allreduce_counters(comm, None, 4) == _lib.ERR_ARG
+    L.scv_comm_destroy(comm)
+
+
+def test_multi_device_engine_all_reduce_is_the_library_communicator():
+    """MultiDeviceEngine.aggregate_device ends with scv_allreduce_counters (no torch collective): EVERY engine's counters
+    buffer holds the sum afterwards, not only the destination's."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import MultiDeviceEngine
+    with MultiDeviceEngine(devices=[0, 0]) as me:
+        cs = [torch.arange(10, dtype=torch.int64, device="cuda:0") * (k + 1) for k in range(2)]
+        me.all_reduce_counters(cs)
+        me.sync()
+        assert cs[0].tolist() == cs[1].tolist() == [3 * i for i in range(10)]

@@ -7,6 +7,10 @@
 //   hbm_probe.bin [cells=10000]          sweep of read variants over cells x 4 MiB (10000 = the bench chunk)
 //   hbm_probe.bin [cells] --quick        the best four variants only (bench.py runs this beside its timed region)
 //   hbm_probe.bin [cells] --short        what wave-per-batch kernels can pull: 2-8 KiB steps, 4-32 waves per CU
+//   hbm_probe.bin [cells] --percu        what ONE workgroup (one CU) can pull, and how that adds up: grids of 1, 4, 16, 64, 128, 256
+//                                        workgroups of 1024 threads, each streaming its own 256 KiB / 512 KiB / 4 MiB segment ONCE
+//                                        (the few-huge-cells shapes: split-N segments, C2's 512 KiB cells) -- GB/s per workgroup
+//                                        and in total, and the time one segment takes (the floor of those shapes)
 //   hbm_probe.bin [cells] --calib        3 launches of ONE variant (read_cells_pipe<4>, grid 250 x 1024) and nothing
 //                                        else: run under `rocprofv3 --pmc FETCH_SIZE` to get FETCH_SIZE per launch
 //                                        for exactly cells * 4 MiB of algorithmic reads
@@ -119,11 +123,12 @@ double time_ms(F f, int reps = 5) {
 
 int main(int argc, char** argv) {
     long ncells = 10000;
-    bool calib = false, shortcells = false, quick = false;
+    bool calib = false, shortcells = false, quick = false, percu = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--calib")) calib = true;
         else if (!strcmp(argv[i], "--short")) shortcells = true;
         else if (!strcmp(argv[i], "--quick")) quick = true;
+        else if (!strcmp(argv[i], "--percu")) percu = true;
         else ncells = atol(argv[i]);
     }
     const long cell_bytes = 4l << 20;
@@ -138,6 +143,35 @@ int main(int argc, char** argv) {
             CK(hipDeviceSynchronize());
         }
         printf("calib: 3 launches of read_cells_pipe<4,nt> grid 250 x 1024, %ld bytes each\n", bytes);
+        return 0;
+    }
+    if (percu) {
+        // Every workgroup reads ONE segment (grid = number of segments): a launch lasts as long as one CU needs for its segment.
+        // Distinct regions of the buffer per repetition (stride below), so nothing is served by the 256 MiB Infinity Cache.
+        printf("percu: one 1024-thread workgroup per segment, U = 4 non-temporal 16-byte loads in flight per lane; launch time incl. ~2 us of launch latency\n");
+        for (long seg_kib : {256l, 512l, 4096l}) {
+            const long seg_vecs = seg_kib * 1024 / 16;
+            for (int grid : {1, 4, 16, 64, 128, 256}) {
+                const long span = (long)grid * seg_vecs;                       // vectors touched per launch
+                const long regions = nvec / span < 64 ? nvec / span : 64;
+                hipEvent_t e0, e1;
+                CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                std::vector<float> ts;
+                for (long r = 0; r < regions; ++r) {
+                    CK(hipEventRecord(e0));
+                    read_cells<4, true><<<grid, 1024>>>(buf + r * span, seg_vecs, grid, sink);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (r >= 2) ts.push_back(ms);
+                }
+                std::sort(ts.begin(), ts.end());
+                const double ms = ts.empty() ? 0 : ts[ts.size() / 2];
+                const double total = span * 16.0 / ms / 1e6;
+                printf("percu   segment %5ld KiB x %3d workgroups : %7.1f us per launch | %7.1f GB/s per workgroup | %7.0f GB/s total\n",
+                       seg_kib, grid, ms * 1e3, total / grid, total);
+            }
+        }
         return 0;
     }
     struct Cfg { int grid, threads; };
