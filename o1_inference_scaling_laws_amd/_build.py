@@ -14,10 +14,11 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(CSRC, "libscvote.so")
 UNITS = ["scvote.hip", "scvote_stream_c4.hip", "scvote_stream_c8.hip", "scvote_stream_c16.hip", "scvote_stream_c32.hip",
-         "scvote_reg_g16.hip", "scvote_reg_g32.hip", "scvote_reg_g64.hip", "scvote_dense.hip", "scvote_comm.hip"]
+         "scvote_reg_g16.hip", "scvote_reg_g32.hip", "scvote_reg_g64.hip", "scvote_dense.hip", "scvote_comm.hip", "scvote_sort.hip"]
 HEADERS = [os.path.join(CSRC, "scvote_kernels.hip.h"), os.path.join(CSRC, "scvote_dispatch.h"),
            os.path.join(os.path.dirname(HERE), "include", "scvote.h")]
-SOURCES = UNITS + ["scvote_kernels.hip.h", "scvote_dispatch.h"]          # (tools/kernel_resources.py lists them)
+UNIT_HEADERS = {"scvote_sort.hip": [os.path.join(CSRC, "scvote_sort.hip.h")]}      # headers only one unit includes
+SOURCES = UNITS + ["scvote_kernels.hip.h", "scvote_sort.hip.h", "scvote_dispatch.h"]          # (tools/kernel_resources.py lists them)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
@@ -37,7 +38,7 @@ def _stale(target: str, deps) -> bool:
 
 
 def needs_build() -> bool:
-    return _stale(LIB_PATH, [os.path.join(CSRC, u) for u in UNITS] + HEADERS)
+    return _stale(LIB_PATH, [os.path.join(CSRC, u) for u in UNITS] + HEADERS + [h for hs in UNIT_HEADERS.values() for h in hs])
 
 
 def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
@@ -45,7 +46,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(OBJDIR, exist_ok=True)
-    todo = [u for u in UNITS if force or _stale(_obj(u), [os.path.join(CSRC, u)] + HEADERS)]
+    todo = [u for u in UNITS if force or _stale(_obj(u), [os.path.join(CSRC, u)] + HEADERS + UNIT_HEADERS.get(u, []))]
 
     def compile_unit(unit):
         cmd = [_hipcc(), *FLAGS, "-c", "-o", _obj(unit), os.path.join(CSRC, unit)]

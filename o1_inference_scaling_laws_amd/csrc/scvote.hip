@@ -168,6 +168,10 @@ struct scv_ctx {
     int reg_shape = 0;       // reg path: force a kernel shape (A/B runs), see launch_aggregate
     int reg_pivots = 0;      // reg path: pivots per lane (votes equal to a pivot are counted in registers): 0 = per batch (2 when it shows two hot values), 1, 2
     int reg_dense4 = 0;      // reg path, 512 < N <= 1024: 1 = dense bin scan instead of the sparse read-back (A/B option)
+    int sort_cells = 1;      // 1: cells of sort_n_min <= N <= 64 votes in 16-byte aligned rows run one lane per cell, rows staged by LDS-DMA, sorted in registers (scv_sort_cells)
+    int sort_n_min = 8;      // shorter cells stay on scv_lane_cells
+    int sort_kb = 0;         // blocks of 64 cells per step (0 = auto: 2 for N <= 16, else 1)
+    int64_t stat_sort_cells = 0;
     int reg_n_max = 4096;    // auto: 32 < N <= this -> register-resident cells kernel (scv_reg_cells); 0 = off (round-1 dispatch)
     bool user_tuned = false; // set_tuning called: auto geometry off
     // split-N scratch (grown on demand)
@@ -229,6 +233,7 @@ using scv::RegKernel;
 using scv::pick_kernel;
 using scv::pick_reg_kernel;
 using scv::pick_dense_kernel;
+using scv::pick_sort_kernel;
 
 // Every entry point runs on the ctx device and leaves the caller's current HIP device as it found it
 // (a process driving several GPUs from one thread -- MultiDeviceEngine -- must not have torch's
@@ -410,6 +415,47 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
 
     EventPair* ev = nullptr;
     if (int rc = next_event_pair(ctx, &ev)) return rc;
+
+    // ---- sorted cells: one lane per cell, the wave's 64 rows staged through LDS by LDS-DMA, sorted in registers (scvote_sort.hip.h).
+    // The reference's own range (N = 1 ... 128, o1.py:267,276) up to 64 votes, rows 16-byte aligned; "path" 5 forces it.
+    if ((ctx->path == 5 || (ctx->path == 0 && ctx->sort_cells && N >= ctx->sort_n_min)) && !pool_rows && reg_vec && N >= 4 && N <= 64) {
+        const int nv = N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : 64));
+        int kb = ctx->sort_kb > 0 ? ctx->sort_kb : 1;          // (measured: one block per step beats two at N = 8, 16)
+        if (nv > 16) kb = 1;
+        const RegKernel rk = pick_sort_kernel(nv, kb, tok);
+        const int64_t ps = (N / 4) | 1;
+        const int64_t region_words = (int64_t)kb * 64 * ps * 4 * (tok ? 2 : 1);
+        const int64_t tail_words = (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0) + ((((int64_t)B * (nv + 1) + 1) & ~(int64_t)1) + 4 * (int64_t)B);
+        int W = rk.waves;
+        while (W > 1 && (W * region_words + tail_words) * 4 > ctx->lds_max) --W;
+        if ((W * region_words + tail_words) * 4 <= ctx->lds_max && W >= (rk.waves >= 16 ? 4 : 2)) {
+            if (use_reduce) {                                         // counters come out of this launch
+                use_reduce = false;
+                a.cells = cells; a.cell_tokens = cell_tokens;
+                a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
+                a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
+                a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
+            }
+            a.wave_lds_words = (int32_t)region_words;
+            const size_t lds = (size_t)(W * region_words + tail_words) * sizeof(uint32_t);
+            SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rk.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const int64_t nsteps = (ncells + (int64_t)kb * 64 - 1) / ((int64_t)kb * 64);
+            int64_t grid = (nsteps + W - 1) / W;
+            // persistent: one workgroup per CU (or as many as the LDS lets be resident)
+            int per_cu = (int)(ctx->lds_max / (int64_t)lds);
+            if (per_cu < 1) per_cu = 1;
+            if (per_cu * W > 16) per_cu = 16 / W > 0 ? 16 / W : 1;
+            if (grid > (int64_t)ctx->num_cus * per_cu) grid = (int64_t)ctx->num_cus * per_cu;
+            // cells per grid step a multiple of B: every lane slot then sees one budget and keeps its counters in registers
+            if ((grid * W * kb * 64) % B != 0 && grid > B) grid -= grid % B;
+            if (ctx->grid_override > 0) grid = ctx->grid_override;
+            ctx->stat_sort_cells += 1;
+            if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+            hipLaunchKernelGGL(rk.fn, dim3((unsigned)grid), dim3((unsigned)(W * 64)), lds, ctx->stream, a);
+            SCV_HIP(hipGetLastError());
+            return finish(ev);
+        }
+    }
 
     if (path == 4) {
         // ---- register-resident cells: single-wave workgroups, 16 KiB of LDS each, 8 per CU
@@ -1042,7 +1088,10 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "stagger_vecs")) { if (value < 0 || value > (1 << 28)) return fail(SCV_ERR_ARG, "stagger out of range"); ctx->stagger_vecs = (int)value; }
     else if (!strcmp(key, "plain_loads")) ctx->plain_loads = value != 0;
     else if (!strcmp(key, "prefetch")) ctx->prefetch = value != 0;
-    else if (!strcmp(key, "path")) { if (value < 0 || value > 4) return fail(SCV_ERR_ARG, "path must be 0..4"); ctx->path = (int)value; }
+    else if (!strcmp(key, "path")) { if (value < 0 || value > 5) return fail(SCV_ERR_ARG, "path must be 0..5"); ctx->path = (int)value; }
+    else if (!strcmp(key, "sort_cells")) ctx->sort_cells = value != 0;
+    else if (!strcmp(key, "sort_n_min")) { if (value < 4 || value > 65) return fail(SCV_ERR_ARG, "sort_n_min must be 4..65"); ctx->sort_n_min = (int)value; }
+    else if (!strcmp(key, "sort_kb")) { if (value < 0 || value > 2) return fail(SCV_ERR_ARG, "sort_kb must be 0, 1 or 2"); ctx->sort_kb = (int)value; }
     else if (!strcmp(key, "reg_dense4")) ctx->reg_dense4 = value != 0;
     else if (!strcmp(key, "reg_pivots")) { if (value < 0 || value > 2) return fail(SCV_ERR_ARG, "reg_pivots must be 0, 1 or 2"); ctx->reg_pivots = (int)value; }
     else if (!strcmp(key, "boot_lds")) ctx->boot_lds = value != 0;
@@ -1507,6 +1556,7 @@ int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
     else if (!strcmp(key, "reg_lds_counters")) *out = ctx->stat_reg_lds_counters;
     else if (!strcmp(key, "prefix_cells")) *out = ctx->stat_prefix_cells;
     else if (!strcmp(key, "prefix_lane")) *out = ctx->stat_prefix_lane;
+    else if (!strcmp(key, "sort_cells")) *out = ctx->stat_sort_cells;
     else if (!strcmp(key, "merge_in_launch")) *out = ctx->stat_merge_in_launch;
     else return fail(SCV_ERR_ARG, "unknown stat '%s'", key);
     return SCV_OK;

@@ -29,6 +29,10 @@ RegKernel pick_reg_g64(int v, bool tok, bool vec, bool dense4);
 // scv_reg_dense<v vectors per lane per part, h parts>: capacity 256 * v * h votes per cell
 RegKernel pick_dense_kernel(int v, int h, bool tok, bool vec);
 
+// scv_sort_cells<nv votes per lane, kb blocks of 64 cells per step>: one lane per cell, 4 <= N <= nv, rows staged by LDS-DMA
+// (scvote_sort.hip.h); .waves = the launch bound in waves
+RegKernel pick_sort_kernel(int nv, int kb, bool tok);
+
 // ---- shared by the table translation units ------------------------------------------------------------------------
 template <int RL2, int T, int U>
 inline KernelFn stream_tok(bool tok) {

@@ -1,0 +1,398 @@
+// scvote_sort.hip.h -- gfx950 (CDNA4 / MI355X): short cells, ONE LANE PER CELL, rows staged through LDS by LDS-DMA and
+// SORTED in registers (scv_sort_cells).  The reference's own range: N = 1 ... 128 samples per cell (o1.py:267,276).
+//
+// Why another kernel for 8 <= N <= 64 (PMC of its predecessors: profiles/r02_regimes_pmc_register_kernels.md, r03_*):
+//  * scv_reg_cells<16, 1, 4> (33 <= N <= 64) spreads a cell over 16 lanes: 4 votes per lane pay for two group reductions, the
+//    pivot merge, the record and ~30 instructions of control -- ~36 VALU per vote with the LDS pipe half busy: 2.7-3.0 TB/s.
+//  * scv_lane_cells<32> (N <= 32) has the right shape (a lane owns a cell, no cross-lane traffic) but every lane reads its own
+//    128-byte row with eight 16-byte loads: a wave instruction touches 64 different cache lines, eight times each: 1.7 TB/s.
+// Here the wave's 64 rows (one contiguous block of 64 * N * 4 bytes) are copied HBM -> LDS by global_load_lds_dwordx4: every
+// instruction moves 1 KiB of consecutive addresses, no VGPR is staged, and the copy of the NEXT block is in flight while the
+// current cells are counted (a block's counting time is several memory latencies, so one LDS buffer per wave is enough: the
+// copy is issued as soon as the rows have been read into registers).  The LDS image is the block with one 16-byte pad slot
+// per row when the row has an even number of slots: a lane's ds_read_b128 of its own row is then conflict-free (row stride
+// odd in 16-byte slots).  The pad is made by the SOURCE addresses (the LDS side of the DMA is lane-linear).
+//
+// Counting (o1.py:181-195 + statistics.multimode + o1.py:204-213) without LDS, without cross-lane traffic, without compares:
+// votes are 10-bit values, so two fit a register and v_pk_min_u16 / v_pk_max_u16 run TWO compare-exchanges per instruction
+// pair.  Element i of the cell sits in half i / NP of register i % NP (NP = NV / 2): a bitonic network in its all-ascending
+// ("flip") form sorts both halves in lockstep and needs the halves to meet in one stage only (5 instructions per register
+// pair there).  NV = 64: 720 instructions for 64 votes.  A scan over the sorted registers then gives, again two elements per
+// instruction, run_i = length of the run of equal values ending at i (running maximum of the 1-based indices of run starts),
+// max_count = max run, len(multimode) = #{ i : run_i == max_count } (a maximal run reaches max_count exactly once, at its last
+// element: no division), min_mode = min x_i over those, truth_count = #{ x_i == truth }: 16 instructions per register.
+// Votes past the valid prefix (n_valid[b] < NV) become DISTINCT sentinels 0x8000 | i: they sort behind every vote, form runs of
+// length 1, and are subtracted from the mode count when max_count == 1.
+#pragma once
+
+#include "scvote_kernels.hip.h"
+
+namespace scv {
+
+// Packed 16-bit arithmetic of the scan as inline asm: written with clang's vector types, instcombine recognises the 0 / 1
+// arithmetic (min(x, 1) * c, 1 -sat x ...) as selects and the backend then emits 16-bit compares + v_cndmask (SDWA) + v_perm --
+// three times the instructions and 60+ live SGPR-pair masks (spilled).  Each step of the scan is ONE asm statement: hipcc pads
+// every asm result that the next instruction reads with an s_nop (it must assume a dst_sel forwarding hazard; full-dword
+// v_pk_* results have none), so single-instruction statements cost a wait state per dependent pair.  Constants are SGPR
+// operands (s_mov literals: scalar issue, not VALU).
+
+// The sorting network itself is plain min / max: nothing for instcombine to "simplify", so it goes through the compiler
+// (which schedules it and needs no hazard padding around it: every inline-asm statement costs an s_nop now and then).
+typedef unsigned short sv_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_c(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(sv_u16x2, a), __builtin_bit_cast(sv_u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_c(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(sv_u16x2, a), __builtin_bit_cast(sv_u16x2, b)));
+}
+// compare-exchange of both halves: the minima to `lo`, the maxima to `hi`
+__device__ __forceinline__ void sv_ce(uint32_t& lo, uint32_t& hi) {
+    const uint32_t mn = pk_min_c(lo, hi), mx = pk_max_c(lo, hi);
+    lo = mn; hi = mx;
+}
+// the one stage where the halves meet: (lo(a), hi(b)) and (lo(b), hi(a)), minima to the low halves
+__device__ __forceinline__ void sv_ce_cross(uint32_t& a, uint32_t& b) {
+    const uint32_t t = __builtin_amdgcn_alignbit(b, b, 16);
+    const uint32_t mn = pk_min_c(a, t), mx = pk_max_c(a, t);
+    a = (mn & 0xffffu) | (mx & 0xffff0000u);
+    b = __builtin_amdgcn_alignbit(mx, mn, 16);
+}
+
+// Ascending sort of the 2 * NP 16-bit elements of R; element i = half i / NP of R[i % NP].
+template <int NP>
+__device__ __forceinline__ void sv_sort(uint32_t (&R)[NP]) {
+    static_assert(NP >= 2 && (NP & (NP - 1)) == 0, "packed registers");
+#pragma unroll
+    for (int k = 2; k <= NP; k <<= 1) {                 // both halves in lockstep: blocks of k registers
+#pragma unroll
+        for (int r = 0; r < NP; ++r) {
+            const int l = r ^ (k - 1);                  // flip: mirror partner inside the block
+            if (l > r) sv_ce(R[r], R[l]);
+        }
+#pragma unroll
+        for (int j = k >> 2; j > 0; j >>= 1) {
+#pragma unroll
+            for (int r = 0; r < NP; ++r) {
+                const int l = r ^ j;
+                if (l > r) sv_ce(R[r], R[l]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NP / 2; ++r) sv_ce_cross(R[r], R[NP - 1 - r]);   // element (0, r) against (1, NP - 1 - r)
+#pragma unroll
+    for (int j = NP >> 1; j > 0; j >>= 1) {
+#pragma unroll
+        for (int r = 0; r < NP; ++r) {
+            const int l = r ^ j;
+            if (l > r) sv_ce(R[r], R[l]);
+        }
+    }
+}
+
+struct SortedStats { uint32_t max_run, at_max, min_at_max, truth_votes; };
+
+// statistics.multimode on the sorted registers (see the header comment); tcmp2 = the truth in both halves (0x7fff7fff: none)
+template <int NP>
+__device__ __forceinline__ SortedStats sv_scan(const uint32_t (&R)[NP], uint32_t tcmp2) {
+    uint32_t run[NP];
+    uint32_t s = 0;
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+        // predecessor of element (h, r): (h, r - 1); of (0, 0): none (0xffff differs from every element); of (1, 0): (0, NP - 1)
+        const uint32_t prev = r ? R[r - 1] : ((R[NP - 1] << 16) | 0xffffu);
+        // 1 where a run starts, times the 1-based index of the element; running maximum = index of the latest start
+        uint32_t t, sn;
+        asm("v_xor_b32 %0, %2, %3\n\t"
+            "v_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_lo_u16 %0, %0, %4\n\t"
+            "v_pk_max_u16 %1, %5, %0"
+            : "=&v"(t), "=v"(sn)
+            : "v"(R[r]), "v"(prev), "s"((uint32_t)(r + 1) | ((uint32_t)(r + NP + 1) << 16)), "v"(s));
+        s = sn;
+        run[r] = sn;
+    }
+    const uint32_t carry = s << 16;                     // a run that crosses from half 0 into half 1 started in half 0
+    uint32_t mx = 0;
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+        // run length ending here = (index + 1) - start; running maximum
+        uint32_t rn, mn;
+        asm("v_pk_max_u16 %0, %2, %3\n\t"
+            "v_pk_sub_u16 %0, %4, %0\n\t"
+            "v_pk_max_u16 %1, %5, %0"
+            : "=&v"(rn), "=v"(mn)
+            : "v"(run[r]), "v"(carry), "s"((uint32_t)(r + 2) | ((uint32_t)(r + NP + 2) << 16)), "v"(mx));
+        run[r] = rn;
+        mx = mn;
+    }
+    SortedStats o;
+    o.max_run = (mx & 0xffffu) > (mx >> 16) ? (mx & 0xffffu) : (mx >> 16);
+    const uint32_t mr2 = o.max_run | (o.max_run << 16);
+    uint32_t below = 0, minc = 0xffffffffu, tc = 0;
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+        // m = 1 where the run ending here is shorter than the longest; candidates for min_mode: the element where it is a mode,
+        // 0xffff elsewhere; 1 where the element equals the truth
+        uint32_t m, t, b2, c2, t2;
+        asm("v_pk_sub_u16 %0, %5, %6\n\t"
+            "v_xor_b32 %1, %7, %8\n\t"
+            "v_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]\n\t"
+            "v_pk_sub_u16 %1, 1, %1 op_sel_hi:[0,1] clamp\n\t"
+            "v_pk_add_u16 %2, %9, %0\n\t"
+            "v_pk_sub_u16 %0, 0, %0 op_sel_hi:[0,1]\n\t"
+            "v_pk_add_u16 %4, %11, %1\n\t"
+            "v_or_b32 %0, %7, %0\n\t"
+            "v_pk_min_u16 %3, %10, %0"
+            : "=&v"(m), "=&v"(t), "=&v"(b2), "=&v"(c2), "=&v"(t2)
+            : "v"(mr2), "v"(run[r]), "v"(R[r]), "v"(tcmp2), "v"(below), "v"(minc), "v"(tc));
+        below = b2; minc = c2; tc = t2;
+    }
+    o.at_max = 2u * NP - ((below & 0xffffu) + (below >> 16));
+    o.min_at_max = (minc & 0xffffu) < (minc >> 16) ? (minc & 0xffffu) : (minc >> 16);
+    o.truth_votes = (tc & 0xffffu) + (tc >> 16);
+    return o;
+}
+
+// slots past the valid prefix become DISTINCT sentinels 0x8000 | i behind every vote, on the packed register, by arithmetic:
+// 1 where the 1-based index exceeds n, times the sentinel, maximum with the slot
+__device__ __forceinline__ uint32_t sv_sentinel(uint32_t x, uint32_t n2, uint32_t idx1, uint32_t sent) {
+    uint32_t t, o;
+    asm("v_pk_sub_u16 %0, %3, %4 clamp\n\t"
+        "v_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_lo_u16 %0, %0, %5\n\t"
+        "v_pk_max_u16 %1, %2, %0"
+        : "=&v"(t), "=v"(o)
+        : "v"(x), "s"(idx1), "v"(n2), "s"(sent));
+    return o;
+}
+
+// one LDS-DMA piece: 64 lanes x 16 bytes, lane l's bytes land at lds_dst + 16 l (M0 is written in the statement that reads it)
+__device__ __forceinline__ void sv_dma16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+constexpr int sort_cells_threads(int nv) { return nv >= 64 ? 512 : 1024; }
+
+// NV: votes per lane (capacity of the shape; 8 / 16 / 32 / 64), KB: blocks of 64 cells per step.  Host contract: N % 4 == 0,
+// 4 <= N <= NV, 16-byte aligned bases, no pool rows; a.wave_lds_words = words of one wave's LDS region (KB * 64 * PS * 4, twice
+// that with tokens; PS = (N / 4) | 1 slots per padded row); the workgroup's LDS = regions | n_valid cache | tie classes | sums.
+template <int NV, int KB, bool TOK>
+__global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const AggArgs a) {
+    constexpr int NP = NV / 2, RSM = NV / 4;
+    constexpr int QMAX = KB * (RSM + 1);                             // DMA pieces per step at the widest row
+    constexpr int TC = NV + 1;                                       // tie classes 0..NV
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, T = (int)blockDim.x, NW = T >> 6;
+    const int32_t N = (int32_t)a.N, B = a.B;
+    const uint32_t RS = (uint32_t)N >> 2, PS = RS | 1u;              // slots of a row, of a padded row
+    const uint32_t rowbytes = (uint32_t)N * 4u;
+    const uint32_t nq = (uint32_t)KB * PS;                           // DMA pieces per step and stream
+    uint32_t* nv_lds = lds + (int64_t)NW * a.wave_lds_words;
+    const bool nv_cached = a.n_valid && B <= kMaxSortedB;
+    uint32_t* tie = nv_lds + (nv_cached ? ((B + 3) & ~3) : 0);       // [B][TC]
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(tie + (((int64_t)B * TC + 1) & ~(int64_t)1));   // [B] truth sums | [B] token sums
+    const bool counters = a.tie_hits || a.truth_sum || (TOK && a.token_sum);
+    if (nv_cached)
+        for (int i = tid; i < B; i += T) nv_lds[i] = (uint32_t)valid_len(a, i);
+    if (counters) {
+        for (int64_t i = tid; i < (int64_t)B * TC; i += T) tie[i] = 0;
+        for (int i = tid; i < 2 * B; i += T) acc[i] = 0;
+    }
+    __syncthreads();
+
+    // this wave's region: votes image [KB * 64 rows][PS slots], then (TOK) the tokens image
+    const uint32_t rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32*)(lds + (int64_t)wid * a.wave_lds_words));
+    const uint32_t img_bytes = (uint32_t)KB * 64u * PS * 16u;
+    // source offset of every slot this lane copies: slot s = 64 q + lane is chunk k = s % PS of row c = s / PS (the pad slot,
+    // k == RS, repeats the row's last chunk)
+    uint32_t off[QMAX];
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+        const uint32_t s = (uint32_t)q * 64u + (uint32_t)lane;
+        const uint32_t c = s / PS, k = s - c * PS;
+        off[q] = c * rowbytes + (k < RS ? k : RS - 1u) * 16u;
+    }
+    const int64_t nwaves = (int64_t)gridDim.x * NW;
+    const int64_t wave = (int64_t)blockIdx.x * NW + wid;
+    constexpr int64_t SC = (int64_t)KB * 64;                         // cells per step
+    const int64_t nsteps = (a.ncells + SC - 1) / SC;
+    const int64_t total_bytes = a.ncells * (int64_t)rowbytes;
+    auto issue = [&](int64_t st) {                                   // (wave-uniform) start the copy of step st into the region
+        const int64_t byte0 = st * SC * (int64_t)rowbytes;
+        const int64_t rem = total_bytes - byte0 - 16;                // last 16-byte chunk of the tensor, relative to the block
+        const uint32_t lim = rem > 0x7fffffffll ? 0x7fffffffu : (uint32_t)rem;
+        const char* g = reinterpret_cast<const char*>(a.answers) + byte0;
+        const char* gt = TOK ? reinterpret_cast<const char*>(a.tokens) + byte0 : nullptr;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the rows of the previous step have left the region
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            if ((uint32_t)q < nq) {
+                const uint32_t o = off[q] < lim ? off[q] : lim;      // (slots past the last cell re-read the tensor's last chunk)
+                sv_dma16(g + o, rbase + (uint32_t)q * 1024u);
+                if (TOK) sv_dma16(gt + o, rbase + img_bytes + (uint32_t)q * 1024u);
+            }
+        }
+    };
+
+    // walkers of this lane's KB cells per step
+    const int64_t stride = nwaves * SC;
+    const int64_t dp = stride / B;
+    const int32_t db = (int32_t)(stride - dp * B);
+    int64_t ccell[KB], cp[KB];
+    int32_t cb[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        ccell[j] = wave * SC + j * 64 + lane;
+        cp[j] = ccell[j] / B;
+        cb[j] = (int32_t)(ccell[j] - cp[j] * B);
+    }
+    // stride % B == 0 (the host rounds the grid): slot j of this lane sees ONE budget, its counters stay in registers
+    const bool fixed_b = counters && db == 0;
+    uint32_t h1[KB];
+    unsigned long long tcs[KB];
+    long long toks[KB];
+    int32_t my_b[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) { h1[j] = 0; tcs[j] = 0; toks[j] = 0; my_b[j] = cb[j]; }
+    auto budget_len = [&](int32_t b) -> uint32_t { return nv_cached ? nv_lds[b] : (uint32_t)valid_len(a, b); };
+
+    uint32_t bad = 0;
+    int32_t trn[KB];                                                 // truth of the NEXT step's cells (loaded behind the DMA issue)
+    auto load_truth = [&]() {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) trn[j] = a.truth[ccell[j] < a.ncells ? cp[j] : 0];
+    };
+    int64_t st = wave;
+    if (st < nsteps) { load_truth(); issue(st); }
+    for (; st < nsteps; st += nwaves) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this step's images have landed (LDS-DMA is counted by vmcnt)
+        uint32_t R[KB][NP];
+        long long tok[KB];
+        uint32_t nvj[KB];
+        int32_t trj[KB];
+        const bool all_live = (st + 1) * SC <= a.ncells;             // (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const bool live = ccell[j] < a.ncells;
+            const uint32_t n = live ? budget_len(cb[j]) : 0u;
+            nvj[j] = n;
+            trj[j] = trn[j];
+            const uint32_t ra = rbase + (uint32_t)(j * 64 + lane) * (PS * 16u);
+            uint32_t w[NV];
+#pragma unroll
+            for (int k = 0; k < RSM; ++k) {                          // (slots past the row read the neighbour / the pad: never valid votes)
+                const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k));
+                w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+            }
+            tok[j] = 0;
+            if (TOK) {
+#pragma unroll
+                for (int k = 0; k < RSM; ++k) {
+                    if ((uint32_t)k < RS) {
+                        const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + img_bytes + 16u * k));
+                        // validity as a MASK (a predicate per element would keep 64 SGPR pairs alive): all ones when element < n
+                        const int32_t nn = (int32_t)n - 4 * k;
+                        tok[j] += (long long)((int32_t)q.x & ((0 - nn) >> 31)) + (long long)((int32_t)q.y & ((1 - nn) >> 31))
+                                + (long long)((int32_t)q.z & ((2 - nn) >> 31)) + (long long)((int32_t)q.w & ((3 - nn) >> 31));
+                    }
+                }
+            }
+            // o1.py:140 int(extracted_answer) is unbounded; the extractor maps it into bins 0..1023: the clamp runs only in the
+            // (wave-uniform, rare) case that some slot -- a vote or not -- holds a larger value
+            uint32_t orv = 0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) orv |= w[i];
+            const bool full = all_live && __all(n == (uint32_t)NV);
+            if (__any(orv > 1023u)) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    bad |= w[i] & (uint32_t)((i - (int32_t)n) >> 31);
+                    w[i] = w[i] < 1023u ? w[i] : 1023u;
+                }
+            }
+            // every slot is <= 1023 now (votes, neighbours, pads): two per register
+#pragma unroll
+            for (int r = 0; r < NP; ++r) R[j][r] = w[r] | (w[r + NP] << 16);
+            if (!full) {
+                const uint32_t n2 = n | (n << 16);
+#pragma unroll
+                for (int r = 0; r < NP; ++r)
+                    R[j][r] = sv_sentinel(R[j][r], n2, (uint32_t)(r + 1) | ((uint32_t)(r + NP + 1) << 16),
+                                          (0x8000u | (uint32_t)r) | ((0x8000u | (uint32_t)(r + NP)) << 16));
+            }
+        }
+        // the next step's copy flies while this step is counted
+        const int64_t nx = st + nwaves;
+        int64_t ecell[KB];
+        int32_t eb[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            ecell[j] = ccell[j]; eb[j] = cb[j];
+            ccell[j] += stride; cp[j] += dp; cb[j] += db;
+            if (cb[j] >= B) { cb[j] -= B; cp[j] += 1; }
+        }
+        if (nx < nsteps) { load_truth(); issue(nx); }
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            sv_sort<NP>(R[j]);
+            const uint32_t tcmp = (trj[j] >= 0 && trj[j] < kBins) ? (uint32_t)trj[j] : 0x7fffu;
+            const SortedStats s = sv_scan<NP>(R[j], tcmp | (tcmp << 16));
+            if (ecell[j] < a.ncells) {
+                const uint32_t n = nvj[j];
+                const bool any = n > 0;
+                const uint32_t maxc = any ? s.max_run : 0u;
+                // sentinels are runs of length 1: they are modes only when every vote is distinct
+                const uint32_t n_modes = any ? s.at_max - (s.max_run == 1u ? (uint32_t)NV - n : 0u) : 0u;
+                const uint32_t tc = s.truth_votes;
+                const uint32_t hit = (any && tc == maxc) ? 1u : 0u;                  // o1.py:206
+                if (a.cells) {
+                    uint4 rec;
+                    rec.x = maxc;
+                    rec.y = tc;
+                    rec.z = (n_modes & 0xffffu) | ((any ? (s.min_at_max & 0xffffu) : 0xffffu) << 16);
+                    rec.w = hit;
+                    reinterpret_cast<uint4*>(a.cells)[ecell[j]] = rec;
+                }
+                if (TOK && a.cell_tokens) a.cell_tokens[ecell[j]] = tok[j];
+                if (fixed_b) {                                                        // o1.py:238-240 as integers
+                    h1[j] += (hit && n_modes == 1u) ? 1u : 0u;
+                    if (hit && n_modes != 1u) atomicAdd(&tie[eb[j] * TC + (int32_t)n_modes], 1u);
+                    tcs[j] += tc;
+                    if (TOK) toks[j] += tok[j];
+                } else if (counters) {                                                // ... per workgroup in LDS
+                    if (hit) atomicAdd(&tie[eb[j] * TC + (int32_t)n_modes], 1u);
+                    if (tc) atomicAdd(&acc[eb[j]], (unsigned long long)tc);
+                    if (TOK) atomicAdd(&acc[B + eb[j]], (unsigned long long)tok[j]);
+                }
+            }
+        }
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+    if (fixed_b) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            if (h1[j]) atomicAdd(&tie[my_b[j] * TC + 1], h1[j]);
+            if (tcs[j]) atomicAdd(&acc[my_b[j]], tcs[j]);
+            if (TOK && toks[j]) atomicAdd(&acc[B + my_b[j]], (unsigned long long)toks[j]);
+        }
+    }
+    if (counters) {
+        __syncthreads();
+        for (int64_t i = tid; i < (int64_t)B * TC; i += T) {
+            const uint32_t v = tie[i];
+            if (v && a.tie_hits) {
+                const int64_t b = i / TC;
+                atomicAdd(&a.tie_hits[b * SCV_TIE_CLASSES + (i - b * TC)], (unsigned long long)v);
+            }
+        }
+        for (int i = tid; i < B; i += T) {
+            if (a.truth_sum && acc[i]) atomicAdd(&a.truth_sum[i], acc[i]);
+            if (TOK && a.token_sum && acc[B + i]) atomicAdd(&a.token_sum[i], acc[B + i]);
+        }
+    }
+}
+
+}  // namespace scv
