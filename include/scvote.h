@@ -107,8 +107,8 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
 /* Launch options (measurement / tests): "grid" (> 0: exact persistent grid, 0: derive from the CU
  * count), "balance" (default 1: shrink the grid so all workgroups stream the same number of items),
  * "path" (0 auto | 1 streaming whole cells | 2 streaming split-N + merge | 3 small-N wave-per-cell | 4 register-resident cells |
- * 5 sorted cells), "sort_cells" (default 1: cells of "sort_n_min" (default 8) <= N <= 64 votes in 16-byte aligned rows run one lane per
- * cell, the wave's rows staged through LDS by LDS-DMA and sorted in registers), "sort_kb" (blocks of 64 cells per step of that kernel, 0 auto),
+ * 5 sorted cells), "sort_cells" (default 1: cells of "sort_n_min" (default 8) <= N <= "sort_n_max" (default 64, at most 128) votes run one lane per
+ * cell, the wave's rows staged through LDS by LDS-DMA and sorted in registers; rows that are not 16-byte aligned: from N = 5, at most 64), "sort_kb" (blocks of 64 cells per step of that kernel, 0 auto),
  * "segs" (split-N segments per cell, 0 auto), "sorted" (default 1: budgets traversed in descending
  * n_valid order), "small_n_max" (auto: N <= this uses the small-N kernel), "tiny_n_max" (<= 32: N <= this
  * uses the register-only several-cells-per-wave kernel inside the small path), "auto_geometry" (default 1),

@@ -95,57 +95,92 @@ struct SortedStats { uint32_t max_run, at_max, min_at_max, truth_votes; };
 // statistics.multimode on the sorted registers (see the header comment); tcmp2 = the truth in both halves (0x7fff7fff: none)
 template <int NP>
 __device__ __forceinline__ SortedStats sv_scan(const uint32_t (&R)[NP], uint32_t tcmp2) {
+    static_assert(NP % 4 == 0, "the scan steps take four registers per asm statement");
     uint32_t run[NP];
     uint32_t s = 0;
+#define SV_IDX(r, d) ((uint32_t)((r) + (d)) | ((uint32_t)((r) + NP + (d)) << 16))   /* (index of element (0, r)) + d | the same for (1, r) */
 #pragma unroll
-    for (int r = 0; r < NP; ++r) {
+    for (int r = 0; r < NP; r += 4) {
         // predecessor of element (h, r): (h, r - 1); of (0, 0): none (0xffff differs from every element); of (1, 0): (0, NP - 1)
         const uint32_t prev = r ? R[r - 1] : ((R[NP - 1] << 16) | 0xffffu);
         // 1 where a run starts, times the 1-based index of the element; running maximum = index of the latest start
-        uint32_t t, sn;
-        asm("v_xor_b32 %0, %2, %3\n\t"
+        uint32_t t0, t1, t2, t3, o0, o1, o2, o3;
+        asm("v_xor_b32 %0, %8, %12\n\t"
+            "v_xor_b32 %1, %9, %8\n\t"
+            "v_xor_b32 %2, %10, %9\n\t"
+            "v_xor_b32 %3, %11, %10\n\t"
             "v_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]\n\t"
-            "v_pk_mul_lo_u16 %0, %0, %4\n\t"
-            "v_pk_max_u16 %1, %5, %0"
-            : "=&v"(t), "=v"(sn)
-            : "v"(R[r]), "v"(prev), "s"((uint32_t)(r + 1) | ((uint32_t)(r + NP + 1) << 16)), "v"(s));
-        s = sn;
-        run[r] = sn;
+            "v_pk_min_u16 %1, %1, 1 op_sel_hi:[1,0]\n\t"
+            "v_pk_min_u16 %2, %2, 1 op_sel_hi:[1,0]\n\t"
+            "v_pk_min_u16 %3, %3, 1 op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_lo_u16 %0, %0, %14\n\t"
+            "v_pk_mul_lo_u16 %1, %1, %15\n\t"
+            "v_pk_mul_lo_u16 %2, %2, %16\n\t"
+            "v_pk_mul_lo_u16 %3, %3, %17\n\t"
+            "v_pk_max_u16 %4, %13, %0\n\t"
+            "v_pk_max_u16 %5, %4, %1\n\t"
+            "v_pk_max_u16 %6, %5, %2\n\t"
+            "v_pk_max_u16 %7, %6, %3"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+            : "v"(R[r]), "v"(R[r + 1]), "v"(R[r + 2]), "v"(R[r + 3]), "v"(prev), "v"(s),
+              "s"(SV_IDX(r, 1)), "s"(SV_IDX(r + 1, 1)), "s"(SV_IDX(r + 2, 1)), "s"(SV_IDX(r + 3, 1)));
+        run[r] = o0; run[r + 1] = o1; run[r + 2] = o2; run[r + 3] = o3;
+        s = o3;
     }
     const uint32_t carry = s << 16;                     // a run that crosses from half 0 into half 1 started in half 0
     uint32_t mx = 0;
 #pragma unroll
-    for (int r = 0; r < NP; ++r) {
+    for (int r = 0; r < NP; r += 4) {
         // run length ending here = (index + 1) - start; running maximum
-        uint32_t rn, mn;
-        asm("v_pk_max_u16 %0, %2, %3\n\t"
-            "v_pk_sub_u16 %0, %4, %0\n\t"
-            "v_pk_max_u16 %1, %5, %0"
-            : "=&v"(rn), "=v"(mn)
-            : "v"(run[r]), "v"(carry), "s"((uint32_t)(r + 2) | ((uint32_t)(r + NP + 2) << 16)), "v"(mx));
-        run[r] = rn;
-        mx = mn;
+        uint32_t n0, n1, n2, n3, mo;
+        asm("v_pk_max_u16 %0, %5, %9\n\t"
+            "v_pk_max_u16 %1, %6, %9\n\t"
+            "v_pk_max_u16 %2, %7, %9\n\t"
+            "v_pk_max_u16 %3, %8, %9\n\t"
+            "v_pk_sub_u16 %0, %11, %0\n\t"
+            "v_pk_sub_u16 %1, %12, %1\n\t"
+            "v_pk_sub_u16 %2, %13, %2\n\t"
+            "v_pk_sub_u16 %3, %14, %3\n\t"
+            "v_pk_max_u16 %4, %10, %0\n\t"
+            "v_pk_max_u16 %4, %4, %1\n\t"
+            "v_pk_max_u16 %4, %4, %2\n\t"
+            "v_pk_max_u16 %4, %4, %3"
+            : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "=&v"(mo)
+            : "v"(run[r]), "v"(run[r + 1]), "v"(run[r + 2]), "v"(run[r + 3]), "v"(carry), "v"(mx),
+              "s"(SV_IDX(r, 2)), "s"(SV_IDX(r + 1, 2)), "s"(SV_IDX(r + 2, 2)), "s"(SV_IDX(r + 3, 2)));
+        run[r] = n0; run[r + 1] = n1; run[r + 2] = n2; run[r + 3] = n3;
+        mx = mo;
     }
+#undef SV_IDX
     SortedStats o;
     o.max_run = (mx & 0xffffu) > (mx >> 16) ? (mx & 0xffffu) : (mx >> 16);
     const uint32_t mr2 = o.max_run | (o.max_run << 16);
     uint32_t below = 0, minc = 0xffffffffu, tc = 0;
 #pragma unroll
-    for (int r = 0; r < NP; ++r) {
+    for (int r = 0; r < NP; r += 2) {
         // m = 1 where the run ending here is shorter than the longest; candidates for min_mode: the element where it is a mode,
         // 0xffff elsewhere; 1 where the element equals the truth
-        uint32_t m, t, b2, c2, t2;
-        asm("v_pk_sub_u16 %0, %5, %6\n\t"
-            "v_xor_b32 %1, %7, %8\n\t"
+        uint32_t m0, m1, t0, t1, b2, c2, t2;
+        asm("v_pk_sub_u16 %0, %7, %8\n\t"
+            "v_pk_sub_u16 %1, %7, %9\n\t"
+            "v_xor_b32 %2, %10, %12\n\t"
+            "v_xor_b32 %3, %11, %12\n\t"
             "v_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]\n\t"
-            "v_pk_sub_u16 %1, 1, %1 op_sel_hi:[0,1] clamp\n\t"
-            "v_pk_add_u16 %2, %9, %0\n\t"
+            "v_pk_min_u16 %1, %1, 1 op_sel_hi:[1,0]\n\t"
+            "v_pk_sub_u16 %2, 1, %2 op_sel_hi:[0,1] clamp\n\t"
+            "v_pk_sub_u16 %3, 1, %3 op_sel_hi:[0,1] clamp\n\t"
+            "v_pk_add_u16 %4, %13, %0\n\t"
+            "v_pk_add_u16 %6, %15, %2\n\t"
             "v_pk_sub_u16 %0, 0, %0 op_sel_hi:[0,1]\n\t"
-            "v_pk_add_u16 %4, %11, %1\n\t"
-            "v_or_b32 %0, %7, %0\n\t"
-            "v_pk_min_u16 %3, %10, %0"
-            : "=&v"(m), "=&v"(t), "=&v"(b2), "=&v"(c2), "=&v"(t2)
-            : "v"(mr2), "v"(run[r]), "v"(R[r]), "v"(tcmp2), "v"(below), "v"(minc), "v"(tc));
+            "v_pk_add_u16 %4, %4, %1\n\t"
+            "v_pk_sub_u16 %1, 0, %1 op_sel_hi:[0,1]\n\t"
+            "v_pk_add_u16 %6, %6, %3\n\t"
+            "v_or_b32 %0, %10, %0\n\t"
+            "v_or_b32 %1, %11, %1\n\t"
+            "v_pk_min_u16 %5, %14, %0\n\t"
+            "v_pk_min_u16 %5, %5, %1"
+            : "=&v"(m0), "=&v"(m1), "=&v"(t0), "=&v"(t1), "=&v"(b2), "=&v"(c2), "=&v"(t2)
+            : "v"(mr2), "v"(run[r]), "v"(run[r + 1]), "v"(R[r]), "v"(R[r + 1]), "v"(tcmp2), "v"(below), "v"(minc), "v"(tc));
         below = b2; minc = c2; tc = t2;
     }
     o.at_max = 2u * NP - ((below & 0xffffu) + (below >> 16));
@@ -174,22 +209,30 @@ __device__ __forceinline__ void sv_dma16(const void* gsrc, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-constexpr int sort_cells_threads(int nv) { return nv >= 64 ? 512 : 1024; }
+constexpr int sort_cells_threads(int nv) { return nv >= 128 ? 256 : (nv >= 64 ? 512 : 1024); }
 
 // NV: votes per lane (capacity of the shape; 8 / 16 / 32 / 64), KB: blocks of 64 cells per step.  Host contract: N % 4 == 0,
 // 4 <= N <= NV, 16-byte aligned bases, no pool rows; a.wave_lds_words = words of one wave's LDS region (KB * 64 * PS * 4, twice
 // that with tokens; PS = (N / 4) | 1 slots per padded row); the workgroup's LDS = regions | n_valid cache | tie classes | sums.
-template <int NV, int KB, bool TOK>
+//
+// LIN (rows that are not all 16-byte aligned: N % 4 != 0 or unaligned bases; the reference's N is arbitrary, o1.py:276): a block
+// of 64 rows is still ONE contiguous run of bytes (64 * N * 4 is a multiple of 16, so every block has the base's misalignment):
+// the image is the 16-byte aligned superset of the block, linear, and a lane reads its row with N ds_read_b32 at lane stride N
+// words (conflict-free for odd N, 2-way for N = 2 mod 4).  Host contract: 1 <= N <= NV, a.wave_lds_words covers
+// KB * 64 * N * 4 + 16 bytes rounded up to whole KiB (twice with tokens: the token base has its own misalignment).
+template <int NV, int KB, bool TOK, bool LIN = false>
 __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const AggArgs a) {
     constexpr int NP = NV / 2, RSM = NV / 4;
-    constexpr int QMAX = KB * (RSM + 1);                             // DMA pieces per step at the widest row
+    constexpr int QMAX = KB * (RSM + 1);                             // DMA pieces per step at the widest row (LIN: 16 N KB + 16 bytes)
     constexpr int TC = NV + 1;                                       // tie classes 0..NV
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, T = (int)blockDim.x, NW = T >> 6;
     const int32_t N = (int32_t)a.N, B = a.B;
     const uint32_t RS = (uint32_t)N >> 2, PS = RS | 1u;              // slots of a row, of a padded row
     const uint32_t rowbytes = (uint32_t)N * 4u;
-    const uint32_t nq = (uint32_t)KB * PS;                           // DMA pieces per step and stream
+    const uint32_t shv = LIN ? (uint32_t)(uintptr_t)a.answers & 15u : 0u;            // LIN: bytes between the aligned superset and the block
+    const uint32_t sht = (LIN && TOK) ? (uint32_t)(uintptr_t)a.tokens & 15u : 0u;
+    const uint32_t nq = LIN ? ((uint32_t)KB * 64u * rowbytes + 16u + 1023u) >> 10 : (uint32_t)KB * PS;   // DMA pieces per step and stream
     uint32_t* nv_lds = lds + (int64_t)NW * a.wave_lds_words;
     const bool nv_cached = a.n_valid && B <= kMaxSortedB;
     uint32_t* tie = nv_lds + (nv_cached ? ((B + 3) & ~3) : 0);       // [B][TC]
@@ -205,15 +248,22 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
 
     // this wave's region: votes image [KB * 64 rows][PS slots], then (TOK) the tokens image
     const uint32_t rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32*)(lds + (int64_t)wid * a.wave_lds_words));
-    const uint32_t img_bytes = (uint32_t)KB * 64u * PS * 16u;
+    const uint32_t img_bytes = LIN ? nq * 1024u : (uint32_t)KB * 64u * PS * 16u;
     // source offset of every slot this lane copies: slot s = 64 q + lane is chunk k = s % PS of row c = s / PS (the pad slot,
     // k == RS, repeats the row's last chunk)
     uint32_t off[QMAX];
+    if (LIN) {
 #pragma unroll
-    for (int q = 0; q < QMAX; ++q) {
-        const uint32_t s = (uint32_t)q * 64u + (uint32_t)lane;
-        const uint32_t c = s / PS, k = s - c * PS;
-        off[q] = c * rowbytes + (k < RS ? k : RS - 1u) * 16u;
+        for (int q = 0; q < QMAX; ++q) off[q] = (uint32_t)q * 1024u + (uint32_t)lane * 16u;
+    } else {
+        uint32_t c = (uint32_t)lane / PS, k = (uint32_t)lane - c * PS;   // one division; then s += 64 is (c, k) += (64 / PS, 64 % PS) with a carry
+        const uint32_t dc = 64u / PS, dk = 64u - dc * PS;
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            off[q] = c * rowbytes + (k < RS ? k : RS - 1u) * 16u;
+            c += dc; k += dk;
+            if (k >= PS) { k -= PS; c += 1; }
+        }
     }
     const int64_t nwaves = (int64_t)gridDim.x * NW;
     const int64_t wave = (int64_t)blockIdx.x * NW + wid;
@@ -222,17 +272,23 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
     const int64_t total_bytes = a.ncells * (int64_t)rowbytes;
     auto issue = [&](int64_t st) {                                   // (wave-uniform) start the copy of step st into the region
         const int64_t byte0 = st * SC * (int64_t)rowbytes;
-        const int64_t rem = total_bytes - byte0 - 16;                // last 16-byte chunk of the tensor, relative to the block
+        // last 16-byte chunk that holds bytes of the tensor, relative to the (aligned superset of the) block
+        const int64_t rem = LIN ? ((total_bytes - byte0 + shv - 1) & ~(int64_t)15) : total_bytes - byte0 - 16;
+        const int64_t remt = (LIN && TOK) ? ((total_bytes - byte0 + sht - 1) & ~(int64_t)15) : rem;
         const uint32_t lim = rem > 0x7fffffffll ? 0x7fffffffu : (uint32_t)rem;
-        const char* g = reinterpret_cast<const char*>(a.answers) + byte0;
-        const char* gt = TOK ? reinterpret_cast<const char*>(a.tokens) + byte0 : nullptr;
+        const uint32_t limt = remt > 0x7fffffffll ? 0x7fffffffu : (uint32_t)remt;
+        const char* g = reinterpret_cast<const char*>(a.answers) + byte0 - shv;
+        const char* gt = TOK ? reinterpret_cast<const char*>(a.tokens) + byte0 - sht : nullptr;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the rows of the previous step have left the region
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) {
             if ((uint32_t)q < nq) {
                 const uint32_t o = off[q] < lim ? off[q] : lim;      // (slots past the last cell re-read the tensor's last chunk)
                 sv_dma16(g + o, rbase + (uint32_t)q * 1024u);
-                if (TOK) sv_dma16(gt + o, rbase + img_bytes + (uint32_t)q * 1024u);
+                if (TOK) {
+                    const uint32_t ot = off[q] < limt ? off[q] : limt;
+                    sv_dma16(gt + ot, rbase + img_bytes + (uint32_t)q * 1024u);
+                }
             }
         }
     };
@@ -280,15 +336,35 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
             const uint32_t n = live ? budget_len(cb[j]) : 0u;
             nvj[j] = n;
             trj[j] = trn[j];
-            const uint32_t ra = rbase + (uint32_t)(j * 64 + lane) * (PS * 16u);
+            const uint32_t ra = LIN ? rbase + shv + (uint32_t)(j * 64 + lane) * rowbytes : rbase + (uint32_t)(j * 64 + lane) * (PS * 16u);
             uint32_t w[NV];
+            if (LIN) {
 #pragma unroll
-            for (int k = 0; k < RSM; ++k) {                          // (slots past the row read the neighbour / the pad: never valid votes)
-                const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k));
-                w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+                for (int i = 0; i < NV; ++i) w[i] = *reinterpret_cast<lds_u32*>((uintptr_t)(ra + 4u * i));   // (past the row: the neighbour's votes, never valid)
+            } else {
+#pragma unroll
+                for (int k = 0; k < RSM / 2; ++k) {
+                    // elements 4k .. 4k + 3 and their partners NP elements further on: both halves of four packed registers
+                    // (slots past the row re-read its last slot: in-domain values that are never valid votes)
+                    const uint32_t k0 = (uint32_t)k < RS ? (uint32_t)k : RS - 1u, k1 = (uint32_t)(k + RSM / 2) < RS ? (uint32_t)(k + RSM / 2) : RS - 1u;
+                    const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k0));
+                    const scv_v4u h = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k1));
+                    w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+                    w[NP + 4 * k] = h.x; w[NP + 4 * k + 1] = h.y; w[NP + 4 * k + 2] = h.z; w[NP + 4 * k + 3] = h.w;
+                }
             }
             tok[j] = 0;
-            if (TOK) {
+            if (TOK && LIN) {
+                const uint32_t rt = rbase + img_bytes + sht + (uint32_t)(j * 64 + lane) * rowbytes;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    if (i < N) {
+                        const int32_t y = (int32_t)*reinterpret_cast<lds_u32*>((uintptr_t)(rt + 4u * i));
+                        tok[j] += (long long)(y & ((i - (int32_t)n) >> 31));      // validity as a mask: all ones when i < n
+                    }
+                }
+            }
+            if (TOK && !LIN) {
 #pragma unroll
                 for (int k = 0; k < RSM; ++k) {
                     if ((uint32_t)k < RS) {

@@ -13,14 +13,14 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def parity(eng):
+def parity(eng, big=False):
     from o1_inference_scaling_laws_amd.engine import AggregateResult
     from oracle import coracle
     from tests._adapters import OracleEngine, assert_results_equal
     bad = []
     n = 0
     rng = np.random.default_rng(3)
-    for N in range(4, 65, 4):
+    for N in list(range(1, 65)) + ([68, 96, 100, 124, 128] if big else []):
         for (P, B) in ((1, 1), (7, 3), (300, 4), (1000, 11), (5000, 8), (70000, 2)):
             if P * B * N > 6_000_000:
                 continue
@@ -57,6 +57,31 @@ def main():
         eng = Engine(device=0, timing=True)
         eng.set_option("path", 5)
         n, bad = parity(eng)
+        # device pointers that are not 16-byte aligned (views into larger buffers): the linear-image form, every alignment class
+        from o1_inference_scaling_laws_amd.engine import AggregateResult, cells_from_torch
+        from oracle import coracle
+        from tests._adapters import OracleEngine, assert_results_equal
+        dev = torch.device("cuda:0")
+        for (P, B, N) in ((300, 3, 61), (300, 2, 64), (500, 3, 7), (200, 4, 32), (1000, 2, 16), (150, 3, 33), (90, 5, 48)):
+            a, t, tr = coracle.synth_fill(P, B, N, 17 + N, 1, want_tokens=True)
+            for off_a, off_t in ((1, 1), (1, 2), (3, 0), (0, 3), (2, 2)):
+                ba = torch.zeros(P * B * N + 8, dtype=torch.int32, device=dev)
+                bt = torch.zeros(P * B * N + 8, dtype=torch.int32, device=dev)
+                va = ba[off_a:off_a + P * B * N].view(P, B, N); vt = bt[off_t:off_t + P * B * N].view(P, B, N)
+                va.copy_(torch.from_numpy(a)); vt.copy_(torch.from_numpy(t))
+                nv = np.array([N, max(0, N - 5), N // 3, 1, N][:B], dtype=np.int32)
+                for tok in (False, True):
+                    for nvv in (None, nv):
+                        n += 1
+                        counters, cells, ctok = eng.aggregate_device(va, torch.from_numpy(tr).to(dev), tokens=vt if tok else None,
+                                                                     n_valid=None if nvv is None else torch.from_numpy(nvv).to(dev))
+                        eng.sync()
+                        got = AggregateResult.from_counters(counters.cpu().numpy(), P, B, cells_from_torch(cells), ctok.cpu().numpy() if tok else None)
+                        want = OracleEngine().aggregate(a, tr, tokens=t if tok else None, n_valid=nvv)
+                        try:
+                            assert_results_equal(got, want, check_tokens=tok)
+                        except AssertionError as e:
+                            bad.append((N, P, B, "unaligned base", off_a, off_t, tok, str(e)[:80]))
         print(f"parity: {n} cases, {len(bad)} mismatches", flush=True)
         for b in bad[:20]:
             print("  MISMATCH", b, flush=True)
@@ -75,7 +100,7 @@ def main():
         eng.aggregate(a, np.zeros(100, dtype=np.int32), n_valid=np.array([32, 5], dtype=np.int32))    # beyond the prefix: no error
         eng.close()
     rows = []
-    shapes = [(3200000, 4, 8), (1600000, 4, 16), (800000, 4, 32), (400000, 4, 48), (400000, 4, 64), (400000, 4, 8), (400000, 4, 16), (400000, 4, 32), (200000, 4, 64)]
+    shapes = [(3200000, 4, 8), (1600000, 4, 16), (800000, 4, 32), (400000, 4, 48), (400000, 4, 64), (3200000, 4, 7), (800000, 4, 30), (800000, 4, 33), (400000, 4, 61), (400000, 4, 8), (400000, 4, 16), (400000, 4, 32), (200000, 4, 64)]
     for (P, B, N) in shapes:
         for tok in (False, True):
             if tok and P > 800000:
@@ -84,9 +109,7 @@ def main():
                 if tok and not cells:
                     continue
                 rec = {"shape": [P, B, N], "tokens": tok, "cell_table": cells}
-                for label, opts in (("old", {"sort_cells": 0}), ("sort", {"sort_cells": 1}), ("sort_kb1", {"sort_cells": 1, "sort_kb": 1})):
-                    if label == "sort_kb1" and N > 16:
-                        continue
+                for label, opts in (("old", {"sort_cells": 0}), ("sort", {"sort_cells": 1})):
                     eng = Engine(device=0, timing=True)
                     for k, v in opts.items():
                         eng.set_option(k, v)
