@@ -113,7 +113,7 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  * n_valid order), "small_n_max" (auto: N <= this uses the small-N kernel), "tiny_n_max" (<= 32: N <= this
  * uses the register-only several-cells-per-wave kernel inside the small path), "auto_geometry" (default 1),
  * "host_pipeline" (default 1; 0: the serial round-1 staging loop), "stage_mb" (HOST-mode chunk size,
- * default 128), "copy_threads" (default 6: threads filling the pinned bounce slots), "reg_n_max" (default 4096: 32 < N <=
+ * default 128), "copy_threads" (default 6: threads filling the pinned bounce slots), "reg_n_max" (default 8192 = its maximum: 32 < N <=
  * this uses the register-resident cell kernels; 0 restores the round-1 dispatch), "reg_shape" / "reg_km" / "reg_dense4" (force a
  * register-kernel shape for A/B runs), "reg_pivots" (register-resident kernels: a lane adds the votes equal to its first and second
  * vote to words of its own instead of the contended histogram bins; 1 switches the second pivot off for A/B runs, default 0), "reg_lds_counters" (default 1: the register-resident kernels accumulate the per-budget

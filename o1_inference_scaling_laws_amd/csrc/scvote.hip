@@ -173,7 +173,7 @@ struct scv_ctx {
     int sort_n_max = 64;     // longer cells go to the register-resident kernels (the 128-vote shape runs one wave per SIMD: measured 3.2 vs 3.8 TB/s)
     int sort_kb = 0;         // blocks of 64 cells per step (0 = auto: 2 for N <= 16, else 1)
     int64_t stat_sort_cells = 0;
-    int reg_n_max = 4096;    // auto: 32 < N <= this -> register-resident cells kernel (scv_reg_cells); 0 = off (round-1 dispatch)
+    int reg_n_max = 8192;    // auto: 32 < N <= this -> register-resident cells kernel (scv_reg_cells); 0 = off (round-1 dispatch)
     bool user_tuned = false; // set_tuning called: auto geometry off
     // split-N scratch (grown on demand)
     void* d_partial = nullptr;
@@ -412,7 +412,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     // register-resident kernels: rows that are not all 16-byte aligned are read as their aligned supersets (up to 3 slots more)
     const bool reg_vec = (N % 4 == 0) && (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0);
     const int64_t Nreg = reg_vec ? N : N + 3;
-    if (path == 4 && (Nreg > 4096 || N < 1)) path = (N <= ctx->small_n_max) ? 3 : 1;   // (forced) reg path outside its range
+    if (path == 4 && (Nreg > 8192 || N < 1)) path = (N <= ctx->small_n_max) ? 3 : 1;   // (forced) reg path outside its range
 
     EventPair* ev = nullptr;
     if (int rc = next_event_pair(ctx, &ev)) return rc;
@@ -474,10 +474,11 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         else if (Nreg <= 512) { g = 32; v = 4; }
         else if (Nreg <= 1024) { g = 64; v = 4; }
         else if (Nreg <= 2048) { v = 4; h = 2; }      // 4 KiB parts: 126-136 VGPRs, 3 waves per SIMD (8 KiB parts: 200, 2 waves; measured 73 vs 79 us)
-        else { v = 4; h = 4; }
+        else if (Nreg <= 4096) { v = 4; h = 4; }
+        else { v = 4; h = 8; }                        // 4096 < N <= 8192: 4.5 -> 5.4 TB/s at N = 4608 against the streaming kernel, equal at 8192
         if (ctx->reg_shape >= 1000) {
             const int fv = (ctx->reg_shape - 1000) / 10, fh = ctx->reg_shape % 10;
-            if (fv == 4 && (fh == 1 || fh == 2 || fh == 4) && (int64_t)256 * fv * fh >= Nreg) { g = 0; v = fv; h = fh; }
+            if (fv == 4 && (fh == 1 || fh == 2 || fh == 4 || fh == 8) && (int64_t)256 * fv * fh >= Nreg) { g = 0; v = fv; h = fh; }
         } else if (ctx->reg_shape > 0) {
             const int fg = ctx->reg_shape / 100, fv = ctx->reg_shape % 100;
             if ((fg == 16 || fg == 32 || fg == 64) && (fv == 1 || fv == 2 || fv == 4) && (int64_t)4 * fg * fv >= Nreg) { g = fg; v = fv; h = 0; }
@@ -1115,7 +1116,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "reg_wpg")) { if (value != 0 && value != 4 && value != 8 && value != 12 && value != 16) return fail(SCV_ERR_ARG, "reg_wpg must be 0, 4, 8, 12 or 16"); ctx->reg_wpg = (int)value; }
     else if (!strcmp(key, "reg_km")) { if (value != 1 && value != 2 && value != 4) return fail(SCV_ERR_ARG, "reg_km must be 1, 2 or 4"); ctx->reg_km = (int)value; }
     else if (!strcmp(key, "reg_shape")) { if (value < 0 || value > 9999) return fail(SCV_ERR_ARG, "reg_shape out of range"); ctx->reg_shape = (int)value; }
-    else if (!strcmp(key, "reg_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "reg_n_max < 0"); ctx->reg_n_max = (int)(value > 4096 ? 4096 : value); }
+    else if (!strcmp(key, "reg_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "reg_n_max < 0"); ctx->reg_n_max = (int)(value > 8192 ? 8192 : value); }
     else if (!strcmp(key, "segs")) { if (value < 0 || value > 4096) return fail(SCV_ERR_ARG, "segs out of range"); ctx->segs_override = (int)value; }
     else if (!strcmp(key, "sorted")) ctx->sorted = value != 0;
     else if (!strcmp(key, "small_reg")) ctx->small_reg = (int)(value < 0 ? 0 : (value > 2 ? 2 : value));

@@ -12,6 +12,13 @@ static RegKernel dense_vh(bool tok, bool vec) {
 //  N = 2048) and are no longer instantiated: with the pivot counters the token variants no longer fit the register file.)
 RegKernel pick_dense_kernel(int v, int h, bool tok, bool vec) {
     (void)v;
-    return h == 1 ? dense_vh<4, 1>(tok, vec) : (h == 2 ? dense_vh<4, 2>(tok, vec) : dense_vh<4, 4>(tok, vec));
+    switch (h) {
+    case 1: return dense_vh<4, 1>(tok, vec);
+    case 2: return dense_vh<4, 2>(tok, vec);
+    case 8: return dense_vh<4, 8>(tok, vec);       // 4096 < N <= 8192: the streaming kernel's 1024 * R-word fold per cell still costs more than 8 parts
+                                                   // through the wave's own 8 KiB histogram (N = 4608: 4.5 -> 5.4 TB/s; from 8192 up they meet, 16 parts lose;
+                                                   // and a count of 2^14 would not fit the key = count << 18 | address)
+    default: return dense_vh<4, 4>(tok, vec);
+    }
 }
 }  // namespace scv

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1), ("small_n_max", 512),
             ("tiny_n_max", 32), ("small_reg", 1), ("prefetch", 1), ("stagger_vecs", 0), ("plain_loads", 0),
-            ("fused_counters_max", 4096), ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_pivots", 0),
+            ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_pivots", 0),
             ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1))
 
 

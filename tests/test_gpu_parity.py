@@ -208,14 +208,16 @@ def _with_options(eng, opts):
         def __exit__(self_, *exc):
             for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
                          ("small_n_max", 512), ("tiny_n_max", 32), ("small_reg", 1), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096),
-                         ("reg_n_max", 4096), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1), ("reg_pivots", 0)):
+                         ("reg_n_max", 8192), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1), ("reg_pivots", 0),
+                         ("sort_cells", 1), ("sort_n_min", 8), ("sort_n_max", 64), ("sort_kb", 0)):
                 eng.set_option(k, v)
     return _Ctx()
 
 
 REG_SHAPES = [(700, 3, 33), (1200, 2, 64), (500, 4, 65), (301, 3, 100), (900, 2, 128), (333, 2, 129), (257, 4, 256), (200, 3, 257),
               (150, 2, 500), (300, 3, 512), (90, 2, 513), (70, 3, 1000), (200, 2, 1024), (41, 2, 1025), (33, 3, 2047),
-              (100, 2, 2048), (20, 2, 2049), (19, 3, 3000), (17, 2, 4095), (60, 2, 4096)]
+              (100, 2, 2048), (20, 2, 2049), (19, 3, 3000), (17, 2, 4095), (60, 2, 4096),
+              (20, 2, 4097), (15, 3, 6000), (12, 2, 8189), (10, 3, 8192)]          # (round 3: 8 parts of 4 vectors per lane up to 8192 votes)
 
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
@@ -229,7 +231,7 @@ def test_register_resident_cells_path(hip_engine, dist, shape):
     nv = np.array([max(0, N - 3 * b) if b % 2 else N >> (b // 2) for b in range(B)], dtype=np.int32)
     # every kernel shape whose capacity covers N: sparse g*100+v (4*g*v votes), dense 1000+10*v+h (256*v*h votes)
     shapes = [g * 100 + v for g in (16, 32, 64) for v in (1, 2, 4) if 4 * g * v >= N]
-    shapes += [1000 + 10 * v + h for v, h in ((4, 1), (4, 2), (4, 4), (8, 1), (8, 2)) if 256 * v * h >= N]
+    shapes += [1000 + 10 * v + h for v, h in ((4, 1), (4, 2), (4, 4), (4, 8)) if 256 * v * h >= N]
     pick = [shapes[(P + dist + i * 3) % len(shapes)] for i in range(3)]
     for opts in ({"path": 4}, {"path": 4, "grid": 7, "fused_counters_max": 0, "reg_shape": pick[0], "reg_lds_counters": 0, "reg_pivots": 2},
                  {"path": 4, "grid": 64, "fused_counters_max": 1 << 30, "reg_shape": pick[1], "reg_lds_counters": 0, "reg_pivots": 1},
@@ -323,7 +325,7 @@ def test_tiny_cells_register_path(hip_engine, dist, shape):
         a, t, tr = coracle.synth_fill(P, B, N, 40 + dist, dist, want_tokens=True)
         a = a % (3 + dist * 300)                                   # few distinct values -> many ties
     nv = np.array([(N >> (b % 4)) if b % 3 else N for b in range(B)], dtype=np.int32)
-    for opts in ({"path": 3}, {"path": 0}, {"path": 3, "tiny_n_max": 0}, {"path": 3, "fused_counters_max": 0}):
+    for opts in ({"path": 3}, {"path": 0}, {"path": 0, "sort_cells": 0}, {"path": 3, "tiny_n_max": 0}, {"path": 3, "fused_counters_max": 0}):
         with _with_options(hip_engine, opts):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
             assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
@@ -342,7 +344,7 @@ def test_tiny_cells_one_lane_per_cell(hip_engine, dist, shape):
     tr2 = (tr % 5).astype(np.int32)
     rng = np.random.default_rng(3)
     nv = rng.integers(0, N + 1, size=(B,), dtype=np.int32)
-    for opts in ({}, {"grid": 3}, {"tiny_lane": 0}):
+    for opts in ({"sort_cells": 0}, {"grid": 3, "sort_cells": 0}, {"tiny_lane": 0, "sort_cells": 0}):     # (sort_cells = 1, the default: next test)
         with _with_options(hip_engine, opts):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
             assert_results_equal(hip_engine.aggregate(a2, tr2, n_valid=nv), oracle(a2, tr2, n_valid=nv), check_tokens=False)
@@ -352,6 +354,65 @@ def test_tiny_cells_one_lane_per_cell(hip_engine, dist, shape):
             assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum)
             assert np.array_equal(got.truth_count_sum, want.truth_count_sum)
     hip_engine.set_option("tiny_lane", 1)
+
+
+SORT_SHAPES = [(700, 3, 4), (41, 11, 8), (3333, 5, 7), (1000, 3, 16), (777, 2, 17), (300, 7, 32), (20000, 2, 12), (9000, 1, 31), (100, 200, 8),
+               (5000, 4, 5), (4000, 3, 20), (2500, 4, 30), (2000, 2, 33), (1500, 3, 48), (1200, 4, 61), (1100, 2, 63), (3000, 4, 64), (1, 1, 64),
+               (65, 1, 36), (40, 600, 24), (900, 64, 64)]
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("shape", SORT_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_sorted_cells_one_lane_per_cell(hip_engine, dist, shape):
+    """scv_sort_cells (round 3; the reference's own range, o1.py:267,276): one lane per cell, the wave's 64 rows staged through
+    LDS by LDS-DMA, packed 16-bit bitonic sort + run-length scan in registers.  Every shape of the kernel (8 / 16 / 32 / 64 votes
+    per lane), rows 16-byte aligned (padded image, b128 reads) and not (linear image, dword reads), a cell count that is not a
+    multiple of 64, tokens, ragged n_valid incl. 0, narrow value ranges (ties everywhere), many budgets (counters in LDS; more
+    budgets than the n_valid cache holds), small forced grids (many steps per wave), two blocks per step, cells wanted or not."""
+    P, B, N = shape
+    a, t, tr = coracle.synth_fill(P, B, N, 700 + dist, dist, want_tokens=True)
+    a2 = (a % 5).astype(np.int32)                                       # 5 distinct values: ties everywhere
+    tr2 = (tr % 5).astype(np.int32)
+    rng = np.random.default_rng(5 + N)
+    nv = rng.integers(0, N + 1, size=(B,), dtype=np.int32)
+    before = hip_engine.stat("sort_cells")
+    for opts in ({}, {"grid": 3}, {"path": 5, "sort_kb": 2}):
+        with _with_options(hip_engine, opts):
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
+            assert_results_equal(hip_engine.aggregate(a2, tr2, n_valid=nv), oracle(a2, tr2, n_valid=nv), check_tokens=False)
+            assert_results_equal(hip_engine.aggregate(a2, tr2, tokens=t, n_valid=nv), oracle(a2, tr2, tokens=t, n_valid=nv))
+            got = hip_engine.aggregate(a, tr, tokens=t, want_cells=False)
+            want = oracle(a, tr, tokens=t)
+            assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum)
+            assert np.array_equal(got.truth_count_sum, want.truth_count_sum)
+    launches = hip_engine.stat("sort_cells") - before
+    assert launches >= (12 if N >= 5 else 4), launches        # (N = 4 runs on scv_lane_cells unless the path is forced; HOST calls may be several chunks)
+
+
+def test_sorted_cells_edges(hip_engine):
+    """Domain errors surface (and only for votes inside the valid prefix), spare bins, a truth outside the histogram, all votes
+    distinct (every vote a mode: the sentinels of a short prefix must not count), the 128-vote shape (option sort_n_max)."""
+    a = np.zeros((100, 2, 32), dtype=np.int32)
+    a[57, 1, 5] = 5000
+    with pytest.raises(_lib.DomainError):
+        hip_engine.aggregate(a, np.zeros(100, dtype=np.int32))
+    hip_engine.aggregate(a, np.zeros(100, dtype=np.int32), n_valid=np.array([32, 5], dtype=np.int32))     # beyond the prefix: not an error
+    rng = np.random.default_rng(9)
+    a = rng.integers(990, 1024, size=(400, 3, 44), dtype=np.int32)
+    tr = rng.integers(-5, 1030, size=(400,), dtype=np.int32)
+    tr[:4] = [-1, 1024, 2 ** 31 - 1, -2 ** 31]
+    assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
+    a = np.tile(np.arange(64, dtype=np.int32)[::-1] * 16, (130, 2, 1))          # 64 distinct values
+    tr = np.full(130, 16 * 7, dtype=np.int32)
+    for nv in (None, np.array([64, 9], dtype=np.int32), np.array([1, 0], dtype=np.int32)):
+        got = hip_engine.aggregate(a, tr, n_valid=nv)
+        assert_results_equal(got, oracle(a, tr, n_valid=nv), check_tokens=False)
+    assert got.cells["n_modes"][0, 0] == 1 and got.cells["n_modes"][0, 1] == 0
+    with _with_options(hip_engine, {"sort_n_max": 128}):
+        for N in (68, 100, 128):
+            a, t, tr = coracle.synth_fill(300, 3, N, N, 3, want_tokens=True)
+            nv = np.array([N, N // 2, 3], dtype=np.int32)
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
 
 
 def test_tiny_cells_reference_family_and_domain(hip_engine, golden):

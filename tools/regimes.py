@@ -86,6 +86,24 @@ def main():
         ("tiny N=32 counters only", 400000, 4, 32, False, None, 1, False),
         ("small N=64 counters only", 200000, 4, 64, False, None, 1, False),
         ("small N=256 counters only", 100000, 4, 256, False, None, 1, False),
+        # the reference's own range at sizes where the launch is not the measurement (200-400 MB of votes; the rows above are 50 MB)
+        ("tiny N=8 P=3.2M", 3200000, 4, 8, False, None),
+        ("tiny N=8 P=3.2M counters only", 3200000, 4, 8, False, None, 1, False),
+        ("tiny N=16 P=1.6M", 1600000, 4, 16, False, None),
+        ("tiny N=16 P=1.6M counters only", 1600000, 4, 16, False, None, 1, False),
+        ("tiny N=32 P=800k", 800000, 4, 32, False, None),
+        ("tiny N=32 P=800k counters only", 800000, 4, 32, False, None, 1, False),
+        ("tiny N=32 P=800k + tokens", 800000, 4, 32, True, None),
+        ("small N=48 P=400k", 400000, 4, 48, False, None),
+        ("small N=64 P=400k", 400000, 4, 64, False, None),
+        ("small N=64 P=400k counters only", 400000, 4, 64, False, None, 1, False),
+        ("small N=64 P=400k + tokens", 400000, 4, 64, True, None),
+        ("N=7 P=3.2M (unaligned rows)", 3200000, 4, 7, False, None),
+        ("N=30 P=800k (unaligned rows)", 800000, 4, 30, False, None),
+        ("N=61 P=400k (unaligned rows)", 400000, 4, 61, False, None),
+        ("N=64 D3 tie", 400000, 4, 64, False, None, 3),
+        ("N=64 D5 degenerate-wrong", 400000, 4, 64, False, None, 5),
+        ("N=96 P=200k", 200000, 4, 96, False, None),
     ]
     # the hot value is NOT the truth (D3 exact ties, D4 a confidently wrong majority, D5 all votes one wrong value) and D0
     for (P, B, N) in ((100000, 4, 256), (50000, 4, 1024), (20000, 8, 4096)):
