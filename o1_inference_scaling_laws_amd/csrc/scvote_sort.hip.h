@@ -202,11 +202,21 @@ __device__ __forceinline__ uint32_t sv_sentinel(uint32_t x, uint32_t n2, uint32_
     return o;
 }
 
-// one LDS-DMA piece: 64 lanes x 16 bytes, lane l's bytes land at lds_dst + 16 l (M0 is written in the statement that reads it)
-__device__ __forceinline__ void sv_dma16(const void* gsrc, uint32_t lds_dst) {
+// one LDS-DMA piece: 64 lanes x 16 bytes, lane l's bytes (from gbase + goff_l) land at lds_dst + 16 l; the source is a scalar base +
+// a 32-bit lane offset (no 64-bit address arithmetic on the VALU); M0 is written in the statement that reads it
+__device__ __forceinline__ void sv_dma16(const void* gbase, uint32_t goff, uint32_t lds_dst, bool nt) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    if (nt)          // read-once stream: non-temporal (the line is not kept for a reuse that never comes)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ int64_t sv_uniform64(int64_t v) {      // tell the compiler a value is wave-uniform (it lives in SGPRs from here on)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v & 0xffffffffu));
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 constexpr int sort_cells_threads(int nv) { return nv >= 128 ? 256 : (nv >= 64 ? 512 : 1024); }
@@ -266,10 +276,11 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
         }
     }
     const int64_t nwaves = (int64_t)gridDim.x * NW;
-    const int64_t wave = (int64_t)blockIdx.x * NW + wid;
+    const int64_t wave = sv_uniform64((int64_t)blockIdx.x * NW + wid);
     constexpr int64_t SC = (int64_t)KB * 64;                         // cells per step
     const int64_t nsteps = (a.ncells + SC - 1) / SC;
     const int64_t total_bytes = a.ncells * (int64_t)rowbytes;
+    const bool nt = a.plain_loads == 0;                              // (option "plain_loads": ordinary loads, for A/B runs)
     auto issue = [&](int64_t st) {                                   // (wave-uniform) start the copy of step st into the region
         const int64_t byte0 = st * SC * (int64_t)rowbytes;
         // last 16-byte chunk that holds bytes of the tensor, relative to the (aligned superset of the) block
@@ -284,43 +295,67 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
         for (int q = 0; q < QMAX; ++q) {
             if ((uint32_t)q < nq) {
                 const uint32_t o = off[q] < lim ? off[q] : lim;      // (slots past the last cell re-read the tensor's last chunk)
-                sv_dma16(g + o, rbase + (uint32_t)q * 1024u);
+                sv_dma16(g, o, rbase + (uint32_t)q * 1024u, nt);
                 if (TOK) {
                     const uint32_t ot = off[q] < limt ? off[q] : limt;
-                    sv_dma16(gt + ot, rbase + img_bytes + (uint32_t)q * 1024u);
+                    sv_dma16(gt, ot, rbase + img_bytes + (uint32_t)q * 1024u, nt);
                 }
             }
         }
     };
 
-    // walkers of this lane's KB cells per step
+    // Walkers.  The step's first cell c0 (problem p0, budget b0) advances on the scalar unit; slot j of this lane is cell c0 + 64 j +
+    // lane = c0 + lq[j] * B + lr[j]: its budget and its problem relative to p0 cost three 32-bit VALU operations per step.
     const int64_t stride = nwaves * SC;
     const int64_t dp = stride / B;
     const int32_t db = (int32_t)(stride - dp * B);
-    int64_t ccell[KB], cp[KB];
-    int32_t cb[KB];
+    int64_t c0 = wave * SC;
+    int64_t p0 = c0 / B;
+    int32_t b0 = (int32_t)(c0 - p0 * B);
+    uint32_t lq[KB], lr[KB];
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
-        ccell[j] = wave * SC + j * 64 + lane;
-        cp[j] = ccell[j] / B;
-        cb[j] = (int32_t)(ccell[j] - cp[j] * B);
+        lq[j] = (uint32_t)(j * 64 + lane) / (uint32_t)B;
+        lr[j] = (uint32_t)(j * 64 + lane) - lq[j] * (uint32_t)B;
     }
-    // stride % B == 0 (the host rounds the grid): slot j of this lane sees ONE budget, its counters stay in registers
-    const bool fixed_b = counters && db == 0;
+    auto slot_budget = [&](int j, uint32_t& prel) -> int32_t {       // budget of slot j in the current step; prel = its problem - p0
+        const uint32_t bs = (uint32_t)b0 + lr[j];
+        const bool carry = bs >= (uint32_t)B;
+        prel = lq[j] + (carry ? 1u : 0u);
+        return (int32_t)(carry ? bs - (uint32_t)B : bs);
+    };
+    // stride % B == 0 (the host rounds the grid): slot j of this lane sees ONE budget -- its valid length is a constant of the
+    // launch and its counters stay in registers
+    const bool same_b = db == 0;
+    const bool fixed_b = counters && same_b;
     uint32_t h1[KB];
     unsigned long long tcs[KB];
     long long toks[KB];
     int32_t my_b[KB];
-#pragma unroll
-    for (int j = 0; j < KB; ++j) { h1[j] = 0; tcs[j] = 0; toks[j] = 0; my_b[j] = cb[j]; }
+    uint32_t my_n[KB];
     auto budget_len = [&](int32_t b) -> uint32_t { return nv_cached ? nv_lds[b] : (uint32_t)valid_len(a, b); };
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        uint32_t prel;
+        h1[j] = 0; tcs[j] = 0; toks[j] = 0;
+        my_b[j] = slot_budget(j, prel);
+        my_n[j] = budget_len(my_b[j]);
+    }
 
     uint32_t bad = 0;
     int32_t trn[KB];                                                 // truth of the NEXT step's cells (loaded behind the DMA issue)
-    auto load_truth = [&]() {
+    auto load_truth = [&]() {                                        // for the step at (c0, p0, b0)
+        const int64_t left = a.ncells - c0;
+        const uint32_t live_cells = left > (int64_t)SC ? (uint32_t)SC : (uint32_t)left;
+        const int32_t* tp = a.truth + p0;                            // (scalar base + 32-bit lane index)
 #pragma unroll
-        for (int j = 0; j < KB; ++j) trn[j] = a.truth[ccell[j] < a.ncells ? cp[j] : 0];
+        for (int j = 0; j < KB; ++j) {
+            uint32_t prel;
+            (void)slot_budget(j, prel);
+            trn[j] = tp[(uint32_t)(j * 64 + lane) < live_cells ? prel : 0u];
+        }
     };
+    auto advance = [&]() { c0 += stride; p0 += dp; b0 += db; if (b0 >= B) { b0 -= B; p0 += 1; } };
     int64_t st = wave;
     if (st < nsteps) { load_truth(); issue(st); }
     for (; st < nsteps; st += nwaves) {
@@ -329,11 +364,16 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
         long long tok[KB];
         uint32_t nvj[KB];
         int32_t trj[KB];
-        const bool all_live = (st + 1) * SC <= a.ncells;             // (wave-uniform)
+        const int64_t left = a.ncells - c0;                          // (wave-uniform) cells from this step's first to the last
+        const bool all_live = left >= (int64_t)SC;
+        const uint32_t live_cells = all_live ? (uint32_t)SC : (uint32_t)left;
+        int32_t eb[KB];
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
-            const bool live = ccell[j] < a.ncells;
-            const uint32_t n = live ? budget_len(cb[j]) : 0u;
+            const bool live = (uint32_t)(j * 64 + lane) < live_cells;
+            uint32_t prel;
+            eb[j] = same_b ? my_b[j] : slot_budget(j, prel);
+            const uint32_t n = live ? (same_b ? my_n[j] : budget_len(eb[j])) : 0u;
             nvj[j] = n;
             trj[j] = trn[j];
             const uint32_t ra = LIN ? rbase + shv + (uint32_t)(j * 64 + lane) * rowbytes : rbase + (uint32_t)(j * 64 + lane) * (PS * 16u);
@@ -401,22 +441,16 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
             }
         }
         // the next step's copy flies while this step is counted
-        const int64_t nx = st + nwaves;
-        int64_t ecell[KB];
-        int32_t eb[KB];
-#pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            ecell[j] = ccell[j]; eb[j] = cb[j];
-            ccell[j] += stride; cp[j] += dp; cb[j] += db;
-            if (cb[j] >= B) { cb[j] -= B; cp[j] += 1; }
-        }
-        if (nx < nsteps) { load_truth(); issue(nx); }
+        uint4* const cells_out = a.cells ? reinterpret_cast<uint4*>(a.cells) + c0 : nullptr;     // (scalar bases of this step's outputs)
+        int64_t* const ctok_out = (TOK && a.cell_tokens) ? a.cell_tokens + c0 : nullptr;
+        advance();
+        if (st + nwaves < nsteps) { load_truth(); issue(st + nwaves); }
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             sv_sort<NP>(R[j]);
             const uint32_t tcmp = (trj[j] >= 0 && trj[j] < kBins) ? (uint32_t)trj[j] : 0x7fffu;
             const SortedStats s = sv_scan<NP>(R[j], tcmp | (tcmp << 16));
-            if (ecell[j] < a.ncells) {
+            if ((uint32_t)(j * 64 + lane) < live_cells) {
                 const uint32_t n = nvj[j];
                 const bool any = n > 0;
                 const uint32_t maxc = any ? s.max_run : 0u;
@@ -430,9 +464,9 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
                     rec.y = tc;
                     rec.z = (n_modes & 0xffffu) | ((any ? (s.min_at_max & 0xffffu) : 0xffffu) << 16);
                     rec.w = hit;
-                    reinterpret_cast<uint4*>(a.cells)[ecell[j]] = rec;
+                    __builtin_nontemporal_store(scv_v4u{rec.x, rec.y, rec.z, rec.w}, reinterpret_cast<scv_v4u*>(cells_out) + (uint32_t)(j * 64 + lane));
                 }
-                if (TOK && a.cell_tokens) a.cell_tokens[ecell[j]] = tok[j];
+                if (TOK && a.cell_tokens) ctok_out[(uint32_t)(j * 64 + lane)] = tok[j];
                 if (fixed_b) {                                                        // o1.py:238-240 as integers
                     h1[j] += (hit && n_modes == 1u) ? 1u : 0u;
                     if (hit && n_modes != 1u) atomicAdd(&tie[eb[j] * TC + (int32_t)n_modes], 1u);
