@@ -104,35 +104,53 @@ int scv_sync(scv_ctx* ctx);
  *   unroll        16-byte loads in flight per lane in {2,4,8}
  */
 int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unroll);
-/* Launch options (measurement / tests): "grid" (> 0: exact persistent grid, 0: derive from the CU
- * count), "balance" (default 1: shrink the grid so all workgroups stream the same number of items),
- * "path" (0 auto | 1 streaming whole cells | 2 streaming split-N + merge | 3 small-N wave-per-cell | 4 register-resident cells |
- * 5 sorted cells), "sort_cells" (default 1: cells of "sort_n_min" (default 8) <= N <= "sort_n_max" (default 64, at most 128) votes run one lane per
- * cell, the wave's rows staged through LDS by LDS-DMA and sorted in registers; rows that are not 16-byte aligned: from N = 5, at most 64), "sort_kb" (blocks of 64 cells per step of that kernel, 0 auto),
- * "segs" (split-N segments per cell, 0 auto), "sorted" (default 1: budgets traversed in descending
- * n_valid order), "small_n_max" (auto: N <= this uses the small-N kernel), "tiny_n_max" (<= 32: N <= this
- * uses the register-only several-cells-per-wave kernel inside the small path), "auto_geometry" (default 1),
- * "host_pipeline" (default 1; 0: the serial round-1 staging loop), "stage_mb" (HOST-mode chunk size,
- * default 128), "copy_threads" (default 6: threads filling the pinned bounce slots), "reg_n_max" (default 8192 = its maximum: 32 < N <=
- * this uses the register-resident cell kernels; 0 restores the round-1 dispatch), "reg_shape" / "reg_km" / "reg_dense4" (force a
- * register-kernel shape for A/B runs), "reg_pivots" (register-resident kernels: a lane adds the votes equal to its first and second
- * vote to words of its own instead of the contended histogram bins; 1 switches the second pivot off for A/B runs, default 0), "reg_lds_counters" (default 1: the register-resident kernels accumulate the per-budget
- * counters in LDS and flush them in the same launch; 0: cell table + scv_reduce_cells), "reg_wpg" (waves per workgroup of the
- * register-resident kernels, 0 = all the waves a CU holds), "prefix_cells" (default 1: scv_aggregate_prefix_i32 on pools of N <= 4096
- * runs on the cell kernels, each cell reading its prefix of the pool row; 0: the one-pass snapshot kernels), "prefix_lane" (default 1:
- * pools of N <= 64 run one lane per problem, every budget out of one pass over its votes), "prefix_stage" (default 1: that kernel
- * keeps its per-boundary snapshots in LDS when they fit; 0: reductions at every boundary), "boot_lds" (default 1: LDS-resident bootstrap table),
- * "fused_counters_max" (cells at or below, or problem rows >= 4 MiB: per-cell atomics inside the hot
- * kernel; otherwise a separate reduction of the cell table; 0 forces the reduction), "small_reg", "pin_host" (default 0; 1: HOST-mode calls hipHostRegister caller buffers
- * of 32 MiB or more for the duration of the call -- measured no faster than pageable copies), "prefetch"
- * (default 1: cross-item prefetch in the streaming kernel), "stagger_vecs", "plain_loads", "tok_skew" (default 0; 1: the tokens
- * row is read rotated by half a row against the votes row), "tiny_lane" (default 1: N <= 32 runs one lane per cell; 0: the
- * several-lanes-per-cell kernel), "overwrite_counters" (default 0; 1: the per-budget counters are OVERWRITTEN, not accumulated
- * into -- with few long cells the streaming kernel's last workgroup does it and the call is one launch, otherwise a memset
- * precedes the launch), "ticket_merge" (default 0; 1: split-N cells are merged inside the launch by the last-arriving segment
- * instead of by a merge kernel -- measured 0-9 % slower), "boot_fused" (default 1: scv_aggregate_bootstrap_i32 runs the bootstrap
- * inside the vote launch when the shape allows it), "boot_cooperative" (default 1: that launch is a cooperative launch), "boot_spin_limit"
- * (default 2^20: polls at the grid barrier before a workgroup gives up and leaves the bootstrap to scv_sync; tests set 1). */
+/*
+ * Launch options.  None is needed for correct results: the defaults are the measured choices; the keys
+ * exist so that every kernel of the family can be forced (parity tests) and every choice re-measured (A/B tools).
+ *
+ * Semantics of a call
+ *   "overwrite_counters"  default 0; 1: DEVICE-mode per-budget counters are OVERWRITTEN, not accumulated into (with few long cells the
+ *                         streaming kernel's last workgroup does it and the call is one launch, otherwise a memset precedes the launch)
+ * Dispatch by cell length N (auto unless forced)
+ *   "path"                0 auto | 1 streaming, whole cells | 2 streaming, split-N + merge | 3 small-N wave-per-cell (round 1) |
+ *                         4 register-resident cells | 5 sorted cells
+ *   "sort_cells"          default 1: cells of "sort_n_min" (default 8) <= N <= "sort_n_max" (default 64, at most 128) votes run one lane
+ *                         per cell, the wave's rows staged through LDS by LDS-DMA and sorted in registers (rows that are not 16-byte
+ *                         aligned: from N = 5, at most 64); "sort_kb": blocks of 64 cells per step of that kernel (0 auto)
+ *   "reg_n_max"           default 8192 = its maximum: 32 < N <= this uses the register-resident cell kernels; 0 restores the round-1 dispatch
+ *   "tiny_n_max"          <= 32: N <= this uses the one-lane / several-lanes-per-cell kernels of the small path; "tiny_lane" (default 1:
+ *                         one lane per cell; 0: the round-1 several-lanes-per-cell kernel)
+ *   "small_n_max"         register kernels off: N <= this uses the round-1 wave-per-cell kernel; "small_reg" (its register variant)
+ *   "fused_counters_max"  cells at or below, or problem rows >= 4 MiB: per-cell atomics inside the hot kernel; otherwise a separate
+ *                         reduction of the cell table; 0 forces the reduction
+ * Register-resident kernels (A/B)
+ *   "reg_shape" / "reg_km" / "reg_dense4"   force a kernel shape; "reg_wpg": waves per workgroup (0 = all the waves a CU holds)
+ *   "reg_pivots"          a lane adds the votes equal to its first and second vote to words of its own instead of the contended
+ *                         histogram bins; 1 switches the second pivot off (default 0)
+ *   "reg_lds_counters"    default 1: per-budget counters accumulate in LDS and are flushed by the same launch; 0: cell table + scv_reduce_cells
+ * Streaming kernel (A/B)
+ *   "grid"                > 0: exact persistent grid (0: from the CU count); "balance" (default 1: shrink the grid so that all
+ *                         workgroups stream the same number of items); "auto_geometry" (default 1; see scv_set_tuning)
+ *   "segs"                split-N segments per cell (0 auto); "ticket_merge" (default 0; 1: split cells are merged inside the launch
+ *                         by the last-arriving segment instead of by a merge kernel -- measured 0-9 % slower)
+ *   "sorted"              default 1: budgets traversed in descending n_valid order
+ *   "prefetch"            default 1: cross-item prefetch; "stagger_vecs", "plain_loads" (ordinary instead of non-temporal loads; also the
+ *                         sorted-cells DMA), "tok_skew" (default 0; 1: the tokens row is read rotated by half a row against the votes row)
+ * Prefix budgets (scv_aggregate_prefix_i32)
+ *   "prefix_lane"         default 1: pools of N <= 64 run one lane per problem, every budget out of one pass over its votes;
+ *                         "prefix_stage" (default 1: that kernel keeps its per-boundary snapshots in LDS when they fit)
+ *   "prefix_cells"        default 1: pools of N <= 4096 run on the cell kernels, each cell reading its prefix of the pool row;
+ *                         0: the one-pass snapshot kernels
+ * Bootstrap
+ *   "boot_lds"            default 1: LDS-resident code table; "boot_fused" (default 1: scv_aggregate_bootstrap_i32 runs the bootstrap
+ *                         inside the vote launch when the shape allows it); "boot_cooperative" (default 1: that launch is a cooperative
+ *                         launch); "boot_spin_limit" (default 2^20: polls at the grid barrier before a workgroup gives up and leaves
+ *                         the bootstrap to scv_sync; tests set 1)
+ * HOST-mode ingestion
+ *   "host_pipeline"       default 1; 0: the serial round-1 staging loop; "stage_mb" (chunk size, default 128); "copy_threads"
+ *                         (default 6: threads filling the pinned bounce slots); "pin_host" (default 0; 1: hipHostRegister caller
+ *                         buffers of 32 MiB or more for the duration of the call -- measured no faster than pageable copies)
+ */
 int scv_set_option(scv_ctx* ctx, const char* key, int64_t value);
 
 /*

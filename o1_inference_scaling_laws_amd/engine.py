@@ -230,6 +230,46 @@ class Engine:
 
     # ---- DEVICE mode (torch tensors; asynchronous on torch's current stream) --------------------
 
+    def _device_call(self, votes, votes_name, row_shape, truth, tokens, n_valid, counters, cells, cell_tokens, overwrite, want_no_cells=True):
+        """Shared by the three DEVICE-mode entry points: validates the tensors (contiguous CUDA int32 of the right shape on the
+        engine's device), binds torch's current stream, allocates the outputs the caller did not pass (``cells=False``: none) and
+        sets the overwrite option.  Returns (P, B, N, counters, cells, cell_tokens, pointer-of, counter pointers)."""
+        import torch
+        nd = len(row_shape) + 1
+        if not (votes.is_cuda and votes.dtype == torch.int32 and votes.is_contiguous() and votes.dim() == nd):
+            raise ValueError(f"{votes_name} must be a contiguous CUDA int32 tensor [{'P, B, N' if nd == 3 else 'P, N'}]")
+        P, N = int(votes.shape[0]), int(votes.shape[-1])
+        B = int(votes.shape[1]) if nd == 3 else int(n_valid.shape[0])
+        dev = votes.device
+        self._check_device(votes, votes_name)
+        if truth is None:
+            raise ValueError("truth is required")
+        for name, t, shape in (("truth", truth, (P,)), ("tokens", tokens, tuple(votes.shape)), ("n_valid", n_valid, (B,))):
+            if t is None:
+                continue
+            if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == shape and t.device == dev):
+                raise ValueError(f"{name} must be a contiguous CUDA int32 tensor {shape} on {dev}")
+        self.use_torch_stream()
+        if counters is None:
+            counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
+        elif not (counters.is_cuda and counters.dtype == torch.int64 and counters.numel() == counters_size(B) and counters.is_contiguous()):
+            raise ValueError("counters must be int64 [counters_size(B)] on the device")
+        if cells is None:
+            cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
+        elif cells is False:
+            if not want_no_cells:
+                raise ValueError("this call needs the cell table")
+            cells = None
+        if cell_tokens is None and tokens is not None and cells is not None:
+            cell_tokens = torch.empty((P, B), dtype=torch.int64, device=dev)
+        if overwrite != self._overwrite:
+            check(self._L.scv_set_option(self._ctx, b"overwrite_counters", int(bool(overwrite))))
+            self._overwrite = bool(overwrite)
+        base = counters.data_ptr()
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        cptrs = (C.c_void_p(base), C.c_void_p(base + 8 * B * TIE_CLASSES), C.c_void_p(base + 8 * (B * TIE_CLASSES + B)))
+        return P, B, N, counters, cells, cell_tokens, ptr, cptrs
+
     def aggregate_device(self, answers, truth, tokens=None, n_valid=None, counters=None, cells=None,
                          cell_tokens=None, overwrite=False):
         """answers torch.int32 cuda [P,B,N].  Accumulates into ``counters`` (int64 [counters_size(B)],
@@ -237,40 +277,10 @@ class Engine:
         to skip).  ``overwrite=True``: the counters are overwritten instead (no zeroing by the caller; with
         few long cells the whole evaluation is then ONE kernel launch).  Returns (counters, cells, cell_tokens).
         Does not synchronise."""
-        import torch
-        if not (answers.is_cuda and answers.dtype == torch.int32 and answers.is_contiguous() and answers.dim() == 3):
-            raise ValueError("answers must be a contiguous CUDA int32 tensor [P, B, N]")
-        P, B, N = answers.shape
-        dev = answers.device
-        self._check_device(answers, "answers")
-        for name, t, shape in (("truth", truth, (P,)), ("tokens", tokens, (P, B, N)), ("n_valid", n_valid, (B,))):
-            if t is None:
-                continue
-            if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == shape and t.device == dev):
-                raise ValueError(f"{name} must be a contiguous CUDA int32 tensor {shape} on {dev}")
-        if truth is None:
-            raise ValueError("truth is required")
-        self.use_torch_stream()
-        if counters is None:
-            counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
-        elif not (counters.is_cuda and counters.dtype == torch.int64 and counters.numel() == counters_size(B)
-                  and counters.is_contiguous()):
-            raise ValueError("counters must be int64 [counters_size(B)] on the device")
-        if cells is None:
-            cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
-        elif cells is False:
-            cells = None
-        if cell_tokens is None and tokens is not None and cells is not None:
-            cell_tokens = torch.empty((P, B), dtype=torch.int64, device=dev)
-        base = counters.data_ptr()
-        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        if overwrite != self._overwrite:
-            check(self._L.scv_set_option(self._ctx, b"overwrite_counters", int(bool(overwrite))))
-            self._overwrite = bool(overwrite)
-        check(self._L.scv_aggregate_i32(
-            self._ctx, ptr(answers), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, _lib.MEM_DEVICE,
-            ptr(cells), ptr(cell_tokens),
-            C.c_void_p(base), C.c_void_p(base + 8 * B * TIE_CLASSES), C.c_void_p(base + 8 * (B * TIE_CLASSES + B))))
+        P, B, N, counters, cells, cell_tokens, ptr, cptrs = self._device_call(answers, "answers", (0, 0), truth, tokens, n_valid, counters, cells,
+                                                                              cell_tokens, overwrite)
+        check(self._L.scv_aggregate_i32(self._ctx, ptr(answers), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, _lib.MEM_DEVICE,
+                                        ptr(cells), ptr(cell_tokens), *cptrs))
         return counters, cells, cell_tokens
 
     def aggregate_bootstrap_device(self, answers, truth, r_begin: int, r_end: int, seed: int, M: int, tokens=None,
@@ -280,69 +290,21 @@ class Engine:
         (all workgroups meet at a grid barrier after their last cell and share the resamples).  Returns
         (counters, cells, cell_tokens, boot int64 [r_end - r_begin, B, M]).  Asynchronous."""
         import torch
-        if not (answers.is_cuda and answers.dtype == torch.int32 and answers.is_contiguous() and answers.dim() == 3):
-            raise ValueError("answers must be a contiguous CUDA int32 tensor [P, B, N]")
-        P, B, N = answers.shape
-        dev = answers.device
-        self._check_device(answers, "answers")
-        for name, t, shape in (("truth", truth, (P,)), ("tokens", tokens, (P, B, N)), ("n_valid", n_valid, (B,))):
-            if t is None:
-                continue
-            if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == shape and t.device == dev):
-                raise ValueError(f"{name} must be a contiguous CUDA int32 tensor {shape} on {dev}")
-        self.use_torch_stream()
-        if counters is None:
-            counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
-        if cells is None:
-            cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
-        if cell_tokens is None and tokens is not None:
-            cell_tokens = torch.empty((P, B), dtype=torch.int64, device=dev)
+        P, B, N, counters, cells, cell_tokens, ptr, cptrs = self._device_call(answers, "answers", (0, 0), truth, tokens, n_valid, counters, cells,
+                                                                              cell_tokens, overwrite, want_no_cells=False)
         if out is None:
-            out = torch.empty((r_end - r_begin, B, M), dtype=torch.int64, device=dev)
-        if overwrite != self._overwrite:
-            check(self._L.scv_set_option(self._ctx, b"overwrite_counters", int(bool(overwrite))))
-            self._overwrite = bool(overwrite)
-        base = counters.data_ptr()
-        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        check(self._L.scv_aggregate_bootstrap_i32(
-            self._ctx, ptr(answers), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, ptr(cells), ptr(cell_tokens),
-            C.c_void_p(base), C.c_void_p(base + 8 * B * TIE_CLASSES), C.c_void_p(base + 8 * (B * TIE_CLASSES + B)),
-            r_begin, r_end, seed, M, ptr(out)))
+            out = torch.empty((r_end - r_begin, B, M), dtype=torch.int64, device=answers.device)
+        check(self._L.scv_aggregate_bootstrap_i32(self._ctx, ptr(answers), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, ptr(cells),
+                                                  ptr(cell_tokens), *cptrs, r_begin, r_end, seed, M, ptr(out)))
         return counters, cells, cell_tokens, out
 
     def aggregate_prefix_device(self, pool, truth, n_valid, tokens=None, counters=None, cells=None, cell_tokens=None,
                                 overwrite=False):
         """pool torch.int32 cuda [P,N], n_valid torch.int32 cuda [B].  Asynchronous; see aggregate_device."""
-        import torch
-        if not (pool.is_cuda and pool.dtype == torch.int32 and pool.is_contiguous() and pool.dim() == 2):
-            raise ValueError("pool must be a contiguous CUDA int32 tensor [P, N]")
-        P, N = pool.shape
-        B = int(n_valid.shape[0])
-        dev = pool.device
-        self._check_device(pool, "pool")
-        for name, t, shape in (("truth", truth, (P,)), ("tokens", tokens, (P, N)), ("n_valid", n_valid, (B,))):
-            if t is None:
-                continue
-            if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == shape and t.device == dev):
-                raise ValueError(f"{name} must be a contiguous CUDA int32 tensor {shape} on {dev}")
-        self.use_torch_stream()
-        if counters is None:
-            counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
-        if cells is None:
-            cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
-        elif cells is False:
-            cells = None
-        if cell_tokens is None and tokens is not None and cells is not None:
-            cell_tokens = torch.empty((P, B), dtype=torch.int64, device=dev)
-        base = counters.data_ptr()
-        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        if overwrite != self._overwrite:
-            check(self._L.scv_set_option(self._ctx, b"overwrite_counters", int(bool(overwrite))))
-            self._overwrite = bool(overwrite)
-        check(self._L.scv_aggregate_prefix_i32(
-            self._ctx, ptr(pool), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, _lib.MEM_DEVICE,
-            ptr(cells), ptr(cell_tokens),
-            C.c_void_p(base), C.c_void_p(base + 8 * B * TIE_CLASSES), C.c_void_p(base + 8 * (B * TIE_CLASSES + B))))
+        P, B, N, counters, cells, cell_tokens, ptr, cptrs = self._device_call(pool, "pool", (0,), truth, tokens, n_valid, counters, cells,
+                                                                              cell_tokens, overwrite)
+        check(self._L.scv_aggregate_prefix_i32(self._ctx, ptr(pool), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, _lib.MEM_DEVICE,
+                                               ptr(cells), ptr(cell_tokens), *cptrs))
         return counters, cells, cell_tokens
 
     def synth_fill_device(self, answers=None, tokens=None, truth=None, *, P, B, N, seed, dist, p_offset=0):
