@@ -32,15 +32,16 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    lib_path = os.environ.get("SCV_LIB_PATH") or LIB_PATH          # (A/B runs of two builds of the library; tools/ only)
+    if not os.path.exists(lib_path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build the HIP extension first "
+            f"{lib_path} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
     # One HIP runtime per process.  Device pointers and stream handles cross this boundary from
     # torch, so libscvote must bind to the libamdhip64 torch has loaded (same SONAME, resolved to the
     # already-loaded copy); loading ours first would bring in a second runtime from /opt/rocm.
     import torch  # noqa: F401
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(lib_path)
     p, i32, i64, u32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
     L.scv_create.argtypes = [C.POINTER(p), C.c_int, u32]
     L.scv_destroy.argtypes = [p]

@@ -2468,15 +2468,25 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_
     const int64_t dp = nwaves / a.B;
     const int32_t db = (int32_t)(nwaves - dp * a.B);
     uint32_t ln = 0;                          // valid_len of the cell being loaded
-    int lpart = 0;
+    int lpart = 0, lneed = 1;                 // part being loaded, parts this cell needs
+    // A cell of n votes is streamed in ceil(slots / PART) parts, not in H (wave-uniform: one cell per wave): N = 4501 on the 8-part
+    // shape costs 5 parts, a budget of 7 votes one.  (slots: the row's aligned superset holds up to 3 more than n; at least one part,
+    // which also carries the cell's pivots.)
+    auto parts_needed = [&](uint32_t n) -> int {
+        const uint32_t slots = n + (VEC ? 0u : 3u);
+        const int need = (int)((slots + PART - 1u) / PART);
+        return need < 1 ? 1 : (need > H ? H : need);
+    };
     auto begin_cell_load = [&]() {
         const bool live = ncell < a.ncells;
         const int32_t bb = live ? nb : 0;
         ln = live ? (nv_cached ? nv_lds[bb] : (uint32_t)valid_len(a, bb)) : 0u;
+        lneed = parts_needed(ln);
     };
     // unconditional loads (constant count per part -> counted vmcnt waits), clamped to vector 0 of the row.  !VEC: the row's
     // 16-byte-aligned superset is read (see scv_reg_cells): slot e of the superset is vote e - sh.
-    auto load_part = [&](Part& t) {
+    auto load_part = [&](Part& t, auto dyn_tag) __attribute__((always_inline)) {
+        constexpr bool DYN = decltype(dyn_tag)::value;        // parts per cell from its length (else: every cell takes H parts)
         const bool live = ncell < a.ncells;
         const int64_t rowoff = (live ? (a.pool_rows ? np : ncell) : 0) * a.N;
         const int32_t* row = a.answers + rowoff;
@@ -2504,7 +2514,7 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_
                 t.tk[4 * k] = y.x; t.tk[4 * k + 1] = y.y; t.tk[4 * k + 2] = y.z; t.tk[4 * k + 3] = y.w;
             }
         }
-        if (++lpart == H) {
+        if (++lpart == (DYN ? lneed : H)) {
             lpart = 0;
             ncell += nwaves; np += dp; nb += db;
             if (nb >= a.B) { nb -= a.B; np += 1; }
@@ -2647,35 +2657,45 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_
         }
     };
 
-    // stream of parts: part q of this wave belongs to its cell number q / H; two buffers ping-pong
-    const int64_t my_cells = wave < a.ncells ? (a.ncells - wave + nwaves - 1) / nwaves : 0;
-    const int64_t nparts = my_cells * H;
+    // stream of parts: the cells of this wave one after the other, each in as many parts as it needs; two buffers ping-pong.  The
+    // loading side runs one part ahead of the counting side over the same sequence, so the loop ends when the last cell is counted.
     int64_t ccell = wave;                     // cell being counted
     int64_t cp = np;
     int32_t cb = nb;
     int cpart = 0;
-    int32_t ctruth = my_cells > 0 ? a.truth[cp] : 0;
-    auto count_part = [&](const Part& c) {
+    auto cell_len = [&](int32_t b) -> uint32_t { return nv_cached ? nv_lds[b] : (uint32_t)valid_len(a, b); };
+    int cneed = ccell < a.ncells ? parts_needed(cell_len(cb)) : 1;
+    int32_t ctruth = ccell < a.ncells ? a.truth[cp] : 0;
+    auto count_part = [&](const Part& c, auto dyn_tag) __attribute__((always_inline)) {
+        constexpr bool DYN = decltype(dyn_tag)::value;
         if (cpart == 0) vote_part(c, std::true_type{});
         else vote_part(c, std::false_type{});
-        if (++cpart == H) {
+        if (++cpart == (DYN ? cneed : H)) {
             cpart = 0;
             finish_cell(ccell, cb, ctruth);
             ccell += nwaves; cp += dp; cb += db;
             if (cb >= a.B) { cb -= a.B; cp += 1; }
-            if (ccell < a.ncells) ctruth = a.truth[cp];
+            if (ccell < a.ncells) { ctruth = a.truth[cp]; if (DYN) cneed = parts_needed(cell_len(cb)); }
         }
     };
     Part pa, pb;
     begin_cell_load();
-    if (nparts > 0) load_part(pa);
-    for (int64_t q = 0; q < nparts; q += 2) {
-        if (q + 1 < nparts) load_part(pb);
-        count_part(pa);
-        if (q + 1 >= nparts) break;
-        if (q + 2 < nparts) load_part(pa);
-        count_part(pb);
-    }
+    // Every cell full length (no n_valid, N needs all H parts): the part count is the compile-time H, and with H even the two
+    // buffers keep their roles (first part / last part) -- the dynamic form costs such launches 5-8 %.
+#define SCV_DENSE_STREAM(TAG)                                                     \
+    do {                                                                          \
+        if (ncell < a.ncells) load_part(pa, TAG);                                 \
+        while (ccell < a.ncells) {                                                \
+            if (ncell < a.ncells) load_part(pb, TAG);                             \
+            count_part(pa, TAG);                                                  \
+            if (ccell >= a.ncells) break;                                         \
+            if (ncell < a.ncells) load_part(pa, TAG);                             \
+            count_part(pb, TAG);                                                  \
+        }                                                                         \
+    } while (0)
+    if (!a.n_valid && parts_needed((uint32_t)a.N) == H) SCV_DENSE_STREAM(std::false_type{});
+    else SCV_DENSE_STREAM(std::true_type{});
+#undef SCV_DENSE_STREAM
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
     wg_counters_flush<TOK>(a, wgc, (int)threadIdx.x, (int)blockDim.x);
 }

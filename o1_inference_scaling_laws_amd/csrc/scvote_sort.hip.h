@@ -25,6 +25,8 @@
 // length 1, and are subtracted from the mode count when max_count == 1.
 #pragma once
 
+#include <utility>
+
 #include "scvote_kernels.hip.h"
 
 namespace scv {
@@ -58,26 +60,37 @@ __device__ __forceinline__ void sv_ce_cross(uint32_t& a, uint32_t& b) {
     b = __builtin_amdgcn_alignbit(mx, mn, 16);
 }
 
-// Ascending sort of the 2 * NP 16-bit elements of R; element i = half i / NP of R[i % NP].
+// Batcher's odd-even mergesort network on N wires, as a compile-time list of compare-exchanges (min to the lower wire): 5 / 19 / 63 /
+// 191 of them for N = 4 / 8 / 16 / 32 against the bitonic network's 6 / 24 / 80 / 240.
+template <int N>
+struct SvNetwork {
+    int a[N * 10], b[N * 10], n;
+};
+template <int N>
+constexpr SvNetwork<N> sv_make_network() {
+    SvNetwork<N> o{};
+    o.n = 0;
+    for (int p = 1; p < N; p *= 2)
+        for (int k = p; k >= 1; k /= 2)
+            for (int j = k % p; j <= N - 1 - k; j += 2 * k)
+                for (int i = 0; i <= (k - 1 < N - j - k - 1 ? k - 1 : N - j - k - 1); ++i)
+                    if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) { o.a[o.n] = i + j; o.b[o.n] = i + j + k; ++o.n; }
+    return o;
+}
+template <int N>
+struct SvNet { static constexpr SvNetwork<N> net = sv_make_network<N>(); };
+template <int NP, int... I>
+__device__ __forceinline__ void sv_sort_halves(uint32_t (&R)[NP], std::integer_sequence<int, I...>) {
+    (sv_ce(R[SvNet<NP>::net.a[I]], R[SvNet<NP>::net.b[I]]), ...);      // (every index is a constant expression: R stays in registers)
+}
+
+// Ascending sort of the 2 * NP 16-bit elements of R; element i = half i / NP of R[i % NP].  Both halves are sorted in lockstep by
+// the odd-even mergesort network on the NP registers (any network whose exchanges all put the minimum on the lower wire runs on both
+// halves at once), then merged by one bitonic merge: the flip stage is the only one where the halves meet.
 template <int NP>
 __device__ __forceinline__ void sv_sort(uint32_t (&R)[NP]) {
     static_assert(NP >= 2 && (NP & (NP - 1)) == 0, "packed registers");
-#pragma unroll
-    for (int k = 2; k <= NP; k <<= 1) {                 // both halves in lockstep: blocks of k registers
-#pragma unroll
-        for (int r = 0; r < NP; ++r) {
-            const int l = r ^ (k - 1);                  // flip: mirror partner inside the block
-            if (l > r) sv_ce(R[r], R[l]);
-        }
-#pragma unroll
-        for (int j = k >> 2; j > 0; j >>= 1) {
-#pragma unroll
-            for (int r = 0; r < NP; ++r) {
-                const int l = r ^ j;
-                if (l > r) sv_ce(R[r], R[l]);
-            }
-        }
-    }
+    sv_sort_halves<NP>(R, std::make_integer_sequence<int, SvNet<NP>::net.n>{});
 #pragma unroll
     for (int r = 0; r < NP / 2; ++r) sv_ce_cross(R[r], R[NP - 1 - r]);   // element (0, r) against (1, NP - 1 - r)
 #pragma unroll
