@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 DEFAULTS = (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1), ("small_n_max", 512),
             ("tiny_n_max", 32), ("small_reg", 1), ("prefetch", 1), ("stagger_vecs", 0), ("plain_loads", 0),
             ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_pivots", 0),
-            ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1))
+            ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1),
+            ("sort_cells", 1), ("sort_n_min", 8), ("sort_n_max", 64), ("sort_kb", 0))
 
 
 def _draw(rng):
@@ -43,7 +44,7 @@ def _draw(rng):
         nv = np.where(rng.integers(0, 2, size=B) == 1, N, 0)
     opts = {}
     if rng.random() < 0.6:
-        opts["path"] = int(rng.integers(0, 5))
+        opts["path"] = int(rng.integers(0, 5))                    # (path 5, the sorted-cells kernel, is drawn below: earlier seeds keep their configurations)
         if opts["path"] == 2:
             opts["segs"] = int(rng.choice([0, 2, 3, 5, 16, 40]))
             opts["ticket_merge"] = int(rng.integers(0, 2))        # merge kernel / last-arriver merge inside the launch
@@ -83,6 +84,17 @@ def _draw(rng):
         opts["prefix_stage"] = 0                                  # one-lane-per-problem kernel without the LDS snapshots
     if rng.random() < 0.4:
         opts["reg_pivots"] = int(rng.integers(1, 3))              # register kernels: one / two pivots per lane forced (default: per batch)
+    # round 3: the sorted-cells kernel (default for 5 <= N <= 64) switched off / forced / two blocks per step / the 128-vote shape
+    r = rng.random()
+    if r < 0.3:
+        opts["sort_cells"] = 0
+    elif r < 0.45:
+        opts["path"] = 5
+    if rng.random() < 0.3:
+        opts["sort_kb"] = int(rng.integers(1, 3))
+    if rng.random() < 0.3:
+        opts["sort_n_max"] = int(rng.choice([16, 128]))
+        opts["sort_n_min"] = int(rng.choice([4, 8, 40]))
     return P, B, N, dist, narrow, tokens, nv, opts, tuning, prefix
 
 

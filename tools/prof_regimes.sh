@@ -20,7 +20,7 @@ for s in $SHAPES; do
     i=$((i+1))
     d=$OUT/N$N/g$i
     mkdir -p $d
-    timeout 300 rocprofv3 --pmc $g --output-format csv -d $d -- python $R/tools/one_case.py --P $P --B $B --N $N --rounds 2 > $d/run.log 2>&1
+    timeout 300 rocprofv3 --pmc $g --output-format csv -d $d -- python $R/tools/one_case.py --P $P --B $B --N $N --rounds 2 --dist ${DIST:-1} > $d/run.log 2>&1
     tail -1 $d/run.log | cut -c1-200
   done
 done
