@@ -14,14 +14,16 @@ multimode and the score (o1.py:202-210) depend only on the equality classes of t
 which class the truth is in, so ALL distinct values of that problem (truth included) are mapped
 injectively, in first-seen order, onto bins 0..k-1 -- exact while the problem has at most 1024
 distinct values (always, for the reference's N <= 128).  Only beyond that DomainOverflow is raised
-(there is no CPU fallback).  For a densely re-encoded problem the cell's ``min_mode`` is a code, not
-an answer; ``VoteTensors.code_tables[p]`` decodes it.
+(there is no CPU fallback).  For a densely re-encoded problem -- and for a spare bin -- the cell's ``min_mode``
+is a code, not an answer; ``VoteTensors.decode_bin(p, bin)`` gives the answer back.
 
 O1_MODEL and PROMPT are parameters: they are part of the key (o1.py:86) and are read from the
 reference module at install time (o1_dropin.install), never copied into this repository.
 """
 from __future__ import annotations
 
+import decimal
+import numbers
 from dataclasses import dataclass
 
 import numpy as np
@@ -70,11 +72,20 @@ def resolve_vote(cache: dict, model: str, prompt: str, problem: str, token_limit
 
 
 def _canonical(v):
-    """Python equality classes as Counter sees them: 3 == 3.0 == Fraction(3); True == 1."""
+    """Python equality classes as Counter sees them (equal values hash equal): 3 == 3.0 == Fraction(3) == Decimal(3) == 3+0j,
+    True == 1.  Every number with an integral value becomes that int; anything else is its own class."""
     if isinstance(v, (int, np.integer)):
         return int(v)
-    if isinstance(v, float) and v == v and v not in (float("inf"), float("-inf")) and v == int(v):
-        return int(v)
+    if isinstance(v, (numbers.Number, decimal.Decimal)):
+        try:
+            if isinstance(v, complex):
+                if v.imag != 0:
+                    return v
+                v = v.real
+            if v == v and v == int(v):       # (NaN != NaN; int(inf) raises OverflowError)
+                return int(v)
+        except (TypeError, ValueError, OverflowError):
+            pass
     return v
 
 
@@ -125,6 +136,19 @@ class VoteTensors:
     n_valid: np.ndarray   # int32 [B]
     truth: np.ndarray     # int32 [P]
     code_tables: dict = None   # p -> [value of bin 0, value of bin 1, ...] for densely re-encoded problems
+    spare_tables: dict = None  # p -> {spare bin 1000..1023: the out-of-domain value it stands for}
+
+    def decode_bin(self, p: int, bin_: int):
+        """The answer value behind bin ``bin_`` of problem ``p`` -- e.g. ``cells["min_mode"][p, b]``: the bin itself for an
+        in-domain answer, the original (canonical) value for a spare bin, the table entry for a densely re-encoded problem;
+        ``None`` for -1 (no votes)."""
+        bin_ = int(bin_)
+        if bin_ < 0:
+            return None
+        dense = (self.code_tables or {}).get(p)
+        if dense is not None:
+            return dense[bin_]
+        return (self.spare_tables or {}).get(p, {}).get(bin_, bin_)
 
 
 def build_vote_tensors(dataset, cache: dict, budgets, model: str, prompt: str) -> VoteTensors:
@@ -139,7 +163,7 @@ def build_vote_tensors(dataset, cache: dict, budgets, model: str, prompt: str) -
     tokens = np.zeros((P, B, max(nmax, 1)), dtype=np.int32)
     n_valid = np.array([n for _, n in budgets], dtype=np.int32).reshape(B)
     truth = np.zeros((P,), dtype=np.int32)
-    code_tables = {}
+    code_tables, spare_tables = {}, {}
     for p, example in enumerate(dataset):
         raw = {}                                                # (key_limit, idx) -> (answer, tokens), first-seen order
         for key_limit, n in budgets:
@@ -156,6 +180,8 @@ def build_vote_tensors(dataset, cache: dict, budgets, model: str, prompt: str) -
             enc = ProblemEncoder()
             truth_code = enc.encode(true_answer)
             codes = {k: enc.encode(ans) for k, (ans, _tok) in raw.items()}
+            if enc._codes:
+                spare_tables[p] = {code: value for value, code in enc._codes.items()}
         except DomainOverflow:                                  # > 24 distinct out-of-domain values: dense re-encoding
             enc = DenseEncoder()
             truth_code = enc.encode(true_answer)
@@ -166,4 +192,4 @@ def build_vote_tensors(dataset, cache: dict, budgets, model: str, prompt: str) -
             for idx in range(n):
                 k = (key_limit, idx)
                 answers[p, b, idx], tokens[p, b, idx] = codes[k], raw[k][1]
-    return VoteTensors(answers, tokens, n_valid, truth, code_tables)
+    return VoteTensors(answers, tokens, n_valid, truth, code_tables, spare_tables)

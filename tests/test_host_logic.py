@@ -281,3 +281,22 @@ def test_c5_host_floats_from_oracle_tables():
         assert abs(host["pass_at_k"][k][0] - exact) < 1e-12
     ks = sorted(host["pass_at_k"])
     assert all(host["pass_at_k"][ks[i]][0] <= host["pass_at_k"][ks[i + 1]][0] + 1e-15 for i in range(len(ks) - 1))
+
+
+def test_canonical_equality_classes_and_decode_bin():
+    """Counter's equality classes (3 == 3.0 == Fraction(3) == Decimal(3) == 3+0j, True == 1) share a bin; a cell's
+    min_mode decodes back to the answer for in-domain, spare-bin and densely re-encoded problems."""
+    from decimal import Decimal
+    from fractions import Fraction
+    from o1_inference_scaling_laws_amd import extract
+    assert [extract._canonical(v) for v in (3, 3.0, Fraction(3), Decimal(3), 3 + 0j, True, np.int64(3))] == [3, 3, 3, 3, 3, 1, 3]
+    assert extract._canonical(2.5) == 2.5 and extract._canonical(Fraction(1, 3)) == Fraction(1, 3)
+    assert extract._canonical("17") == "17" and extract._canonical(3 + 1j) == 3 + 1j
+    nan = float("nan")
+    assert extract._canonical(nan) is nan and extract._canonical(float("inf")) == float("inf")
+    enc = extract.ProblemEncoder()
+    assert enc.encode(7) == enc.encode(Fraction(7)) == enc.encode(Decimal("7.0")) == 7
+    assert enc.encode(-4) == enc.encode(-4.0) == extract.SPARE_BASE and enc.encode(1000) == extract.SPARE_BASE + 1
+    vt = extract.VoteTensors(None, None, None, None, {2: ["x", -9, 5]}, {0: {1000: -4, 1001: 1000}})
+    assert vt.decode_bin(0, 12) == 12 and vt.decode_bin(0, 1000) == -4 and vt.decode_bin(0, 1001) == 1000
+    assert vt.decode_bin(2, 1) == -9 and vt.decode_bin(1, 999) == 999 and vt.decode_bin(1, -1) is None
