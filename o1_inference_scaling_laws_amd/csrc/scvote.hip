@@ -472,7 +472,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         else if (Nreg <= 128) { g = 16; v = 2; }
         else if (Nreg <= 256) { g = 16; v = 4; }
         else if (Nreg <= 512) { g = 32; v = 4; }
-        else if (Nreg <= 1024) { g = 64; v = 4; }
+        else if (Nreg <= 896) { g = 64; v = 4; }
+        else if (Nreg <= 1024) { v = 4; h = 1; }      // round 3 (with the pivots): one dense part beats the sparse read-back from ~900 votes (N = 1024: 189 vs 200 us; 768: 224 vs 215)
         else if (Nreg <= 2048) { v = 4; h = 2; }      // 4 KiB parts: 126-136 VGPRs, 3 waves per SIMD (8 KiB parts: 200, 2 waves; measured 73 vs 79 us)
         else if (Nreg <= 4096) { v = 4; h = 4; }
         else { v = 4; h = 8; }                        // 4096 < N <= 8192: 4.5 -> 5.4 TB/s at N = 4608 against the streaming kernel, equal at 8192

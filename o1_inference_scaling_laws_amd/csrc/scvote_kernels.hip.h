@@ -2566,27 +2566,45 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_
                 if (TOK) tsum += c.tk[i];
             }
         } else {
+            // A part that is not full: vector by vector (one cell per wave, so every test is wave-uniform).  Vectors past the end
+            // of the cell are skipped, vectors whose 256 slots are all votes (and tokens) run unmasked -- only the vector that
+            // holds the end of the row (and, for unaligned rows, the first vector of the cell) pays for masks: a cell of 1000
+            // votes costs what its votes cost, not 1024 masked ones (N = 1000 on the one-part shape: 210 -> 19x us).
+            const int32_t beyond = (TOK && !VEC && (int32_t)c.tnrel > (int32_t)c.nrel) ? (int32_t)c.tnrel : (int32_t)c.nrel;
 #pragma unroll
-            for (int i = 0; i < E; ++i) {
-                // slots at or beyond the end of the cell are skipped (wave-uniform: one cell per wave) -- except the pivot
-                // slots of a first part, which must define the pivots (an inactive one becomes the lane's trash address)
-                const int32_t beyond = (TOK && !VEC && (int32_t)c.tnrel > (int32_t)c.nrel) ? (int32_t)c.tnrel : (int32_t)c.nrel;
-                if ((i >> 2) * 256 >= beyond) continue;
-                const uint32_t v = c.v[i];
-                const int32_t ci = (i >> 2) * 256 + (i & 3);
-                uint32_t m = (uint32_t)((ci - nl) >> 31);                       // all ones when the vote is valid
-                if (!VEC && FIRST && i < 3) m &= ~(uint32_t)((int32_t)(4 * lane + i - (int32_t)c.sh) >> 31);   // the <= 3 slots before the row
-                if (clamp) bad |= v & m;
-                uint32_t A = bin_address<S>(KB, clamp ? (v < 1023u ? v : 1023u) : v);
-                A = (A & m) | (ATR & ~m);
-                one(i, A);
-                if (TOK) {
-                    uint32_t mt = m;
-                    if (!VEC) {
-                        mt = (uint32_t)((ci - tnl) >> 31);
-                        if (FIRST && i < 3) mt &= ~(uint32_t)((int32_t)(4 * lane + i - (int32_t)c.tsh) >> 31);
+            for (int k = 0; k < V; ++k) {
+                if (k * 256 >= beyond) continue;
+                bool vfull = (int32_t)c.nrel >= (k + 1) * 256 && (!TOK || VEC || (int32_t)c.tnrel >= (k + 1) * 256);
+                if (!VEC && FIRST && k == 0) vfull = vfull && c.sh == 0u && c.tsh == 0u;
+                if (vfull) {
+                    if (clamp) bad |= c.v[4 * k] | c.v[4 * k + 1] | c.v[4 * k + 2] | c.v[4 * k + 3];
+#pragma unroll
+                    for (int i = 4 * k; i < 4 * k + 4; ++i) {
+                        const uint32_t v = c.v[i];
+                        one(i, bin_address<S>(KB, clamp ? (v < 1023u ? v : 1023u) : v));
+                        if (TOK) tsum += c.tk[i];
                     }
-                    tsum += (long long)(c.tk[i] & (int32_t)mt);
+                    continue;
+                }
+#pragma unroll
+                for (int i = 4 * k; i < 4 * k + 4; ++i) {
+                    // (the pivot slots of a first part must define the pivots: an inactive one becomes the lane's trash address)
+                    const uint32_t v = c.v[i];
+                    const int32_t ci = (i >> 2) * 256 + (i & 3);
+                    uint32_t m = (uint32_t)((ci - nl) >> 31);                       // all ones when the vote is valid
+                    if (!VEC && FIRST && i < 3) m &= ~(uint32_t)((int32_t)(4 * lane + i - (int32_t)c.sh) >> 31);   // the <= 3 slots before the row
+                    if (clamp) bad |= v & m;
+                    uint32_t A = bin_address<S>(KB, clamp ? (v < 1023u ? v : 1023u) : v);
+                    A = (A & m) | (ATR & ~m);
+                    one(i, A);
+                    if (TOK) {
+                        uint32_t mt = m;
+                        if (!VEC) {
+                            mt = (uint32_t)((ci - tnl) >> 31);
+                            if (FIRST && i < 3) mt &= ~(uint32_t)((int32_t)(4 * lane + i - (int32_t)c.tsh) >> 31);
+                        }
+                        tsum += (long long)(c.tk[i] & (int32_t)mt);
+                    }
                 }
             }
         }
