@@ -171,7 +171,8 @@ struct scv_ctx {
     int sort_cells = 1;      // 1: cells of sort_n_min <= N <= 64 votes in 16-byte aligned rows run one lane per cell, rows staged by LDS-DMA, sorted in registers (scv_sort_cells)
     int sort_n_min = 8;      // shorter cells stay on scv_lane_cells
     int sort_n_max = 64;     // longer cells go to the register-resident kernels (the 128-vote shape runs one wave per SIMD: measured 3.2 vs 3.8 TB/s)
-    int sort_kb = 0;         // blocks of 64 cells per step (0 = auto: 2 for N <= 16, else 1)
+    int sort_kb = 0;         // blocks of 64 cells per step (0 = auto: 1)
+    int sort_db = 0;         // 1: N <= 16 gets two image buffers per wave, the copy two steps ahead (measured 5-13 % SLOWER: N = 16 81.7 vs 72.4 us; off)
     int64_t stat_sort_cells = 0;
     int reg_n_max = 8192;    // auto: 32 < N <= this -> register-resident cells kernel (scv_reg_cells); 0 = off (round-1 dispatch)
     bool user_tuned = false; // set_tuning called: auto geometry off
@@ -426,10 +427,12 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         const int nv = N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : (N <= 64 ? 64 : 128)));
         int kb = (ctx->sort_kb > 0 && !sort_lin) ? ctx->sort_kb : 1;          // (measured: one block per step beats two at N = 8, 16)
         if (nv > 16) kb = 1;
-        const RegKernel rk = pick_sort_kernel(nv, kb, tok, sort_lin);
+        const bool db = nv <= 16 && kb == 1 && ctx->sort_db != 0;           // short rows: two image buffers per wave, the copy two steps ahead
+        const RegKernel rk = pick_sort_kernel(nv, kb, tok, sort_lin, db);
         const int64_t ps = (N / 4) | 1;
         const int64_t image_words = sort_lin ? (((int64_t)kb * 64 * N * 4 + 16 + 1023) >> 10) * 256 : (int64_t)kb * 64 * ps * 4;
-        const int64_t region_words = image_words * (tok ? 2 : 1);
+        // one buffer: votes image | tokens image | the cells' truth values (256 bytes per block of 64 cells)
+        const int64_t region_words = (image_words * (tok ? 2 : 1) + (int64_t)kb * 64) * (db ? 2 : 1);
         const int64_t tail_words = (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0) + ((((int64_t)B * (nv + 1) + 1) & ~(int64_t)1) + 4 * (int64_t)B);
         int W = rk.waves;
         while (W > 1 && (W * region_words + tail_words) * 4 > ctx->lds_max) --W;
@@ -1099,6 +1102,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "sort_cells")) ctx->sort_cells = value != 0;
     else if (!strcmp(key, "sort_n_min")) { if (value < 4 || value > 129) return fail(SCV_ERR_ARG, "sort_n_min must be 4..129"); ctx->sort_n_min = (int)value; }
     else if (!strcmp(key, "sort_n_max")) { if (value < 4 || value > 128) return fail(SCV_ERR_ARG, "sort_n_max must be 4..128"); ctx->sort_n_max = (int)value; }
+    else if (!strcmp(key, "sort_db")) ctx->sort_db = value != 0;
     else if (!strcmp(key, "sort_kb")) { if (value < 0 || value > 2) return fail(SCV_ERR_ARG, "sort_kb must be 0, 1 or 2"); ctx->sort_kb = (int)value; }
     else if (!strcmp(key, "reg_dense4")) ctx->reg_dense4 = value != 0;
     else if (!strcmp(key, "reg_pivots")) { if (value < 0 || value > 2) return fail(SCV_ERR_ARG, "reg_pivots must be 0, 1 or 2"); ctx->reg_pivots = (int)value; }

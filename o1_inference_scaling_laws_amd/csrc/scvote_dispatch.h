@@ -31,7 +31,7 @@ RegKernel pick_dense_kernel(int v, int h, bool tok, bool vec);
 
 // scv_sort_cells<nv votes per lane, kb blocks of 64 cells per step>: one lane per cell, 4 <= N <= nv, rows staged by LDS-DMA
 // (scvote_sort.hip.h); .waves = the launch bound in waves
-RegKernel pick_sort_kernel(int nv, int kb, bool tok, bool lin);
+RegKernel pick_sort_kernel(int nv, int kb, bool tok, bool lin, bool db);
 
 // ---- shared by the table translation units ------------------------------------------------------------------------
 template <int RL2, int T, int U>

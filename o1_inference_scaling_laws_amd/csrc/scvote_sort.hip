@@ -2,14 +2,18 @@
 #include "scvote_sort.hip.h"
 #include "scvote_dispatch.h"
 namespace scv {
-template <int NV, int KB, bool LIN>
+template <int NV, int KB, bool LIN, bool DB = false>
 static RegKernel sort_nk(bool tok) {
-    return tok ? RegKernel{(KernelFn)scv_sort_cells<NV, KB, true, LIN>, sort_cells_threads(NV) / 64}
-               : RegKernel{(KernelFn)scv_sort_cells<NV, KB, false, LIN>, sort_cells_threads(NV) / 64};
+    return tok ? RegKernel{(KernelFn)scv_sort_cells<NV, KB, true, LIN, DB>, sort_cells_threads(NV) / 64}
+               : RegKernel{(KernelFn)scv_sort_cells<NV, KB, false, LIN, DB>, sort_cells_threads(NV) / 64};
 }
 // nv: votes per lane (8 / 16 / 32 / 64 / 128); kb: blocks of 64 cells per step (2 only for aligned rows and nv <= 16);
-// lin: rows that are not all 16-byte aligned (linear image, dword reads)
-RegKernel pick_sort_kernel(int nv, int kb, bool tok, bool lin) {
+// lin: rows that are not all 16-byte aligned (linear image, dword reads); db: two buffers per wave (nv <= 16, kb = 1)
+RegKernel pick_sort_kernel(int nv, int kb, bool tok, bool lin, bool db) {
+    if (db && nv <= 16) {                                             // two image buffers per wave, the copy two steps ahead (short rows)
+        if (lin) return nv == 8 ? sort_nk<8, 1, true, true>(tok) : sort_nk<16, 1, true, true>(tok);
+        return nv == 8 ? sort_nk<8, 1, false, true>(tok) : sort_nk<16, 1, false, true>(tok);
+    }
     if (lin) {
         switch (nv) {
         case 8: return sort_nk<8, 1, true>(tok);

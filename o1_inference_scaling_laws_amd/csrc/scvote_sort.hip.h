@@ -226,10 +226,25 @@ __device__ __forceinline__ void sv_dma16(const void* gbase, uint32_t goff, uint3
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
 }
+// ... and 64 lanes x 4 bytes (lane l's dword lands at lds_dst + 4 l): the per-lane gather of the cells' truth values
+__device__ __forceinline__ void sv_dma4(const void* gbase, uint32_t goff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ int64_t sv_uniform64(int64_t v) {      // tell the compiler a value is wave-uniform (it lives in SGPRs from here on)
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v & 0xffffffffu));
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
     return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// s_waitcnt vmcnt(k) for a wave-uniform k (the immediate must be a constant): the largest available value <= k
+__device__ __forceinline__ void sv_wait_vmcnt_le(uint32_t k) {
+#define SV_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+    switch (k > 12u ? 12u : k) {
+        SV_W(0) SV_W(1) SV_W(2) SV_W(3) SV_W(4) SV_W(5) SV_W(6) SV_W(7) SV_W(8) SV_W(9) SV_W(10) SV_W(11) SV_W(12)
+    }
+#undef SV_W
 }
 
 constexpr int sort_cells_threads(int nv) { return nv >= 128 ? 256 : (nv >= 64 ? 512 : 1024); }
@@ -243,7 +258,13 @@ constexpr int sort_cells_threads(int nv) { return nv >= 128 ? 256 : (nv >= 64 ? 
 // the image is the 16-byte aligned superset of the block, linear, and a lane reads its row with N ds_read_b32 at lane stride N
 // words (conflict-free for odd N, 2-way for N = 2 mod 4).  Host contract: 1 <= N <= NV, a.wave_lds_words covers
 // KB * 64 * N * 4 + 16 bytes rounded up to whole KiB (twice with tokens: the token base has its own misalignment).
-template <int NV, int KB, bool TOK, bool LIN = false>
+//
+// DB (short rows, N <= 16; option "sort_db", OFF): TWO image buffers per wave, the copy runs two steps ahead.  A wave of the 8-vote
+// shape has 3 KB in flight behind ~170 instructions of counting and waits on memory 0.53 of its cycles (r03_sort_cells_pmc.md) --
+// but twice the bytes in flight made it SLOWER (N = 8: 87.6 vs 83.2 us, N = 16: 81.7 vs 72.4): the copies are not latency-bound,
+// the LDS-DMA stream itself tops out near 5-5.6 TB/s for these shapes.  The wait at the top of a step is then
+// vmcnt(<pieces of the next step's copy>): loads complete in order, so while a piece of THIS step's copy is outstanding all of those are too.
+template <int NV, int KB, bool TOK, bool LIN = false, bool DB = false>
 __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const AggArgs a) {
     constexpr int NP = NV / 2, RSM = NV / 4;
     constexpr int QMAX = KB * (RSM + 1);                             // DMA pieces per step at the widest row (LIN: 16 N KB + 16 bytes)
@@ -270,8 +291,10 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
     __syncthreads();
 
     // this wave's region: votes image [KB * 64 rows][PS slots], then (TOK) the tokens image
-    const uint32_t rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32*)(lds + (int64_t)wid * a.wave_lds_words));
+    const uint32_t rbase0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32*)(lds + (int64_t)wid * a.wave_lds_words));
     const uint32_t img_bytes = LIN ? nq * 1024u : (uint32_t)KB * 64u * PS * 16u;
+    const uint32_t tru_off = img_bytes * (TOK ? 2u : 1u);            // one buffer: votes image | tokens image | the cells' truth values
+    const uint32_t buf_bytes = tru_off + (uint32_t)KB * 256u;        // (DB: two buffers)
     // source offset of every slot this lane copies: slot s = 64 q + lane is chunk k = s % PS of row c = s / PS (the pad slot,
     // k == RS, repeats the row's last chunk)
     uint32_t off[QMAX];
@@ -294,7 +317,7 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
     const int64_t nsteps = (a.ncells + SC - 1) / SC;
     const int64_t total_bytes = a.ncells * (int64_t)rowbytes;
     const bool nt = a.plain_loads == 0;                              // (option "plain_loads": ordinary loads, for A/B runs)
-    auto issue = [&](int64_t st) {                                   // (wave-uniform) start the copy of step st into the region
+    auto issue = [&](int64_t st, uint32_t rbase) {                   // (wave-uniform) start the copy of step st into the buffer at rbase
         const int64_t byte0 = st * SC * (int64_t)rowbytes;
         // last 16-byte chunk that holds bytes of the tensor, relative to the (aligned superset of the) block
         const int64_t rem = LIN ? ((total_bytes - byte0 + shv - 1) & ~(int64_t)15) : total_bytes - byte0 - 16;
@@ -320,10 +343,10 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
     // Walkers.  The step's first cell c0 (problem p0, budget b0) advances on the scalar unit; slot j of this lane is cell c0 + 64 j +
     // lane = c0 + lq[j] * B + lr[j]: its budget and its problem relative to p0 cost three 32-bit VALU operations per step.
     const int64_t stride = nwaves * SC;
-    const int64_t dp = stride / B;
+    const int64_t dp = sv_uniform64(stride / B);                     // (64-bit divisions run on the VALU: back to SGPRs)
     const int32_t db = (int32_t)(stride - dp * B);
     int64_t c0 = wave * SC;
-    int64_t p0 = c0 / B;
+    int64_t p0 = sv_uniform64(c0 / B);
     int32_t b0 = (int32_t)(c0 - p0 * B);
     uint32_t lq[KB], lr[KB];
 #pragma unroll
@@ -356,23 +379,38 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
     }
 
     uint32_t bad = 0;
-    int32_t trn[KB];                                                 // truth of the NEXT step's cells (loaded behind the DMA issue)
-    auto load_truth = [&]() {                                        // for the step at (c0, p0, b0)
-        const int64_t left = a.ncells - c0;
+    // The prefetch runs D steps ahead of the counting (D = 2 with two buffers) with a scalar walker of its own (cf, pf, bf).
+    constexpr int D = DB ? 2 : 1;
+    int64_t cf = c0, pf = p0;
+    int32_t bf = b0;
+    // The truth of a step's cells travels with its images (a per-lane 4-byte LDS-DMA gather): the loop then holds no load the
+    // compiler counts, so it cannot put a vmcnt(0) of its own in front of a use and drain the prefetch.
+    auto issue_truth = [&](uint32_t rbase) {                         // for the step at (cf, pf, bf); then the walker moves on
+        const int64_t left = a.ncells - cf;
         const uint32_t live_cells = left > (int64_t)SC ? (uint32_t)SC : (uint32_t)left;
-        const int32_t* tp = a.truth + p0;                            // (scalar base + 32-bit lane index)
+        // (scalar base + 32-bit lane offset; the walker is uniform but the compiler may keep it in VGPRs: an "s" operand it cannot
+        //  satisfy is silently replaced by a VGPR pair, which does not assemble)
+        const int32_t* tp = reinterpret_cast<const int32_t*>(sv_uniform64((int64_t)(uintptr_t)(a.truth + pf)));
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
-            uint32_t prel;
-            (void)slot_budget(j, prel);
-            trn[j] = tp[(uint32_t)(j * 64 + lane) < live_cells ? prel : 0u];
+            const uint32_t bs = (uint32_t)bf + lr[j];
+            const uint32_t prel = lq[j] + (bs >= (uint32_t)B ? 1u : 0u);
+            sv_dma4(tp, ((uint32_t)(j * 64 + lane) < live_cells ? prel : 0u) * 4u, rbase + tru_off + (uint32_t)j * 256u);
         }
+        cf += stride; pf += dp; bf += db;
+        if (bf >= B) { bf -= B; pf += 1; }
     };
     auto advance = [&]() { c0 += stride; p0 += dp; b0 += db; if (b0 >= B) { b0 -= B; p0 += 1; } };
     int64_t st = wave;
-    if (st < nsteps) { load_truth(); issue(st); }
-    for (; st < nsteps; st += nwaves) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this step's images have landed (LDS-DMA is counted by vmcnt)
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (st + d * nwaves < nsteps) { issue(st + d * nwaves, rbase0 + (uint32_t)d * buf_bytes); issue_truth(rbase0 + (uint32_t)d * buf_bytes); }
+    uint32_t parity = 0;
+    for (; st < nsteps; st += nwaves, parity ^= 1u) {
+        const uint32_t rbase = DB ? rbase0 + parity * buf_bytes : rbase0;
+        // this step's images have landed (LDS-DMA is counted by vmcnt; hipcc does not count asm loads)
+        if (DB && st + nwaves < nsteps) sv_wait_vmcnt_le(nq * (TOK ? 2u : 1u) + (uint32_t)KB);       // (the pieces of the next step's copy)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t R[KB][NP];
         long long tok[KB];
         uint32_t nvj[KB];
@@ -388,7 +426,7 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
             eb[j] = same_b ? my_b[j] : slot_budget(j, prel);
             const uint32_t n = live ? (same_b ? my_n[j] : budget_len(eb[j])) : 0u;
             nvj[j] = n;
-            trj[j] = trn[j];
+            trj[j] = (int32_t)*reinterpret_cast<lds_u32*>((uintptr_t)(rbase + tru_off + (uint32_t)(j * 64 + lane) * 4u));
             const uint32_t ra = LIN ? rbase + shv + (uint32_t)(j * 64 + lane) * rowbytes : rbase + (uint32_t)(j * 64 + lane) * (PS * 16u);
             uint32_t w[NV];
             if (LIN) {
@@ -457,7 +495,7 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
         uint4* const cells_out = a.cells ? reinterpret_cast<uint4*>(a.cells) + c0 : nullptr;     // (scalar bases of this step's outputs)
         int64_t* const ctok_out = (TOK && a.cell_tokens) ? a.cell_tokens + c0 : nullptr;
         advance();
-        if (st + nwaves < nsteps) { load_truth(); issue(st + nwaves); }
+        if (st + (int64_t)D * nwaves < nsteps) { issue(st + (int64_t)D * nwaves, rbase); issue_truth(rbase); }   // into the buffer just read
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             sv_sort<NP>(R[j]);

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--dist", type=int, default=1)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (scv_set_option)")
+    ap.add_argument("--no-cells", action="store_true", help="counters only: no cell table is written")
     ap.add_argument("--prefix", action="store_true", help="prefix budgets 1, 2, 4 ... N over one pool [P, N] (B is ignored)")
     args = ap.parse_args()
     import torch
@@ -59,7 +60,7 @@ def main():
     if args.prefix:
         r = run_prefix(eng, torch, args.P, args.N, args.tokens, args.dist, args.rounds)
     else:
-        r = run(eng, torch, args.P, args.B, args.N, args.tokens, dist=args.dist, rounds=args.rounds)
+        r = run(eng, torch, args.P, args.B, args.N, args.tokens, dist=args.dist, rounds=args.rounds, want_cells=not args.no_cells)
     r["opts"] = args.opt
     print(json.dumps(r))
 
