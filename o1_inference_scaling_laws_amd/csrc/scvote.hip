@@ -172,6 +172,7 @@ struct scv_ctx {
     int sort_n_min = 8;      // shorter cells stay on scv_lane_cells
     int sort_n_max = 64;     // longer cells go to the register-resident kernels (the 128-vote shape runs one wave per SIMD: measured 3.2 vs 3.8 TB/s)
     int sort_kb = 0;         // blocks of 64 cells per step (0 = auto: 1)
+    int sort_waves = 0;      // resident waves per CU of the sorted-cells kernel (0 = 16; 32 needs <= 64 VGPRs: the 8-vote shape)
     int sort_db = 0;         // 1: N <= 16 gets two image buffers per wave, the copy two steps ahead (measured 5-13 % SLOWER: N = 16 81.7 vs 72.4 us; off)
     int64_t stat_sort_cells = 0;
     int reg_n_max = 8192;    // auto: 32 < N <= this -> register-resident cells kernel (scv_reg_cells); 0 = off (round-1 dispatch)
@@ -452,7 +453,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             // persistent: one workgroup per CU (or as many as the LDS lets be resident)
             int per_cu = (int)(ctx->lds_max / (int64_t)lds);
             if (per_cu < 1) per_cu = 1;
-            if (per_cu * W > 16) per_cu = 16 / W > 0 ? 16 / W : 1;
+            const int max_waves = ctx->sort_waves > 0 ? ctx->sort_waves : 16;             // (option "sort_waves": resident waves per CU, A/B)
+            if (per_cu * W > max_waves) per_cu = max_waves / W > 0 ? max_waves / W : 1;
             if (grid > (int64_t)ctx->num_cus * per_cu) grid = (int64_t)ctx->num_cus * per_cu;
             // cells per grid step a multiple of B: every lane slot then sees one budget and keeps its counters in registers
             if ((grid * W * kb * 64) % B != 0 && grid > B) grid -= grid % B;
@@ -1103,6 +1105,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "sort_n_min")) { if (value < 4 || value > 129) return fail(SCV_ERR_ARG, "sort_n_min must be 4..129"); ctx->sort_n_min = (int)value; }
     else if (!strcmp(key, "sort_n_max")) { if (value < 4 || value > 128) return fail(SCV_ERR_ARG, "sort_n_max must be 4..128"); ctx->sort_n_max = (int)value; }
     else if (!strcmp(key, "sort_db")) ctx->sort_db = value != 0;
+    else if (!strcmp(key, "sort_waves")) { if (value < 0 || value > 32) return fail(SCV_ERR_ARG, "sort_waves must be 0..32"); ctx->sort_waves = (int)value; }
     else if (!strcmp(key, "sort_kb")) { if (value < 0 || value > 2) return fail(SCV_ERR_ARG, "sort_kb must be 0, 1 or 2"); ctx->sort_kb = (int)value; }
     else if (!strcmp(key, "reg_dense4")) ctx->reg_dense4 = value != 0;
     else if (!strcmp(key, "reg_pivots")) { if (value < 0 || value > 2) return fail(SCV_ERR_ARG, "reg_pivots must be 0, 1 or 2"); ctx->reg_pivots = (int)value; }

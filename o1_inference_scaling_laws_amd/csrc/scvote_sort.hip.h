@@ -261,8 +261,8 @@ constexpr int sort_cells_threads(int nv) { return nv >= 128 ? 256 : (nv >= 64 ? 
 //
 // DB (short rows, N <= 16; option "sort_db", OFF): TWO image buffers per wave, the copy runs two steps ahead.  A wave of the 8-vote
 // shape has 3 KB in flight behind ~170 instructions of counting and waits on memory 0.53 of its cycles (r03_sort_cells_pmc.md) --
-// but twice the bytes in flight made it SLOWER (N = 8: 87.6 vs 83.2 us, N = 16: 81.7 vs 72.4): the copies are not latency-bound,
-// the LDS-DMA stream itself tops out near 5-5.6 TB/s for these shapes.  The wait at the top of a step is then
+// but twice the bytes in flight made it SLOWER (N = 8: 87.6 vs 83.2 us, N = 16: 81.7 vs 72.4): the shapes are not latency-bound (and
+// not copy-bound: waves that only copy stream 6.9-7.2 TB/s, tools/hbm_probe.bin --dma).  The wait at the top of a step is then
 // vmcnt(<pieces of the next step's copy>): loads complete in order, so while a piece of THIS step's copy is outstanding all of those are too.
 template <int NV, int KB, bool TOK, bool LIN = false, bool DB = false>
 __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const AggArgs a) {

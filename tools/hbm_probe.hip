@@ -11,6 +11,7 @@
 //                                        workgroups of 1024 threads, each streaming its own 256 KiB / 512 KiB / 4 MiB segment ONCE
 //                                        (the few-huge-cells shapes: split-N segments, C2's 512 KiB cells) -- GB/s per workgroup
 //                                        and in total, and the time one segment takes (the floor of those shapes)
+//   hbm_probe.bin [cells] --dma          the ceiling of the LDS-DMA input path of scv_sort_cells: waves that only copy 2-16 KiB blocks HBM -> LDS
 //   hbm_probe.bin [cells] --calib        3 launches of ONE variant (read_cells_pipe<4>, grid 250 x 1024) and nothing
 //                                        else: run under `rocprofv3 --pmc FETCH_SIZE` to get FETCH_SIZE per launch
 //                                        for exactly cells * 4 MiB of algorithmic reads
@@ -97,6 +98,35 @@ __global__ void read_gridstride(const v4i* __restrict__ src, long nvec, int* sin
     if (acc == 0x12345678) *sink = acc;
 }
 
+// LDS-DMA stream (the input path of scv_sort_cells): every wave copies consecutive blocks of `pieces` KiB HBM -> LDS with
+// global_load_lds_dwordx4 (1 KiB per instruction), waits for the block, reads one word of it and goes on -- nothing else.
+// `pad`: every 17th 16-byte slot re-reads the slot before it (the padded image of 64-vote rows: 17 pieces per 16 KiB block).
+__global__ void dma_blocks(const char* __restrict__ src, long nblocks, int pieces, int pad, int nt, int* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned region = (unsigned)pieces * 1024u + (pad ? 1024u : 0u);
+    const unsigned rbase = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned*)lds_dyn + (unsigned)wid * region));
+    const long wave = (long)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(wid), nwaves = (long)gridDim.x * nw;
+    const int np = pieces + (pad ? 1 : 0);
+    int acc = 0;
+    for (long b = wave; b < nblocks; b += nwaves) {
+        const char* g = src + b * (long)pieces * 1024;
+        for (int q = 0; q < np; ++q) {
+            unsigned s = (unsigned)q * 64u + (unsigned)lane;                 // slot of the image
+            unsigned off = pad ? ((s / 17u) * 16u + (s % 17u < 16u ? s % 17u : 15u)) * 16u : s * 16u;
+            if (off > (unsigned)pieces * 1024u - 16u) off = (unsigned)pieces * 1024u - 16u;
+            unsigned keep;
+            const unsigned dst = rbase + (unsigned)q * 1024u;
+            if (nt) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
+            else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        acc ^= (int)lds_dyn[(rbase - (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned*)lds_dyn) / 4u + (unsigned)lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (acc == 0x12345678) *sink = acc;
+}
+
 __global__ void fill(v4i* dst, long nvec) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -123,12 +153,13 @@ double time_ms(F f, int reps = 5) {
 
 int main(int argc, char** argv) {
     long ncells = 10000;
-    bool calib = false, shortcells = false, quick = false, percu = false;
+    bool calib = false, shortcells = false, quick = false, percu = false, dma = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--calib")) calib = true;
         else if (!strcmp(argv[i], "--short")) shortcells = true;
         else if (!strcmp(argv[i], "--quick")) quick = true;
         else if (!strcmp(argv[i], "--percu")) percu = true;
+        else if (!strcmp(argv[i], "--dma")) dma = true;
         else ncells = atol(argv[i]);
     }
     const long cell_bytes = 4l << 20;
@@ -143,6 +174,26 @@ int main(int argc, char** argv) {
             CK(hipDeviceSynchronize());
         }
         printf("calib: 3 launches of read_cells_pipe<4,nt> grid 250 x 1024, %ld bytes each\n", bytes);
+        return 0;
+    }
+    if (dma) {
+        // the ceiling of the LDS-DMA input path: blocks of 2 / 4 / 8 / 16 KiB per wave (the 8 / 16 / 32 / 64-vote shapes), 8 or 16 waves per CU
+        printf("dma: every wave copies consecutive blocks HBM -> LDS (global_load_lds_dwordx4, one buffer per wave, wait, next block); one workgroup per CU\n");
+        for (int pieces : {2, 4, 8, 16}) {
+            for (int waves : {8, 16}) {
+                for (int pad : {0, 1}) {
+                    if (pad && pieces != 16) continue;
+                    for (int nt : {1, 0}) {
+                        const size_t lds = (size_t)waves * ((size_t)pieces * 1024 + (pad ? 1024 : 0));
+                        if (lds > 160 * 1024) continue;
+                        CK(hipFuncSetAttribute((const void*)dma_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        const long nblocks = bytes / ((long)pieces * 1024);
+                        const double ms = time_ms([&] { dma_blocks<<<256, waves * 64, lds>>>((const char*)buf, nblocks, pieces, pad, nt, sink); CK(hipGetLastError()); });
+                        printf("dma     %2d KiB blocks%s x %2d waves per CU %s : %7.3f ms = %6.0f GB/s\n", pieces, pad ? " (padded image)" : "", waves, nt ? "nt   " : "plain", ms, bytes / ms / 1e6);
+                    }
+                }
+            }
+        }
         return 0;
     }
     if (percu) {
