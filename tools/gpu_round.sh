@@ -15,6 +15,9 @@ echo "== bench dists"; for d in 0 2 3; do timeout 600 python bench.py --dist $d 
 echo "== bench tokens"; timeout 600 python bench.py --tokens --problems-per-step 625 --no-cpu-baseline --steps 6 2>/dev/null > gpurun_out/bench_tokens.json; cut -c1-300 gpurun_out/bench_tokens.json
 echo "== probe"; timeout 300 ./tools/hbm_probe.bin 10000 2>&1 | tee gpurun_out/hbm_probe.log | tail -4
 echo "== regimes"; timeout 900 python tools/regimes.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/regimes.log | tail -30
+echo "== sorted cells: parity sweep + old vs new"; timeout 900 python tools/sort_check.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/sort_check.log | grep -v "tok=1" | head -12
+echo "== dense 4096 < N <= 8192"; timeout 600 python tools/dense_ab.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/dense_ab.log | tail -9
+echo "== LDS-DMA path ceiling"; timeout 300 ./tools/hbm_probe.bin 1000 --dma 2>&1 | tee gpurun_out/hbm_probe_dma.log | tail -8
 echo "== prefix budgets over short pools"; timeout 600 python tools/prefix_small.py 2>&1 | grep -v amdgpu.ids | tail -14
 echo "== host mode"; timeout 600 python tools/host_mode_bench.py 2>&1 | grep -v amdgpu | tee gpurun_out/host_mode.log | tail -12
 echo "== rocprof kernel-trace"; cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_trace.log 2>&1; tail -2 $R/gpurun_out/prof_trace.log | cut -c1-300
