@@ -28,6 +28,7 @@
 #include <utility>
 
 #include "scvote_kernels.hip.h"
+#include "scvote_sortnet.h"
 
 namespace scv {
 
@@ -60,23 +61,7 @@ __device__ __forceinline__ void sv_ce_cross(uint32_t& a, uint32_t& b) {
     b = __builtin_amdgcn_alignbit(mx, mn, 16);
 }
 
-// Batcher's odd-even mergesort network on N wires, as a compile-time list of compare-exchanges (min to the lower wire): 5 / 19 / 63 /
-// 191 of them for N = 4 / 8 / 16 / 32 against the bitonic network's 6 / 24 / 80 / 240.
-template <int N>
-struct SvNetwork {
-    int a[N * 10], b[N * 10], n;
-};
-template <int N>
-constexpr SvNetwork<N> sv_make_network() {
-    SvNetwork<N> o{};
-    o.n = 0;
-    for (int p = 1; p < N; p *= 2)
-        for (int k = p; k >= 1; k /= 2)
-            for (int j = k % p; j <= N - 1 - k; j += 2 * k)
-                for (int i = 0; i <= (k - 1 < N - j - k - 1 ? k - 1 : N - j - k - 1); ++i)
-                    if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) { o.a[o.n] = i + j; o.b[o.n] = i + j + k; ++o.n; }
-    return o;
-}
+// (the network generator is plain C++: csrc/scvote_sortnet.h, also compiled by the CPU test tests/test_sort_network.py)
 template <int N>
 struct SvNet { static constexpr SvNetwork<N> net = sv_make_network<N>(); };
 template <int NP, int... I>

@@ -1,0 +1,24 @@
+// scvote_sortnet.h -- the compare-exchange network of scv_sort_cells as a compile-time list.  Plain C++17 (no HIP): included by
+// csrc/scvote_sort.hip.h for the device code and by tests/sortnet_check.cpp, which proves it on the CPU (0-1 principle).
+#pragma once
+
+namespace scv {
+
+// Batcher's odd-even mergesort network on N wires, as a compile-time list of compare-exchanges (min to the lower wire): 5 / 19 / 63 /
+// 191 of them for N = 4 / 8 / 16 / 32 against the bitonic network's 6 / 24 / 80 / 240.
+template <int N>
+struct SvNetwork {
+    int a[N * 10], b[N * 10], n;
+};
+template <int N>
+constexpr SvNetwork<N> sv_make_network() {
+    SvNetwork<N> o{};
+    o.n = 0;
+    for (int p = 1; p < N; p *= 2)
+        for (int k = p; k >= 1; k /= 2)
+            for (int j = k % p; j <= N - 1 - k; j += 2 * k)
+                for (int i = 0; i <= (k - 1 < N - j - k - 1 ? k - 1 : N - j - k - 1); ++i)
+                    if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) { o.a[o.n] = i + j; o.b[o.n] = i + j + k; ++o.n; }
+    return o;
+}
+}  // namespace scv

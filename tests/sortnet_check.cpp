@@ -1,0 +1,127 @@
+// CPU proof of the counting core of scv_sort_cells (csrc/scvote_sort.hip.h): built and run by tests/test_sort_network.py.
+//  1. the compile-time compare-exchange list of csrc/scvote_sortnet.h sorts (0-1 principle: exhaustively for N <= 16 wires,
+//     2^20 random 0-1 inputs for N = 32, 64);
+//  2. a scalar emulation of the device code's packed form -- two 16-bit elements per register, both halves through the same
+//     network in lockstep, ONE bitonic merge whose first stage crosses the halves, then the run-length scan with the carry
+//     between the halves, distinct sentinels behind the valid prefix -- gives statistics.multimode's (max count, number of modes,
+//     smallest mode) and the truth count, against a brute-force count, for every shape NV = 8 ... 128.
+// The packed operations are restated here with the semantics of v_pk_min_u16 / v_pk_max_u16 / v_pk_add_u16 / v_pk_sub_u16 (clamp) /
+// v_pk_mul_lo_u16 / v_alignbit_b32 / v_bfi_b32; the order of operations is the device code's.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../o1_inference_scaling_laws_amd/csrc/scvote_sortnet.h"
+
+using scv::sv_make_network;
+using scv::SvNetwork;
+
+template <typename F>
+static uint32_t pk(uint32_t a, uint32_t b, F f) {
+    return (uint32_t)(f(a & 0xffffu, b & 0xffffu) & 0xffffu) | ((uint32_t)(f(a >> 16, b >> 16) & 0xffffu) << 16);
+}
+static uint32_t pk_min(uint32_t a, uint32_t b) { return pk(a, b, [](uint32_t x, uint32_t y) { return x < y ? x : y; }); }
+static uint32_t pk_max(uint32_t a, uint32_t b) { return pk(a, b, [](uint32_t x, uint32_t y) { return x > y ? x : y; }); }
+static uint32_t pk_add(uint32_t a, uint32_t b) { return pk(a, b, [](uint32_t x, uint32_t y) { return x + y; }); }
+static uint32_t pk_sub(uint32_t a, uint32_t b) { return pk(a, b, [](uint32_t x, uint32_t y) { return x - y; }); }
+static uint32_t pk_sub_sat(uint32_t a, uint32_t b) { return pk(a, b, [](uint32_t x, uint32_t y) { return x > y ? x - y : 0u; }); }
+static uint32_t pk_mul(uint32_t a, uint32_t b) { return pk(a, b, [](uint32_t x, uint32_t y) { return x * y; }); }
+static uint32_t alignbit(uint32_t hi, uint32_t lo, int s) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> s); }
+
+template <int N>
+static bool network_sorts_all_01() {
+    static constexpr SvNetwork<N> net = sv_make_network<N>();
+    const uint64_t total = N <= 16 ? (1ull << N) : (1ull << 20);
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    for (uint64_t t = 0; t < total; ++t) {
+        uint64_t bits = t;
+        if (N > 16) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; bits = rng; }
+        int x[N];
+        for (int i = 0; i < N; ++i) x[i] = (int)((bits >> i) & 1);
+        for (int c = 0; c < net.n; ++c)
+            if (x[net.a[c]] > x[net.b[c]]) { const int tmp = x[net.a[c]]; x[net.a[c]] = x[net.b[c]]; x[net.b[c]] = tmp; }
+        for (int i = 1; i < N; ++i) if (x[i - 1] > x[i]) return false;
+    }
+    return true;
+}
+
+template <int NV>
+static bool packed_count_matches_bruteforce(int rounds) {
+    constexpr int NP = NV / 2;
+    static constexpr SvNetwork<NP> net = sv_make_network<NP>();
+    uint64_t rng = 88172645463325252ull + NV;
+    auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    for (int it = 0; it < rounds; ++it) {
+        const int dom = (int[]){2, 3, 5, 50, 1024}[next() % 5];
+        const int pick = (int)(next() % 6);
+        const uint32_t n = pick == 0 ? 0u : pick == 1 ? 1u : pick <= 3 ? (uint32_t)NV : (uint32_t)(next() % (NV + 1));
+        uint32_t w[NV];
+        for (int i = 0; i < NV; ++i) w[i] = (uint32_t)(next() % dom);
+        const uint32_t truth = (next() & 1) ? w[next() % NV] : (uint32_t)(next() % 1024);
+        // ---- device order: pack, sentinels, sort halves, cross merge, scan
+        uint32_t R[NP];
+        for (int r = 0; r < NP; ++r) R[r] = w[r] | (w[r + NP] << 16);
+        if (n != (uint32_t)NV) {
+            const uint32_t n2 = n | (n << 16);
+            for (int r = 0; r < NP; ++r) {
+                const uint32_t idx1 = (uint32_t)(r + 1) | ((uint32_t)(r + NP + 1) << 16), sent = (0x8000u | r) | ((0x8000u | (r + NP)) << 16);
+                R[r] = pk_max(R[r], pk_mul(pk_min(pk_sub_sat(idx1, n2), 0x00010001u), sent));
+            }
+        }
+        for (int c = 0; c < net.n; ++c) { const uint32_t lo = R[net.a[c]], hi = R[net.b[c]]; R[net.a[c]] = pk_min(lo, hi); R[net.b[c]] = pk_max(lo, hi); }
+        for (int r = 0; r < NP / 2; ++r) {
+            uint32_t &a = R[r], &b = R[NP - 1 - r];
+            const uint32_t t = alignbit(b, b, 16), mn = pk_min(a, t), mx = pk_max(a, t);
+            a = (mn & 0xffffu) | (mx & 0xffff0000u);
+            b = alignbit(mx, mn, 16);
+        }
+        for (int j = NP >> 1; j > 0; j >>= 1)
+            for (int r = 0; r < NP; ++r) { const int l = r ^ j; if (l > r) { const uint32_t lo = R[r], hi = R[l]; R[r] = pk_min(lo, hi); R[l] = pk_max(lo, hi); } }
+        uint32_t run[NP], s = 0;
+        for (int r = 0; r < NP; ++r) {
+            const uint32_t prev = r ? R[r - 1] : ((R[NP - 1] << 16) | 0xffffu);
+            s = pk_max(s, pk_mul(pk_min(R[r] ^ prev, 0x00010001u), (uint32_t)(r + 1) | ((uint32_t)(r + NP + 1) << 16)));
+            run[r] = s;
+        }
+        const uint32_t carry = s << 16;
+        uint32_t mx = 0;
+        for (int r = 0; r < NP; ++r) { run[r] = pk_sub((uint32_t)(r + 2) | ((uint32_t)(r + NP + 2) << 16), pk_max(run[r], carry)); mx = pk_max(mx, run[r]); }
+        const uint32_t max_run = (mx & 0xffffu) > (mx >> 16) ? (mx & 0xffffu) : (mx >> 16), mr2 = max_run | (max_run << 16);
+        const uint32_t tcmp = truth < 1024u ? truth : 0x7fffu, t2 = tcmp | (tcmp << 16);
+        uint32_t below = 0, minc = 0xffffffffu, tc = 0;
+        for (int r = 0; r < NP; ++r) {
+            const uint32_t m = pk_min(pk_sub(mr2, run[r]), 0x00010001u);
+            below = pk_add(below, m);
+            minc = pk_min(minc, R[r] | pk_sub(0u, m));
+            tc = pk_add(tc, pk_sub_sat(0x00010001u, R[r] ^ t2));
+        }
+        const uint32_t at_max = 2u * NP - ((below & 0xffffu) + (below >> 16));
+        const bool any = n > 0;
+        const uint32_t got_max = any ? max_run : 0u, got_modes = any ? at_max - (max_run == 1u ? (uint32_t)NV - n : 0u) : 0u;
+        const uint32_t got_min = any ? ((minc & 0xffffu) < (minc >> 16) ? (minc & 0xffffu) : (minc >> 16)) : 0xffffu;
+        const uint32_t got_tc = (tc & 0xffffu) + (tc >> 16);
+        // ---- brute force (statistics.multimode on the valid prefix)
+        uint32_t cnt[1024] = {0}, want_max = 0, want_modes = 0, want_min = 0xffffu, want_tc = 0;
+        for (uint32_t i = 0; i < n; ++i) { cnt[w[i]]++; want_tc += w[i] == truth; }
+        for (int v = 0; v < 1024; ++v) if (cnt[v] > want_max) want_max = cnt[v];
+        for (int v = 1023; v >= 0; --v) if (want_max && cnt[v] == want_max) { want_modes++; want_min = (uint32_t)v; }
+        if (got_max != want_max || got_modes != want_modes || got_min != want_min || got_tc != want_tc) {
+            printf("NV=%d n=%u: got (%u, %u, %u, %u) want (%u, %u, %u, %u)\n", NV, n, got_max, got_modes, got_min, got_tc, want_max, want_modes, want_min, want_tc);
+            return false;
+        }
+    }
+    return true;
+}
+
+int main() {
+    bool ok = true;
+    ok &= network_sorts_all_01<2>() && network_sorts_all_01<4>() && network_sorts_all_01<8>() && network_sorts_all_01<16>();
+    ok &= network_sorts_all_01<32>() && network_sorts_all_01<64>();
+    printf("network: %s (exchanges on 4 / 8 / 16 / 32 / 64 wires: %d %d %d %d %d)\n", ok ? "sorts" : "FAILS", sv_make_network<4>().n, sv_make_network<8>().n,
+           sv_make_network<16>().n, sv_make_network<32>().n, sv_make_network<64>().n);
+    bool ok2 = packed_count_matches_bruteforce<8>(20000) && packed_count_matches_bruteforce<16>(20000) && packed_count_matches_bruteforce<32>(20000) &&
+               packed_count_matches_bruteforce<64>(20000) && packed_count_matches_bruteforce<128>(10000);
+    printf("packed sort + scan: %s\n", ok2 ? "equals statistics.multimode" : "DIFFERS");
+    return ok && ok2 ? 0 : 1;
+}

@@ -1,0 +1,19 @@
+"""CPU proof of the counting core of the sorted-cells kernel (csrc/scvote_sort.hip.h): the compile-time compare-exchange
+network (csrc/scvote_sortnet.h, plain C++) sorts -- 0-1 principle -- and a scalar emulation of the device code's packed form
+(lockstep halves, one cross merge, run-length scan with the carry between the halves, sentinels) equals a brute-force
+statistics.multimode for every shape.  tests/sortnet_check.cpp is compiled with g++ and run here; no GPU."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_sorting_network_and_packed_scan_on_cpu(tmp_path):
+    exe = tmp_path / "sortnet_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", str(exe), os.path.join(HERE, "sortnet_check.cpp")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    sys.stdout.write(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "network: sorts (exchanges on 4 / 8 / 16 / 32 / 64 wires: 5 19 63 191 543)" in out.stdout
+    assert "packed sort + scan: equals statistics.multimode" in out.stdout
