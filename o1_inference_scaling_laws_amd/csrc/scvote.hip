@@ -424,14 +424,15 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     // Rows that are not all 16-byte aligned (N % 4 != 0, unaligned bases) take the linear-image form (dword reads), N <= 64.
     const bool sort_lin = !reg_vec;
     if ((ctx->path == 5 || (ctx->path == 0 && ctx->sort_cells && N >= (sort_lin ? 5 : ctx->sort_n_min))) && !pool_rows && N >= (sort_lin ? 1 : 4) &&
-        N <= (sort_lin && ctx->sort_n_max > 64 ? 64 : ctx->sort_n_max)) {
+        N <= ((sort_lin || tok) && ctx->sort_n_max > 64 ? 64 : ctx->sort_n_max)) {      // (the 128-vote shape: aligned rows, votes only)
         const int nv = N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : (N <= 64 ? 64 : 128)));
         int kb = (ctx->sort_kb > 0 && !sort_lin) ? ctx->sort_kb : 1;          // (measured: one block per step beats two at N = 8, 16)
         if (nv > 16) kb = 1;
         const bool db = nv <= 16 && kb == 1 && ctx->sort_db != 0;           // short rows: two image buffers per wave, the copy two steps ahead
         const RegKernel rk = pick_sort_kernel(nv, kb, tok, sort_lin, db);
         const int64_t ps = (N / 4) | 1;
-        const int64_t image_words = sort_lin ? (((int64_t)kb * 64 * N * 4 + 16 + 1023) >> 10) * 256 : (int64_t)kb * 64 * ps * 4;
+        // (128 votes: the rows are staged in two halves of 16 slots through one image of 64 x 17 slots)
+        const int64_t image_words = nv == 128 ? (int64_t)64 * 17 * 4 : (sort_lin ? (((int64_t)kb * 64 * N * 4 + 16 + 1023) >> 10) * 256 : (int64_t)kb * 64 * ps * 4);
         // one buffer: votes image | tokens image | the cells' truth values (256 bytes per block of 64 cells)
         const int64_t region_words = (image_words * (tok ? 2 : 1) + (int64_t)kb * 64) * (db ? 2 : 1);
         const int64_t tail_words = (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0) + ((((int64_t)B * (nv + 1) + 1) & ~(int64_t)1) + 4 * (int64_t)B);

@@ -4,8 +4,9 @@
 namespace scv {
 template <int NV, int KB, bool LIN, bool DB = false>
 static RegKernel sort_nk(bool tok) {
-    return tok ? RegKernel{(KernelFn)scv_sort_cells<NV, KB, true, LIN, DB>, sort_cells_threads(NV) / 64}
-               : RegKernel{(KernelFn)scv_sort_cells<NV, KB, false, LIN, DB>, sort_cells_threads(NV) / 64};
+    if constexpr (NV == 128) return RegKernel{(KernelFn)scv_sort_cells<NV, KB, false, LIN, DB>, sort_cells_threads(NV) / 64};   // (votes only)
+    else return tok ? RegKernel{(KernelFn)scv_sort_cells<NV, KB, true, LIN, DB>, sort_cells_threads(NV) / 64}
+                    : RegKernel{(KernelFn)scv_sort_cells<NV, KB, false, LIN, DB>, sort_cells_threads(NV) / 64};
 }
 // nv: votes per lane (8 / 16 / 32 / 64 / 128); kb: blocks of 64 cells per step (2 only for aligned rows and nv <= 16);
 // lin: rows that are not all 16-byte aligned (linear image, dword reads); db: two buffers per wave (nv <= 16, kb = 1)

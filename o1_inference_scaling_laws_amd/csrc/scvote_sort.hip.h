@@ -232,7 +232,7 @@ __device__ __forceinline__ void sv_wait_vmcnt_le(uint32_t k) {
 #undef SV_W
 }
 
-constexpr int sort_cells_threads(int nv) { return nv >= 128 ? 256 : (nv >= 64 ? 512 : 1024); }
+constexpr int sort_cells_threads(int nv) { return nv >= 64 ? 512 : 1024; }
 
 // NV: votes per lane (capacity of the shape; 8 / 16 / 32 / 64), KB: blocks of 64 cells per step.  Host contract: N % 4 == 0,
 // 4 <= N <= NV, 16-byte aligned bases, no pool rows; a.wave_lds_words = words of one wave's LDS region (KB * 64 * PS * 4, twice
@@ -249,8 +249,17 @@ constexpr int sort_cells_threads(int nv) { return nv >= 128 ? 256 : (nv >= 64 ? 
 // but twice the bytes in flight made it SLOWER (N = 8: 87.6 vs 83.2 us, N = 16: 81.7 vs 72.4): the shapes are not latency-bound (and
 // not copy-bound: waves that only copy stream 6.9-7.2 TB/s, tools/hbm_probe.bin --dma).  The wait at the top of a step is then
 // vmcnt(<pieces of the next step's copy>): loads complete in order, so while a piece of THIS step's copy is outstanding all of those are too.
+//
+// NV = 128 (64 < N <= 128, aligned rows, no tokens: HALF): a whole 64-row block of 512-byte rows would take 33.8 KB of LDS per wave
+// -- one wave per SIMD, measured 3.0 TB/s against 3.8 for the register-resident kernels.  The rows are staged in two HALVES of 16
+// slots through ONE 17 KB image instead: slots 0..15 of every row, read into the first 32 packed registers, then slots 16.. into the
+// same image (that copy's latency is exposed to this wave and covered by the other wave of the SIMD), then the next step's first
+// half flies while the 128 votes are counted.  The initial placement of the votes in the registers is irrelevant to the sort; only
+// the sentinels name original positions.  8 waves per CU as for 64 votes.
 template <int NV, int KB, bool TOK, bool LIN = false, bool DB = false>
 __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const AggArgs a) {
+    constexpr bool HALF = NV == 128;
+    static_assert(!HALF || (KB == 1 && !TOK && !LIN && !DB), "the 128-vote shape: aligned rows, votes only");
     constexpr int NP = NV / 2, RSM = NV / 4;
     constexpr int QMAX = KB * (RSM + 1);                             // DMA pieces per step at the widest row (LIN: 16 N KB + 16 bytes)
     constexpr int TC = NV + 1;                                       // tie classes 0..NV
@@ -277,13 +286,15 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
 
     // this wave's region: votes image [KB * 64 rows][PS slots], then (TOK) the tokens image
     const uint32_t rbase0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32*)(lds + (int64_t)wid * a.wave_lds_words));
-    const uint32_t img_bytes = LIN ? nq * 1024u : (uint32_t)KB * 64u * PS * 16u;
+    const uint32_t img_bytes = HALF ? 64u * 17u * 16u : (LIN ? nq * 1024u : (uint32_t)KB * 64u * PS * 16u);
     const uint32_t tru_off = img_bytes * (TOK ? 2u : 1u);            // one buffer: votes image | tokens image | the cells' truth values
     const uint32_t buf_bytes = tru_off + (uint32_t)KB * 256u;        // (DB: two buffers)
     // source offset of every slot this lane copies: slot s = 64 q + lane is chunk k = s % PS of row c = s / PS (the pad slot,
     // k == RS, repeats the row's last chunk)
-    uint32_t off[QMAX];
-    if (LIN) {
+    uint32_t off[HALF ? 1 : QMAX];
+    if (HALF) {
+        off[0] = 0;
+    } else if (LIN) {
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) off[q] = (uint32_t)q * 1024u + (uint32_t)lane * 16u;
     } else {
@@ -321,6 +332,30 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
                     const uint32_t ot = off[q] < limt ? off[q] : limt;
                     sv_dma16(gt, ot, rbase + img_bytes + (uint32_t)q * 1024u, nt);
                 }
+            }
+        }
+    };
+
+    // HALF: the copy of one half of the step's rows (which = 0: slots 0..15, 1: slots 16..RS-1) into the image at rbase; the source
+    // offsets are computed piece by piece (slot s = 64 q + lane is chunk s % PSh of row s / PSh; the pad slot repeats the last chunk)
+    const uint32_t RS2 = HALF ? RS - 16u : 0u, PSB = RS2 | 1u;        // second half: slots, padded slots (first half: 16, 17)
+    const uint32_t cB0 = HALF ? (uint32_t)lane / PSB : 0u, kB0 = HALF ? (uint32_t)lane - cB0 * PSB : 0u;
+    auto issue_half = [&](int64_t st, uint32_t rbase, int which) {
+        const int64_t byte0 = st * SC * (int64_t)rowbytes;
+        const int64_t rem = total_bytes - byte0 - 16;
+        const uint32_t lim = rem > 0x7fffffffll ? 0x7fffffffu : (uint32_t)rem;
+        const char* g = reinterpret_cast<const char*>(a.answers) + byte0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the previous half has left the image
+        const uint32_t PSh = which ? PSB : 17u, RSh = which ? RS2 : 16u, kbase = which ? 16u : 0u;
+        uint32_t c = which ? cB0 : (uint32_t)lane / 17u, k = which ? kB0 : (uint32_t)lane % 17u;
+        const uint32_t dc = 64u / PSh, dk = 64u - dc * PSh;
+#pragma unroll
+        for (int q = 0; q < 17; ++q) {
+            if ((uint32_t)q < PSh) {
+                const uint32_t o0 = c * rowbytes + (kbase + (k < RSh ? k : RSh - 1u)) * 16u;
+                sv_dma16(g, o0 < lim ? o0 : lim, rbase + (uint32_t)q * 1024u, nt);
+                c += dc; k += dk;
+                if (k >= PSh) { k -= PSh; c += 1; }
             }
         }
     };
@@ -389,7 +424,10 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
     int64_t st = wave;
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (st + d * nwaves < nsteps) { issue(st + d * nwaves, rbase0 + (uint32_t)d * buf_bytes); issue_truth(rbase0 + (uint32_t)d * buf_bytes); }
+        if (st + d * nwaves < nsteps) {
+            if (HALF) issue_half(st + d * nwaves, rbase0, 0); else issue(st + d * nwaves, rbase0 + (uint32_t)d * buf_bytes);
+            issue_truth(rbase0 + (uint32_t)d * buf_bytes);
+        }
     uint32_t parity = 0;
     for (; st < nsteps; st += nwaves, parity ^= 1u) {
         const uint32_t rbase = DB ? rbase0 + parity * buf_bytes : rbase0;
@@ -404,6 +442,54 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
         const bool all_live = left >= (int64_t)SC;
         const uint32_t live_cells = all_live ? (uint32_t)SC : (uint32_t)left;
         int32_t eb[KB];
+        if constexpr (HALF) {
+            const bool live = (uint32_t)lane < live_cells;
+            uint32_t prel;
+            eb[0] = same_b ? my_b[0] : slot_budget(0, prel);
+            const uint32_t n = live ? (same_b ? my_n[0] : budget_len(eb[0])) : 0u;
+            nvj[0] = n;
+            tok[0] = 0;
+            trj[0] = (int32_t)*reinterpret_cast<lds_u32*>((uintptr_t)(rbase + tru_off + (uint32_t)lane * 4u));
+            const bool full = all_live && __all(n == (uint32_t)NV);
+            const uint32_t n2 = n | (n << 16);
+            // one half: 16 slots of this lane's row (padded stride PSh) -> 32 packed registers Rh[0..31]: slot k holds the half's elements
+            // 4k..4k+3, paired with the elements 32 further on (slot k + 8); ebase: the half's first element in the row
+            auto read_half = [&](uint32_t (&Rall)[NP], int rb, uint32_t PSh, uint32_t RSh, uint32_t ebase) {
+                const uint32_t ra = rbase + (uint32_t)lane * (PSh * 16u);
+                uint32_t w[64];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t k0 = (uint32_t)k < RSh ? (uint32_t)k : RSh - 1u, k1 = (uint32_t)(k + 8) < RSh ? (uint32_t)(k + 8) : RSh - 1u;
+                    const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k0));
+                    const scv_v4u h = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k1));
+                    w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+                    w[32 + 4 * k] = h.x; w[32 + 4 * k + 1] = h.y; w[32 + 4 * k + 2] = h.z; w[32 + 4 * k + 3] = h.w;
+                }
+                uint32_t orv = 0;
+#pragma unroll
+                for (int i = 0; i < 64; ++i) orv |= w[i];
+                if (__any(orv > 1023u)) {
+#pragma unroll
+                    for (int i = 0; i < 64; ++i) {
+                        bad |= w[i] & (uint32_t)(((int32_t)(ebase + (uint32_t)i) - (int32_t)n) >> 31);
+                        w[i] = w[i] < 1023u ? w[i] : 1023u;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 32; ++r) Rall[rb + r] = w[r] | (w[r + 32] << 16);
+                if (!full) {
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) {
+                        const uint32_t e0 = ebase + (uint32_t)r, e1 = e0 + 32u;     // original positions of the register's two votes
+                        Rall[rb + r] = sv_sentinel(Rall[rb + r], n2, (e0 + 1u) | ((e1 + 1u) << 16), (0x8000u | e0) | ((0x8000u | e1) << 16));
+                    }
+                }
+            };
+            read_half(R[0], 0, 17u, 16u, 0u);
+            issue_half(st, rbase, 1);                                 // the second half of this step's rows, into the same image
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_half(R[0], 32, PSB, RS2, 64u);
+        } else {
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             const bool live = (uint32_t)(j * 64 + lane) < live_cells;
@@ -476,11 +562,15 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
                                           (0x8000u | (uint32_t)r) | ((0x8000u | (uint32_t)(r + NP)) << 16));
             }
         }
+        }
         // the next step's copy flies while this step is counted
         uint4* const cells_out = a.cells ? reinterpret_cast<uint4*>(a.cells) + c0 : nullptr;     // (scalar bases of this step's outputs)
         int64_t* const ctok_out = (TOK && a.cell_tokens) ? a.cell_tokens + c0 : nullptr;
         advance();
-        if (st + (int64_t)D * nwaves < nsteps) { issue(st + (int64_t)D * nwaves, rbase); issue_truth(rbase); }   // into the buffer just read
+        if (st + (int64_t)D * nwaves < nsteps) {                     // into the buffer just read
+            if (HALF) issue_half(st + (int64_t)D * nwaves, rbase, 0); else issue(st + (int64_t)D * nwaves, rbase);
+            issue_truth(rbase);
+        }
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             sv_sort<NP>(R[j]);
