@@ -116,7 +116,8 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  *                         4 register-resident cells | 5 sorted cells
  *   "sort_cells"          default 1: cells of "sort_n_min" (default 8) <= N <= "sort_n_max" (default 64, at most 128) votes run one lane
  *                         per cell, the wave's rows staged through LDS by LDS-DMA and sorted in registers (rows that are not 16-byte
- *                         aligned: from N = 5, at most 64); "sort_kb": blocks of 64 cells per step of that kernel (0 auto); "sort_waves" (resident waves per CU of that kernel, 0 = 16), "sort_db" (default 0; 1:
+ *                         aligned: from N = 5, at most 64); "sort_kb": blocks of 64 cells per step of that kernel (0 auto); "sort_spread" (default 1: the next step's LDS-DMA pieces are issued between the compare-exchanges
+ *                         of the sort instead of back to back), "sort_waves" (resident waves per CU of that kernel, 0 = 16), "sort_db" (default 0; 1:
  *                         cells of N <= 16 votes get two image buffers per wave, the copy two steps ahead -- measured 5-13 % slower)
  *   "reg_n_max"           default 8192 = its maximum: 32 < N <= this uses the register-resident cell kernels; 0 restores the round-1 dispatch
  *   "tiny_n_max"          <= 32: N <= this uses the one-lane / several-lanes-per-cell kernels of the small path; "tiny_lane" (default 1:

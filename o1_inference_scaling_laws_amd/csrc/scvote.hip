@@ -172,6 +172,7 @@ struct scv_ctx {
     int sort_n_min = 8;      // shorter cells stay on scv_lane_cells
     int sort_n_max = 64;     // longer cells go to the register-resident kernels (the 128-vote shape runs one wave per SIMD: measured 3.2 vs 3.8 TB/s)
     int sort_kb = 0;         // blocks of 64 cells per step (0 = auto: 1)
+    int sort_spread = 1;     // sorted cells: the next step's LDS-DMA pieces are issued between the compare-exchanges of the sort (3-5 %; 0: back to back)
     int sort_waves = 0;      // resident waves per CU of the sorted-cells kernel (0 = 16; 32 needs <= 64 VGPRs: the 8-vote shape)
     int sort_db = 0;         // 1: N <= 16 gets two image buffers per wave, the copy two steps ahead (measured 5-13 % SLOWER: N = 16 81.7 vs 72.4 us; off)
     int64_t stat_sort_cells = 0;
@@ -345,7 +346,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.prefetch = ctx->prefetch;
     a.tok_skew = ctx->tok_skew;
     a.sorted = ctx->sorted;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0; a.reg_pivots = ctx->reg_pivots;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0; a.reg_pivots = ctx->reg_pivots; a.sort_spread = ctx->sort_spread;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
     const bool tok = tokens != nullptr;
 
@@ -1106,6 +1107,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "sort_n_min")) { if (value < 4 || value > 129) return fail(SCV_ERR_ARG, "sort_n_min must be 4..129"); ctx->sort_n_min = (int)value; }
     else if (!strcmp(key, "sort_n_max")) { if (value < 4 || value > 128) return fail(SCV_ERR_ARG, "sort_n_max must be 4..128"); ctx->sort_n_max = (int)value; }
     else if (!strcmp(key, "sort_db")) ctx->sort_db = value != 0;
+    else if (!strcmp(key, "sort_spread")) ctx->sort_spread = value != 0;
     else if (!strcmp(key, "sort_waves")) { if (value < 0 || value > 32) return fail(SCV_ERR_ARG, "sort_waves must be 0..32"); ctx->sort_waves = (int)value; }
     else if (!strcmp(key, "sort_kb")) { if (value < 0 || value > 2) return fail(SCV_ERR_ARG, "sort_kb must be 0, 1 or 2"); ctx->sort_kb = (int)value; }
     else if (!strcmp(key, "reg_dense4")) ctx->reg_dense4 = value != 0;

@@ -72,6 +72,7 @@ struct AggArgs {
                             // row p of answers / tokens [P, N] (its first n_valid[b] votes) instead of row p * B + b of [P, B, N]
     int32_t lane_stage;     // scv_lane_prefix: != 0 = a wave's 64 x B cell records are transposed through LDS and written as one
                             // contiguous block (a lane's own records are B * 16 bytes apart)
+    int32_t sort_spread;    // sorted-cells kernel: != 0 = the next step's LDS-DMA pieces are issued between the compare-exchanges of the sort, not back to back
     int32_t reg_pivots;     // register-resident kernels: 1 = the lanes' second pivot is switched off (A/B runs); otherwise two pivots per lane
     int32_t acc_classes;    // register-resident kernels: > 0 = per-budget counters accumulate in LDS (this many tie classes per
                             // budget; larger classes go to memory directly) and are flushed once per workgroup

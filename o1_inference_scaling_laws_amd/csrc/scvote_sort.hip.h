@@ -64,26 +64,35 @@ __device__ __forceinline__ void sv_ce_cross(uint32_t& a, uint32_t& b) {
 // (the network generator is plain C++: csrc/scvote_sortnet.h, also compiled by the CPU test tests/test_sort_network.py)
 template <int N>
 struct SvNet { static constexpr SvNetwork<N> net = sv_make_network<N>(); };
-template <int NP, int... I>
-__device__ __forceinline__ void sv_sort_halves(uint32_t (&R)[NP], std::integer_sequence<int, I...>) {
-    (sv_ce(R[SvNet<NP>::net.a[I]], R[SvNet<NP>::net.b[I]]), ...);      // (every index is a constant expression: R stays in registers)
+struct SvNoTick { __device__ __forceinline__ void operator()(uint32_t&) const {} };
+template <int NP, typename Tick, int... I>
+__device__ __forceinline__ void sv_sort_halves(uint32_t (&R)[NP], Tick& tick, std::integer_sequence<int, I...>) {
+    ((sv_ce(R[SvNet<NP>::net.a[I]], R[SvNet<NP>::net.b[I]]), tick(R[SvNet<NP>::net.a[I]])), ...);      // (every index is a constant expression: R stays in registers)
+}
+// compare-exchanges (= calls of `tick`) of one sv_sort<NP>
+template <int NP>
+constexpr int sv_sort_ticks() {
+    int stages = 0;
+    for (int j = NP >> 1; j > 0; j >>= 1) ++stages;
+    return SvNet<NP>::net.n + NP / 2 + stages * (NP / 2);
 }
 
 // Ascending sort of the 2 * NP 16-bit elements of R; element i = half i / NP of R[i % NP].  Both halves are sorted in lockstep by
 // the odd-even mergesort network on the NP registers (any network whose exchanges all put the minimum on the lower wire runs on both
-// halves at once), then merged by one bitonic merge: the flip stage is the only one where the halves meet.
-template <int NP>
-__device__ __forceinline__ void sv_sort(uint32_t (&R)[NP]) {
+// halves at once), then merged by one bitonic merge: the flip stage is the only one where the halves meet.  `tick(reg)` is called after
+// every compare-exchange with a register it has just written (the kernel spreads the next step's LDS-DMA pieces over the sort with it).
+template <int NP, typename Tick>
+__device__ __forceinline__ void sv_sort(uint32_t (&R)[NP], Tick& tick) {
     static_assert(NP >= 2 && (NP & (NP - 1)) == 0, "packed registers");
-    sv_sort_halves<NP>(R, std::make_integer_sequence<int, SvNet<NP>::net.n>{});
+    sv_sort_halves<NP>(R, tick, std::make_integer_sequence<int, SvNet<NP>::net.n>{});
 #pragma unroll
-    for (int r = 0; r < NP / 2; ++r) sv_ce_cross(R[r], R[NP - 1 - r]);   // element (0, r) against (1, NP - 1 - r)
+    for (int r = 0; r < NP / 2; ++r) { sv_ce_cross(R[r], R[NP - 1 - r]); tick(R[r]); }   // element (0, r) against (1, NP - 1 - r)
 #pragma unroll
     for (int j = NP >> 1; j > 0; j >>= 1) {
 #pragma unroll
         for (int r = 0; r < NP; ++r) {
             const int l = r ^ j;
-            if (l > r) sv_ce(R[r], R[l]);
+            if (l > r) { sv_ce(R[r], R[l]); tick(R[r]); }
         }
     }
 }
@@ -212,6 +221,18 @@ __device__ __forceinline__ void sv_dma16(const void* gbase, uint32_t goff, uint3
                      : "=&s"(keep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
 }
 // ... and 64 lanes x 4 bytes (lane l's dword lands at lds_dst + 4 l): the per-lane gather of the cells' truth values
+// ... the same, pinned in the data flow of the sort: `dep` (a register the preceding compare-exchange wrote and a later one reads) is
+// an in/out operand the statement does not touch, so the exchanges before it stay before and the ones after it stay after -- without it
+// the compiler sinks the whole sort below the pieces (asm statements only keep their order among themselves)
+__device__ __forceinline__ void sv_dma16_pinned(const void* gbase, uint32_t goff, uint32_t lds_dst, bool nt, uint32_t& dep) {
+    uint32_t keep;
+    if (nt)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "+v"(dep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "+v"(dep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ void sv_dma4(const void* gbase, uint32_t goff, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
@@ -326,10 +347,10 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) {
             if ((uint32_t)q < nq) {
-                const uint32_t o = off[q] < lim ? off[q] : lim;      // (slots past the last cell re-read the tensor's last chunk)
+                const uint32_t o = off[HALF ? 0 : q] < lim ? off[HALF ? 0 : q] : lim;      // (slots past the last cell re-read the tensor's last chunk)
                 sv_dma16(g, o, rbase + (uint32_t)q * 1024u, nt);
                 if (TOK) {
-                    const uint32_t ot = off[q] < limt ? off[q] : limt;
+                    const uint32_t ot = off[HALF ? 0 : q] < limt ? off[HALF ? 0 : q] : limt;
                     sv_dma16(gt, ot, rbase + img_bytes + (uint32_t)q * 1024u, nt);
                 }
             }
@@ -567,13 +588,47 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
         uint4* const cells_out = a.cells ? reinterpret_cast<uint4*>(a.cells) + c0 : nullptr;     // (scalar bases of this step's outputs)
         int64_t* const ctok_out = (TOK && a.cell_tokens) ? a.cell_tokens + c0 : nullptr;
         advance();
-        if (st + (int64_t)D * nwaves < nsteps) {                     // into the buffer just read
-            if (HALF) issue_half(st + (int64_t)D * nwaves, rbase, 0); else issue(st + (int64_t)D * nwaves, rbase);
-            issue_truth(rbase);
+        // The next step's copy goes into the buffer just read.  SPREAD (votes only, one block per step, 16 votes or more; option
+        // "sort_spread"): its pieces are issued one every few compare-exchanges of the sort -- pinned there through a register operand,
+        // or the compiler sinks the sort below them -- instead of back to back: 3-5 % (N = 64: 96.3 -> 92.1 us, N = 30: 86.2 -> 81.7).
+        const bool have_next = st + (int64_t)D * nwaves < nsteps;
+        constexpr bool CAN_SPREAD = KB == 1 && !HALF && !TOK && NV >= 16;
+        const bool spread = CAN_SPREAD && a.sort_spread != 0 && have_next;
+        // (source base and limit of the next step's copy: wave-uniform values of this iteration)
+        const int64_t nbyte0 = (st + (int64_t)D * nwaves) * SC * (int64_t)rowbytes;
+        const int64_t nrem = LIN ? ((total_bytes - nbyte0 + shv - 1) & ~(int64_t)15) : total_bytes - nbyte0 - 16;
+        const uint32_t nlim = nrem > 0x7fffffffll ? 0x7fffffffu : (nrem < 0 ? 0u : (uint32_t)nrem);
+        const char* const ng = reinterpret_cast<const char*>(a.answers) + nbyte0 - shv;
+        if (have_next) {
+            if (HALF) { issue_half(st + (int64_t)D * nwaves, rbase, 0); issue_truth(rbase); }
+            else if (spread) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_truth(rbase); }
+            else { issue(st + (int64_t)D * nwaves, rbase); issue_truth(rbase); }
         }
+        constexpr int STEP = sv_sort_ticks<NP>() / QMAX > 0 ? sv_sort_ticks<NP>() / QMAX : 1;
+        int ticks = 0;                                               // (a constant at every call site after unrolling)
+        auto piece = [&](int q, uint32_t& dep) {
+            if constexpr (CAN_SPREAD) {
+                if ((uint32_t)q < nq) sv_dma16_pinned(ng, off[q] < nlim ? off[q] : nlim, rbase + (uint32_t)q * 1024u, nt, dep);
+            }
+        };
+        auto tick = [&](uint32_t& reg) {
+            if constexpr (CAN_SPREAD) {
+                if (spread && ticks % STEP == 0 && ticks / STEP < QMAX) piece(ticks / STEP, reg);
+            }
+            ++ticks;
+        };
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
-            sv_sort<NP>(R[j]);
+            if constexpr (CAN_SPREAD) {
+                sv_sort<NP>(R[j], tick);
+                if (spread) {
+#pragma unroll
+                    for (int q = (sv_sort_ticks<NP>() + STEP - 1) / STEP; q < QMAX; ++q) piece(q, R[j][0]);   // (pieces the sort did not reach)
+                }
+            } else {
+                SvNoTick none;
+                sv_sort<NP>(R[j], none);
+            }
             const uint32_t tcmp = (trj[j] >= 0 && trj[j] < kBins) ? (uint32_t)trj[j] : 0x7fffu;
             const SortedStats s = sv_scan<NP>(R[j], tcmp | (tcmp << 16));
             if ((uint32_t)(j * 64 + lane) < live_cells) {

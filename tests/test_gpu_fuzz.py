@@ -15,7 +15,7 @@ DEFAULTS = (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1)
             ("tiny_n_max", 32), ("small_reg", 1), ("prefetch", 1), ("stagger_vecs", 0), ("plain_loads", 0),
             ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_pivots", 0),
             ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1),
-            ("sort_cells", 1), ("sort_n_min", 8), ("sort_n_max", 64), ("sort_kb", 0), ("sort_db", 0))
+            ("sort_cells", 1), ("sort_n_min", 8), ("sort_n_max", 64), ("sort_kb", 0), ("sort_db", 0), ("sort_spread", 1), ("sort_waves", 0))
 
 
 def _draw(rng):
@@ -94,6 +94,8 @@ def _draw(rng):
         opts["sort_kb"] = int(rng.integers(1, 3))
     if rng.random() < 0.3:
         opts["sort_db"] = 1
+    if rng.random() < 0.3:
+        opts["sort_spread"] = 0
     if rng.random() < 0.3:
         opts["sort_n_max"] = int(rng.choice([16, 128]))
         opts["sort_n_min"] = int(rng.choice([4, 8, 40]))

@@ -209,7 +209,7 @@ def _with_options(eng, opts):
             for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
                          ("small_n_max", 512), ("tiny_n_max", 32), ("small_reg", 1), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096),
                          ("reg_n_max", 8192), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1), ("reg_pivots", 0),
-                         ("sort_cells", 1), ("sort_n_min", 8), ("sort_n_max", 64), ("sort_kb", 0), ("sort_db", 0)):
+                         ("sort_cells", 1), ("sort_n_min", 8), ("sort_n_max", 64), ("sort_kb", 0), ("sort_db", 0), ("sort_spread", 1), ("sort_waves", 0)):
                 eng.set_option(k, v)
     return _Ctx()
 
@@ -376,7 +376,7 @@ def test_sorted_cells_one_lane_per_cell(hip_engine, dist, shape):
     rng = np.random.default_rng(5 + N)
     nv = rng.integers(0, N + 1, size=(B,), dtype=np.int32)
     before = hip_engine.stat("sort_cells")
-    for opts in ({}, {"grid": 3, "sort_db": 1}, {"path": 5, "sort_kb": 2}):
+    for opts in ({}, {"grid": 3, "sort_db": 1, "sort_spread": 0}, {"path": 5, "sort_kb": 2}):
         with _with_options(hip_engine, opts):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
             assert_results_equal(hip_engine.aggregate(a2, tr2, n_valid=nv), oracle(a2, tr2, n_valid=nv), check_tokens=False)
