@@ -186,9 +186,27 @@ def cpu_baseline(args, B, N, gpu_first_cells, first_off, gpu_last_cells, last_of
               "sample": f"{P1} problems x {B} x {N}, {votes // a.size} passes, {dt:.1f} s",
               "all_cores": {"value": mt_rate, "threads": threads, "sample": f"{Pm} problems x {B} x {N}, {passes} passes, OpenMP over problems"}}
     # (4) the UNMODIFIED reference loop on this box's host: o1.run_experiments from oracle/_ref (a subprocess)
-    ref = reference_loop(args)
+    ref, ref_note = reference_loop(args)
     if ref is not None:
         big = ref["results"][-1]
+        # the same calls with the drop-in installed into the live reference module (the product path on the cached responses:
+        # extract.py -> pinned vote tensors -> HOST-mode HIP engine -> host floats), wall time split, result equal to the reference's
+        dropin_loop = None
+        if any("dropin" in r for r in ref["results"]):
+            dropin_loop = {
+                "what": "o1.run_experiments(dataset, cache, 2048, N) with o1_dropin.install(o1, engine=Engine(timing=True)) in force, on the SAME "
+                        "synthetic caches as reference_loop (P = 30; o1.py:216-247 replaced, o1.py:85-88,119 key scheme kept); seconds = best of 2; "
+                        "split_s: extract (cache -> pinned vote tensors) / engine_call (blocking HOST-mode call: staging + kernel + results) / "
+                        "kernel (hipEvents, inside engine_call) / floats",
+                "engine": ref.get("dropin_engine"),
+                "results": [dict(P=r["P"], N=r["N"], reference_seconds=r["seconds"], **r["dropin"]) for r in ref["results"] if "dropin" in r],
+            }
+            dropin_loop["speedup_vs_reference_at_largest_N"] = dropin_loop["results"][-1]["speedup_vs_reference"]
+            dropin_loop["all_equal_to_reference"] = all(r["equal_to_reference"] for r in dropin_loop["results"])
+            if not dropin_loop["all_equal_to_reference"]:
+                sys.exit("PARITY FAILURE: the drop-in's (accuracy, avg_tokens_used) differ from the live reference's on the same cache")
+        elif ref.get("dropin_error"):
+            dropin_loop = {"error": ref["dropin_error"]}
         base = {
             "value": big["votes_per_s"], "unit": "sample-votes/s", "cores": 1, "kind": "reference",
             "what": "the UNMODIFIED reference loop o1.run_experiments (o1.py:216-247: nested thread pools, per-sample cache-key lookups, "
@@ -198,29 +216,31 @@ def cpu_baseline(args, B, N, gpu_first_cells, first_off, gpu_last_cells, last_of
             "sample": "; ".join(f"P={r['P']} x N={r['N']}: {r['seconds']:.2f} s = {r['votes_per_s']:.0f} votes/s" for r in ref["results"])
                       + f" (votes of the workload's generator, dist {args.dist}; accuracy equal to the restatement's: "
                       + str(all(r["accuracy_matches_restatement"] for r in ref["results"])) + f"); {cores} host cores",
-            "reference_loop": ref["results"],
+            "reference_loop": [{k: v for k, v in r.items() if k != "dropin"} for r in ref["results"]],
+            "dropin_loop": dropin_loop,
             "arithmetic": arithmetic,
             "c_port": c_port,
         }
     else:
-        base = dict(arithmetic, c_port=c_port, reference_loop=None,
-                    note="oracle/_ref is absent (build() did not run where /root/reference exists): the restatement is the baseline")
+        base = dict(arithmetic, c_port=c_port, reference_loop=None, dropin_loop=None,
+                    note=ref_note or "oracle/_ref is absent (build() did not run where /root/reference exists): the restatement is the baseline")
     return parity, base
 
 
 def reference_loop(args):
-    """oracle/refbaseline.py as a subprocess: the unmodified o1.run_experiments at P = 30, N = 2^8, 2^11, 2^13 (SURVEY 8d "R0"; ~10 s).
-    None when oracle/_ref is not there."""
-    cmd = [sys.executable, "-m", "oracle.refbaseline", "--N", "256", "2048", "8192", "--seed", str(args.seed), "--dist", str(args.dist)]
+    """oracle/refbaseline.py as a subprocess: the unmodified o1.run_experiments at P = 30, N = 2^8, 2^11, 2^13 (SURVEY 8d "R0"; ~10 s),
+    and the same calls with the drop-in installed (--dropin).  -> (result | None, note): None when oracle/_ref is not there, when the
+    subprocess timed out or when it failed (e.g. a bytecode magic mismatch on the box) -- the headline line is emitted either way."""
+    cmd = [sys.executable, "-m", "oracle.refbaseline", "--N", "256", "2048", "8192", "--seed", str(args.seed), "--dist", str(args.dist), "--dropin"]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, timeout=300, env=dict(os.environ, MPLBACKEND="Agg"))
     except subprocess.TimeoutExpired:
-        return None
+        return None, "oracle.refbaseline timed out (300 s): the restatement is the baseline"
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if out.returncode != 0 or not lines:
-        sys.exit("reference loop baseline failed: " + out.stderr[-2000:])
+        return None, "oracle.refbaseline failed (rc %d): %s" % (out.returncode, out.stderr[-500:].replace("\n", " | "))
     ref = json.loads(lines[-1])
-    return ref if ref.get("available") else None
+    return (ref, None) if ref.get("available") else (None, ref.get("why"))
 
 
 # ---- helpers -------------------------------------------------------------------------------------------------

@@ -150,6 +150,11 @@ class Engine:
     def sync(self):
         check(self._L.scv_sync(self._ctx))
 
+    @staticmethod
+    def pinned_empty(shape, dtype=np.int32) -> np.ndarray:
+        """Page-locked host memory for HOST-mode inputs (module-level ``pinned_empty``; scv_host_alloc)."""
+        return pinned_empty(shape, dtype)
+
     def stat(self, key: str) -> int:
         """Monotonic counters of the single-launch forms taken by this context (scv_get_stat)."""
         v = C.c_int64()

@@ -74,7 +74,7 @@ def resolve_vote(cache: dict, model: str, prompt: str, problem: str, token_limit
 def _canonical(v):
     """Python equality classes as Counter sees them (equal values hash equal): 3 == 3.0 == Fraction(3) == Decimal(3) == 3+0j,
     True == 1.  Every number with an integral value becomes that int; anything else is its own class."""
-    if isinstance(v, (int, np.integer)):
+    if isinstance(v, (int, np.integer, np.bool_)):          # (bool is an int; np.bool_ is neither, but np.True_ == 1 for Counter)
         return int(v)
     if isinstance(v, (numbers.Number, decimal.Decimal)):
         try:
@@ -84,7 +84,7 @@ def _canonical(v):
                 v = v.real
             if v == v and v == int(v):       # (NaN != NaN; int(inf) raises OverflowError)
                 return int(v)
-        except (TypeError, ValueError, OverflowError):
+        except (TypeError, ValueError, ArithmeticError):     # (OverflowError: int(inf); decimal.InvalidOperation: Decimal('sNaN') == ...)
             pass
     return v
 
@@ -151,45 +151,131 @@ class VoteTensors:
         return (self.spare_tables or {}).get(p, {}).get(bin_, bin_)
 
 
-def build_vote_tensors(dataset, cache: dict, budgets, model: str, prompt: str) -> VoteTensors:
+def _in_domain_codes(vals):
+    """int32 codes of one sample pool when EVERY answer is an int (or bool: True == 1) in 0..999 -- the only case the
+    reference's extractor produces for AIME (o1.py:140 int(extracted_answer)) -- else None (the caller then encodes
+    value by value).  One numpy conversion instead of a dictionary probe per vote."""
+    try:
+        arr = np.asarray(vals)
+    except (ValueError, OverflowError, TypeError):
+        return None
+    if arr.ndim != 1 or arr.dtype.kind not in "iub":
+        return None
+    if arr.size and (int(arr.min()) < 0 or int(arr.max()) >= SPARE_BASE):
+        return None
+    return arr.astype(np.int32, copy=False)
+
+
+def _token_codes(toks):
+    """int32 token counts of one sample pool (o1.py:102 stores completion_tokens as a JSON number)."""
+    try:
+        arr = np.asarray(toks)
+        if arr.ndim == 1 and arr.dtype.kind in "iub" and (not arr.size or (-2 ** 31 <= int(arr.min()) and int(arr.max()) < 2 ** 31)):
+            return arr.astype(np.int32, copy=False)
+    except (ValueError, OverflowError, TypeError):
+        pass
+    out = np.empty((len(toks),), dtype=np.int32)
+    for i, tok in enumerate(toks):
+        tok = int(tok)
+        if not -2 ** 31 <= tok < 2 ** 31:
+            raise ValueError(f"token count {tok} does not fit int32")
+        out[i] = tok
+    return out
+
+
+_MISSING = object()
+
+
+def build_vote_tensors(dataset, cache: dict, budgets, model: str, prompt: str, alloc=None) -> VoteTensors:
     """budgets: [(key_token_limit, N)] -- the (actual_token_limit, N) pairs of o1.py:274-277 / :302.
 
     Budget b of problem p votes over samples idx = 0..N_b-1 of key_token_limit_b (prefix of one
     sample pool when several budgets share a key_token_limit).
+
+    ``alloc(shape, dtype) -> ndarray`` supplies the answers / tokens tensors (``Engine.pinned_empty``: page-locked memory
+    the HOST-mode call DMAs in place); default: ordinary numpy memory.
+
+    Cost per sample: what the reference's key scheme forces -- one generation key built and hashed (o1.py:85-88: the
+    ~0.6 KB prompt + the problem text are part of EVERY key), one extraction key built and hashed (o1.py:119: the whole
+    completion text) -- and nothing else: the key prefix is formatted once per (problem, token limit), the loop body is
+    three dictionary probes on local names, answers and token counts are collected per sample pool and converted by numpy
+    in one piece, and every budget of a pool is a slice copy of it.  (resolve_vote() above is the same rule, one sample
+    at a time.)
     """
     P, B = len(dataset), len(budgets)
     nmax = max([n for _, n in budgets], default=0)
-    answers = np.zeros((P, B, max(nmax, 1)), dtype=np.int32)
-    tokens = np.zeros((P, B, max(nmax, 1)), dtype=np.int32)
+    shape = (P, B, max(nmax, 1))
+    if alloc is None:
+        answers = np.zeros(shape, dtype=np.int32)
+        tokens = np.zeros(shape, dtype=np.int32)
+    else:
+        answers, tokens = alloc(shape, np.int32), alloc(shape, np.int32)
+        answers[...] = 0
+        tokens[...] = 0
     n_valid = np.array([n for _, n in budgets], dtype=np.int32).reshape(B)
     truth = np.zeros((P,), dtype=np.int32)
     code_tables, spare_tables = {}, {}
+    pools = {}                                                  # key_limit -> samples needed (first-seen order of the budgets)
+    for key_limit, n in budgets:
+        pools[key_limit] = max(pools.get(key_limit, 0), n)
+    suffix = [""] + [f"_{i}" for i in range(1, nmax)]           # o1.py:85-88: idx 0 has no suffix
+    get = cache.get
+    missing = _MISSING
     for p, example in enumerate(dataset):
-        raw = {}                                                # (key_limit, idx) -> (answer, tokens), first-seen order
-        for key_limit, n in budgets:
+        problem = example["problem"]
+        raw = {}                                                # key_limit -> (answers, tokens) of its sample pool
+        for key_limit, n in pools.items():
+            prefix = f"{model}_{prompt}_{problem}_{key_limit}"
+            vals, toks = [0] * n, [0] * n                       # FAILED_VOTE = (0, 0) unless the sample resolves (o1.py:190-192)
             for idx in range(n):
-                k = (key_limit, idx)
-                if k not in raw:
-                    ans, tok = resolve_vote(cache, model, prompt, example["problem"], key_limit, idx)
-                    tok = int(tok)
-                    if not -2 ** 31 <= tok < 2 ** 31:
-                        raise ValueError(f"token count {tok} does not fit int32")
-                    raw[k] = (ans, tok)
+                response = get(prefix + suffix[idx])
+                if response is None:
+                    continue
+                try:
+                    content, tok = response["content"], response["tokens"]
+                except (KeyError, TypeError):
+                    continue
+                ans = get(f"extract_answer_{content}", missing)
+                if ans is missing or ans is None:               # o1.py:163 assert answer is not None
+                    continue
+                vals[idx], toks[idx] = ans, tok
+            raw[key_limit] = (vals, _token_codes(toks))
         true_answer = int(example["answer"])                    # o1.py:206
-        try:
-            enc = ProblemEncoder()
-            truth_code = enc.encode(true_answer)
-            codes = {k: enc.encode(ans) for k, (ans, _tok) in raw.items()}
-            if enc._codes:
-                spare_tables[p] = {code: value for value, code in enc._codes.items()}
-        except DomainOverflow:                                  # > 24 distinct out-of-domain values: dense re-encoding
-            enc = DenseEncoder()
-            truth_code = enc.encode(true_answer)
-            codes = {k: enc.encode(ans) for k, (ans, _tok) in raw.items()}
-            code_tables[p] = enc.table()
+        codes = {}
+        if 0 <= true_answer < SPARE_BASE:
+            truth_code = true_answer
+            for key_limit, (vals, _toks) in raw.items():
+                arr = _in_domain_codes(vals)
+                if arr is None:
+                    codes = None
+                    break
+                codes[key_limit] = arr
+        else:
+            codes = None
+        if codes is None:
+            # some answer is not an in-domain int: encode value by value, in the first-seen order of the budgets' samples
+            order, seen = [], set()
+            for key_limit, n in budgets:
+                for idx in range(n):
+                    if (key_limit, idx) not in seen:
+                        seen.add((key_limit, idx))
+                        order.append((key_limit, idx))
+            try:
+                enc = ProblemEncoder()
+                truth_code = enc.encode(true_answer)
+                flat = {k: enc.encode(raw[k[0]][0][k[1]]) for k in order}
+                if enc._codes:
+                    spare_tables[p] = {code: value for value, code in enc._codes.items()}
+            except DomainOverflow:                              # > 24 distinct out-of-domain values: dense re-encoding
+                enc = DenseEncoder()
+                truth_code = enc.encode(true_answer)
+                flat = {k: enc.encode(raw[k[0]][0][k[1]]) for k in order}
+                code_tables[p] = enc.table()
+            codes = {key_limit: np.fromiter((flat[(key_limit, i)] for i in range(n)), dtype=np.int32, count=n)
+                     for key_limit, n in pools.items()}
         truth[p] = truth_code
         for b, (key_limit, n) in enumerate(budgets):
-            for idx in range(n):
-                k = (key_limit, idx)
-                answers[p, b, idx], tokens[p, b, idx] = codes[k], raw[k][1]
+            if n:
+                answers[p, b, :n] = codes[key_limit][:n]
+                tokens[p, b, :n] = raw[key_limit][1][:n]
     return VoteTensors(answers, tokens, n_valid, truth, code_tables, spare_tables)

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import json
 import os
+import time
 from dataclasses import dataclass, field
 from typing import Any, Callable
 
@@ -49,6 +50,12 @@ class DropInConfig:
     engine: Any = None                            # anything with .aggregate(answers, truth, tokens, n_valid)
     helper_folder: str = "helpers"                # plot_helpers.py:7
     extra: dict = field(default_factory=dict)
+    # wall-clock split of the calls made through this config, in seconds (bench.py's cpu_baseline.dropin_loop reads it):
+    #   extract  cache -> vote tensors (extract.build_vote_tensors: the reference's key scheme, o1.py:85-88,119)
+    #   engine   the blocking HOST-mode engine call (staging H2D + kernel + results back)
+    #   kernel   of that, the hot-path kernel itself (hipEvents; only when the engine was created with timing=True)
+    #   floats   integer counters -> the reference's floats (scoring.py; o1.py:244-245)
+    timings: dict = field(default_factory=lambda: {"extract": 0.0, "engine": 0.0, "kernel": 0.0, "floats": 0.0, "calls": 0, "votes": 0})
 
     def get_engine(self):
         return self.engine if self.engine is not None else default_engine()
@@ -70,9 +77,40 @@ def just_ask_nicely_budgets(run_full_range: bool = False):
     return [(t, t, 1) for t in token_limits]
 
 
+def _extract(cfg: DropInConfig, eng, dataset, cache, budgets):
+    """cache -> vote tensors, written straight into page-locked memory when the engine hands it out (Engine.pinned_empty:
+    the HOST-mode call then DMAs the tensors in place instead of copying them through its bounce slots)."""
+    t0 = time.perf_counter()
+    vt = build_vote_tensors(dataset, cache, budgets, cfg.model, cfg.prompt, alloc=getattr(eng, "pinned_empty", None))
+    cfg.timings["extract"] += time.perf_counter() - t0
+    cfg.timings["votes"] += int(len(dataset)) * int(sum(n for _, n in budgets))
+    return vt
+
+
+def _timed_engine_call(cfg: DropInConfig, eng, fn, *args, **kwargs):
+    drain = getattr(eng, "drain_kernel_ns", None) if getattr(eng, "timing", False) else None
+    if drain is not None:
+        drain()
+    t0 = time.perf_counter()
+    res = fn(*args, **kwargs)
+    cfg.timings["engine"] += time.perf_counter() - t0
+    cfg.timings["calls"] += 1
+    if drain is not None:
+        cfg.timings["kernel"] += drain()[0] * 1e-9
+    return res
+
+
 def _aggregate(cfg: DropInConfig, dataset, cache, budgets):
-    vt = build_vote_tensors(dataset, cache, budgets, cfg.model, cfg.prompt)
-    return cfg.get_engine().aggregate(vt.answers, vt.truth, tokens=vt.tokens, n_valid=vt.n_valid)
+    eng = cfg.get_engine()
+    vt = _extract(cfg, eng, dataset, cache, budgets)
+    return _timed_engine_call(cfg, eng, eng.aggregate, vt.answers, vt.truth, tokens=vt.tokens, n_valid=vt.n_valid)
+
+
+def _floats(cfg: DropInConfig, res, b: int):
+    t0 = time.perf_counter()
+    out = (res.accuracy(b), res.avg_tokens_used(b))
+    cfg.timings["floats"] += time.perf_counter() - t0
+    return out
 
 
 def process_single_example(cfg: DropInConfig, example: dict, token_limit: int, cache: dict, N: int):
@@ -88,7 +126,7 @@ def run_experiments(cfg: DropInConfig, dataset, cache: dict, token_limit: int, N
     res = _aggregate(cfg, dataset, cache, [(token_limit, N)])
     if cfg.save_cache is not None:
         cfg.save_cache(cache, cfg.cache_filename)                # o1.py:242
-    return res.accuracy(0), res.avg_tokens_used(0)
+    return _floats(cfg, res, 0)
 
 
 def _run_family(cfg: DropInConfig, dataset, cache, budgets):
@@ -110,14 +148,14 @@ def _run_family(cfg: DropInConfig, dataset, cache, budgets):
     if dense:
         res = _aggregate(cfg, dataset, cache, [(budgets[i][1], budgets[i][2]) for i in dense])
         for j, i in enumerate(dense):
-            floats[i] = (res.accuracy(j), res.avg_tokens_used(j))
+            floats[i] = _floats(cfg, res, j)
     for key_limit, idx in pooled.items():
         ns = [budgets[i][2] for i in idx]
-        vt = build_vote_tensors(dataset, cache, [(key_limit, max(ns))], cfg.model, cfg.prompt)
-        res = eng.aggregate_prefix(vt.answers[:, 0, :], vt.truth, np.asarray(ns, dtype=np.int32),
-                                   tokens=vt.tokens[:, 0, :])
+        vt = _extract(cfg, eng, dataset, cache, [(key_limit, max(ns))])
+        res = _timed_engine_call(cfg, eng, eng.aggregate_prefix, vt.answers[:, 0, :], vt.truth, np.asarray(ns, dtype=np.int32),
+                                 tokens=vt.tokens[:, 0, :])
         for j, i in enumerate(idx):
-            floats[i] = (res.accuracy(j), res.avg_tokens_used(j))
+            floats[i] = _floats(cfg, res, j)
     if cfg.save_cache is not None:
         cfg.save_cache(cache, cfg.cache_filename)
     results = []

@@ -11,6 +11,12 @@ The votes are the workload's own generator (include/scvote.h, distribution ``--d
 row (p, 0, :) of ``synth_fill(30, 1, N)``; the returned accuracy is compared with the rational value the restatement
 (oracle/pyoracle.py) gives for the same votes, so the timing is of a run that produced the right answer.
 
+``--dropin`` (bench.py's ``cpu_baseline.dropin_loop``): after the reference has been timed on a cache, the SAME call on the SAME
+cache is made once more with ``o1_dropin.install(o1, engine=Engine(timing=True))`` in force -- the product path: extract.py's key
+scheme -> pinned vote tensors -> HOST-mode HIP engine -> host floats -- and its (accuracy, avg_tokens_used) must equal the
+reference's.  The wall time is split into extract / engine call / kernel / floats (DropInConfig.timings).  ``--engine oracle``
+puts the CPU oracle adapter behind the drop-in instead (no GPU: checks this script, measures only the extractor).
+
 CLI: prints ONE JSON line.  Run by bench.py as a subprocess (the bench process holds a HIP runtime; the reference
 starts ~300 threads per call).  Never imported by the product package.
 """
@@ -21,7 +27,47 @@ import os
 import time
 
 
-def run(ns, seed: int, dist: int, repeats: int = 1):
+_REBOUND = ("process_single_example", "run_experiments", "run_majority_vote_inference_experiments", "run_just_ask_nicely_experiments")
+
+
+def _dropin_engine(kind: str):
+    if kind == "oracle":
+        from tests._adapters import OracleEngine
+        return OracleEngine(), "oracle adapter (CPU; NOT the product: script self-check only)"
+    from o1_inference_scaling_laws_amd.engine import Engine
+    return Engine(timing=True), "HIP engine (libscvote.so, HOST mode)"
+
+
+def _time_dropin(o1, engine, ds, cache, N, ref_acc, ref_avg, repeats):
+    """o1.run_experiments(ds, cache, 2048, N) with the drop-in installed into the live reference module; then the module's own
+    functions are put back."""
+    from o1_inference_scaling_laws_amd import o1_dropin
+    saved = {k: getattr(o1, k) for k in _REBOUND}
+    try:
+        cfg = o1_dropin.install(o1, engine=engine, batched=True)      # (cfg.save_cache = the no-op'd o1.save_cache)
+        P = len(ds)
+        best, split, got = None, None, None
+        for _ in range(max(1, repeats)):
+            for k in cfg.timings:
+                cfg.timings[k] = 0
+            c0 = time.perf_counter()
+            got = o1.run_experiments(ds, cache, 2048, N)
+            dt = time.perf_counter() - c0
+            if best is None or dt < best:
+                best, split = dt, dict(cfg.timings)
+        acc, avg = got
+        return {"seconds": best, "votes_per_s": P * N / best,
+                "split_s": {"extract": split["extract"], "engine_call": split["engine"], "kernel": split["kernel"],
+                            "staging_in_engine_call": max(0.0, split["engine"] - split["kernel"]), "floats": split["floats"],
+                            "other": max(0.0, best - split["extract"] - split["engine"] - split["floats"])},
+                "accuracy": acc, "avg_tokens_used": float(avg),
+                "equal_to_reference": bool(abs(acc - ref_acc) < 1e-12 and float(avg) == float(ref_avg))}
+    finally:
+        for k, v in saved.items():
+            setattr(o1, k, v)
+
+
+def run(ns, seed: int, dist: int, repeats: int = 1, dropin: bool = False, engine_kind: str = "hip"):
     from oracle import coracle, pyoracle
     from oracle import ref_harness as rh
     kind = rh.reference_kind()
@@ -35,8 +81,17 @@ def run(ns, seed: int, dist: int, repeats: int = 1):
     boot = [(p, T, 0, int(a0[p, 0, 0]), int(t0[p, 0, 0])) for p in range(P) for T in [2 ** i for i in range(4, 11)]]
     boot += [(p, 2048, i, int(a0[p, 0, i]), int(t0[p, 0, i])) for p in range(P) for i in range(8)]
     results = []
+    engine, engine_what, dropin_error = None, None, None
+    if dropin:
+        try:
+            engine, engine_what = _dropin_engine(engine_kind)
+        except Exception as e:                                 # no library / no GPU: the reference timing is still reported
+            dropin_error = f"{type(e).__name__}: {e}"
     with rh.imported_reference(ds, rh.build_cache(consts, ds, boot)) as (o1, _workdir):
         o1.save_cache = lambda cache, filename: None           # o1.py:242 -- file I/O, not the vote loop
+        if engine is not None:                                 # first call of a process: context, staging pipeline, pinned slots
+            cache8 = rh.build_cache(consts, ds, [(p, 2048, i, int(a0[p, 0, i]), int(t0[p, 0, i])) for p in range(P) for i in range(8)])
+            _time_dropin(o1, engine, ds, cache8, 8, *o1.run_experiments(ds, cache8, 2048, 8), 1)
         for N in ns:
             a, t, tr = coracle.synth_fill(P, 1, N, seed, dist, want_tokens=True)
             assert [int(x) for x in tr] == [int(x) for x in tr0]
@@ -51,9 +106,17 @@ def run(ns, seed: int, dist: int, repeats: int = 1):
             want = pyoracle.exact_accuracy(votes, [int(x) for x in tr])
             want_avg = sum(sum(v[1]) for v in votes) / P
             ok = abs(acc - float(want)) < 1e-12 and float(avg) == want_avg
-            results.append({"P": P, "N": N, "seconds": best, "votes_per_s": P * N / best, "accuracy": acc,
-                            "accuracy_matches_restatement": bool(ok)})
+            row = {"P": P, "N": N, "seconds": best, "votes_per_s": P * N / best, "accuracy": acc,
+                   "accuracy_matches_restatement": bool(ok)}
+            if engine is not None:
+                d = _time_dropin(o1, engine, ds, cache, N, acc, avg, max(2, repeats))
+                d["speedup_vs_reference"] = best / d["seconds"]
+                row["dropin"] = d
+            results.append(row)
+    if engine is not None and hasattr(engine, "close"):
+        engine.close()
     return {"available": True, "reference": kind, "host_cores": os.cpu_count(), "results": results,
+            "dropin_engine": engine_what, "dropin_error": dropin_error,
             "what": "unmodified o1.run_experiments (o1.py:216-247) on a warm in-memory synthetic cache, save_cache no-op'd"}
 
 
@@ -64,8 +127,10 @@ def main():
     ap.add_argument("--seed", type=int, default=20240914)
     ap.add_argument("--dist", type=int, default=1)
     ap.add_argument("--repeats", type=int, default=1)
+    ap.add_argument("--dropin", action="store_true", help="also time the same calls with the drop-in installed (needs the GPU)")
+    ap.add_argument("--engine", choices=["hip", "oracle"], default="hip", help="engine behind the drop-in (oracle: CPU self-check of this script)")
     args = ap.parse_args()
-    print(json.dumps(run(args.N, args.seed, args.dist, args.repeats)), flush=True)
+    print(json.dumps(run(args.N, args.seed, args.dist, args.repeats, args.dropin, args.engine)), flush=True)
 
 
 if __name__ == "__main__":

@@ -300,3 +300,95 @@ def test_canonical_equality_classes_and_decode_bin():
     vt = extract.VoteTensors(None, None, None, None, {2: ["x", -9, 5]}, {0: {1000: -4, 1001: 1000}})
     assert vt.decode_bin(0, 12) == 12 and vt.decode_bin(0, 1000) == -4 and vt.decode_bin(0, 1001) == 1000
     assert vt.decode_bin(2, 1) == -9 and vt.decode_bin(1, 999) == 999 and vt.decode_bin(1, -1) is None
+
+
+def _slow_vote_tensors(dataset, cache, budgets):
+    """The extractor's contract, one sample at a time: extract.resolve_vote per (key limit, idx) in the first-seen order of the
+    budgets' samples, ProblemEncoder -> DenseEncoder on overflow (what build_vote_tensors did before it was vectorised)."""
+    P, B = len(dataset), len(budgets)
+    nmax = max(1, max((n for _, n in budgets), default=0))
+    answers, tokens = np.zeros((P, B, nmax), np.int32), np.zeros((P, B, nmax), np.int32)
+    truth = np.zeros((P,), np.int32)
+    for p, ex in enumerate(dataset):
+        raw = {}
+        for key_limit, n in budgets:
+            for idx in range(n):
+                if (key_limit, idx) not in raw:
+                    raw[(key_limit, idx)] = extract.resolve_vote(cache, TEST_MODEL, TEST_PROMPT, ex["problem"], key_limit, idx)
+        try:
+            enc = extract.ProblemEncoder()
+            t = enc.encode(int(ex["answer"]))
+            codes = {k: enc.encode(a) for k, (a, _) in raw.items()}
+        except extract.DomainOverflow:
+            enc = extract.DenseEncoder()
+            t = enc.encode(int(ex["answer"]))
+            codes = {k: enc.encode(a) for k, (a, _) in raw.items()}
+        truth[p] = t
+        for b, (key_limit, n) in enumerate(budgets):
+            for idx in range(n):
+                answers[p, b, idx], tokens[p, b, idx] = codes[(key_limit, idx)], int(raw[(key_limit, idx)][1])
+    return answers, tokens, truth
+
+
+def test_vectorised_extractor_equals_the_per_sample_rule():
+    """Round 4: build_vote_tensors formats the key prefix once per (problem, key limit), probes the cache with local names and
+    converts whole sample pools with numpy -- same tensors as resolve_vote + the encoders applied sample by sample, for
+    in-domain ints, failures of all three kinds, out-of-domain / non-int answers, shared pools and odd token types."""
+    from fractions import Fraction
+    rng = random.Random(2024)
+    odd = [-7, 1000, 10 ** 12, 3.0, 2.5, Fraction(9, 3), True, "x", np.int64(17), np.True_]
+    for trial in range(60):
+        P = rng.randint(1, 4)
+        budgets = rng.choice([[(2048, 5)], [(16, 1), (32, 1), (2048, 1), (2048, 2), (2048, 8)], [(64, 3), (2048, 6), (64, 1)], [(2048, 0), (16, 2)]])
+        truths = [str(rng.choice([0, 7, 33, 999, 1000, -1])) if trial % 5 == 0 else f"{rng.randrange(1000):03d}" for _ in range(P)]
+        ds = make_dataset(truths)
+        samples = []
+        for p in range(P):
+            for key_limit, n in {(k, max(m for kk, m in budgets if kk == k)) for k, _ in budgets}:
+                many_odd = trial % 7 == 0
+                for idx in range(n):
+                    r = rng.random()
+                    if r < 0.1:
+                        a = None
+                    elif r < 0.2:
+                        a = "MISSING"
+                    elif r < (0.9 if many_odd else 0.35):
+                        a = rng.choice(odd) if not many_odd else 5000 + rng.randrange(40)
+                    else:
+                        a = rng.choice([0, 1, 7, 999, int(truths[p]) if 0 <= int(truths[p]) < 1000 else 3])
+                    samples.append((p, key_limit, idx, a, rng.randrange(0, 5000)))
+        cache = build_cache(ds, samples)
+        if trial % 3 == 0 and samples:                              # a generation entry without its extraction entry; odd token types
+            p, key_limit, idx, _, _ = samples[0]
+            gk = extract.generation_key(TEST_MODEL, TEST_PROMPT, ds[p]["problem"], key_limit, idx)
+            if gk in cache:
+                cache[gk] = {"content": "never extracted", "tokens": 5}
+            p, key_limit, idx, _, _ = samples[-1]
+            gk = extract.generation_key(TEST_MODEL, TEST_PROMPT, ds[p]["problem"], key_limit, idx)
+            if gk in cache:
+                cache[gk]["tokens"] = 17.0
+        vt = extract.build_vote_tensors(ds, cache, budgets, TEST_MODEL, TEST_PROMPT)
+        a, t, tr = _slow_vote_tensors(ds, cache, budgets)
+        assert np.array_equal(vt.answers, a) and np.array_equal(vt.tokens, t) and np.array_equal(vt.truth, tr), trial
+        assert vt.n_valid.tolist() == [n for _, n in budgets]
+    # alloc= supplies the tensors (Engine.pinned_empty on the GPU box); stale contents must not leak into the tail
+    calls = []
+    def alloc(shape, dtype):
+        calls.append(shape)
+        return np.full(shape, 777, dtype=dtype)
+    ds = make_dataset(["5"])
+    cache = build_cache(ds, [(0, 2048, i, 5, 9) for i in range(3)])
+    vt = extract.build_vote_tensors(ds, cache, [(2048, 2), (2048, 3)], TEST_MODEL, TEST_PROMPT, alloc=alloc)
+    assert calls == [(1, 2, 3)] * 2 and vt.answers.tolist() == [[[5, 5, 0], [5, 5, 5]]] and vt.tokens.tolist() == [[[9, 9, 0], [9, 9, 9]]]
+    with pytest.raises(ValueError):
+        cache[extract.generation_key(TEST_MODEL, TEST_PROMPT, ds[0]["problem"], 2048, 0)]["tokens"] = 2 ** 40
+        extract.build_vote_tensors(ds, cache, [(2048, 2)], TEST_MODEL, TEST_PROMPT)
+
+
+def test_dropin_records_its_wall_time_split():
+    ds = make_dataset(["5", "6"])
+    cache = build_cache(ds, [(p, 2048, i, 5, 9) for p in range(2) for i in range(4)])
+    cfg = o1_dropin.DropInConfig(model=TEST_MODEL, prompt=TEST_PROMPT, engine=OracleEngine())
+    acc, avg = o1_dropin.run_experiments(cfg, ds, cache, 2048, 4)
+    assert acc == 0.5 and float(avg) == 36.0
+    assert cfg.timings["calls"] == 1 and cfg.timings["votes"] == 8 and cfg.timings["extract"] > 0 and cfg.timings["engine"] > 0
