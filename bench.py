@@ -89,6 +89,10 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="single GPU: capture memset + hot-path launch of every resident chunk into a hipGraph and replay it "
                          "(launch-bound workloads such as --workload c2); kernel time is then taken from the wall clock")
+    ap.add_argument("--comm", choices=["torch", "peer", "rccl"], default="torch",
+                    help="who runs the exchange step.  torch (default): one PROCESS per GPU, torch.distributed all-reduce (--backend).  "
+                         "peer / rccl: ONE process -- the reference's shape, o1.py:312-315 -- drives the library's own communicator over --gpus devices "
+                         "(scv_comm_create: one-shot all-reduce over xGMI peer access / single-process RCCL), same chunk schedule, same JSON line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--share-device", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 (1-GPU box, with --backend gloo) to exercise the multi-process path")
@@ -352,8 +356,180 @@ def committed_evidence():
     return ev
 
 
+def main_single_process(args):
+    """--comm peer | rccl: ONE process, one scv_ctx per GPU inside one scv_comm (include/scvote.h), the reference's process shape
+    (o1.py:312-315).  Same workload, chunk schedule, timed region and JSON line as the torch.distributed path; the exchange step is
+    scv_allreduce_counters.  c5: MultiDeviceEngine.evaluate_c5 (vote, all-reduce, scv_allgather_cells, per-rank bootstrap slices,
+    scv_allgather_i64)."""
+    import numpy as np
+    import torch
+    from o1_inference_scaling_laws_amd._lib import ScvError
+    from o1_inference_scaling_laws_amd.dist import shard_bounds
+    from o1_inference_scaling_laws_amd.engine import AggregateResult, MultiDeviceEngine, cells_from_torch, counters_size
+    world = args.gpus
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    ndev = torch.cuda.device_count()
+    if not args.share_device and ndev < world:
+        print(json.dumps({"error": f"bench.py --gpus {world} --comm {args.comm}: only {ndev} HIP device(s) visible; one rank per GPU is required "
+                                   f"(--share-device exists for the 1-GPU test box only)",
+                          "metric": "sample-votes/sec (problems x samples)", "value": None, "n_gpus": world, "hip_devices_visible": ndev}), flush=True)
+        sys.exit(2)
+    devices = [0] * world if args.share_device else list(range(world))
+    t_create = time.perf_counter()
+    try:
+        mde = MultiDeviceEngine(devices, rccl=args.comm == "rccl", timing=True)      # create ends with the communicator's self-test
+    except ScvError as e:
+        print(json.dumps({"error": f"scv_comm_create({devices}, {args.comm}) failed: {e}", "metric": "sample-votes/sec (problems x samples)",
+                          "value": None, "n_gpus": world, "hip_devices_visible": ndev}), flush=True)
+        sys.exit(2)
+    t_create = time.perf_counter() - t_create
+    c5 = args.workload == "c5"
+    if args.workload == "c2":
+        args.problems_per_step, args.budgets, args.samples = 30, 8, 1 << 17
+        args.resident = max(args.resident, 5)
+    if c5:
+        args.budgets, args.resident = 1, 1
+    B, N = args.budgets, args.samples
+    rows = [shard_bounds(args.problems, g, world)[1] - shard_bounds(args.problems, g, world)[0] for g in range(world)] if c5 else [args.problems_per_step] * world
+    Pc = rows[0]
+    for e in mde.engines:
+        e.set_tuning(args.copies, args.threads, args.wg_per_cu, args.unroll)
+    want_R = args.resident if args.resident > 0 else (8 if args.workload == "c3" else 1)
+    R = max(1, min(want_R, args.steps + args.warmup)) if args.workload == "c3" else max(1, want_R)
+    chunk_bytes = Pc * B * N * 4 * (2 if args.tokens else 1)
+    free_b = min(torch.cuda.mem_get_info(torch.device("cuda", d))[0] for d in set(devices))
+    usable = free_b // (world if args.share_device else 1) - (3 << 30)
+    while R > 1 and R * chunk_bytes > usable:
+        R -= 1
+    if chunk_bytes > usable:
+        sys.exit(f"one chunk ({chunk_bytes / 1e9:.1f} GB) does not fit in free HBM ({free_b / 1e9:.1f} GB)")
+    slots = [[] for _ in range(world)]                          # slots[g][s] = (answers, tokens, truth, p_off)
+    for g, e in enumerate(mde.engines):
+        dev = torch.device("cuda", devices[g])
+        with torch.cuda.device(dev):
+            for s_ in range(R):
+                p_off = shard_bounds(args.problems, g, world)[0] if c5 else (s_ * world + g) * Pc
+                ans = torch.empty((rows[g], B, N), dtype=torch.int32, device=dev)
+                tok = torch.empty((rows[g], B, N), dtype=torch.int32, device=dev) if args.tokens else None
+                tr = torch.empty((rows[g],), dtype=torch.int32, device=dev)
+                e.synth_fill_device(ans, tok, tr, P=rows[g], B=B, N=N, seed=args.seed, dist=args.dist, p_offset=p_off)
+                slots[g].append((ans, tok, tr, p_off))
+    ncount = counters_size(B)
+    bufs = [[torch.zeros(ncount, dtype=torch.int64, device=torch.device("cuda", devices[g])) for _ in range(2)] for g in range(world)]
+    cells = [torch.empty((rows[g], B, 16), dtype=torch.uint8, device=torch.device("cuda", devices[g])) for g in range(world)]
+    ctok = [torch.empty((rows[g], B), dtype=torch.int64, device=torch.device("cuda", devices[g])) if args.tokens else None for g in range(world)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps + args.warmup + 1)]
+    c5_state = {"M": None, "last": None, "boot_seed": args.seed ^ 0xB007}
+    ow = args.workload == "c2"
+
+    def step(i, timed_slot=None):
+        if c5:
+            shards = [(slots[g][0][0], slots[g][0][2], slots[g][0][1]) for g in range(world)]
+            out = mde.evaluate_c5(shards, args.resamples, c5_state["boot_seed"], M=c5_state["M"])
+            c5_state["M"], c5_state["last"] = out[3], out
+            return out[0][:ncount]
+        cur = []
+        for g, e in enumerate(mde.engines):
+            ans, tok, tr, _ = slots[g][i % R]
+            with torch.cuda.device(ans.device):
+                c = bufs[g][i % 2]
+                if not ow:
+                    c.zero_()
+                e.aggregate_device(ans, tr, tokens=tok, counters=c, cells=cells[g], cell_tokens=ctok[g], overwrite=ow)
+                cur.append(c)
+        if timed_slot is not None:
+            with torch.cuda.device(cur[0].device):
+                ev[timed_slot][0].record()                      # rank 0's stream: its vote kernel is done here ...
+        mde.all_reduce_counters(cur)
+        if timed_slot is not None:
+            with torch.cuda.device(cur[0].device):
+                ev[timed_slot][1].record()                      # ... and here its buffer holds the sum (waits for the slowest rank included)
+        return cur[0]
+
+    def fence():
+        mde.sync()
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+
+    step(0)
+    fence()
+    first_cells = cells_from_torch(cells[0]) if not c5 else cells_from_torch(c5_state["last"][1])[: rows[0]]
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    for e in mde.engines:
+        e.drain_kernel_ns()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(args.warmup + i, timed_slot=None if c5 else i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    per_rank = [e.drain_kernel_ns() for e in mde.engines]
+    # c5 launches two timed kernels per evaluation on a rank? no: only aggregation launches are timed (scv_bootstrap is not)
+    kern_ms = [ns / max(n, 1) / 1e6 for ns, n in per_rank]
+    exposed_us = None if c5 or args.steps == 0 else float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(args.steps)])) * 1e3
+    last_off = slots[0][(args.warmup + args.steps - 1) % R][3] if args.steps > 0 else slots[0][0][3]
+    last_cells = cells_from_torch(cells[0]) if not c5 else cells_from_torch(c5_state["last"][1])[: rows[0]]
+    votes_per_step_per_gpu = Pc * B * N
+    total_votes = (args.problems * B * N if c5 else votes_per_step_per_gpu * world) * args.steps
+    bytes_per_launch = votes_per_step_per_gpu * BYTES_PER_VOTE * (2 if args.tokens else 1)
+    kern_avg_ms = max(kern_ms)
+    achieved = bytes_per_launch / (kern_avg_ms * 1e-3) / 1e9
+    final = AggregateResult.from_counters(last.cpu().numpy(), Pc, B, num_problems=args.problems if c5 else Pc * world)
+    out = {
+        "metric": "sample-votes/sec (problems x samples)", "value": total_votes / elapsed, "unit": "sample-votes/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
+        "scaling": "strong" if c5 else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {
+            "workload": (f"C5: P={args.problems} x N={N} sharded by problem over {world} GPU(s) of ONE process; step = vote + counters all-reduce + "
+                         f"scv_allgather_cells + per-rank bootstrap slices of {args.resamples} resamples + scv_allgather_i64 (M={c5_state['M']})") if c5 else
+                        (f"{args.workload.upper()} chunks: step = {Pc} problems x {B} budgets x {N} samples int32 ({bytes_per_launch / 1e9:.2f} GB) per GPU"),
+            "distribution": DISTS[args.dist], "resident_chunks": R, "chunks_distinct": R, "tokens_stream": bool(args.tokens),
+            "parallelism": f"problems sharded over {world} GPU(s) driven by ONE process, one int64 all-reduce of {ncount} counters per step (scv_allreduce_counters)",
+            "seed": args.seed, "launch": "eager", "comm": args.comm, "backend": None,
+            "comm_what": ("one-shot all-reduce over xGMI peer access (pure HIP, csrc/scvote_comm.hip)" if args.comm == "peer"
+                          else "single-process RCCL: ncclCommInitAll + grouped ncclAllReduce(int64, sum)"),
+            "rccl_ranks": world if args.comm == "rccl" else None, "comm_ranks": world, "hip_devices_visible": ndev,
+            "comm_create_s": t_create, "comm_selftest_words_per_rank": mde.stat("selftest_words"),
+            "ranks_started_by": "none: one process", "devices_shared_by_ranks": bool(args.share_device), "devices": devices,
+        },
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "scv_hist_argmax", "kernel_avg_ms": kern_avg_ms, "kernel_avg_ms_per_rank_min": min(kern_ms), "kernel_avg_ms_per_rank_max": max(kern_ms),
+                     "launches_timed": per_rank[0][1], "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "exposed_allreduce_us": exposed_us,
+                     "exposed_allreduce_what": "rank 0's stream, hipEvents: from the end of its vote kernel to its buffer holding the sum (waiting for the slowest rank included)"},
+        "parity": None, "cpu_baseline": None,
+        "accuracy_last_step": [round(final.accuracy(b), 6) for b in range(B)],
+    }
+    if not args.no_cpu_baseline:
+        n = check_cells_vs_c_oracle(last_cells, min(16, last_cells.shape[0]), B, N, args.seed, args.dist, last_off)
+        n0 = check_cells_vs_c_oracle(first_cells, min(4, first_cells.shape[0]), B, N, args.seed, args.dist, slots[0][0][3])
+        out["parity"] = f"bit-exact: rank 0's first {n} problems x {B} budgets x {N} votes of the last timed chunk (+ {n0} of the sanity pass) vs oracle/scv_oracle.c"
+        out["metric"] += ", bit-exact vs CPU (see parity)"
+    else:
+        out["metric"] += " (parity not checked in this run)"
+    if c5:
+        cnt, table, boot, M = c5_state["last"]
+        out["c5"] = {"tie_classes_M": M, "device_error_word": int(cnt.cpu()[ncount])}
+        if not args.no_cpu_baseline:
+            from oracle import coracle
+            rc, want_boot = coracle.bootstrap(cells_from_torch(table), 0, args.resamples, c5_state["boot_seed"], M)
+            if rc != 0 or not np.array_equal(boot.cpu().numpy(), want_boot):
+                sys.exit("PARITY FAILURE: bootstrap table differs from oracle scvo_bootstrap")
+            out["c5"]["bootstrap_parity"] = f"all {args.resamples} x {B} x {M} resample counters bit-exact vs oracle/scv_oracle.c"
+        if args.dump:
+            np.savez(args.dump, counters=cnt.cpu().numpy()[:ncount], cells=table.cpu().numpy(), boot=boot.cpu().numpy())
+    elif args.dump:
+        np.savez(args.dump, counters=last.cpu().numpy())
+    print(json.dumps(out), flush=True)
+    mde.close()
+
+
 def main():
     args = parse()
+    if args.comm != "torch":
+        return main_single_process(args)
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("SCV_FORCE_COLLECTIVES") == "1"):
         sys.exit(spawn_ranks(args))             # plain `python bench.py --gpus N`: start the ranks ourselves
     if "SCV_HSA_IPC_NOTE" in os.environ:
@@ -597,6 +773,7 @@ def main():
             "parallelism": f"problems sharded over {world} GPU(s), one int64 all-reduce of {counters_size(B)} counters per step",
             "seed": args.seed,
             "launch": (f"hipGraph replay ({gs} step(s) per graph launch)" if use_graph else "eager"),
+            "comm": "torch",
             "backend": args.backend if (world > 1 or force) else None,
             "collectives_forced_on_one_rank": bool(force),
             "rccl_ranks": rccl_ranks,

@@ -95,63 +95,41 @@ int scv_set_stream(scv_ctx* ctx, void* hip_stream);
 int scv_sync(scv_ctx* ctx);
 
 /*
- * Streaming-kernel geometry (for A/B measurement; 0 / negative = keep current).  By default the
- * library picks the geometry from the shape (measured bands); any explicit value here
- * switches that off until scv_set_option(ctx, "auto_geometry", 1).
- *   copies        LDS sub-histogram replication R in {4,8,16,32}
- *   threads       workgroup size in {256,512,1024}
+ * Streaming-kernel geometry (for A/B measurement; 0 / negative = keep current).  By default the library picks the geometry
+ * from the shape (measured bands); any explicit value here switches that off until
+ * scv_set_option(ctx, "auto_geometry", 1).  Instantiated: (copies, threads) in (4, 256) with unroll 2; (8, 256) (8, 512)
+ * (16, 256) (16, 512) (16, 1024) with unroll 4 -- anything else is SCV_ERR_ARG.
+ *   copies        LDS sub-histogram replication R        threads     workgroup size
  *   wg_per_cu     persistent workgroups per CU (clamped by LDS and wave capacity)
- *   unroll        16-byte loads in flight per lane in {2,4,8}
+ *   unroll        16-byte loads in flight per lane
  */
 int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unroll);
 /*
- * Launch options.  None is needed for correct results: the defaults are the measured choices; the keys
- * exist so that every kernel of the family can be forced (parity tests) and every choice re-measured (A/B tools).
- *
- * Semantics of a call
+ * Launch options.  None is needed for correct results: the defaults are the measured choices.  The keys exist
+ * so that every kernel of the family can be forced (parity tests) and the dispatch bounds re-measured; every choice that was
+ * measured slower in rounds 1-3 is gone from the library (DESIGN.md 4 lists them with their numbers).
  *   "overwrite_counters"  default 0; 1: DEVICE-mode per-budget counters are OVERWRITTEN, not accumulated into (with few long cells the
  *                         streaming kernel's last workgroup does it and the call is one launch, otherwise a memset precedes the launch)
- * Dispatch by cell length N (auto unless forced)
- *   "path"                0 auto | 1 streaming, whole cells | 2 streaming, split-N + merge | 3 small-N wave-per-cell (round 1) |
- *                         4 register-resident cells | 5 sorted cells
- *   "sort_cells"          default 1: cells of "sort_n_min" (default 8) <= N <= "sort_n_max" (default 64, at most 128) votes run one lane
- *                         per cell, the wave's rows staged through LDS by LDS-DMA and sorted in registers (rows that are not 16-byte
- *                         aligned: from N = 5, at most 64); "sort_kb": blocks of 64 cells per step of that kernel (0 auto); "sort_spread" (default 1: the next step's LDS-DMA pieces are issued between the compare-exchanges
- *                         of the sort instead of back to back), "sort_waves" (resident waves per CU of that kernel, 0 = 16), "sort_db" (default 0; 1:
- *                         cells of N <= 16 votes get two image buffers per wave, the copy two steps ahead -- measured 5-13 % slower)
- *   "reg_n_max"           default 8192 = its maximum: 32 < N <= this uses the register-resident cell kernels; 0 restores the round-1 dispatch
- *   "tiny_n_max"          <= 32: N <= this uses the one-lane / several-lanes-per-cell kernels of the small path; "tiny_lane" (default 1:
- *                         one lane per cell; 0: the round-1 several-lanes-per-cell kernel)
- *   "small_n_max"         register kernels off: N <= this uses the round-1 wave-per-cell kernel; "small_reg" (its register variant)
- *   "fused_counters_max"  cells at or below, or problem rows >= 4 MiB: per-cell atomics inside the hot kernel; otherwise a separate
- *                         reduction of the cell table; 0 forces the reduction
- * Register-resident kernels (A/B)
- *   "reg_shape" / "reg_km" / "reg_dense4"   force a kernel shape; "reg_wpg": waves per workgroup (0 = all the waves a CU holds)
- *   "reg_pivots"          a lane adds the votes equal to its first and second vote to words of its own instead of the contended
- *                         histogram bins; 1 switches the second pivot off (default 0)
- *   "reg_lds_counters"    default 1: per-budget counters accumulate in LDS and are flushed by the same launch; 0: cell table + scv_reduce_cells
- * Streaming kernel (A/B)
- *   "grid"                > 0: exact persistent grid (0: from the CU count); "balance" (default 1: shrink the grid so that all
- *                         workgroups stream the same number of items); "auto_geometry" (default 1; see scv_set_tuning)
- *   "segs"                split-N segments per cell (0 auto); "ticket_merge" (default 0; 1: split cells are merged inside the launch
- *                         by the last-arriving segment instead of by a merge kernel -- measured 0-9 % slower)
- *   "sorted"              default 1: budgets traversed in descending n_valid order
- *   "prefetch"            default 1: cross-item prefetch; "stagger_vecs", "plain_loads" (ordinary instead of non-temporal loads; also the
- *                         sorted-cells DMA), "tok_skew" (default 0; 1: the tokens row is read rotated by half a row against the votes row)
- * Prefix budgets (scv_aggregate_prefix_i32)
- *   "prefix_lane"         default 1: pools of N <= 64 run one lane per problem, every budget out of one pass over its votes;
- *                         "prefix_stage" (default 1: that kernel keeps its per-boundary snapshots in LDS when they fit)
- *   "prefix_cells"        default 1: pools of N <= 4096 run on the cell kernels, each cell reading its prefix of the pool row;
- *                         0: the one-pass snapshot kernels
- * Bootstrap
- *   "boot_lds"            default 1: LDS-resident code table; "boot_fused" (default 1: scv_aggregate_bootstrap_i32 runs the bootstrap
- *                         inside the vote launch when the shape allows it); "boot_cooperative" (default 1: that launch is a cooperative
- *                         launch); "boot_spin_limit" (default 2^20: polls at the grid barrier before a workgroup gives up and leaves
- *                         the bootstrap to scv_sync; tests set 1)
- * HOST-mode ingestion
- *   "host_pipeline"       default 1; 0: the serial round-1 staging loop; "stage_mb" (chunk size, default 128); "copy_threads"
- *                         (default 6: threads filling the pinned bounce slots); "pin_host" (default 0; 1: hipHostRegister caller
- *                         buffers of 32 MiB or more for the duration of the call -- measured no faster than pageable copies)
+ *   "path"                0 auto | 1 streaming, whole cells | 2 streaming, split-N + merge | 4 register-resident cells | 5 sorted cells
+ *   "sort_n_min" / "sort_n_max"   defaults 8 / 64: cells of that many votes run one lane per cell, the wave's rows staged through LDS
+ *                         by LDS-DMA and sorted in registers (rows that are not 16-byte aligned: from 5); "sort_n_max" = 0: off
+ *   "reg_n_max"           default 8192 = its maximum: 32 < N <= this uses the register-resident cell kernels; 0: the streaming kernel
+ *   "reg_shape"           force a register-resident shape: g * 100 + v (g lanes per cell, v vectors per lane: 1601 1602 1604 3204 6404)
+ *                         or 1000 + 40 + h (dense scan, h = 1, 2, 4, 8 parts of 4 KiB)
+ *   "fused_counters_max"  default 4096: streaming kernel -- at or below this many cells (or problem rows >= 4 MiB) per-cell atomics inside
+ *                         the hot kernel, otherwise a separate reduction of the cell table; 0: EVERY kernel leaves the counters to that
+ *                         reduction (the cell kernels otherwise keep per-workgroup LDS tables and flush them in the same launch)
+ *   "grid"                > 0: exact persistent grid (0: from the CU count, balanced so that all workgroups stream the same number of items)
+ *   "segs"                split-N segments per cell (0 auto)
+ *   "auto_geometry"       default 1; see scv_set_tuning
+ *   "prefix_path"         scv_aggregate_prefix_i32: 0 auto | 1 one lane per problem, every budget out of one pass (pools <= 64) |
+ *                         2 the cell kernels on pool rows (pools <= 4096) | 3 one streaming pass, a histogram snapshot per boundary
+ *   "boot_path"           scv_aggregate_bootstrap_i32: 0 auto (ONE cooperative launch when the shape allows it) | 1 one ORDINARY launch |
+ *                         2 two launches, LDS-resident code table | 3 two launches, global gathers (also scv_bootstrap's kernel)
+ *   "boot_spin_limit"     default 2^20: polls at the grid barrier before a workgroup of an ordinary one-launch form gives up and leaves
+ *                         the bootstrap to scv_sync; tests set 1
+ *   "stage_mb"            HOST mode: chunk size of the staging pipeline (default 128)
+ *   "copy_threads"        HOST mode: threads filling the pinned bounce slots (default 6)
  */
 int scv_set_option(scv_ctx* ctx, const char* key, int64_t value);
 
@@ -186,7 +164,7 @@ int scv_aggregate_i32(scv_ctx* ctx,
  * read from HBM once: 4 * max_b n_valid[b] algorithmic bytes per problem instead of 4 * sum_b n_valid[b].
  * Dispatch by pool length: N <= 64 (the reference's pools) one lane per problem, every budget a snapshot of one
  * pass over its votes; N <= 4096 the cell kernels, each cell reading its prefix of the problem's row; longer pools
- * the streaming kernel with a snapshot of the histogram at every boundary.
+ * the streaming kernel with a snapshot of the histogram at every boundary (option "prefix_path" forces one).
  */
 int scv_aggregate_prefix_i32(scv_ctx* ctx,
                              const int32_t* pool, const int32_t* tokens,
@@ -212,11 +190,11 @@ int scv_bootstrap(scv_ctx* ctx, const scv_cell* cells, int64_t P, int32_t B,
  * scv_bootstrap over the cell table it has just written, with the same outputs as the two calls.  When the shape
  * allows it (whole-cell streaming kernel, the [P, B] code table fits the workgroup's LDS, the persistent grid is
  * resident at once) both run in ONE kernel launch: all workgroups meet at a grid barrier after their last cell and
- * then share the resamples.  Otherwise (or with option "boot_fused" = 0) the bootstrap kernel is queued behind the
+ * then share the resamples.  Otherwise (or with option "boot_path" >= 2) the bootstrap kernel is queued behind the
  * vote kernel on the same stream.  cells_out and counts_out are required.  Asynchronous like every DEVICE-mode call.
  * Co-tenancy cannot make a valid call fail: the one-launch form is started with hipLaunchCooperativeKernel (the
  * runtime starts it only when the whole grid is resident, whatever other streams, RCCL or other processes run; a
- * refused cooperative launch becomes two launches; option "boot_cooperative" = 0 uses an ordinary launch, as does a
+ * refused cooperative launch becomes two launches; option "boot_path" = 1 uses an ordinary launch, as does a
  * call made while the stream is being captured into a hipGraph).  Under an ordinary launch a workgroup gives up at the
  * barrier after "boot_spin_limit" polls; the vote outputs are complete by then, and the next scv_sync resets the
  * barrier, runs scv_bootstrap over cells_out as a separate launch and returns its status (stat "boot_recovered").
@@ -254,7 +232,9 @@ int scv_synth_fill_i32(scv_ctx* ctx, int32_t* answers, int32_t* tokens, int32_t*
                        uint64_t seed, int dist);
 
 /*
- * The device error word (bit 0: a vote outside bins 0..1023, bit 1: a drawn bootstrap hit had n_modes >= M), widened to
+ * The device error word (bit 0: a vote outside bins 0..1023 -- exported as 0 under SCV_FLAG_CLAMP_TO_INVALID_BIN, where
+ * scv_sync does not treat it as an error either; bit 1: a drawn bootstrap hit had n_modes >= M; bit 2: the one-launch vote +
+ * bootstrap of a NON-cooperative launch gave up at its grid barrier -- not an error: the next scv_sync repairs it), widened to
  * int64 and written to *dst_device IN STREAM ORDER behind everything queued so far; it is not cleared (scv_sync does
  * that).  For multi-GPU callers: the reference sums scores over problems in one process (o1.py:236-245); when the
  * problems are sharded over ranks, the word goes into one extra element behind the packed counters so that the ONE
@@ -279,10 +259,30 @@ int scv_export_error_word(scv_ctx* ctx, int64_t* dst_device);
  *                SCV_COMM_RCCL: ncclCommInitAll + grouped ncclAllReduce(ncclInt64, ncclSum); librccl is resolved at run time
  *                (the copy the process already holds, else /opt/rocm's); distinct devices only.
  *
+ * scv_comm_create with more than one rank ends with a SELF-TEST (first contact with the devices is loud, not a wrong accuracy
+ * later): two rounds of known int64 patterns -- (PEER) every rank reads every other rank's buffer directly through the access
+ * path of the all-reduce, then one whole scv_allreduce_counters of the production payload (8217 words) and one scv_allgather_i64,
+ * each verified on every device.  A failure returns SCV_ERR_ARG with a message that names the device pair (peer read) or the
+ * device (collective); the second round catches a reader that kept stale lines of a peer's first-round buffer.
+ *
  * scv_allreduce_counters: buffers[r] is a DEVICE pointer on rank r's device (count int64 each, e.g. the packed counters
  * tie_class_hits | token_sum | truth_count_sum, optionally one more word from scv_export_error_word); in place, SUM, ordered
  * behind everything queued on the ranks' ctx streams, asynchronous.  Integer sums => the same bits at any device count.
- * scv_comm_sync = scv_sync on every rank (first error wins).
+ * The one-shot form stages through a buffer allocated at create (1 MiB per rank: no allocation on the launch path, legal
+ * under hipGraph capture); a larger count grows it (synchronising), which is refused while a rank's stream is being captured.
+ *
+ * BASELINE config 5 (pass@k + bootstrap) on several GPUs without torch: the bootstrap resamples over ALL
+ * problems, so after the vote every rank needs every rank's cells --
+ * scv_allgather_cells: tables[r] is a DEVICE pointer on rank r's device to the WHOLE table scv_cell [sum(rows), B] in which rank r
+ *   has written its own block (rows[r] problems, starting at row rows[0] + ... + rows[r - 1]: pass cells_out = that row to
+ *   scv_aggregate_i32); afterwards every rank's table holds every block.  PEER: every rank pulls the other blocks over its own
+ *   links (device-to-device copies ordered by the same events); RCCL: one grouped ncclBroadcast per block.
+ * then every rank runs scv_bootstrap over its slice [r_begin, r_end) of the resamples, and
+ * scv_allgather_i64: the same in-place all-gather for int64 blocks (counts[r] words per rank, rank r's block at word offset
+ *   counts[0] + ... + counts[r - 1] of buffers[r]) -- the gather of the resample slices counts_out [r_end - r_begin, B, M].
+ * Both are asynchronous and ordered behind everything queued on the ranks' ctx streams.
+ * scv_comm_sync = scv_sync on every rank (first error wins).  scv_comm_get_stat: "selftest_words" (words verified per rank at
+ * create; 0 with one rank), "staging_bytes" (current size of the all-reduce's staging buffer).
  */
 typedef struct scv_comm scv_comm;
 #define SCV_COMM_PEER 0x0u
@@ -292,7 +292,10 @@ int scv_comm_destroy(scv_comm* comm);
 int scv_comm_size(const scv_comm* comm);
 scv_ctx* scv_comm_ctx(scv_comm* comm, int rank);       /* owned by the communicator: do not scv_destroy it */
 int scv_allreduce_counters(scv_comm* comm, int64_t* const* buffers, int64_t count);
+int scv_allgather_cells(scv_comm* comm, scv_cell* const* tables, const int64_t* rows, int32_t B);
+int scv_allgather_i64(scv_comm* comm, int64_t* const* buffers, const int64_t* counts);
 int scv_comm_sync(scv_comm* comm);
+int scv_comm_get_stat(scv_comm* comm, const char* key, int64_t* out);
 
 /* Duration of the most recent aggregation kernel launch on this ctx, from hipEvents recorded on
  * the launch stream (needs SCV_FLAG_TIMING).  Blocks until that launch has finished. */
@@ -310,12 +313,12 @@ int scv_drain_kernel_ns(scv_ctx* ctx, uint64_t* total_ns_out, uint64_t* launches
 int scv_host_alloc(void** out, size_t bytes);
 int scv_host_free(void* p);
 
-/* How often this ctx took a single-launch form (monotonic counters, for tests and bench lines): "boot_fused" /
- * "boot_separate" (scv_aggregate_bootstrap_i32: one launch / two), "boot_cooperative" (one-launch forms started as cooperative
- * launches), "boot_recovered" (grid-barrier timeouts repaired by scv_sync with a separate bootstrap launch), "overwrite_fused" (counters overwritten by the
- * vote kernel's last workgroup), "merge_in_launch" (split-N merged by the last-arriving segment), "reg_lds_counters"
- * (register-resident launches that produced their counters themselves), "prefix_cells" / "prefix_lane" (prefix calls served by the cell
- * kernels / by the one-lane-per-problem kernel). */
+/* How often this ctx took a form (monotonic counters, for tests and bench lines): "boot_fused" / "boot_separate"
+ * (scv_aggregate_bootstrap_i32: one launch / two), "boot_cooperative" (one-launch forms started as cooperative launches),
+ * "boot_recovered" (grid-barrier timeouts repaired by scv_sync with a separate bootstrap launch), "overwrite_fused" (counters
+ * overwritten by the vote kernel's last workgroup), "lds_counters" (register-resident launches that produced their counters
+ * themselves), "sort_cells" (sorted-cells launches), "prefix_cells" / "prefix_lane" (prefix calls served by the cell kernels / by
+ * the one-lane-per-problem kernel). */
 int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out);
 
 int scv_device_count(void);

@@ -1,6 +1,6 @@
 """Build recipe for the HIP extension: hipcc cross-compiles gfx950 without a GPU.
 
-The ~200 kernel instantiations are spread over several translation units (csrc/scvote_dispatch.h); each is compiled
+The ~120 kernel instantiations are spread over several translation units (csrc/scvote_dispatch.h); each is compiled
 to an object file under csrc/build/ by its own hipcc process (in parallel, skipped when the object is newer than its
 sources) and the objects are linked into csrc/libscvote.so, in-tree, so that it travels to the GPU box."""
 from __future__ import annotations
@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(CSRC, "libscvote.so")
-UNITS = ["scvote.hip", "scvote_stream_c4.hip", "scvote_stream_c8.hip", "scvote_stream_c16.hip", "scvote_stream_c32.hip",
+UNITS = ["scvote.hip", "scvote_stream_c4.hip", "scvote_stream_c8.hip", "scvote_stream_c16.hip",
          "scvote_reg_g16.hip", "scvote_reg_g32.hip", "scvote_reg_g64.hip", "scvote_dense.hip", "scvote_comm.hip", "scvote_sort.hip"]
 HEADERS = [os.path.join(CSRC, "scvote_kernels.hip.h"), os.path.join(CSRC, "scvote_dispatch.h"),
            os.path.join(os.path.dirname(HERE), "include", "scvote.h")]

@@ -62,6 +62,9 @@ def load():
     L.scv_comm_ctx.restype = p
     L.scv_allreduce_counters.argtypes = [p, C.POINTER(p), i64]
     L.scv_comm_sync.argtypes = [p]
+    L.scv_allgather_cells.argtypes = [p, C.POINTER(p), C.POINTER(i64), i32]
+    L.scv_allgather_i64.argtypes = [p, C.POINTER(p), C.POINTER(i64)]
+    L.scv_comm_get_stat.argtypes = [p, C.c_char_p, C.POINTER(i64)]
     L.scv_last_kernel_ns.argtypes = [p, C.POINTER(u64)]
     L.scv_drain_kernel_ns.argtypes = [p, C.POINTER(u64), C.POINTER(u64)]
     L.scv_get_stat.argtypes = [p, C.c_char_p, C.POINTER(i64)]
@@ -76,7 +79,8 @@ def load():
     for name in ("scv_create", "scv_destroy", "scv_set_stream", "scv_sync", "scv_set_tuning", "scv_set_option", "scv_aggregate_i32", "scv_aggregate_prefix_i32",
                  "scv_bootstrap", "scv_aggregate_bootstrap_i32", "scv_synth_fill_i32", "scv_last_kernel_ns", "scv_drain_kernel_ns",
                  "scv_device_count", "scv_device_info", "scv_host_alloc", "scv_host_free", "scv_get_stat", "scv_export_error_word",
-                 "scv_comm_create", "scv_comm_destroy", "scv_comm_size", "scv_allreduce_counters", "scv_comm_sync"):
+                 "scv_comm_create", "scv_comm_destroy", "scv_comm_size", "scv_allreduce_counters", "scv_comm_sync",
+                 "scv_allgather_cells", "scv_allgather_i64", "scv_comm_get_stat"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

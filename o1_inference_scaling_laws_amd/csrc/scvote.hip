@@ -131,62 +131,39 @@ struct scv_ctx {
     int64_t lds_max = 65536;
     int64_t clock_khz = 0;
     int64_t hbm_bytes = 0;
-    // tuning
+    // streaming-kernel geometry (scv_set_tuning; auto unless user_tuned)
     int copies = 16, threads = 1024, wg_per_cu = 1, unroll = 4;
-    int stagger_vecs = 0;    // rotate each workgroup's start inside its cell (16-byte vectors per workgroup index)
-    int plain_loads = 0;
-    int prefetch = 1;        // streaming kernel: first tile of the next item is loaded before the current epilogue
-    int path = 0;            // 0 auto | 1 streaming, whole cells | 2 streaming, split-N | 3 small-N (wave per cell)
+    bool user_tuned = false; // set_tuning called: auto geometry off
+    // options (scv_set_option; include/scvote.h documents every key)
+    int path = 0;            // 0 auto | 1 streaming, whole cells | 2 streaming, split-N | 4 register-resident cells | 5 sorted cells
     int segs_override = 0;   // > 0: segments per cell for path 2
-    int sorted = 1;          // traverse budgets in descending n_valid order
-    int small_reg = 1;       // small path: 1 = register-resident variant for N <= 128 (measured +10 %), 2 = also for N <= 512 (measured slower)
-    int tok_skew = 0;        // streaming kernel, tokens stream: 1 = read the token row rotated by half a row (measured: no effect, off)
-    int tiny_lane = 1;       // N <= 32: 1 = one lane per cell (scv_lane_cells), 0 = the round-1 several-lanes-per-cell kernel
-    int tiny_n_max = 32;     // auto/small path: N <= this -> register-only kernel, several cells per wave
-    int small_n_max = 512;   // auto (reg path off): N <= this -> wave-per-cell kernel (crossover measured: profiles/r01_crossover_d*.log)
     int overwrite_counters = 0;  // DEVICE mode: per-budget outputs are overwritten instead of accumulated into (no caller memset)
-    int ticket_merge = 0;    // split-N: 1 = merge inside the launch (last-arriver tree) instead of a second launch; measured 0-9 % slower than the merge kernel, off
+    int sort_n_min = 8;      // sorted cells (scv_sort_cells): sort_n_min <= N <= sort_n_max (rows that are not 16-byte aligned: from 5); shorter
+    int sort_n_max = 64;     // cells stay on scv_lane_cells, longer ones go to the register-resident kernels; sort_n_max = 0: off
+    int reg_n_max = 8192;    // auto: 32 < N <= this -> register-resident cells (scv_reg_cells / scv_reg_dense); 0 = off (streaming kernel)
+    int reg_shape = 0;       // force a register-resident shape (parity tests, A/B runs), see launch_aggregate
+    int fused_counters_max = 4096;  // cells: at or below, counters inside the hot kernel; above, scv_reduce_cells; 0: always the reduction
+    int grid_override = 0;   // > 0: exact persistent grid size
+    int prefix_path = 0;     // prefix budgets: 0 auto | 1 one lane per problem | 2 cell kernels on pool rows | 3 one-pass streaming snapshots
+    int boot_path = 0;       // vote + bootstrap: 0 auto (one cooperative launch when the shape allows) | 1 one ORDINARY launch | 2 two launches,
+                             // LDS-resident code table | 3 two launches, global gathers
+    int boot_spin_limit = 1 << 20;   // polls (x s_sleep 8) a workgroup waits at the grid barrier before giving up (tests force 1)
+    int stage_mb = 128;      // HOST mode: chunk size (votes + tokens) of the staging pipeline
+    int copy_threads = 6;    // HOST mode (4-8 reach the link rate; 16+ were unstable: 30-55 GB/s run to run): threads copying pageable caller memory
+    // fixed choices that used to be options (measured: DESIGN.md 4 "dead ends")
+    static constexpr int tiny_n_max = 32;   // N <= this (and below sort_n_min): one lane per cell, registers only (scv_lane_cells)
     void* d_tickets = nullptr;   // arrival counters of the single-launch modes (all zero between launches)
     size_t d_tickets_words = 0;
-    void* d_partial2 = nullptr;  // split-N group histograms
-    size_t d_partial2_bytes = 0;
-    int64_t stat_boot_fused = 0, stat_boot_separate = 0, stat_overwrite_fused = 0, stat_merge_in_launch = 0, stat_reg_lds_counters = 0, stat_prefix_cells = 0, stat_prefix_lane = 0;   // scv_get_stat
-    int boot_fused = 1;      // scv_aggregate_bootstrap_i32: run the bootstrap inside the vote launch when the shape allows it
+    int64_t stat_boot_fused = 0, stat_boot_separate = 0, stat_overwrite_fused = 0, stat_lds_counters = 0, stat_prefix_cells = 0, stat_prefix_lane = 0;   // scv_get_stat
     struct BootReq { int32_t r0, r1, M; uint64_t seed; int64_t* out; bool fused; }* boot_req = nullptr;   // set for the duration of one call
     // the last fused request, kept so that a grid-barrier timeout can be repaired at scv_sync by a separate bootstrap launch
     struct BootLast { const scv_cell* cells = nullptr; int64_t P = 0; int32_t B = 0, r0 = 0, r1 = 0, M = 0; uint64_t seed = 0; int64_t* out = nullptr; bool valid = false; } boot_last;
-    int64_t stat_boot_recovered = 0, stat_boot_cooperative = 0;
-    int boot_spin_limit = 1 << 20;   // polls (x s_sleep 8) a workgroup waits at the grid barrier before giving up (option, tests force 1)
-    int boot_cooperative = 1;        // fused form is launched with hipLaunchCooperativeKernel (0: ordinary launch; A/B + tests)
-    int boot_lds = 1;        // bootstrap: LDS-resident code table when it fits (0: always the global-gather kernel)
-    int reg_km = 1;          // reg path: batches in flight per wave = km x 4 KiB
-    int prefix_stage = 1;    // scv_lane_prefix: snapshots staged in LDS when they fit (0: reductions at every boundary)
-    int prefix_lane = 1;     // prefix budgets over pools of N <= 64: one lane per problem, all budgets in one pass (scv_lane_prefix)
-    int prefix_cells = 1;    // prefix budgets over short pools (N <= 4096) run on the cell kernels (0: the one-pass kernels)
-    int reg_wpg = 0;         // reg path: waves per workgroup (0 = the kernel's own: all the waves a CU holds)
-    int reg_lds_counters = 1; // reg path: per-budget counters accumulate in LDS and are flushed by the same launch
-    int reg_shape = 0;       // reg path: force a kernel shape (A/B runs), see launch_aggregate
-    int reg_pivots = 0;      // reg path: pivots per lane (votes equal to a pivot are counted in registers): 0 = per batch (2 when it shows two hot values), 1, 2
-    int reg_dense4 = 0;      // reg path, 512 < N <= 1024: 1 = dense bin scan instead of the sparse read-back (A/B option)
-    int sort_cells = 1;      // 1: cells of sort_n_min <= N <= 64 votes in 16-byte aligned rows run one lane per cell, rows staged by LDS-DMA, sorted in registers (scv_sort_cells)
-    int sort_n_min = 8;      // shorter cells stay on scv_lane_cells
-    int sort_n_max = 64;     // longer cells go to the register-resident kernels (the 128-vote shape runs one wave per SIMD: measured 3.2 vs 3.8 TB/s)
-    int sort_kb = 0;         // blocks of 64 cells per step (0 = auto: 1)
-    int sort_spread = 1;     // sorted cells: the next step's LDS-DMA pieces are issued between the compare-exchanges of the sort (3-5 %; 0: back to back)
-    int sort_waves = 0;      // resident waves per CU of the sorted-cells kernel (0 = 16; 32 needs <= 64 VGPRs: the 8-vote shape)
-    int sort_db = 0;         // 1: N <= 16 gets two image buffers per wave, the copy two steps ahead (measured 5-13 % SLOWER: N = 16 81.7 vs 72.4 us; off)
-    int64_t stat_sort_cells = 0;
-    int reg_n_max = 8192;    // auto: 32 < N <= this -> register-resident cells kernel (scv_reg_cells); 0 = off (round-1 dispatch)
-    bool user_tuned = false; // set_tuning called: auto geometry off
+    int64_t stat_boot_recovered = 0, stat_boot_cooperative = 0, stat_sort_cells = 0;
     // split-N scratch (grown on demand)
     void* d_partial = nullptr;
     size_t d_partial_bytes = 0;
     void* d_cells = nullptr;  // cell table scratch for the reduce kernel when the caller wants no cells
     size_t d_cells_bytes = 0;
-    int pin_host = 0;         // HOST mode: hipHostRegister large caller buffers (measured: no gain over pageable copies, off)
-    int fused_counters_max = 4096;  // cells: at or below, per-cell atomics inside the hot kernel; above, scv_reduce_cells
-    int grid_override = 0;   // > 0: exact persistent grid size
-    int balance = 1;         // shrink the grid so every workgroup streams the same number of cells
     // device scratch
     uint32_t* d_err = nullptr;
     bool err_dirty = false;
@@ -197,9 +174,6 @@ struct scv_ctx {
     void* d_stage = nullptr;
     size_t d_stage_bytes = 0;
     HostPipe* pipe = nullptr;       // HOST-mode ingestion pipeline (created on the first HOST call)
-    int host_pipeline = 1;          // 0: the round-1 serial staging loop (A/B runs)
-    int stage_mb = 128;             // HOST mode: chunk size (votes + tokens) of the staging pipeline
-    int copy_threads = 6;           // HOST mode (4-8 reach the link rate; 16+ were unstable: 30-55 GB/s run to run): threads copying pageable caller memory into the pinned bounce slots
 };
 
 namespace {
@@ -221,14 +195,6 @@ int next_event_pair(scv_ctx* ctx, EventPair** out) {
     return SCV_OK;
 }
 
-int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
-
-bool valid_copies(int c) { return c == 4 || c == 8 || c == 16 || c == 32; }
-bool valid_threads(int t) { return t == 256 || t == 512 || t == 1024; }
-bool valid_unroll(int u) { return u == 2 || u == 4 || u == 8; }
 
 // Kernel variant tables live in their own translation units (scvote_stream_*.hip, scvote_reg.hip, scvote_dense.hip):
 // the template instantiations are compiled in parallel and only the table that changed is rebuilt (csrc/scvote_dispatch.h).
@@ -276,35 +242,10 @@ int ensure_cells(scv_ctx* ctx, size_t bytes) {
     return SCV_OK;
 }
 
-// Arrival counters: zero when allocated, and every counter is reset by the workgroup that completes it, so the
-// buffer is all-zero again whenever no launch is in flight.  scv_create allocates kTicketWordsAtCreate words (zeroed
-// synchronously), which covers the fixed-size users (overwrite mode, fused bootstrap: 4 words) -- those never allocate
-// on the launch path, so they are legal inside hipGraph capture and independent of later scv_set_stream calls.  Only
-// split-N cells merged inside the launch (option "ticket_merge") can outgrow it; growing synchronises, frees and
-// allocates, which is refused with a clear error while the stream is being captured.
-constexpr size_t kTicketWordsAtCreate = 4096;
-int ensure_tickets(scv_ctx* ctx, size_t words) {
-    if (words <= ctx->d_tickets_words) return SCV_OK;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-    if (cap != hipStreamCaptureStatusNone)
-        return fail(SCV_ERR_ARG, "ticket buffer must grow to %zu words while the stream is being captured: run this shape once outside the capture first", words);
-    if (ctx->d_tickets) { SCV_HIP(hipStreamSynchronize(ctx->stream)); SCV_HIP(hipFree(ctx->d_tickets)); ctx->d_tickets = nullptr; ctx->d_tickets_words = 0; }
-    words = (words + 1023) & ~(size_t)1023;
-    SCV_HIP(hipMalloc(&ctx->d_tickets, words * sizeof(uint32_t)));
-    SCV_HIP(hipMemset(ctx->d_tickets, 0, words * sizeof(uint32_t)));      // synchronous: ordered before anything on any stream
-    SCV_HIP(hipDeviceSynchronize());
-    ctx->d_tickets_words = words;
-    return SCV_OK;
-}
-
-int ensure_partial2(scv_ctx* ctx, size_t bytes) {
-    if (bytes <= ctx->d_partial2_bytes) return SCV_OK;
-    if (ctx->d_partial2) { SCV_HIP(hipFree(ctx->d_partial2)); ctx->d_partial2 = nullptr; ctx->d_partial2_bytes = 0; }
-    SCV_HIP(hipMalloc(&ctx->d_partial2, bytes));
-    ctx->d_partial2_bytes = bytes;
-    return SCV_OK;
-}
+// Arrival counters of the single-launch modes (overwrite-counters, vote + bootstrap): 4 words, zero when allocated at scv_create,
+// and every counter is reset by the workgroup that completes it, so they are all-zero again whenever no launch is in flight.
+// Nothing allocates on the launch path: legal inside hipGraph capture and independent of later scv_set_stream calls.
+constexpr size_t kTicketWords = 64;
 
 int ensure_partial(scv_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->d_partial_bytes) return SCV_OK;
@@ -317,11 +258,12 @@ int ensure_partial(scv_ctx* ctx, size_t bytes) {
 // Launch the hot path on device pointers.  Accumulates into the per-budget counters.
 //
 // Regimes behind one entry point (auto-selected from the shape; the "path" option forces one):
-//   tiny      N <= 32                      64/G cells per wave, registers only          (scv_tiny_cells)
-//   small-N   N <= small_n_max            one wave per cell, sparse clear              (scv_small_cells[_reg])
-//   split-N   cells <= CUs/2, big N        several workgroups per cell + merge kernel   (scv_hist_argmax + scv_merge_partials)
-//   stream    everything else              one persistent workgroup streams whole cells (scv_hist_argmax)
-// plus scv_reduce_cells behind any of them when the per-budget counters are not fused.
+//   lane      N <= 4 (and pool rows <= 32)  one lane per cell, registers only                (scv_lane_cells)
+//   sorted    5 / 8 <= N <= 64              one lane per cell, rows by LDS-DMA, sorted       (scv_sort_cells)
+//   register  up to 8192                    a cell in the registers of 16 / 32 / 64 lanes    (scv_reg_cells, scv_reg_dense)
+//   split-N   cells <= CUs/2, big N         several workgroups per cell + merge kernel       (scv_hist_argmax + scv_merge_partials)
+//   stream    everything else               one persistent workgroup streams whole cells     (scv_hist_argmax)
+// plus scv_reduce_cells behind the streaming kernel when the per-budget counters are not fused.
 // lds bytes of the one-lane-per-cell kernel (tie classes 0..nv and two sums per budget)
 size_t lane_kernel_lds(int32_t B, int nv) { return (((size_t)B * (nv + 1) + 1) & ~(size_t)1) * sizeof(uint32_t) + 2 * (size_t)B * sizeof(unsigned long long); }
 
@@ -341,19 +283,33 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
-    a.stagger_vecs = ctx->stagger_vecs;
-    a.plain_loads = ctx->plain_loads;
-    a.prefetch = ctx->prefetch;
-    a.tok_skew = ctx->tok_skew;
-    a.sorted = ctx->sorted;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0; a.reg_pivots = ctx->reg_pivots; a.sort_spread = ctx->sort_spread;
-    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
+    a.prefetch = 1;
+    a.sorted = 1;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0;
+    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr;
     const bool tok = tokens != nullptr;
-
-    // per-budget counters: fused per-cell atomics for few cells, a separate reduction of the cell
-    // table for many (same-address device atomics serialise at ~12 ns each)
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
-    bool use_reduce = want_counters && reduce_counters_separately(ctx, ncells, B, N);
+    const bool rows_aligned = (N % 4 == 0) && (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0);
+    const int64_t Nreg = rows_aligned ? N : N + 3;     // register-resident kernels read unaligned rows as their aligned supersets (up to 3 slots more)
+
+    // ---- which kernel (one decision, before anything is set up for it) -------------------------------------------------------
+    enum Kind { LANE, SORT, REG, STREAM } kind;
+    {
+        const bool sort_ok = !pool_rows && ctx->sort_n_max > 0 && N >= (rows_aligned ? 4 : 1) && N <= (ctx->sort_n_max < 64 ? ctx->sort_n_max : 64);
+        if (ctx->path == 5) kind = sort_ok ? SORT : (N <= ctx->tiny_n_max ? LANE : (Nreg <= 8192 ? REG : STREAM));
+        else if (ctx->path == 4) kind = (Nreg <= 8192 && N >= 1) ? REG : STREAM;
+        else if (ctx->path == 1 || ctx->path == 2) kind = STREAM;
+        else if (sort_ok && N >= (rows_aligned ? ctx->sort_n_min : (ctx->sort_n_min < 5 ? ctx->sort_n_min : 5))) kind = SORT;
+        else if (N <= ctx->tiny_n_max) kind = LANE;
+        else if (N <= ctx->reg_n_max && Nreg <= 8192) kind = REG;
+        else kind = STREAM;
+        if (kind == LANE && lane_kernel_lds(B, N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : 32))) > (size_t)60 * 1024) kind = REG;   // (thousands of budgets)
+    }
+
+    // ---- per-budget counters: inside the launch (LDS tables of the cell kernels; per-cell atomics of the streaming kernel for few
+    // cells) or from the cell table by scv_reduce_cells (same-address device atomics serialise at ~12 ns each; measured,
+    // profiles/r01_crossover_r4_d1.log: 65536 cells of 64 KiB with fused atomics 4.1 TB/s, with the separate reduction 6.6)
+    bool use_reduce = want_counters && (ctx->fused_counters_max == 0 || (kind == STREAM && ncells > ctx->fused_counters_max && N * (int64_t)B < (1 << 20)));
     auto need_cell_scratch = [&]() -> int {          // the counters will be computed from the cell table: make sure there is one
         a.tie_hits = nullptr; a.token_sum = nullptr; a.truth_sum = nullptr;
         if (!a.cells || (tok && tok_sum && !a.cell_tokens)) {
@@ -364,8 +320,29 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         }
         return SCV_OK;
     };
-    if (use_reduce)
+    // Overwrite semantics (option "overwrite_counters"): the streaming kernel turns its cell table into the counters with its
+    // last workgroup (single launch: no memset, no reduce launch) when the cells are few; every other kernel gets a memset node
+    // in front and accumulates as usual.
+    bool overwrite_fused = false;
+    if (ctx->overwrite_counters && want_counters) {
+        if (kind == STREAM && ncells <= 8192 && B <= 64) {
+            overwrite_fused = true;
+            use_reduce = false;
+        } else {
+            if (tie) SCV_HIP(hipMemsetAsync(tie, 0, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), ctx->stream));
+            if (tok_sum) SCV_HIP(hipMemsetAsync(tok_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
+            if (truth_sum) SCV_HIP(hipMemsetAsync(truth_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
+        }
+    }
+    if (use_reduce || overwrite_fused)
         if (int rc = need_cell_scratch()) return rc;
+    if (overwrite_fused) {
+        a.overwrite = 1;
+        a.tickets = static_cast<uint32_t*>(ctx->d_tickets);
+        a.ow_tie = reinterpret_cast<unsigned long long*>(tie);
+        a.ow_tok = reinterpret_cast<unsigned long long*>(tok_sum);
+        a.ow_truth = reinterpret_cast<unsigned long long*>(truth_sum);
+    }
     auto finish = [&](EventPair* ev_) -> int {
         if (use_reduce) {
             int64_t chunks = (P + 2047) / 2048;
@@ -385,81 +362,36 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         return SCV_OK;
     };
 
-    int path = ctx->path;
-    // Overwrite semantics (option "overwrite_counters"): the streaming kernel turns its cell table into the counters
-    // with its last workgroup (single launch: no memset, no reduce launch) when the cells are few; every other
-    // regime gets a memset node in front and accumulates as usual.
-    const bool stream_path = (path == 1 || path == 2) || (path == 0 && !(N > ctx->tiny_n_max && N <= ctx->reg_n_max) && N > ctx->small_n_max);
-    bool overwrite_fused = false;
-    if (ctx->overwrite_counters && want_counters) {
-        if (stream_path && ncells <= 8192 && B <= 64) {
-            overwrite_fused = true;
-            use_reduce = false;
-            if (int rc = need_cell_scratch()) return rc;
-            if (int rc = ensure_tickets(ctx, 4)) return rc;
-            a.overwrite = 1;
-            a.tickets = static_cast<uint32_t*>(ctx->d_tickets);
-            a.ow_tie = reinterpret_cast<unsigned long long*>(tie);
-            a.ow_tok = reinterpret_cast<unsigned long long*>(tok_sum);
-            a.ow_truth = reinterpret_cast<unsigned long long*>(truth_sum);
-        } else {
-            if (tie) SCV_HIP(hipMemsetAsync(tie, 0, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), ctx->stream));
-            if (tok_sum) SCV_HIP(hipMemsetAsync(tok_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
-            if (truth_sum) SCV_HIP(hipMemsetAsync(truth_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
-        }
-    }
-    if (path == 0) {
-        if (N > ctx->tiny_n_max && N <= ctx->reg_n_max) path = 4;
-        else path = (N <= ctx->small_n_max) ? 3 : 1;
-    }
-    // register-resident kernels: rows that are not all 16-byte aligned are read as their aligned supersets (up to 3 slots more)
-    const bool reg_vec = (N % 4 == 0) && (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0);
-    const int64_t Nreg = reg_vec ? N : N + 3;
-    if (path == 4 && (Nreg > 8192 || N < 1)) path = (N <= ctx->small_n_max) ? 3 : 1;   // (forced) reg path outside its range
-
     EventPair* ev = nullptr;
     if (int rc = next_event_pair(ctx, &ev)) return rc;
 
-    // ---- sorted cells: one lane per cell, the wave's 64 rows staged through LDS by LDS-DMA, sorted in registers (scvote_sort.hip.h).
-    // The reference's own range (N = 1 ... 128, o1.py:267,276), rows 16-byte aligned; "path" 5 forces it.
-    // Rows that are not all 16-byte aligned (N % 4 != 0, unaligned bases) take the linear-image form (dword reads), N <= 64.
-    const bool sort_lin = !reg_vec;
-    if ((ctx->path == 5 || (ctx->path == 0 && ctx->sort_cells && N >= (sort_lin ? 5 : ctx->sort_n_min))) && !pool_rows && N >= (sort_lin ? 1 : 4) &&
-        N <= ((sort_lin || tok) && ctx->sort_n_max > 64 ? 64 : ctx->sort_n_max)) {      // (the 128-vote shape: aligned rows, votes only)
-        const int nv = N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : (N <= 64 ? 64 : 128)));
-        int kb = (ctx->sort_kb > 0 && !sort_lin) ? ctx->sort_kb : 1;          // (measured: one block per step beats two at N = 8, 16)
-        if (nv > 16) kb = 1;
-        const bool db = nv <= 16 && kb == 1 && ctx->sort_db != 0;           // short rows: two image buffers per wave, the copy two steps ahead
-        const RegKernel rk = pick_sort_kernel(nv, kb, tok, sort_lin, db);
+    if (kind == SORT) {
+        // ---- sorted cells: one lane per cell, the wave's 64 rows staged through LDS by LDS-DMA, sorted in registers (scvote_sort.hip.h).
+        // The reference's own range (N = 1 ... 128, o1.py:267,276).  Rows that are not all 16-byte aligned (N % 4 != 0, unaligned
+        // bases) take the linear-image form (dword reads).
+        const bool sort_lin = !rows_aligned;
+        const int nv = N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : (N <= 48 ? 48 : 64)));
+        const RegKernel rk = pick_sort_kernel(nv, tok, sort_lin);
         const int64_t ps = (N / 4) | 1;
-        // (128 votes: the rows are staged in two halves of 16 slots through one image of 64 x 17 slots)
-        const int64_t image_words = nv == 128 ? (int64_t)64 * 17 * 4 : (sort_lin ? (((int64_t)kb * 64 * N * 4 + 16 + 1023) >> 10) * 256 : (int64_t)kb * 64 * ps * 4);
-        // one buffer: votes image | tokens image | the cells' truth values (256 bytes per block of 64 cells)
-        const int64_t region_words = (image_words * (tok ? 2 : 1) + (int64_t)kb * 64) * (db ? 2 : 1);
+        const int64_t image_words = sort_lin ? ((64 * N * 4 + 16 + 1023) >> 10) * 256 : 64 * ps * 4;
+        // one region per wave: votes image | tokens image | the cells' truth values (256 bytes)
+        const int64_t region_words = image_words * (tok ? 2 : 1) + 64;
         const int64_t tail_words = (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0) + ((((int64_t)B * (nv + 1) + 1) & ~(int64_t)1) + 4 * (int64_t)B);
         int W = rk.waves;
         while (W > 1 && (W * region_words + tail_words) * 4 > ctx->lds_max) --W;
         if ((W * region_words + tail_words) * 4 <= ctx->lds_max && W >= (rk.waves >= 16 ? 4 : 2)) {
-            if (use_reduce) {                                         // counters come out of this launch
-                use_reduce = false;
-                a.cells = cells; a.cell_tokens = cell_tokens;
-                a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
-                a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
-                a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
-            }
             a.wave_lds_words = (int32_t)region_words;
             const size_t lds = (size_t)(W * region_words + tail_words) * sizeof(uint32_t);
             SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rk.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            const int64_t nsteps = (ncells + (int64_t)kb * 64 - 1) / ((int64_t)kb * 64);
+            const int64_t nsteps = (ncells + 63) / 64;
             int64_t grid = (nsteps + W - 1) / W;
-            // persistent: one workgroup per CU (or as many as the LDS lets be resident)
+            // persistent: one workgroup per CU (or as many as the LDS lets be resident), 16 waves per CU at most
             int per_cu = (int)(ctx->lds_max / (int64_t)lds);
             if (per_cu < 1) per_cu = 1;
-            const int max_waves = ctx->sort_waves > 0 ? ctx->sort_waves : 16;             // (option "sort_waves": resident waves per CU, A/B)
-            if (per_cu * W > max_waves) per_cu = max_waves / W > 0 ? max_waves / W : 1;
+            if (per_cu * W > 16) per_cu = 16 / W > 0 ? 16 / W : 1;
             if (grid > (int64_t)ctx->num_cus * per_cu) grid = (int64_t)ctx->num_cus * per_cu;
             // cells per grid step a multiple of B: every lane slot then sees one budget and keeps its counters in registers
-            if ((grid * W * kb * 64) % B != 0 && grid > B) grid -= grid % B;
+            if ((grid * W * 64) % B != 0 && grid > B) grid -= grid % B;
             if (ctx->grid_override > 0) grid = ctx->grid_override;
             ctx->stat_sort_cells += 1;
             if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
@@ -467,11 +399,12 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             SCV_HIP(hipGetLastError());
             return finish(ev);
         }
+        kind = N <= ctx->tiny_n_max && lane_kernel_lds(B, N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : 32))) <= (size_t)60 * 1024 ? LANE : REG;   // (hundreds of budgets: the LDS tables do not fit)
     }
 
-    if (path == 4) {
-        // ---- register-resident cells: single-wave workgroups, 16 KiB of LDS each, 8 per CU
-        const bool vec = reg_vec;
+    if (kind == REG) {
+        // ---- register-resident cells: workgroups of independent waves, 8 KiB of LDS each
+        const bool vec = rows_aligned;
         // shape of the kernel from the slots a row needs (N, or N + 3 for unaligned rows); the "reg_shape" option forces one for
         // A/B runs: g*100 + v (sparse: g lanes per cell, v vectors per lane) or 1000 + v*10 + h (dense: h parts of v vectors)
         int g = 0, v = 0, h = 0;
@@ -489,19 +422,17 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             if (fv == 4 && (fh == 1 || fh == 2 || fh == 4 || fh == 8) && (int64_t)256 * fv * fh >= Nreg) { g = 0; v = fv; h = fh; }
         } else if (ctx->reg_shape > 0) {
             const int fg = ctx->reg_shape / 100, fv = ctx->reg_shape % 100;
-            if ((fg == 16 || fg == 32 || fg == 64) && (fv == 1 || fv == 2 || fv == 4) && (int64_t)4 * fg * fv >= Nreg) { g = fg; v = fv; h = 0; }
+            const bool have = (fg == 16 && (fv == 1 || fv == 2 || fv == 4)) || ((fg == 32 || fg == 64) && fv == 4);
+            if (have && (int64_t)4 * fg * fv >= Nreg) { g = fg; v = fv; h = 0; }
         }
         const int64_t cpw = h ? 1 : 64 / g;
         const int64_t nbatches = (ncells + cpw - 1) / cpw;
-        // 16-bit bins (8.3 KiB of LDS per wave) everywhere but the A/B dense scan of scv_reg_cells (32-bit, 16.4 KiB)
-        const bool bins16 = !(h == 0 && g == 64 && v == 4 && ctx->reg_dense4 != 0);
-        a.wave_lds_words = (int32_t)((bins16 ? scv::kRegWaveWords16 : scv::kRegWaveWords) + (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0));
-        const RegKernel rk = h ? pick_dense_kernel(v, h, tok, vec) : pick_reg_kernel(g, v, tok, vec, ctx->reg_dense4 != 0, ctx->reg_km);
+        a.wave_lds_words = (int32_t)(scv::kRegWaveWords16 + (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0));
+        const RegKernel rk = h ? pick_dense_kernel(v, h, tok, vec) : pick_reg_kernel(g, v, tok, vec);
         KernelFn fn = rk.fn;
-        // workgroup = all the waves of the shape a CU holds (16 / 12 / 8 / 4: the kernel's launch bounds), fewer when the
-        // n_valid cache makes 16 regions overflow the LDS, or when "reg_wpg" asks (A/B runs)
+        // workgroup = all the waves of the shape a CU holds (16 / 12 / 8: the kernel's launch bounds), fewer when the
+        // n_valid cache makes 16 regions overflow the LDS
         int WPG = rk.waves;
-        if (ctx->reg_wpg > 0 && ctx->reg_wpg < WPG) WPG = ctx->reg_wpg;
         while (WPG > 4 && (int64_t)WPG * a.wave_lds_words * 4 + 1024 > ctx->lds_max) WPG -= 4;
         size_t lds = (size_t)WPG * a.wave_lds_words * sizeof(uint32_t);
         SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -513,7 +444,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         // Per-budget counters in the LDS the resident workgroups leave free (no occupancy lost): [B][TCL] tie classes +
         // 2 B sums per workgroup, flushed by the same launch -> no scv_reduce_cells launch, no cell scratch.  Tie
         // classes that do not fit (TCL < min(N, 1024) + 1; only with many budgets) go to memory directly.
-        if (want_counters && ctx->reg_lds_counters) {
+        if (want_counters && !use_reduce) {
             const int64_t spare_words = (ctx->lds_max / per_cu - (int64_t)lds) / 4 - 64;
             const int64_t full = (N < 1024 ? N : 1024) + 1;
             int64_t tcl = spare_words > 4 * (int64_t)B + 2 ? (spare_words - 4 * (int64_t)B - 2) / B : 0;
@@ -521,18 +452,11 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             if (tcl >= 8 || tcl == full) {
                 a.acc_classes = (int32_t)tcl;
                 lds += ((((size_t)B * tcl + 1) & ~(size_t)1) + 4 * (size_t)B) * sizeof(uint32_t);
-                if (use_reduce) {                                 // undo the separate-reduction setup
-                    use_reduce = false;
-                    a.cells = cells; a.cell_tokens = cell_tokens;
-                }
-                a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
-                a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
-                a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
                 SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 int again = 0;
                 SCV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&again, reinterpret_cast<const void*>(fn), WPG * 64, lds));
                 if (again >= 1 && again < per_cu) per_cu = again;   // (not expected: the region was sized from the spare LDS)
-                ctx->stat_reg_lds_counters += 1;
+                ctx->stat_lds_counters += 1;
             }
         }
         int64_t grid = (int64_t)ctx->num_cus * per_cu;                     // workgroups of WPG independent waves
@@ -551,73 +475,24 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         return finish(ev);
     }
 
-    if (path == 3 && N <= ctx->tiny_n_max && N <= 32 && ctx->tiny_lane && N >= 1) {
+    if (kind == LANE) {
         // ---- tiny cells, one lane per cell; counters accumulated in LDS and flushed by the same launch
         const int nv = N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : 32));
         const int threads = (nv == 32 || (nv == 16 && tok)) ? 512 : 1024;      // register budget: 2 x nv votes (+ tokens) per lane
         const size_t lds = lane_kernel_lds(B, nv);
-        if (lds <= (size_t)60 * 1024) {
-            // counters come out of this launch: undo the separate-reduction setup
-            if (use_reduce) {
-                use_reduce = false;
-                a.cells = cells; a.cell_tokens = cell_tokens;
-                a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
-                a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
-                a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
-            }
-            a.wave_lds_words = ((N % 4 == 0) && (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0)) ? 1 : 0;   // "vec" flag
-            int64_t grid = (ncells + threads - 1) / threads;
-            if (grid > ctx->num_cus) grid = ctx->num_cus;            // one workgroup per CU: the flush costs one atomic per workgroup and counter
-            // grid * threads a multiple of B: every lane then sees one budget and keeps its counters in registers
-            if ((grid * threads) % B != 0 && grid > B) grid -= grid % B;
-            if (ctx->grid_override > 0) grid = ctx->grid_override;
-            if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+        a.wave_lds_words = rows_aligned ? 1 : 0;   // "vec" flag
+        int64_t grid = (ncells + threads - 1) / threads;
+        if (grid > ctx->num_cus) grid = ctx->num_cus;            // one workgroup per CU: the flush costs one atomic per workgroup and counter
+        // grid * threads a multiple of B: every lane then sees one budget and keeps its counters in registers
+        if ((grid * threads) % B != 0 && grid > B) grid -= grid % B;
+        if (ctx->grid_override > 0) grid = ctx->grid_override;
+        if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
 #define SCV_LANE(NVV, TT, TOKK) hipLaunchKernelGGL((scv::scv_lane_cells<NVV, TT, TOKK>), dim3((unsigned)grid), dim3(TT), lds, ctx->stream, a)
-            if (nv == 4) { if (tok) SCV_LANE(4, 1024, true); else SCV_LANE(4, 1024, false); }
-            else if (nv == 8) { if (tok) SCV_LANE(8, 1024, true); else SCV_LANE(8, 1024, false); }
-            else if (nv == 16) { if (tok) SCV_LANE(16, 512, true); else SCV_LANE(16, 1024, false); }
-            else { if (tok) SCV_LANE(32, 512, true); else SCV_LANE(32, 512, false); }
+        if (nv == 4) { if (tok) SCV_LANE(4, 1024, true); else SCV_LANE(4, 1024, false); }
+        else if (nv == 8) { if (tok) SCV_LANE(8, 1024, true); else SCV_LANE(8, 1024, false); }
+        else if (nv == 16) { if (tok) SCV_LANE(16, 512, true); else SCV_LANE(16, 1024, false); }
+        else { if (tok) SCV_LANE(32, 512, true); else SCV_LANE(32, 512, false); }
 #undef SCV_LANE
-            SCV_HIP(hipGetLastError());
-            return finish(ev);
-        }
-    }
-    if (path == 3 && N <= ctx->tiny_n_max && N <= 32) {
-        // ---- tiny cells: 64/G cells per wave, registers only
-        const int G = N <= 8 ? 8 : (N <= 16 ? 16 : 32);
-        const int64_t cells_per_wg = (int64_t)(64 / G) * 4;
-        int64_t grid = (ncells + cells_per_wg - 1) / cells_per_wg;
-        const int64_t cap = (int64_t)ctx->num_cus * 8;
-        if (grid > cap) grid = cap;
-        if (ctx->grid_override > 0) grid = ctx->grid_override;
-        if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
-#define SCV_TINY(GG)                                                                                          \
-        do {                                                                                                  \
-            if (tok) hipLaunchKernelGGL((scv::scv_tiny_cells<GG, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, a); \
-            else hipLaunchKernelGGL((scv::scv_tiny_cells<GG, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);    \
-        } while (0)
-        if (G == 8) SCV_TINY(8); else if (G == 16) SCV_TINY(16); else SCV_TINY(32);
-#undef SCV_TINY
-        SCV_HIP(hipGetLastError());
-        return finish(ev);
-    }
-    if (path == 3) {
-        // ---- small-N: 8 waves per workgroup, 32 KiB of private histograms, up to 4 workgroups per CU
-        constexpr int T = 512, NW = T / 64;
-        const size_t lds = ((size_t)NW * scv::kBins + scv::kMaxSortedB) * sizeof(uint32_t);
-        int64_t grid = (ncells + NW - 1) / NW;
-        const int64_t cap = (int64_t)ctx->num_cus * 4;
-        if (grid > cap) grid = cap;
-        if (ctx->grid_override > 0) grid = ctx->grid_override;
-        if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
-        if (N <= 128 && ctx->small_reg) {
-            if (tok) hipLaunchKernelGGL((scv::scv_small_cells_reg<T, 2, true>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
-            else hipLaunchKernelGGL((scv::scv_small_cells_reg<T, 2, false>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
-        } else if (N <= 512 && ctx->small_reg > 1) {
-            if (tok) hipLaunchKernelGGL((scv::scv_small_cells_reg<T, 8, true>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
-            else hipLaunchKernelGGL((scv::scv_small_cells_reg<T, 8, false>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
-        } else if (tok) hipLaunchKernelGGL((scv::scv_small_cells<T, true>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
-        else hipLaunchKernelGGL((scv::scv_small_cells<T, false>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
         SCV_HIP(hipGetLastError());
         return finish(ev);
     }
@@ -647,20 +522,16 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     // Measured (tools/segs_sweep.py): best is ONE round of items (at most one per workgroup slot) with
     // segments of at least 512 KiB -- more, smaller segments only add fold/publish/merge work.
     int64_t S = 1;
-    if (path == 2 || (ctx->path == 0 && 2 * ncells <= slots && N * 4 >= (1 << 20))) {
+    if (ctx->path == 2 || (ctx->path == 0 && 2 * ncells <= slots && N * 4 >= (1 << 20))) {
         if (ctx->segs_override > 0) S = ctx->segs_override;
         else {
             S = slots / ncells;
-            // two launches: segments of at least 512 KiB (more, smaller ones only add fold / publish / merge work);
-            // merged inside the launch: down to 256 KiB, so that ONE huge cell still gets a workgroup on every CU
-            const int64_t by_size = (N * 4) / ((ctx->ticket_merge ? 256 : 512) << 10);
+            const int64_t by_size = (N * 4) / (512 << 10);
             if (S > by_size) S = by_size;
-            if (ctx->ticket_merge && S > 256) S = 256;
         }
         if (S > 4096) S = 4096;
         if (S < 1) S = 1;
     }
-    bool merge_in_launch = false;
     if (S > 1) {
         a.segs = (int32_t)S;
         a.seg_len = ((N + S - 1) / S + 3) & ~(int64_t)3;     // multiple of 4 votes: segments start 16-byte aligned in aligned rows
@@ -670,27 +541,17 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         if (int rc = ensure_partial(ctx, hist_bytes + items * sizeof(long long) + 256)) return rc;
         a.partial = static_cast<uint32_t*>(ctx->d_partial);
         a.partial_tok = reinterpret_cast<long long*>(static_cast<char*>(ctx->d_partial) + ((hist_bytes + 255) / 256) * 256);
-        if (ctx->ticket_merge && S <= 256) {
-            // merge inside the launch: groups of <= 16 segments, then <= 16 groups (scv::merge_split_cell)
-            merge_in_launch = true;
-            ctx->stat_merge_in_launch += 1;
-            const int64_t G = (S + 15) / 16;
-            a.ticket_merge = 1;
-            a.ngroups = (int32_t)G;
-            const size_t h2 = (size_t)ncells * (size_t)G * scv::kBins * sizeof(uint32_t);
-            if (int rc = ensure_partial2(ctx, h2 + (size_t)ncells * G * sizeof(long long) + 256)) return rc;
-            a.partial2 = static_cast<uint32_t*>(ctx->d_partial2);
-            a.partial2_tok = reinterpret_cast<long long*>(static_cast<char*>(ctx->d_partial2) + ((h2 + 255) / 256) * 256);
-            if (int rc = ensure_tickets(ctx, 4 + (size_t)ncells * G + (size_t)ncells)) return rc;
-            a.tickets = static_cast<uint32_t*>(ctx->d_tickets);
-        }
     }
-    if (a.overwrite && S > 1 && !merge_in_launch) {
-        // split cells finished by the merge KERNEL: the main launch's last workgroup would read an unfinished cell
-        // table.  Overwrite = memset node + accumulate here.
+    // the single-launch epilogues exist for the geometries the library picks itself (scvote_dispatch.h)
+    const bool have_xtra = pick_kernel(copies, threads, unroll, tok, true) != nullptr;
+    if (a.overwrite && (S > 1 || !have_xtra)) {
+        // split cells are finished by the merge KERNEL (the main launch's last workgroup would read an unfinished cell table), and a
+        // hand-tuned geometry may have no epilogue variant: overwrite = memset node + accumulate here.
         a.overwrite = 0;
         overwrite_fused = false;
+        a.tickets = nullptr;
         a.ow_tie = a.ow_tok = a.ow_truth = nullptr;
+        a.cells = cells; a.cell_tokens = cell_tokens;
         a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
         a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
         a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
@@ -698,13 +559,12 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         if (tok_sum) SCV_HIP(hipMemsetAsync(tok_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
         if (truth_sum) SCV_HIP(hipMemsetAsync(truth_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
     }
-    if (a.overwrite || a.ticket_merge) a.tickets = static_cast<uint32_t*>(ctx->d_tickets);   // (the buffer may have grown)
     if (overwrite_fused) ctx->stat_overwrite_fused += 1;                                     // counted once the form is final
     const int64_t nitems = ncells * S;
     int64_t grid = slots;
     if (ctx->grid_override > 0) grid = ctx->grid_override;
     if (grid > nitems) grid = nitems;
-    if (ctx->balance && ctx->grid_override <= 0) {
+    if (ctx->grid_override <= 0) {
         // A 4 MiB cell is several percent of a launch: a ragged last round (10000 cells over 256
         // workgroups = 39.06 rounds) idles most of the chip for a whole cell.  Use the smallest grid
         // with the same number of rounds, so every workgroup streams `rounds` (or rounds-1) items.
@@ -714,15 +574,14 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
 
     // bootstrap inside this launch (scv_aggregate_bootstrap_i32): whole cells only, code table + counters in the
     // histogram's LDS, and the whole grid resident at once (it meets at a grid barrier)
-    if (ctx->boot_req && ctx->boot_fused && S == 1 && a.cells && unroll == 4) {
+    if (ctx->boot_req && ctx->boot_path <= 1 && S == 1 && a.cells && have_xtra) {
         const scv_ctx::BootReq& rq = *ctx->boot_req;
         const size_t need_words = (((size_t)B * rq.M + 3) & ~(size_t)3) + ((size_t)ncells + 1) / 2;
-        KernelFn fx = pick_kernel(copies, threads, 4, tok, true);
+        KernelFn fx = pick_kernel(copies, threads, unroll, tok, true);
         int per_cu = 0;
         SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         SCV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fx), threads, lds));
         if (need_words <= (size_t)scv::kBins * copies && grid <= (int64_t)per_cu * ctx->num_cus && P <= 0xFFFFFFFFll) {
-            if (int rc = ensure_tickets(ctx, 4)) return rc;
             a.boot = 1;
             a.boot_r0 = rq.r0; a.boot_r1 = rq.r1; a.boot_M = rq.M; a.boot_seed = rq.seed;
             a.boot_spins = (uint32_t)(ctx->boot_spin_limit > 0 ? ctx->boot_spin_limit : 1);
@@ -730,7 +589,9 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             a.tickets = static_cast<uint32_t*>(ctx->d_tickets);
         }
     }
-    KernelFn fn = pick_kernel(copies, threads, unroll, tok, a.overwrite != 0 || a.ticket_merge != 0 || a.boot != 0);
+    const bool xtra = a.overwrite != 0 || a.boot != 0;
+    KernelFn fn = pick_kernel(copies, threads, unroll, tok, xtra);
+    if (!fn) return fail(SCV_ERR_ARG, "streaming geometry copies=%d threads=%d unroll=%d is not instantiated (scv_set_tuning lists the ones that are)", copies, threads, unroll);
     SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
     bool launched = false;
@@ -741,7 +602,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         // the bounded spin + the repair in scv_sync cover a grid that turned out not to be co-resident.
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-        if (ctx->boot_cooperative && cap == hipStreamCaptureStatusNone) {
+        if (ctx->boot_path == 0 && cap == hipStreamCaptureStatusNone) {
             void* kargs[] = {const_cast<scv::AggArgs*>(&a)};
             const hipError_t ce = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3((unsigned)grid), dim3((unsigned)threads), kargs, (unsigned)lds, ctx->stream);
             if (ce == hipSuccess) { launched = true; ctx->stat_boot_cooperative += 1; }
@@ -749,7 +610,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
                 // refused (grid too large for a cooperative launch right now, or no support): two kernels instead
                 (void)hipGetLastError();
                 a.boot = 0; a.boot_out = nullptr;
-                fn = pick_kernel(copies, threads, unroll, tok, a.overwrite != 0 || a.ticket_merge != 0);
+                fn = pick_kernel(copies, threads, unroll, tok, a.overwrite != 0);
                 SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             }
         }
@@ -763,7 +624,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     }
     if (!launched) hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)threads), lds, ctx->stream, a);
     SCV_HIP(hipGetLastError());
-    if (S > 1 && !merge_in_launch) {
+    if (S > 1) {
         int64_t mgrid = ncells < (int64_t)ctx->num_cus * 8 ? ncells : (int64_t)ctx->num_cus * 8;
         if (tok) hipLaunchKernelGGL((scv::scv_merge_partials<true>), dim3((unsigned)mgrid), dim3(1024), 0, ctx->stream, a);
         else hipLaunchKernelGGL((scv::scv_merge_partials<false>), dim3((unsigned)mgrid), dim3(1024), 0, ctx->stream, a);
@@ -772,32 +633,32 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     return finish(ev);
 }
 
-// Prefix budgets over one pool [P, N]: one pass, snapshots at the boundaries (scv_prefix_hist /
-// scv_small_prefix).  Same outputs as launch_aggregate on the dense [P, B, N] expansion.
 int launch_dense(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
                  const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells, int64_t* cell_tokens,
                  int64_t* tie, int64_t* tok_sum, int64_t* truth_sum) {
     return launch_aggregate(ctx, answers, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, false);
 }
 
-// Short pools (N <= 4096: the reference's own sizes) go through the cell kernels instead: the pool row is re-read
-// per budget, but out of the cache, and a cell costs what its n_valid votes cost -- the one-pass kernels below pay a
-// workgroup-wide fold per boundary (measured at P x N = 10^5 x 256, budgets 1, 2, 4 ... N: 240 -> 60 us).
+// Short pools (N <= 4096: the reference's own sizes) go through the cell kernels: the pool row is re-read per budget, but out of
+// the cache, and a cell costs what its n_valid votes cost -- the one-pass streaming kernel pays a workgroup-wide fold per
+// boundary (measured at P x N = 10^5 x 256, budgets 1, 2, 4 ... N: 240 -> 60 us).
 bool pool_rows_eligible(const scv_ctx* ctx, int32_t B, int64_t N, bool rows_aligned) {
-    if (ctx->path != 0 || !ctx->prefix_cells || N < 1) return false;
+    if (ctx->path != 0 || N < 1) return false;
     if (N > ctx->tiny_n_max) return N <= ctx->reg_n_max && N + (rows_aligned ? 0 : 3) <= 4096;   // (+ 3: an unaligned pool row is read as its aligned superset)
     const int nv = N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : 32));
-    return N <= 32 && ctx->tiny_lane && lane_kernel_lds(B, nv) <= (size_t)60 * 1024;
+    return lane_kernel_lds(B, nv) <= (size_t)60 * 1024;
 }
 
 // pools of up to 64 samples: scv_lane_prefix (tie classes 0..nv, two sums, order + sorted n_valid per budget in LDS)
 bool prefix_lane_eligible(const scv_ctx* ctx, int32_t B, int64_t N, int* nv, size_t* lds) {
-    if (ctx->path != 0 || !ctx->prefix_lane || N < 1 || N > 64 || B > scv::kMaxSortedB) return false;
+    if (ctx->path != 0 || N < 1 || N > 64 || B > scv::kMaxSortedB) return false;
     *nv = N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : 64)));
     *lds = ((((size_t)B * (*nv + 1) + 1) & ~(size_t)1) + 6 * (size_t)B) * sizeof(uint32_t);
     return *lds <= (size_t)24 * 1024;   // + up to 128 KiB for the staged cell records (B <= 8)
 }
 
+// Prefix budgets over one pool [P, N] (scv_aggregate_prefix_i32).  Same outputs as launch_aggregate on the dense [P, B, N]
+// expansion.  Option "prefix_path" forces one of the three forms (parity tests).
 int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, const int32_t* n_valid,
                   const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells, int64_t* cell_tokens,
                   int64_t* tie, int64_t* tok_sum, int64_t* truth_sum) {
@@ -805,9 +666,9 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     if (ncells == 0) return SCV_OK;
     int lane_nv = 0;
     size_t lane_lds = 0;
-    const bool lane_ok = prefix_lane_eligible(ctx, B, N, &lane_nv, &lane_lds);
+    const bool lane_ok = prefix_lane_eligible(ctx, B, N, &lane_nv, &lane_lds) && (ctx->prefix_path == 0 || ctx->prefix_path == 1);
     const bool rows_aligned = (N % 4 == 0) && (((uintptr_t)pool & 15u) == 0) && (!tokens || ((uintptr_t)tokens & 15u) == 0);
-    if (!lane_ok && pool_rows_eligible(ctx, B, N, rows_aligned)) {
+    if (!lane_ok && pool_rows_eligible(ctx, B, N, rows_aligned) && (ctx->prefix_path == 0 || ctx->prefix_path == 2)) {
         ctx->stat_prefix_cells += 1;
         return launch_aggregate(ctx, pool, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, true);
     }
@@ -820,14 +681,14 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
-    a.stagger_vecs = 0; a.plain_loads = ctx->plain_loads; a.prefetch = 0; a.tok_skew = ctx->tok_skew; a.sorted = 1;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0; a.reg_pivots = ctx->reg_pivots;
-    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr; a.ticket_merge = 0; a.ngroups = 1; a.partial2 = nullptr; a.partial2_tok = nullptr;
+    a.prefetch = 0; a.sorted = 1;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0;
+    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
     // pools of up to 64 samples: one lane per problem, every budget out of one pass (scv_lane_prefix); its counters
     // come out of the same launch
-    const bool use_reduce = want_counters && !lane_ok && reduce_counters_separately(ctx, ncells, B, N);
+    const bool use_reduce = want_counters && !lane_ok && (ctx->fused_counters_max == 0 || (ncells > ctx->fused_counters_max && N * (int64_t)B < (1 << 20)));
     if (use_reduce) {
         a.tie_hits = nullptr; a.token_sum = nullptr; a.truth_sum = nullptr;
         if (!a.cells || (tok && tok_sum && !a.cell_tokens)) {
@@ -845,10 +706,8 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     EventPair* ev = nullptr;
     if (int rc = next_event_pair(ctx, &ev)) return rc;
     if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
-    int path = ctx->path;
-    if (path == 0 || path == 2) path = (N <= ctx->small_n_max) ? 3 : 1;
     if (lane_ok) {
-        a.wave_lds_words = ((N % 4 == 0) && (((uintptr_t)pool & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0)) ? 1 : 0;   // "vec" flag
+        a.wave_lds_words = rows_aligned ? 1 : 0;   // "vec" flag
         // Workgroup size.  N <= 32: 1024 threads, one workgroup per CU (the end-of-launch flush is one device atomic per
         // workgroup and counter, ~12 ns each on one address).  N = 64 needs 95-151 VGPRs: 256 threads, as many workgroups
         // as are resident (measured 61-64 us against 84-86 us with 768 / 1024 threads, which spill or leave a second, nearly
@@ -861,7 +720,6 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
         for (int t = T; t >= 256; t >>= 1) {
             if (counters_bytes + (size_t)(t / 64) * per_wave + 1024 <= (size_t)ctx->lds_max) { T = t; staged = true; break; }
         }
-        if (!ctx->prefix_stage) { staged = false; T = lane_nv == 64 ? 256 : 1024; }
         const size_t lds_total = staged ? counters_bytes + (size_t)(T / 64) * per_wave : lane_lds;
         a.lane_stage = staged ? 1 : 0;
         KernelFn fn;
@@ -878,15 +736,8 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
         if (ctx->grid_override > 0) grid = ctx->grid_override;
         hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)T), lds_total, ctx->stream, a);
         ctx->stat_prefix_lane += 1;
-    } else if (path == 3) {
-        constexpr int T = 512, NW = T / 64;
-        const size_t lds = ((size_t)NW * scv::kBins + scv::kMaxSortedB) * sizeof(uint32_t);
-        int64_t grid = (P + NW - 1) / NW;
-        const int64_t cap = (int64_t)ctx->num_cus * 4;
-        if (grid > cap) grid = cap;
-        if (tok) hipLaunchKernelGGL((scv::scv_small_prefix<T, true>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
-        else hipLaunchKernelGGL((scv::scv_small_prefix<T, false>), dim3((unsigned)grid), dim3(T), lds, ctx->stream, a);
     } else {
+        // one pass over the pool, a snapshot of the LDS histogram at every boundary (scv_prefix_hist): pools longer than 4096 votes
         int copies, threads, wg_per_cu;
         if (N < 32768) { copies = 8; threads = 256; wg_per_cu = 4; }
         else if (N < 262144) { copies = 16; threads = 512; wg_per_cu = 2; }
@@ -894,7 +745,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
         const size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords + scv::kMaxSortedB) * sizeof(uint32_t);
         int64_t grid = (int64_t)ctx->num_cus * wg_per_cu;
         if (grid > P) grid = P;
-        if (ctx->balance) { const int64_t rounds = (P + grid - 1) / grid; grid = (P + rounds - 1) / rounds; }
+        { const int64_t rounds = (P + grid - 1) / grid; grid = (P + rounds - 1) / rounds; }
         KernelFn fn;
         if (threads == 256) fn = tok ? (KernelFn)scv::scv_prefix_hist<3, 256, 4, true> : (KernelFn)scv::scv_prefix_hist<3, 256, 4, false>;
         else if (threads == 512) fn = tok ? (KernelFn)scv::scv_prefix_hist<4, 512, 4, true> : (KernelFn)scv::scv_prefix_hist<4, 512, 4, false>;
@@ -950,7 +801,7 @@ int check_err_word(scv_ctx* ctx, uint32_t w) {
 int recover_fused_bootstrap(scv_ctx* ctx, uint32_t* w) {
     SCV_HIP(hipMemsetAsync(ctx->d_tickets, 0, 4 * sizeof(uint32_t), ctx->stream));      // arrivals / generation: a clean barrier again
     if (!ctx->boot_last.valid)
-        return fail(SCV_ERR_ARG, "fused bootstrap: grid barrier timed out and the request is not known any more (graph replay of an older capture?); use option boot_fused = 0");
+        return fail(SCV_ERR_ARG, "fused bootstrap: grid barrier timed out and the request is not known any more (graph replay of an older capture?); use option boot_path = 2");
     const scv_ctx::BootLast q = ctx->boot_last;
     *w &= ~(4u | 2u);                            // bit 2 (class overflow) is re-derived by the re-run over the complete table
     if (int rc = scv_bootstrap(ctx, q.cells, q.P, q.B, q.r0, q.r1, q.seed, q.M, SCV_MEM_DEVICE, q.out)) return rc;
@@ -1002,9 +853,9 @@ int scv_create(scv_ctx** out, int device, uint32_t flags) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) { ctx->own_stream = true; e = hipMalloc((void**)&ctx->d_err, 256); }
     if (e == hipSuccess) e = hipMemset(ctx->d_err, 0, 256);
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_tickets, kTicketWordsAtCreate * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(ctx->d_tickets, 0, kTicketWordsAtCreate * sizeof(uint32_t));
-    if (e == hipSuccess) { ctx->d_tickets_words = kTicketWordsAtCreate; e = hipDeviceSynchronize(); }
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_tickets, kTicketWords * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(ctx->d_tickets, 0, kTicketWords * sizeof(uint32_t));
+    if (e == hipSuccess) { ctx->d_tickets_words = kTicketWords; e = hipDeviceSynchronize(); }
     if (e != hipSuccess) {
         int code = fail(-(int)e, "scv_create: %s", hipGetErrorString(e));
         if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
@@ -1017,26 +868,6 @@ int scv_create(scv_ctx** out, int device, uint32_t flags) {
     ctx->lds_max = 160 * 1024;  // gfx950: a single workgroup may declare all 160 KiB
     ctx->clock_khz = prop.clockRate;
     ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
-    ctx->copies = env_int("SCV_COPIES", ctx->copies);
-    ctx->threads = env_int("SCV_THREADS", ctx->threads);
-    ctx->wg_per_cu = env_int("SCV_WG_PER_CU", ctx->wg_per_cu);
-    ctx->unroll = env_int("SCV_UNROLL", ctx->unroll);
-    ctx->grid_override = env_int("SCV_GRID", 0);
-    ctx->balance = env_int("SCV_BALANCE", 1);
-    ctx->stagger_vecs = env_int("SCV_STAGGER_VECS", ctx->stagger_vecs);
-    ctx->plain_loads = env_int("SCV_PLAIN_LOADS", 0);
-    ctx->path = env_int("SCV_PATH", 0);
-    ctx->sorted = env_int("SCV_SORTED", 1);
-    ctx->small_n_max = env_int("SCV_SMALL_N_MAX", ctx->small_n_max);
-    ctx->copy_threads = env_int("SCV_COPY_THREADS", ctx->copy_threads);
-    ctx->host_pipeline = env_int("SCV_HOST_PIPELINE", ctx->host_pipeline);
-    if (ctx->copy_threads < 1) ctx->copy_threads = 1;
-    if (getenv("SCV_COPIES") || getenv("SCV_THREADS") || getenv("SCV_WG_PER_CU") || getenv("SCV_UNROLL")) ctx->user_tuned = true;
-    if (!valid_copies(ctx->copies) || !valid_threads(ctx->threads) || !valid_unroll(ctx->unroll) || ctx->wg_per_cu < 1) {
-        int code = fail(SCV_ERR_ARG, "bad SCV_* tuning environment");
-        scv_destroy(ctx);
-        return code;
-    }
     *out = ctx;
     return SCV_OK;
 }
@@ -1050,7 +881,6 @@ int scv_destroy(scv_ctx* ctx) {
     if (ctx->pipe) { ctx->pipe->shutdown(); delete ctx->pipe; ctx->pipe = nullptr; }
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
-    if (ctx->d_partial2) (void)hipFree(ctx->d_partial2);
     if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
     if (ctx->d_cells) (void)hipFree(ctx->d_cells);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
@@ -1087,58 +917,34 @@ int scv_sync(scv_ctx* ctx) {
 
 int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unroll) {
     if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
-    if (copies > 0) { if (!valid_copies(copies)) return fail(SCV_ERR_ARG, "copies must be 4, 8, 16 or 32"); ctx->copies = copies; }
-    if (threads > 0) { if (!valid_threads(threads)) return fail(SCV_ERR_ARG, "threads must be 256, 512 or 1024"); ctx->threads = threads; }
+    const int c = copies > 0 ? copies : ctx->copies, t = threads > 0 ? threads : ctx->threads, u = unroll > 0 ? unroll : ctx->unroll;
+    if (copies > 0 || threads > 0 || unroll > 0)
+        if (!scv::pick_kernel(c, t, u, false, false))
+            return fail(SCV_ERR_ARG, "streaming geometry copies=%d threads=%d unroll=%d is not instantiated: (copies, threads) in (4, 256) [unroll 2], "
+                        "(8, 256) (8, 512) (16, 256) (16, 512) (16, 1024) [unroll 4]", c, t, u);
+    ctx->copies = c; ctx->threads = t; ctx->unroll = u;
     if (wg_per_cu > 0) ctx->wg_per_cu = wg_per_cu;
-    if (unroll > 0) { if (!valid_unroll(unroll)) return fail(SCV_ERR_ARG, "unroll must be 2, 4 or 8"); ctx->unroll = unroll; }
-    if (copies > 0 || threads > 0 || wg_per_cu > 0 || unroll > 0) ctx->user_tuned = true;   // explicit geometry wins over the mid-N auto choice
+    if (copies > 0 || threads > 0 || wg_per_cu > 0 || unroll > 0) ctx->user_tuned = true;   // explicit geometry wins over the auto choice
     return SCV_OK;
 }
 
 int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return fail(SCV_ERR_ARG, "NULL argument");
-    if (!strcmp(key, "grid")) { if (value < 0 || value > (1 << 20)) return fail(SCV_ERR_ARG, "grid out of range"); ctx->grid_override = (int)value; }
-    else if (!strcmp(key, "balance")) ctx->balance = value != 0;
-    else if (!strcmp(key, "stagger_vecs")) { if (value < 0 || value > (1 << 28)) return fail(SCV_ERR_ARG, "stagger out of range"); ctx->stagger_vecs = (int)value; }
-    else if (!strcmp(key, "plain_loads")) ctx->plain_loads = value != 0;
-    else if (!strcmp(key, "prefetch")) ctx->prefetch = value != 0;
-    else if (!strcmp(key, "path")) { if (value < 0 || value > 5) return fail(SCV_ERR_ARG, "path must be 0..5"); ctx->path = (int)value; }
-    else if (!strcmp(key, "sort_cells")) ctx->sort_cells = value != 0;
-    else if (!strcmp(key, "sort_n_min")) { if (value < 4 || value > 129) return fail(SCV_ERR_ARG, "sort_n_min must be 4..129"); ctx->sort_n_min = (int)value; }
-    else if (!strcmp(key, "sort_n_max")) { if (value < 4 || value > 128) return fail(SCV_ERR_ARG, "sort_n_max must be 4..128"); ctx->sort_n_max = (int)value; }
-    else if (!strcmp(key, "sort_db")) ctx->sort_db = value != 0;
-    else if (!strcmp(key, "sort_spread")) ctx->sort_spread = value != 0;
-    else if (!strcmp(key, "sort_waves")) { if (value < 0 || value > 32) return fail(SCV_ERR_ARG, "sort_waves must be 0..32"); ctx->sort_waves = (int)value; }
-    else if (!strcmp(key, "sort_kb")) { if (value < 0 || value > 2) return fail(SCV_ERR_ARG, "sort_kb must be 0, 1 or 2"); ctx->sort_kb = (int)value; }
-    else if (!strcmp(key, "reg_dense4")) ctx->reg_dense4 = value != 0;
-    else if (!strcmp(key, "reg_pivots")) { if (value < 0 || value > 2) return fail(SCV_ERR_ARG, "reg_pivots must be 0, 1 or 2"); ctx->reg_pivots = (int)value; }
-    else if (!strcmp(key, "boot_lds")) ctx->boot_lds = value != 0;
-    else if (!strcmp(key, "tiny_lane")) ctx->tiny_lane = value != 0;
-    else if (!strcmp(key, "tok_skew")) ctx->tok_skew = value != 0;
-    else if (!strcmp(key, "boot_fused")) ctx->boot_fused = value != 0;
-    else if (!strcmp(key, "boot_cooperative")) ctx->boot_cooperative = value != 0;
-    else if (!strcmp(key, "boot_spin_limit")) { if (value < 1 || value > (1 << 30)) return fail(SCV_ERR_ARG, "boot_spin_limit out of range"); ctx->boot_spin_limit = (int)value; }
-    else if (!strcmp(key, "overwrite_counters")) ctx->overwrite_counters = value != 0;
-    else if (!strcmp(key, "ticket_merge")) ctx->ticket_merge = value != 0;
-    else if (!strcmp(key, "reg_lds_counters")) ctx->reg_lds_counters = value != 0;
-    else if (!strcmp(key, "prefix_cells")) ctx->prefix_cells = value != 0;
-    else if (!strcmp(key, "prefix_lane")) ctx->prefix_lane = value != 0;
-    else if (!strcmp(key, "prefix_stage")) ctx->prefix_stage = value != 0;
-    else if (!strcmp(key, "reg_wpg")) { if (value != 0 && value != 4 && value != 8 && value != 12 && value != 16) return fail(SCV_ERR_ARG, "reg_wpg must be 0, 4, 8, 12 or 16"); ctx->reg_wpg = (int)value; }
-    else if (!strcmp(key, "reg_km")) { if (value != 1 && value != 2 && value != 4) return fail(SCV_ERR_ARG, "reg_km must be 1, 2 or 4"); ctx->reg_km = (int)value; }
-    else if (!strcmp(key, "reg_shape")) { if (value < 0 || value > 9999) return fail(SCV_ERR_ARG, "reg_shape out of range"); ctx->reg_shape = (int)value; }
+    if (!strcmp(key, "overwrite_counters")) ctx->overwrite_counters = value != 0;
+    else if (!strcmp(key, "path")) { if (value < 0 || value > 5 || value == 3) return fail(SCV_ERR_ARG, "path must be 0, 1, 2, 4 or 5"); ctx->path = (int)value; }
+    else if (!strcmp(key, "sort_n_min")) { if (value < 1 || value > 65) return fail(SCV_ERR_ARG, "sort_n_min must be 1..65"); ctx->sort_n_min = (int)value; }
+    else if (!strcmp(key, "sort_n_max")) { if (value < 0 || value > 64) return fail(SCV_ERR_ARG, "sort_n_max must be 0..64"); ctx->sort_n_max = (int)value; }
     else if (!strcmp(key, "reg_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "reg_n_max < 0"); ctx->reg_n_max = (int)(value > 8192 ? 8192 : value); }
+    else if (!strcmp(key, "reg_shape")) { if (value < 0 || value > 9999) return fail(SCV_ERR_ARG, "reg_shape out of range"); ctx->reg_shape = (int)value; }
+    else if (!strcmp(key, "fused_counters_max")) { if (value < 0) return fail(SCV_ERR_ARG, "fused_counters_max < 0"); ctx->fused_counters_max = (int)(value > (1 << 30) ? (1 << 30) : value); }
+    else if (!strcmp(key, "grid")) { if (value < 0 || value > (1 << 20)) return fail(SCV_ERR_ARG, "grid out of range"); ctx->grid_override = (int)value; }
     else if (!strcmp(key, "segs")) { if (value < 0 || value > 4096) return fail(SCV_ERR_ARG, "segs out of range"); ctx->segs_override = (int)value; }
-    else if (!strcmp(key, "sorted")) ctx->sorted = value != 0;
-    else if (!strcmp(key, "small_reg")) ctx->small_reg = (int)(value < 0 ? 0 : (value > 2 ? 2 : value));
-    else if (!strcmp(key, "tiny_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "tiny_n_max < 0"); ctx->tiny_n_max = (int)(value > 32 ? 32 : value); }
-    else if (!strcmp(key, "small_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "small_n_max < 0"); ctx->small_n_max = (int)(value > 32768 ? 32768 : value); }
     else if (!strcmp(key, "auto_geometry")) ctx->user_tuned = value == 0;
-    else if (!strcmp(key, "pin_host")) ctx->pin_host = value != 0;
-    else if (!strcmp(key, "host_pipeline")) ctx->host_pipeline = value != 0;
+    else if (!strcmp(key, "prefix_path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "prefix_path must be 0..3"); ctx->prefix_path = (int)value; }
+    else if (!strcmp(key, "boot_path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "boot_path must be 0..3"); ctx->boot_path = (int)value; }
+    else if (!strcmp(key, "boot_spin_limit")) { if (value < 1 || value > (1 << 30)) return fail(SCV_ERR_ARG, "boot_spin_limit out of range"); ctx->boot_spin_limit = (int)value; }
     else if (!strcmp(key, "stage_mb")) { if (value < 1 || value > 65536) return fail(SCV_ERR_ARG, "stage_mb out of range"); ctx->stage_mb = (int)value; }
     else if (!strcmp(key, "copy_threads")) { if (value < 1 || value > 256) return fail(SCV_ERR_ARG, "copy_threads out of range"); ctx->copy_threads = (int)value; }
-    else if (!strcmp(key, "fused_counters_max")) { if (value < 0) return fail(SCV_ERR_ARG, "fused_counters_max < 0"); ctx->fused_counters_max = (int)(value > (1 << 30) ? (1 << 30) : value); }
     else return fail(SCV_ERR_ARG, "unknown option '%s'", key);
     return SCV_OK;
 }
@@ -1146,79 +952,6 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
 }  // extern "C" (reopened below)
 
 namespace {
-
-// The round-1 HOST path, kept for A/B runs (option "host_pipeline" = 0): one staging block, copy -> kernel ->
-// sync per chunk, pageable copies through the runtime's bounce buffers.
-int host_serial(scv_ctx* ctx, bool prefix, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
-                const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells_out, int64_t* cell_tokens_out,
-                int64_t* tie_class_hits_out, int64_t* token_sum_out, int64_t* truth_count_sum_out) {
-    auto launch = prefix ? launch_prefix : launch_dense;
-    // ---- HOST: stage problem-chunks through HBM ------------------------------------------------
-    const size_t row_bytes = (prefix ? (size_t)1 : (size_t)B) * (size_t)N * sizeof(int32_t);   // votes of one problem
-    // Pageable host memory is copied through the runtime's bounce buffers at a fraction of the link
-    // rate; pinning the caller's pages in place makes every chunk one DMA.  Best effort: a buffer that
-    // cannot be registered (already registered, not page-able) is simply copied the slow way.
-    struct Pin {
-        const void* p = nullptr;
-        ~Pin() { if (p) (void)hipHostUnregister(const_cast<void*>(p)); }
-        void pin(const void* q, size_t bytes) {
-            if (q && bytes >= ((size_t)32 << 20) && hipHostRegister(const_cast<void*>(q), bytes, hipHostRegisterDefault) == hipSuccess) p = q;
-            else (void)hipGetLastError();
-        }
-    } pin_a, pin_t;
-    if (ctx->pin_host) {
-        pin_a.pin(answers, (size_t)P * row_bytes);
-        pin_t.pin(tokens, (size_t)P * row_bytes);
-    }
-    const size_t budget = (size_t)env_int("SCV_STAGE_MB", 2048) << 20;                          // votes (+tokens) per chunk
-    const size_t per_problem = row_bytes * (tokens ? 2 : 1);
-    int64_t chunk = per_problem ? (int64_t)(budget / per_problem) : P;
-    if (chunk < 1) chunk = 1;
-    if (chunk > P) chunk = P;
-    const size_t counters_bytes = ((size_t)B * SCV_TIE_CLASSES + 2 * (size_t)B) * sizeof(int64_t);
-    size_t off = 0;
-    const size_t o_ans = off; off = align_up(off + (size_t)chunk * row_bytes, 256);
-    const size_t o_tok = off; off = align_up(off + (tokens ? (size_t)chunk * row_bytes : 0), 256);
-    const size_t o_truth = off; off = align_up(off + (size_t)chunk * sizeof(int32_t), 256);
-    const size_t o_nv = off; off = align_up(off + (size_t)B * sizeof(int32_t), 256);
-    const size_t o_cells = off; off = align_up(off + (size_t)chunk * B * sizeof(scv_cell), 256);
-    const size_t o_ctok = off; off = align_up(off + (size_t)chunk * B * sizeof(int64_t), 256);
-    const size_t o_cnt = off; off = align_up(off + counters_bytes, 256);
-    if (int rc = ensure_stage(ctx, off > 0 ? off : 256)) return rc;
-    char* base = static_cast<char*>(ctx->d_stage);
-    int64_t* d_tie = reinterpret_cast<int64_t*>(base + o_cnt);
-    int64_t* d_tok = d_tie + (size_t)B * SCV_TIE_CLASSES;
-    int64_t* d_ts = d_tok + B;
-    hipStream_t s = ctx->stream;
-    SCV_HIP(hipMemsetAsync(base + o_cnt, 0, counters_bytes > 0 ? counters_bytes : 1, s));
-    if (n_valid && B > 0) SCV_HIP(hipMemcpyAsync(base + o_nv, n_valid, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    const size_t row_elems = row_bytes / sizeof(int32_t);
-    for (int64_t p0 = 0; p0 < P; p0 += chunk) {
-        const int64_t pc = (P - p0 < chunk) ? (P - p0) : chunk;
-        if (row_bytes) SCV_HIP(hipMemcpyAsync(base + o_ans, answers + (size_t)p0 * row_elems, (size_t)pc * row_bytes, hipMemcpyHostToDevice, s));
-        if (tokens && row_bytes) SCV_HIP(hipMemcpyAsync(base + o_tok, tokens + (size_t)p0 * row_elems, (size_t)pc * row_bytes, hipMemcpyHostToDevice, s));
-        SCV_HIP(hipMemcpyAsync(base + o_truth, truth + p0, (size_t)pc * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        if (int rc = launch(ctx, reinterpret_cast<const int32_t*>(base + o_ans),
-                            tokens ? reinterpret_cast<const int32_t*>(base + o_tok) : nullptr,
-                            n_valid ? reinterpret_cast<const int32_t*>(base + o_nv) : nullptr,
-                            reinterpret_cast<const int32_t*>(base + o_truth), pc, B, N,
-                            reinterpret_cast<scv_cell*>(base + o_cells),
-                            reinterpret_cast<int64_t*>(base + o_ctok), d_tie, d_tok, d_ts))
-            return rc;
-        if (cells_out && B > 0) SCV_HIP(hipMemcpyAsync(cells_out + (size_t)p0 * B, base + o_cells, (size_t)pc * B * sizeof(scv_cell), hipMemcpyDeviceToHost, s));
-        if (cell_tokens_out && B > 0) SCV_HIP(hipMemcpyAsync(cell_tokens_out + (size_t)p0 * B, base + o_ctok, (size_t)pc * B * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        SCV_HIP(hipStreamSynchronize(s));  // the single staging block is reused by the next chunk
-    }
-    if (B > 0) {
-        if (tie_class_hits_out) SCV_HIP(hipMemcpyAsync(tie_class_hits_out, d_tie, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        if (token_sum_out) SCV_HIP(hipMemcpyAsync(token_sum_out, d_tok, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        if (truth_count_sum_out) SCV_HIP(hipMemcpyAsync(truth_count_sum_out, d_ts, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    }
-    SCV_HIP(hipStreamSynchronize(s));
-    uint32_t w = 0;
-    if (int rc = fetch_err(ctx, &w)) return rc;
-    return check_err_word(ctx, w);
-}
 
 bool is_pinned_host(const void* p) {
     if (!p) return false;
@@ -1284,7 +1017,6 @@ int host_pipelined(scv_ctx* ctx, bool prefix, const int32_t* answers, const int3
     const size_t total = per_problem * (size_t)P;
     // chunk: at most stage_mb, and small enough that a call of a few tens of MB still overlaps copy and DMA
     size_t target = (size_t)(ctx->stage_mb > 0 ? ctx->stage_mb : 128) << 20;
-    if (const char* e = getenv("SCV_STAGE_MB")) { if (*e) target = (size_t)atoi(e) << 20; }
     if (total / 8 < target) target = total / 8 > ((size_t)4 << 20) ? total / 8 : ((size_t)4 << 20);
     int64_t chunk = per_problem ? (int64_t)(target / per_problem) : P;
     if (chunk < 1) chunk = 1;
@@ -1401,11 +1133,8 @@ int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const in
     // HOST mode accumulates its own zeroed counters over the chunks: the DEVICE-mode overwrite option must not apply
     struct Restore { scv_ctx* c; int v; ~Restore() { c->overwrite_counters = v; } } restore{ctx, ctx->overwrite_counters};
     ctx->overwrite_counters = 0;
-    if (ctx->host_pipeline)
-        return host_pipelined(ctx, prefix, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
-                              tie_class_hits_out, token_sum_out, truth_count_sum_out);
-    return host_serial(ctx, prefix, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
-                       tie_class_hits_out, token_sum_out, truth_count_sum_out);
+    return host_pipelined(ctx, prefix, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
+                          tie_class_hits_out, token_sum_out, truth_count_sum_out);
 }
 
 }  // namespace
@@ -1443,9 +1172,9 @@ int scv_bootstrap(scv_ctx* ctx, const scv_cell* cells, int64_t P, int32_t B, int
     hipStream_t s = ctx->stream;
     const size_t out_bytes = (size_t)R * B * M * sizeof(int64_t);
     // LDS-resident kernel when the 2-byte code table + counters fit (P * B up to ~70 k cells); otherwise the
-    // global-gather kernel.  "boot_lds" = 0 forces the latter (A/B runs, tests).
+    // global-gather kernel.  "boot_path" = 3 forces the latter (parity tests).
     const size_t lds_fast = (((size_t)B * M + 3) & ~(size_t)3) * sizeof(uint32_t) + (((size_t)P * B + 7) & ~(size_t)7) * sizeof(uint16_t);
-    const bool fast = ctx->boot_lds && lds_fast <= (size_t)144 * 1024;
+    const bool fast = ctx->boot_path != 3 && lds_fast <= (size_t)144 * 1024;
     auto launch_boot = [&](const scv_cell* d_cells, unsigned long long* d_out) -> int {
         if (fast) {
             int64_t grid = (int64_t)ctx->num_cus;                          // one 1024-thread workgroup per CU, R / grid resamples each
@@ -1515,7 +1244,9 @@ int scv_synth_fill_i32(scv_ctx* ctx, int32_t* answers, int32_t* tokens, int32_t*
 int scv_export_error_word(scv_ctx* ctx, int64_t* dst_device) {
     if (!ctx || !dst_device) return fail(SCV_ERR_ARG, "NULL argument");
     SCV_ENTER(ctx);
-    hipLaunchKernelGGL(scv::scv_export_err_k, dim3(1), dim3(1), 0, ctx->stream, ctx->d_err, reinterpret_cast<long long*>(dst_device));
+    // the word as scv_sync would JUDGE it: under SCV_FLAG_CLAMP_TO_INVALID_BIN an out-of-domain vote is not an error (bit 0 dropped)
+    const uint32_t mask = (ctx->flags & SCV_FLAG_CLAMP_TO_INVALID_BIN) ? ~1u : ~0u;
+    hipLaunchKernelGGL(scv::scv_export_err_k, dim3(1), dim3(1), 0, ctx->stream, ctx->d_err, mask, reinterpret_cast<long long*>(dst_device));
     SCV_HIP(hipGetLastError());
     return SCV_OK;
 }
@@ -1571,11 +1302,10 @@ int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
     else if (!strcmp(key, "boot_recovered")) *out = ctx->stat_boot_recovered;
     else if (!strcmp(key, "boot_cooperative")) *out = ctx->stat_boot_cooperative;
     else if (!strcmp(key, "overwrite_fused")) *out = ctx->stat_overwrite_fused;
-    else if (!strcmp(key, "reg_lds_counters")) *out = ctx->stat_reg_lds_counters;
+    else if (!strcmp(key, "lds_counters")) *out = ctx->stat_lds_counters;
     else if (!strcmp(key, "prefix_cells")) *out = ctx->stat_prefix_cells;
     else if (!strcmp(key, "prefix_lane")) *out = ctx->stat_prefix_lane;
     else if (!strcmp(key, "sort_cells")) *out = ctx->stat_sort_cells;
-    else if (!strcmp(key, "merge_in_launch")) *out = ctx->stat_merge_in_launch;
     else return fail(SCV_ERR_ARG, "unknown stat '%s'", key);
     return SCV_OK;
 }
@@ -1610,15 +1340,13 @@ KernelFn pick_kernel(int copies, int t, int u, bool tok, bool xtra) {
     switch (copies) {
     case 4: return pick_stream_c4(t, u, tok, xtra);
     case 8: return pick_stream_c8(t, u, tok, xtra);
-    case 32: return pick_stream_c32(t, u, tok, xtra);
-    default: return pick_stream_c16(t, u, tok, xtra);
+    case 16: return pick_stream_c16(t, u, tok, xtra);
+    default: return nullptr;
     }
 }
-RegKernel pick_reg_kernel(int g, int v, bool tok, bool vec, bool dense4, int km) {
-    (void)km;   // 8 and 16 KiB in flight per wave (KM = 2, 4) were measured equal / slower (profiles/r02 notes): not instantiated
+RegKernel pick_reg_kernel(int g, int v, bool tok, bool vec) {
     if (g == 16) return pick_reg_g16(v, tok, vec);
     if (g == 32) return pick_reg_g32(v, tok, vec);
-    return pick_reg_g64(v, tok, vec, dense4);
+    return pick_reg_g64(v, tok, vec);
 }
 }  // namespace scv
-

@@ -19,6 +19,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <new>
 #include <vector>
 
@@ -41,6 +42,23 @@ __global__ __launch_bounds__(256) void scv_sum_peers_k(PeerPtrs in, int n, long 
         out[i] = s;
     }
 }
+
+// ---- self-test of a new communicator (scv_comm_create) ---------------------------------------------------------------------
+// pattern of rank r, round k, word i: every rank / round / word differs, sums over ranks are closed-form
+__device__ __host__ inline long long comm_pattern(int r, int k, int64_t i) {
+    return (long long)(r + 1) * 0x100000001ll + (long long)i * (2 * r + 1) + (long long)k * 0x10001ll * (r + 3);
+}
+__global__ __launch_bounds__(256) void scv_comm_fill_k(long long* buf, int r, int k, int64_t count) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) buf[i] = comm_pattern(r, k, i);
+}
+// res[0] += words of `buf` that differ from `rank_lo..rank_hi`'s summed patterns; res[1] = min(first differing word)
+__global__ __launch_bounds__(256) void scv_comm_verify_k(const long long* buf, int rank_lo, int rank_hi, int k, int64_t count, unsigned long long* res) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        long long want = 0;
+        for (int r = rank_lo; r < rank_hi; ++r) want += comm_pattern(r, k, i);
+        if (__builtin_nontemporal_load(buf + i) != want) { atomicAdd(&res[0], 1ull); atomicMin(&res[1], (unsigned long long)i); }
+    }
+}
 }  // namespace scv
 
 // ---- RCCL, resolved at run time -------------------------------------------------------------------------------------
@@ -51,6 +69,7 @@ struct Rccl {
     int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -63,14 +82,15 @@ struct Rccl {
         CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
         AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        Broadcast = (decltype(Broadcast))dlsym(lib, "ncclBroadcast");
         GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-        return CommInitAll && CommDestroy && AllReduce && GroupStart && GroupEnd && GetErrorString;
+        return CommInitAll && CommDestroy && AllReduce && Broadcast && GroupStart && GroupEnd && GetErrorString;
     }
 };
 Rccl g_rccl;
-constexpr int kNcclInt64 = 4, kNcclSum = 0;     // rccl.h: ncclDataType_t / ncclRedOp_t
+constexpr int kNcclInt8 = 0, kNcclInt64 = 4, kNcclSum = 0;     // rccl.h: ncclDataType_t / ncclRedOp_t
 
 struct DeviceScope {
     int prev = -1;
@@ -88,7 +108,14 @@ struct scv_comm {
     std::vector<void*> tmp;
     size_t tmp_bytes = 0;
     std::vector<ncclComm_t> nccl;
+    int64_t stat_selftest_words = 0;     // words verified per rank by the create-time self-test (0: one rank, nothing to test)
 };
+
+namespace {
+constexpr size_t kTmpBytesAtCreate = 1 << 20;   // staging buffer of the one-shot all-reduce: 131072 int64 (B <= 127 budgets' counters) without
+                                                // ever allocating on the launch path (legal under hipGraph capture)
+int comm_selftest(scv_comm* c);
+}
 
 #define COMM_HIP(expr)                                                                                     \
     do {                                                                                                   \
@@ -171,6 +198,18 @@ int scv_comm_create(scv_comm** out, const int* devices, int n, uint32_t ctx_flag
             return scv::comm_fail(-1000 - rc, "ncclCommInitAll: %s", msg);
         }
     }
+    if (n > 1 || (comm_flags & SCV_COMM_RCCL)) {
+        for (int r = 0; r < n; ++r) {
+            if (hipSetDevice(c->devices[r]) != hipSuccess || hipMalloc(&c->tmp[r], kTmpBytesAtCreate) != hipSuccess) {
+                scv_comm_destroy(c);
+                return scv::comm_fail(SCV_ERR_ALLOC, "scv_comm_create: staging buffer on device %d", c->devices[r]);
+            }
+        }
+        c->tmp_bytes = kTmpBytesAtCreate;
+        // First contact with the devices happens HERE, loudly: known patterns through every peer path and through one whole
+        // all-reduce, verified on every device -- wrong xGMI visibility is an error at create, not a wrong accuracy later.
+        if (int rc = comm_selftest(c)) { scv_comm_destroy(c); return rc; }
+    }
     *out = c;
     return SCV_OK;
 }
@@ -184,9 +223,9 @@ int scv_allreduce_counters(scv_comm* c, int64_t* const* buffers, int64_t count) 
     if (count < 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allreduce_counters: negative count");
     for (int r = 0; r < c->n; ++r)
         if (!buffers[r] && count > 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allreduce_counters: buffer of rank %d is NULL", r);
-    if (count == 0 || c->n == 1) return SCV_OK;                // one rank: the buffer already holds the sum
+    if (count == 0 || (c->n == 1 && !(c->flags & SCV_COMM_RCCL))) return SCV_OK;    // one rank: the buffer already holds the sum
     DeviceScope scope;
-    if (c->flags & SCV_COMM_RCCL) {
+    if (c->flags & SCV_COMM_RCCL) {                            // (one rank included: a 1-GPU box then executes the RCCL call path itself)
         int rc = g_rccl.GroupStart();
         for (int r = 0; r < c->n && rc == 0; ++r)
             rc = g_rccl.AllReduce(buffers[r], buffers[r], (size_t)count, kNcclInt64, kNcclSum, c->nccl[r], scv::ctx_stream(c->ctx[r]));
@@ -198,6 +237,13 @@ int scv_allreduce_counters(scv_comm* c, int64_t* const* buffers, int64_t count) 
     // ---- one-shot over peer access --------------------------------------------------------------------------------
     const size_t bytes = (size_t)count * sizeof(int64_t);
     if (bytes > c->tmp_bytes) {
+        for (int r = 0; r < c->n; ++r) {                       // growing synchronises, frees and allocates: not while a stream is being captured
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(scv::ctx_stream(c->ctx[r]), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+            if (cap != hipStreamCaptureStatusNone)
+                return scv::comm_fail(SCV_ERR_ARG, "scv_allreduce_counters: %lld words need a larger staging buffer while rank %d's stream is being captured: "
+                                      "run this size once outside the capture first", (long long)count, r);
+        }
         for (int r = 0; r < c->n; ++r) {
             COMM_HIP(hipSetDevice(c->devices[r]));
             COMM_HIP(hipStreamSynchronize(scv::ctx_stream(c->ctx[r])));
@@ -231,6 +277,85 @@ int scv_allreduce_counters(scv_comm* c, int64_t* const* buffers, int64_t count) 
     return SCV_OK;
 }
 
+// In-place all-gather of byte blocks: bufs[r] (on rank r's device) is the WHOLE gathered buffer, in which rank r has written its
+// own block [off_r, off_r + bytes[r]), off_r = bytes[0] + ... + bytes[r - 1]; afterwards every rank's buffer holds every block.
+static int allgather_blocks(scv_comm* c, void* const* bufs, const int64_t* bytes, const char* who) {
+    if (!c || !bufs || !bytes) return scv::comm_fail(SCV_ERR_ARG, "%s: NULL argument", who);
+    int64_t total = 0;
+    std::vector<int64_t> off(c->n);
+    for (int r = 0; r < c->n; ++r) {
+        if (bytes[r] < 0) return scv::comm_fail(SCV_ERR_ARG, "%s: negative block size of rank %d", who, r);
+        off[r] = total;
+        total += bytes[r];
+    }
+    for (int r = 0; r < c->n; ++r)
+        if (!bufs[r] && total > 0) return scv::comm_fail(SCV_ERR_ARG, "%s: buffer of rank %d is NULL", who, r);
+    if (total == 0 || (c->n == 1 && !(c->flags & SCV_COMM_RCCL))) return SCV_OK;
+    DeviceScope scope;
+    if (c->flags & SCV_COMM_RCCL) {                            // one broadcast per block, all in one group
+        int rc = g_rccl.GroupStart();
+        for (int root = 0; root < c->n && rc == 0; ++root) {
+            if (bytes[root] == 0) continue;
+            for (int r = 0; r < c->n && rc == 0; ++r) {
+                char* blk = static_cast<char*>(bufs[r]) + off[root];
+                rc = g_rccl.Broadcast(blk, blk, (size_t)bytes[root], kNcclInt8, root, c->nccl[r], scv::ctx_stream(c->ctx[r]));
+            }
+        }
+        const int rc2 = g_rccl.GroupEnd();
+        if (rc == 0) rc = rc2;
+        if (rc != 0) return scv::comm_fail(-1000 - rc, "%s: ncclBroadcast: %s", who, g_rccl.GetErrorString(rc));
+        return SCV_OK;
+    }
+    for (int r = 0; r < c->n; ++r) {                           // 1. every rank's own block is complete at `ready`
+        COMM_HIP(hipSetDevice(c->devices[r]));
+        COMM_HIP(hipEventRecord(c->ready[r], scv::ctx_stream(c->ctx[r])));
+    }
+    for (int r = 0; r < c->n; ++r) {                           // 2. every rank PULLS the other ranks' blocks over its own links
+        COMM_HIP(hipSetDevice(c->devices[r]));
+        hipStream_t s = scv::ctx_stream(c->ctx[r]);
+        for (int j = 0; j < c->n; ++j) {
+            if (j == r || bytes[j] == 0) continue;
+            COMM_HIP(hipStreamWaitEvent(s, c->ready[j], 0));
+            COMM_HIP(hipMemcpyAsync(static_cast<char*>(bufs[r]) + off[j], static_cast<const char*>(bufs[j]) + off[j], (size_t)bytes[j], hipMemcpyDeviceToDevice, s));
+        }
+        COMM_HIP(hipEventRecord(c->done[r], s));
+    }
+    for (int r = 0; r < c->n; ++r) {                           // 3. a rank's later work may overwrite its block only when every reader has it
+        COMM_HIP(hipSetDevice(c->devices[r]));
+        hipStream_t s = scv::ctx_stream(c->ctx[r]);
+        for (int j = 0; j < c->n; ++j) if (j != r) COMM_HIP(hipStreamWaitEvent(s, c->done[j], 0));
+    }
+    return SCV_OK;
+}
+
+int scv_allgather_cells(scv_comm* c, scv_cell* const* tables, const int64_t* rows, int32_t B) {
+    if (!c || !rows || B < 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allgather_cells: bad argument");
+    std::vector<int64_t> bytes(c->n);
+    for (int r = 0; r < c->n; ++r) {
+        if (rows[r] < 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allgather_cells: negative row count of rank %d", r);
+        bytes[r] = rows[r] * (int64_t)B * (int64_t)sizeof(scv_cell);
+    }
+    return allgather_blocks(c, reinterpret_cast<void* const*>(tables), bytes.data(), "scv_allgather_cells");
+}
+
+int scv_allgather_i64(scv_comm* c, int64_t* const* buffers, const int64_t* counts) {
+    if (!c || !counts) return scv::comm_fail(SCV_ERR_ARG, "scv_allgather_i64: bad argument");
+    std::vector<int64_t> bytes(c->n);
+    for (int r = 0; r < c->n; ++r) {
+        if (counts[r] < 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allgather_i64: negative count of rank %d", r);
+        bytes[r] = counts[r] * (int64_t)sizeof(int64_t);
+    }
+    return allgather_blocks(c, reinterpret_cast<void* const*>(buffers), bytes.data(), "scv_allgather_i64");
+}
+
+int scv_comm_get_stat(scv_comm* c, const char* key, int64_t* out) {
+    if (!c || !key || !out) return scv::comm_fail(SCV_ERR_ARG, "scv_comm_get_stat: NULL argument");
+    if (!strcmp(key, "selftest_words")) *out = c->stat_selftest_words;
+    else if (!strcmp(key, "staging_bytes")) *out = (int64_t)c->tmp_bytes;
+    else return scv::comm_fail(SCV_ERR_ARG, "scv_comm_get_stat: unknown key '%s'", key);
+    return SCV_OK;
+}
+
 int scv_comm_sync(scv_comm* c) {
     if (!c) return scv::comm_fail(SCV_ERR_ARG, "comm is NULL");
     int first = SCV_OK;
@@ -242,3 +367,98 @@ int scv_comm_sync(scv_comm* c) {
 }
 
 }  // extern "C"
+
+namespace {
+// Create-time self-test (ranks > 1).  Two rounds with different patterns -- the second round catches a reader that kept stale
+// lines of a peer's buffer from the first:
+//   (a) SCV_COMM_PEER: every rank reads every OTHER rank's pattern buffer directly (the access path of scv_sum_peers_k, ordered by
+//       the same cross-device events) and compares it with that rank's closed-form pattern -> an error names the device PAIR;
+//   (b) one scv_allreduce_counters of the pattern buffers, verified on every device against the closed-form sum -> names the device;
+//   (c) one scv_allgather_i64 of per-rank blocks, verified on every device.
+int comm_selftest(scv_comm* c) {
+    constexpr int64_t K = 8216 + 1;                            // the production payload: packed counters at B = 8 + the error word
+    const int n = c->n;
+    std::vector<long long*> buf(n, nullptr), gat(n, nullptr);
+    std::vector<unsigned long long*> res(n, nullptr);
+    auto cleanup = [&]() {
+        for (int r = 0; r < n; ++r) {
+            (void)hipSetDevice(c->devices[r]);
+            if (buf[r]) (void)hipFree(buf[r]);
+            if (gat[r]) (void)hipFree(gat[r]);
+            if (res[r]) (void)hipFree(res[r]);
+        }
+    };
+    struct Cleanup { decltype(cleanup)& f; ~Cleanup() { f(); } } guard{cleanup};
+    DeviceScope scope;
+    const int64_t blk = 1031;                                  // all-gather block of every rank (words)
+    const size_t res_bytes = (size_t)(2 * (n + 2)) * sizeof(unsigned long long);
+    for (int r = 0; r < n; ++r) {
+        COMM_HIP(hipSetDevice(c->devices[r]));
+        COMM_HIP(hipMalloc((void**)&buf[r], K * sizeof(long long)));
+        COMM_HIP(hipMalloc((void**)&gat[r], (size_t)n * blk * sizeof(long long)));
+        COMM_HIP(hipMalloc((void**)&res[r], res_bytes));
+    }
+    std::vector<unsigned long long> init(2 * (n + 2));
+    for (size_t i = 0; i < init.size(); i += 2) { init[i] = 0; init[i + 1] = ~0ull; }
+    std::vector<unsigned long long> host(2 * (n + 2));
+    for (int round = 0; round < 2; ++round) {
+        for (int r = 0; r < n; ++r) {
+            COMM_HIP(hipSetDevice(c->devices[r]));
+            hipStream_t s = scv::ctx_stream(c->ctx[r]);
+            COMM_HIP(hipMemcpyAsync(res[r], init.data(), res_bytes, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(scv::scv_comm_fill_k, dim3(8), dim3(256), 0, s, buf[r], r, round, K);
+            hipLaunchKernelGGL(scv::scv_comm_fill_k, dim3(8), dim3(256), 0, s, gat[r] + (int64_t)r * blk, r, round + 2, blk);
+            COMM_HIP(hipGetLastError());
+            COMM_HIP(hipEventRecord(c->ready[r], s));
+        }
+        if (!(c->flags & SCV_COMM_RCCL)) {                     // (a) pairwise peer reads
+            for (int r = 0; r < n; ++r) {
+                COMM_HIP(hipSetDevice(c->devices[r]));
+                hipStream_t s = scv::ctx_stream(c->ctx[r]);
+                for (int j = 0; j < n; ++j) {
+                    if (j == r) continue;
+                    COMM_HIP(hipStreamWaitEvent(s, c->ready[j], 0));
+                    hipLaunchKernelGGL(scv::scv_comm_verify_k, dim3(8), dim3(256), 0, s, buf[j], j, j + 1, round, K, res[r] + 2 * j);
+                    COMM_HIP(hipGetLastError());
+                }
+                COMM_HIP(hipEventRecord(c->done[r], s));
+            }
+            for (int r = 0; r < n; ++r) {                      // nobody overwrites its buffer (the all-reduce below) before the readers are done
+                COMM_HIP(hipSetDevice(c->devices[r]));
+                for (int j = 0; j < n; ++j) if (j != r) COMM_HIP(hipStreamWaitEvent(scv::ctx_stream(c->ctx[r]), c->done[j], 0));
+            }
+        }
+        std::vector<int64_t*> bp(n), gp(n);
+        std::vector<int64_t> cnt(n, blk);
+        for (int r = 0; r < n; ++r) { bp[r] = reinterpret_cast<int64_t*>(buf[r]); gp[r] = reinterpret_cast<int64_t*>(gat[r]); }
+        if (int rc = scv_allreduce_counters(c, bp.data(), K)) return rc;                 // (b)
+        if (int rc = scv_allgather_i64(c, gp.data(), cnt.data())) return rc;             // (c)
+        for (int r = 0; r < n; ++r) {
+            COMM_HIP(hipSetDevice(c->devices[r]));
+            hipStream_t s = scv::ctx_stream(c->ctx[r]);
+            hipLaunchKernelGGL(scv::scv_comm_verify_k, dim3(8), dim3(256), 0, s, buf[r], 0, n, round, K, res[r] + 2 * n);
+            for (int j = 0; j < n; ++j)                        // block j of the gathered buffer = rank j's pattern (round + 2); one slot for all blocks
+                hipLaunchKernelGGL(scv::scv_comm_verify_k, dim3(8), dim3(256), 0, s, gat[r] + (int64_t)j * blk, j, j + 1, round + 2, blk, res[r] + 2 * (n + 1));
+            COMM_HIP(hipGetLastError());
+        }
+        for (int r = 0; r < n; ++r) {
+            COMM_HIP(hipSetDevice(c->devices[r]));
+            COMM_HIP(hipMemcpyAsync(host.data(), res[r], res_bytes, hipMemcpyDeviceToHost, scv::ctx_stream(c->ctx[r])));
+            COMM_HIP(hipStreamSynchronize(scv::ctx_stream(c->ctx[r])));
+            for (int j = 0; j < n; ++j)
+                if (host[2 * j])
+                    return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create self-test (round %d): device %d (rank %d) reads %llu of %lld words of device %d's (rank %d) buffer wrong "
+                                          "over peer access, first at word %llu: peer visibility between this device pair is broken -- use SCV_COMM_RCCL",
+                                          round, c->devices[r], r, host[2 * j], (long long)K, c->devices[j], j, host[2 * j + 1]);
+            if (host[2 * n])
+                return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create self-test (round %d): after one all-reduce of known patterns device %d (rank %d) holds %llu of %lld wrong sums "
+                                      "(first at word %llu; %s)", round, c->devices[r], r, host[2 * n], (long long)K, host[2 * n + 1], (c->flags & SCV_COMM_RCCL) ? "RCCL" : "one-shot over peer access");
+            if (host[2 * (n + 1)])
+                return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create self-test (round %d): after one all-gather of known blocks device %d (rank %d) holds %llu wrong words "
+                                      "(first at word %llu of a block; %s)", round, c->devices[r], r, host[2 * (n + 1)], host[2 * (n + 1) + 1], (c->flags & SCV_COMM_RCCL) ? "RCCL" : "peer copies");
+        }
+    }
+    c->stat_selftest_words = 2 * (K * (int64_t)((c->flags & SCV_COMM_RCCL) ? 1 : n) + (int64_t)n * blk);
+    return SCV_OK;
+}
+}  // namespace

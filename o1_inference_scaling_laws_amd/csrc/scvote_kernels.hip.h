@@ -59,10 +59,7 @@ struct AggArgs {
     unsigned long long* token_sum;
     unsigned long long* truth_sum;
     uint32_t* err_flag;
-    int32_t stagger_vecs;   // > 0: workgroup w starts each cell rotated by (w * stagger_vecs) 16-byte vectors
-    int32_t plain_loads;    // != 0: ordinary loads instead of non-temporal ones
     int32_t prefetch;       // != 0: load the first tile of the next item before the current item's epilogue
-    int32_t tok_skew;       // != 0: the token row is read rotated by half a row against the vote row
     int64_t P;              // problems (for the budget-major traversal)
     int32_t sorted;         // != 0: traverse budgets in descending n_valid order
     int32_t segs;           // split-N: segments per cell (1 = whole cells)
@@ -72,13 +69,11 @@ struct AggArgs {
                             // row p of answers / tokens [P, N] (its first n_valid[b] votes) instead of row p * B + b of [P, B, N]
     int32_t lane_stage;     // scv_lane_prefix: != 0 = a wave's 64 x B cell records are transposed through LDS and written as one
                             // contiguous block (a lane's own records are B * 16 bytes apart)
-    int32_t sort_spread;    // sorted-cells kernel: != 0 = the next step's LDS-DMA pieces are issued between the compare-exchanges of the sort, not back to back
-    int32_t reg_pivots;     // register-resident kernels: 1 = the lanes' second pivot is switched off (A/B runs); otherwise two pivots per lane
     int32_t acc_classes;    // register-resident kernels: > 0 = per-budget counters accumulate in LDS (this many tie classes per
                             // budget; larger classes go to memory directly) and are flushed once per workgroup
     // single-launch modes of the streaming kernel (agent-scope hand-offs inside the launch, no second kernel):
-    uint32_t* tickets;      // [0] workgroups finished | [1] barrier arrivals | [2] barrier generation | [4 ..] split-N arrival
-                            // counters; [0], [1] and [4 ..] are zero between launches, [2] only ever grows
+    uint32_t* tickets;      // [0] workgroups finished | [1] barrier arrivals | [2] barrier generation; [0] and [1] are zero between
+                            // launches, [2] only ever grows
     int32_t overwrite;      // != 0: per-budget counters are OVERWRITTEN by the last workgroup to finish (from the cell table)
     unsigned long long* ow_tie;     // overwrite outputs (tie_hits / token_sum / truth_sum are NULL in this mode)
     unsigned long long* ow_tok;
@@ -89,10 +84,6 @@ struct AggArgs {
                             // as a separate launch at the next scv_sync)
     uint64_t boot_seed;
     unsigned long long* boot_out;   // [r1 - r0][B][M]
-    int32_t ticket_merge;   // != 0: split-N cells are merged by the last segment to arrive (2-level tree, fan-in 16)
-    int32_t ngroups;        // split-N: groups of <= 16 segments per cell
-    uint32_t* partial2;     // split-N: [ncells * ngroups][1024] group histograms
-    long long* partial2_tok;
     uint32_t* partial;      // split-N: [ncells * segs][1024] partial histograms
     long long* partial_tok; // split-N: [ncells * segs] partial token sums
 };
@@ -178,19 +169,19 @@ __device__ __forceinline__ int4 stream_load(const int4* p) {
 
 // Stream the 16-byte vectors [lo, hi) of one cell into the replicated LDS histogram:
 // U loads in flight per lane, each wave instruction covering 1 KiB contiguous.
-template <int RL2, int T, int U, bool NT>
+template <int RL2, int T, int U>
 __device__ __forceinline__ void stream_votes(uint32_t* hist, uint32_t copy, const int4* v4, int64_t lo, int64_t hi,
                                              int tid, uint32_t& bad) {
     int64_t i = lo + tid;
     for (; i + (int64_t)(U - 1) * T < hi; i += (int64_t)U * T) {
         int4 x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = NT ? stream_load(v4 + i + (int64_t)u * T) : v4[i + (int64_t)u * T];
+        for (int u = 0; u < U; ++u) x[u] = stream_load(v4 + i + (int64_t)u * T);
 #pragma unroll
         for (int u = 0; u < U; ++u) vote4<RL2>(hist, copy, x[u], bad);
     }
     for (; i < hi; i += T) {
-        const int4 x = NT ? stream_load(v4 + i) : v4[i];
+        const int4 x = stream_load(v4 + i);
         vote4<RL2>(hist, copy, x, bad);
     }
 }
@@ -383,17 +374,7 @@ __device__ __forceinline__ void stream_row(const AggArgs& a, uint32_t* hist, uin
     const int64_t nvec = (n - head) >> 2;
     int64_t i = tid;
     if (!TOK) {
-        // votes are order-independent, so a workgroup may start anywhere in its cell (measurement
-        // option "stagger_vecs"; measured null-to-negative on MI355X, default off).
-        int64_t rot = 0;
-        if (a.stagger_vecs > 0 && nvec > 0) rot = ((int64_t)blockIdx.x * a.stagger_vecs) % nvec;
-        if (a.plain_loads) {
-            stream_votes<RL2, T, U, false>(hist, copy, v4, rot, nvec, tid, bad);
-            if (rot) stream_votes<RL2, T, U, false>(hist, copy, v4, 0, rot, tid, bad);
-        } else {
-            stream_votes<RL2, T, U, true>(hist, copy, v4, rot, nvec, tid, bad);
-            if (rot) stream_votes<RL2, T, U, true>(hist, copy, v4, 0, rot, tid, bad);
-        }
+        stream_votes<RL2, T, U>(hist, copy, v4, 0, nvec, tid, bad);
     } else {
         // the token row is 16-byte congruent with the vote row for the layouts the ABI accepts when
         // both bases are; a token base that is not takes the scalar route.
@@ -401,17 +382,12 @@ __device__ __forceinline__ void stream_row(const AggArgs& a, uint32_t* hist, uin
         if (tok_vec) {
             const int4* t4 = reinterpret_cast<const int4*>(trow + head);
             constexpr int UT = U > 1 ? U / 2 : 1;
-            // Option tok_skew: the token row read ROTATED by half a row against the vote row (only its sum matters), in
-            // case reading two separately allocated tensors at the same offset made a workgroup's two streams collide on
-            // an HBM channel.  Measured: no effect (6.6-6.9 TB/s either way); off by default.
-            const int64_t skew = a.tok_skew ? (nvec >> 1) : 0;
-            auto tix = [&](int64_t k) -> int64_t { const int64_t j = k + skew; return j < nvec ? j : j - nvec; };
             for (; i + (int64_t)(UT - 1) * T < nvec; i += (int64_t)UT * T) {
                 int4 x[UT], y[UT];
 #pragma unroll
                 for (int u = 0; u < UT; ++u) {
                     x[u] = stream_load(v4 + i + (int64_t)u * T);
-                    y[u] = stream_load(t4 + tix(i + (int64_t)u * T));
+                    y[u] = stream_load(t4 + i + (int64_t)u * T);
                 }
 #pragma unroll
                 for (int u = 0; u < UT; ++u) {
@@ -421,7 +397,7 @@ __device__ __forceinline__ void stream_row(const AggArgs& a, uint32_t* hist, uin
             }
             for (; i < nvec; i += T) {
                 const int4 x = stream_load(v4 + i);
-                const int4 y = stream_load(t4 + tix(i));
+                const int4 y = stream_load(t4 + i);
                 vote4<RL2>(hist, copy, x, bad);
                 tsum += (long long)y.x + (long long)y.y + (long long)y.z + (long long)y.w;
             }
@@ -509,7 +485,6 @@ constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
 // (a) counters without a memset or a reduce launch: every workgroup bumps tickets[0] when it has finished its
 //     items; the one that finds gridDim.x - 1 there knows every cell record of the launch has been written (write-
 //     through) and OVERWRITES the per-budget counters from the cell table (o1.py:236-245 as integers).
-// (b) split-N without a merge launch: see merge_split_cell below.
 template <int T, bool TOK>
 __device__ __forceinline__ void overwrite_counters_from_cells(const AggArgs& a, uint32_t* lds, int lds_words /* >= 4096 */, int tid) {
     // budgets are handled GB at a time, all in parallel: LDS holds GB tie-class rows of 1025 words + 2 * GB 64-bit sums
@@ -594,103 +569,9 @@ __device__ __forceinline__ void bootstrap_in_launch(const AggArgs& a, uint32_t* 
     }
 }
 
-// (b) A cell split over S segments (one workgroup each): a segment publishes its 1024-bin partial histogram write-
-//     through and bumps the arrival counter of its GROUP of <= 16 segments; the last arriver of a group sums the
-//     group's partials (<= 64 KB) and, when the cell has several groups, publishes the group histogram and bumps the
-//     cell's counter; the last group sums <= 16 group histograms and finishes the cell.  Nobody waits: a workgroup
-//     that is not last simply goes on to its next item.  Counters are reset by the workgroup that completes them,
-//     so the state is all-zero again when the launch ends (graph replays included).
-//     Returns true (to every thread) when this workgroup finished the cell; then cnt / tsum hold the totals.
-template <int T, bool TOK>
-__device__ __forceinline__ bool merge_split_cell(const AggArgs& a, uint32_t* red, uint32_t (&cnt)[kBins / T], long long& tsum,
-                                                 int tid, int64_t cell, int32_t seg) {
-    constexpr int NB = kBins / T;
-    constexpr int F = 16;
-    const int32_t S = a.segs, G = a.ngroups;
-    const int32_t g = seg / F;
-    const int32_t gs = (S - g * F) < F ? (S - g * F) : F;
-    // publish this segment
-    uint32_t* out = a.partial + ((cell * S + seg) << 10);
-#pragma unroll
-    for (int k = 0; k < NB; ++k) st_agent(out + tid + k * T, cnt[k]);
-    {
-        const long long wt = TOK ? wave_sum_i64(tsum) : 0;
-        if (TOK && (tid & 63) == 0) {
-            red[64 + 2 * (tid >> 6)] = (uint32_t)((unsigned long long)wt & 0xffffffffull);
-            red[65 + 2 * (tid >> 6)] = (uint32_t)((unsigned long long)wt >> 32);
-        }
-    }
-    drain_stores();                                   // every storing wave, before the arrival is announced
-    __syncthreads();
-    if (tid == 0) {
-        if (TOK) {
-            long long tok = 0;
-            for (int w = 0; w < T / 64; ++w) tok += (long long)(((unsigned long long)red[65 + 2 * w] << 32) | red[64 + 2 * w]);
-            st_agent(reinterpret_cast<unsigned long long*>(a.partial_tok) + cell * S + seg, (unsigned long long)tok);
-            drain_stores();
-        }
-        uint32_t* t1 = a.tickets + 4 + cell * G + g;
-        const uint32_t arrived = atomicAdd(t1, 1u);
-        red[50] = (arrived == (uint32_t)gs - 1u) ? 1u : 0u;
-        if (red[50]) st_agent(t1, 0u);
-    }
-    __syncthreads();
-    if (!red[50]) { __syncthreads(); return false; }  // (second barrier: red[50] may be rewritten by the next item)
-    // last of the group: sum the group's partials
-    const uint32_t* in = a.partial + ((cell * S + (int64_t)g * F) << 10);
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        uint32_t sum = 0;
-        for (int32_t q = 0; q < gs; ++q) sum += ld_agent(in + ((int64_t)q << 10) + tid + k * T);
-        cnt[k] = sum;
-    }
-    tsum = 0;
-    if (TOK && tid < gs) tsum = (long long)ld_agent(reinterpret_cast<const unsigned long long*>(a.partial_tok) + cell * S + (int64_t)g * F + tid);
-    __syncthreads();                                  // everyone has read red[50]
-    if (G == 1) return true;
-    // several groups: publish the group histogram, the last group finishes the cell
-    uint32_t* out2 = a.partial2 + ((cell * G + g) << 10);
-#pragma unroll
-    for (int k = 0; k < NB; ++k) st_agent(out2 + tid + k * T, cnt[k]);
-    {
-        const long long wt = TOK ? wave_sum_i64(tsum) : 0;
-        if (TOK && (tid & 63) == 0) {
-            red[64 + 2 * (tid >> 6)] = (uint32_t)((unsigned long long)wt & 0xffffffffull);
-            red[65 + 2 * (tid >> 6)] = (uint32_t)((unsigned long long)wt >> 32);
-        }
-    }
-    drain_stores();
-    __syncthreads();
-    if (tid == 0) {
-        if (TOK) {
-            long long tok = 0;
-            for (int w = 0; w < T / 64; ++w) tok += (long long)(((unsigned long long)red[65 + 2 * w] << 32) | red[64 + 2 * w]);
-            st_agent(reinterpret_cast<unsigned long long*>(a.partial2_tok) + cell * G + g, (unsigned long long)tok);
-            drain_stores();
-        }
-        uint32_t* t2 = a.tickets + 4 + a.ncells * G + cell;
-        const uint32_t arrived = atomicAdd(t2, 1u);
-        red[50] = (arrived == (uint32_t)G - 1u) ? 1u : 0u;
-        if (red[50]) st_agent(t2, 0u);
-    }
-    __syncthreads();
-    if (!red[50]) { __syncthreads(); return false; }
-    const uint32_t* in2 = a.partial2 + ((cell * G) << 10);
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        uint32_t sum = 0;
-        for (int32_t q = 0; q < G; ++q) sum += ld_agent(in2 + ((int64_t)q << 10) + tid + k * T);
-        cnt[k] = sum;
-    }
-    tsum = 0;
-    if (TOK && tid < G) tsum = (long long)ld_agent(reinterpret_cast<const unsigned long long*>(a.partial2_tok) + cell * G + tid);
-    __syncthreads();
-    return true;
-}
-
 // ---- kernel 1: streaming histogram / argmax (large N) -------------------------------------------
 // RL2 = log2(copies), T = threads per workgroup, U = 16-byte loads in flight per lane.
-// XTRA: the single-launch epilogues (overwrite-counters, split-N merge inside the launch) are compiled in.  They are
+// XTRA: the single-launch epilogues (overwrite-counters, bootstrap behind a grid barrier) are compiled in.  They are
 // a separate instantiation so that the default hot path keeps round 1's register allocation (with them in, the
 // headline variant went from 0 to 36 bytes of scratch and from 18 to 41 spilled SGPRs).
 template <int RL2, int T, int U, bool TOK, bool XTRA = false>
@@ -721,11 +602,11 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
     // Cross-item prefetch (votes-only variant): the first U*T vectors of the NEXT item are loaded into
     // registers before the current item's epilogue (B1 / fold / reductions), so a short cell's load
     // latency overlaps the previous cell's epilogue instead of following it.
-    const bool pf = !TOK && a.prefetch && a.stagger_vecs == 0 && !a.plain_loads;
+    const bool pf = !TOK && a.prefetch;
     // ... and with the tokens stream: the first UT vectors of BOTH rows of the next item (round 2 had no prefetch here: 6.4-6.6
     // against 6.9-7.1 TB/s votes-only).  Items whose token row is not 16-byte congruent with the vote row take stream_row.
     constexpr int UT = U > 1 ? U / 2 : 1;
-    const bool pft = TOK && !(U == 8 && T == 1024) /* (that A/B variant has no registers to spare) */ && a.prefetch && a.stagger_vecs == 0 && !a.plain_loads && !a.tok_skew;
+    const bool pft = TOK && a.prefetch;
     int4 pret[TOK ? UT : 1];
     const int4* cur_t4 = nullptr;             // first aligned vector of the current item's token row (NULL: not congruent)
     auto token_vectors = [&](const StreamItem& it, int64_t lo) -> const int4* {
@@ -766,7 +647,7 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (tid + (int64_t)u * T < cur.nvec) vote4<RL2>(hist, copy, pre[u], bad);
-            if (cur.nvec > (int64_t)U * T) stream_votes<RL2, T, U, true>(hist, copy, cur.v4, (int64_t)U * T, cur.nvec, tid, bad);
+            if (cur.nvec > (int64_t)U * T) stream_votes<RL2, T, U>(hist, copy, cur.v4, (int64_t)U * T, cur.nvec, tid, bad);
             const int64_t t0 = cur.head + (cur.nvec << 2);
             if (tid < cur.n - t0) vote<RL2>(hist, copy, (uint32_t)cur.row[t0 + tid], bad);
         } else if (TOK && pft && cur_t4) {
@@ -816,15 +697,7 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
 
         uint32_t cnt[NB];
         fold_copies<RL2, T, true>(hist, tid, cnt);     // and zero them for the next item
-        if (XTRA && S > 1 && a.ticket_merge) {
-            // split-N, single launch: the last segment (group) to arrive merges and finishes the cell
-            const int32_t seg = (int32_t)(item - cell * S);
-            if (merge_split_cell<T, TOK>(a, red, cnt, tsum, tid, cell, seg)) {
-                if (tid == 0) red[48] = 0;
-                __syncthreads();
-                finalize_cell<T, TOK, XTRA>(a, red, cnt, tsum, tid, cell, b, a.truth[p]);
-            }
-        } else if (S > 1) {
+        if (S > 1) {
             // split-N: publish the partial histogram; scv_merge_partials finishes the cell
             uint32_t* out = a.partial + (item << 10);
 #pragma unroll
@@ -984,360 +857,13 @@ __device__ __forceinline__ uint32_t exact_quotient(uint32_t votes_at_max, uint32
     return (uint32_t)((float)votes_at_max * __builtin_amdgcn_rcpf((float)maxc) + 0.5f);
 }
 
-// ---- kernel 1c: small-N cells, one wave per cell, sparse clear ------------------------------------
-//
-// For N up to a few thousand the 64 KiB fold-and-zero of kernel 1 dominates.  Here every wave owns a
-// private 1024-word histogram and touches ONLY the bins its cell votes for:
-//   pass 1  h[v] += 1 for every vote               (ds_add_u32)
-//   pass 2  c = h[v]; max over votes -> max_count   (every modal value is seen by its own voters)
-//   pass 3  #votes with h[v] == max_count, divided by max_count = number of DISTINCT modal values
-//           (statistics.multimode's len); min over those v = min_mode; truth_count = h[truth]
-//   pass 4  h[v] = 0 for every vote                 (sparse clear: O(N), not O(1024))
-// No workgroup barrier at all: LDS operations of one wave execute in order.  Passes 2-4 re-read the
-// cell (<= 8 KiB, L1/L2 resident), so HBM traffic stays 4 B per vote.
-template <int T, bool TOK>
-__global__ __launch_bounds__(T) void scv_small_cells(const AggArgs a) {
-    constexpr int NW = T / 64;
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    uint32_t* h = smem + wid * kBins;
-    int32_t* ord = reinterpret_cast<int32_t*>(smem + NW * kBins);
-    for (int i = lane; i < kBins; i += 64) h[i] = 0;
-    const bool use_ord = build_budget_order(a, ord, tid, T);
-    __syncthreads();
-
-    uint32_t bad = 0;
-    const int64_t wave0 = (int64_t)blockIdx.x * NW + wid, nwaves = (int64_t)gridDim.x * NW;
-    CellWalker walk(a, use_ord, wave0, nwaves);
-    for (int64_t ci = wave0; ci < a.ncells; ci += nwaves) {
-        int64_t p; int32_t b;
-        walk.get(use_ord, ord, p, b);
-        walk.advance();
-        const int64_t cell = p * a.B + b;
-        const int64_t n = valid_len(a, b);
-        const int32_t* row = a.answers + cell * a.N;
-        const int32_t truth = a.truth[p];
-        long long tsum = 0;
-        for (int64_t i = lane; i < n; i += 64) {                  // pass 1 (o1.py:181-195)
-            const uint32_t v = (uint32_t)row[i];
-            bad |= v;
-            atomicAdd(&h[v < 1023u ? v : 1023u], 1u);
-            if (TOK) tsum += a.tokens[cell * a.N + i];
-        }
-        __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order: only pin the compiler's order
-        uint32_t lmax = 0;
-        for (int64_t i = lane; i < n; i += 64) {                  // pass 2
-            const uint32_t v = (uint32_t)row[i];
-            const uint32_t c = h[v < 1023u ? v : 1023u];
-            lmax = c > lmax ? c : lmax;
-        }
-        const uint32_t maxc = wave_max_u32(lmax);
-        uint32_t votes_at_max = 0, mm = 1024u;
-        for (int64_t i = lane; i < n; i += 64) {                  // pass 3 (statistics.py:599-601)
-            const uint32_t v = (uint32_t)row[i];
-            const uint32_t bin = v < 1023u ? v : 1023u;
-            if (h[bin] == maxc) { votes_at_max += 1; mm = bin < mm ? bin : mm; }
-        }
-        votes_at_max = wave_sum_u32(votes_at_max);
-        mm = wave_min_u32(mm);
-        const uint32_t tc = (truth >= 0 && truth < kBins) ? h[truth] : 0u;
-        __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order: only pin the compiler's order
-        for (int64_t i = lane; i < n; i += 64) {                  // pass 4: sparse clear
-            const uint32_t v = (uint32_t)row[i];
-            h[v < 1023u ? v : 1023u] = 0;
-        }
-        __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order: only pin the compiler's order
-        long long tok = 0;
-        if (TOK) tok = wave_sum_i64(tsum);
-        if (lane == 0) {
-            const bool any = maxc > 0;
-            const uint32_t n_modes = any ? exact_quotient(votes_at_max, maxc) : 0u;
-            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;         // o1.py:206
-            if (a.cells) {
-                uint4 rec;
-                rec.x = maxc;
-                rec.y = tc;
-                rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
-                rec.w = hit;
-                reinterpret_cast<uint4*>(a.cells)[cell] = rec;
-            }
-            if (a.cell_tokens) a.cell_tokens[cell] = tok;
-            if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
-            if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
-            if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
-        }
-    }
-    if (bad > 1023u) atomicOr(a.err_flag, 1u);
-}
-
-// Register-resident variant for N <= 64*KV: every lane keeps its KV votes (and the counts it reads
-// back) in registers, so the cell is read from memory once and the LDS sees exactly N atomics, N reads
-// and N clears; K cells are loaded per batch so enough bytes are in flight to cover memory latency.
-template <int T, int KV, bool TOK>
-__global__ __launch_bounds__(T) void scv_small_cells_reg(const AggArgs a) {
-    constexpr int NW = T / 64;
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    uint32_t* h = smem + wid * kBins;
-    int32_t* ord = reinterpret_cast<int32_t*>(smem + NW * kBins);
-    for (int i = lane; i < kBins; i += 64) h[i] = 0;
-    const bool use_ord = build_budget_order(a, ord, tid, T);
-    __syncthreads();
-
-    struct Cell {                 // everything the passes need, loaded (not yet used) by the prefetch
-        uint32_t raw[KV];         // this lane's votes, unclamped
-        int32_t tokv[KV];
-        uint32_t mask;            // bit k: vote k exists (lane + 64k < n)
-        int32_t truth, b;
-        int64_t cell;
-    };
-    uint32_t bad = 0;
-    const int64_t wave0 = (int64_t)blockIdx.x * NW + wid, nwaves = (int64_t)gridDim.x * NW;
-    CellWalker walk(a, use_ord, wave0, nwaves);
-
-    auto prefetch = [&](Cell& c) {          // issues loads only: nothing here waits on memory
-        int64_t p;
-        walk.get(use_ord, ord, p, c.b);
-        walk.advance();
-        c.cell = p * a.B + c.b;
-        const int64_t n = valid_len(a, c.b);
-        const int32_t* row = a.answers + c.cell * a.N;
-        c.truth = a.truth[p];
-        c.mask = 0;
-#pragma unroll
-        for (int k = 0; k < KV; ++k) {
-            const int64_t i = lane + 64 * k;
-            c.raw[k] = 0; c.tokv[k] = 0;
-            if (i < n) {
-                c.mask |= 1u << k;
-                c.raw[k] = (uint32_t)row[i];
-                if (TOK) c.tokv[k] = a.tokens[c.cell * a.N + i];
-            }
-        }
-    };
-
-    // K cells per batch: a wave's single cell (<= 512 B) in flight cannot cover HBM latency (32 waves x
-    // 256 B = 8 KB per CU ~ 1 TB/s by Little's law); K cells are loaded back to back, then counted one
-    // after the other through the same wave-private histogram.
-    constexpr int K = KV <= 2 ? 4 : 2;
-    Cell batch[K];
-    for (int64_t ci = wave0; ci < a.ncells; ci += nwaves * K) {
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-            if (ci + j * nwaves < a.ncells) prefetch(batch[j]);
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            if (ci + j * nwaves >= a.ncells) break;
-            const Cell& cur = batch[j];
-            uint32_t bin[KV];
-            long long tsum = 0;
-#pragma unroll
-            for (int k = 0; k < KV; ++k) {
-                const bool on = (cur.mask >> k) & 1u;
-                bin[k] = cur.raw[k] < 1023u ? cur.raw[k] : 1023u;
-                if (on) { bad |= cur.raw[k]; if (TOK) tsum += cur.tokv[k]; }
-            }
-            // LDS operations of one wave execute in order, so the passes need no fence -- and must not
-            // have one: a fence would wait (vmcnt) for loads still in flight.  wave_barrier() only pins
-            // the compiler's order.
-#pragma unroll
-            for (int k = 0; k < KV; ++k) if ((cur.mask >> k) & 1u) atomicAdd(&h[bin[k]], 1u);   // pass 1
-            __builtin_amdgcn_wave_barrier();
-            uint32_t c[KV];
-#pragma unroll
-            for (int k = 0; k < KV; ++k) c[k] = ((cur.mask >> k) & 1u) ? h[bin[k]] : 0u;        // pass 2
-            const uint32_t tc = (cur.truth >= 0 && cur.truth < kBins) ? h[cur.truth] : 0u;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < KV; ++k) if ((cur.mask >> k) & 1u) h[bin[k]] = 0;               // pass 4: sparse clear
-            __builtin_amdgcn_wave_barrier();
-            // one max over (count << 10 | 1023 - bin): max_count and the smallest modal bin together
-            uint32_t lkey = 0;
-#pragma unroll
-            for (int k = 0; k < KV; ++k) {
-                const uint32_t key = ((cur.mask >> k) & 1u) ? ((c[k] << 10) | (1023u - bin[k])) : 0u;
-                lkey = key > lkey ? key : lkey;
-            }
-            const uint32_t wkey = wave_max_u32(lkey);
-            const uint32_t maxc = wkey >> 10;
-            const uint32_t mm = 1023u - (wkey & 1023u);
-            uint32_t votes_at_max = 0;
-#pragma unroll
-            for (int k = 0; k < KV; ++k)                                                         // pass 3, from registers
-                votes_at_max += (((cur.mask >> k) & 1u) && c[k] == maxc) ? 1u : 0u;
-            votes_at_max = wave_sum_u32(votes_at_max);
-            long long tok = 0;
-            if (TOK) tok = wave_sum_i64(tsum);
-            if (lane == 0) {
-                const bool any = maxc > 0;
-                const uint32_t n_modes = any ? exact_quotient(votes_at_max, maxc) : 0u;
-                const uint32_t hit = (any && tc == maxc) ? 1u : 0u;                               // o1.py:206
-                if (a.cells) {
-                    uint4 rec;
-                    rec.x = maxc;
-                    rec.y = tc;
-                    rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
-                    rec.w = hit;
-                    reinterpret_cast<uint4*>(a.cells)[cur.cell] = rec;
-                }
-                if (a.cell_tokens) a.cell_tokens[cur.cell] = tok;
-                if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)cur.b * SCV_TIE_CLASSES + n_modes], 1ull);
-                if (TOK && a.token_sum) atomicAdd(&a.token_sum[cur.b], (unsigned long long)tok);
-                if (a.truth_sum) atomicAdd(&a.truth_sum[cur.b], (unsigned long long)tc);
-            }
-        }
-    }
-    if (bad > 1023u) atomicOr(a.err_flag, 1u);
-}
-
-// ---- kernel 1f: tiny cells (N <= 32), several cells per wave, registers only --------------------
-//
-// The reference's own budgets are N = 1, 1, ..., 2, 4, 8 (o1.py:276; up to 128 with shade_regions).
-// A cell of N <= G votes occupies G = 8 / 16 / 32 adjacent lanes, one vote per lane, so a wave holds
-// 64/G cells.  count_i = #{j : v_j == v_i} by rotating the votes through the lane group (G-1
-// ds_bpermute + compare); then the same identities as scv_small_cells: max_count = max_i count_i,
-// len(multimode) = #{i : count_i == max_count} / max_count, min_mode = min v_i over those.
-// No histogram, no LDS memory, no barrier.  Cells are taken in natural (memory) order so a wave reads
-// and writes contiguous bytes; (p, b) advance incrementally (no per-cell division).
+// ---- DPP helpers of the cell kernels ---------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
-// lane i <- lane i ^ 16 inside each 32-lane half (LDS crossbar, no LDS memory): swizzle bit mode, and 0x1f, xor 0x10
-__device__ __forceinline__ uint32_t swap_rows(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); }
-
-constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kQuadXor3 = 0x1B;   // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E;                      // quad_perm [1,0,3,2] [2,3,0,1]
 constexpr int kHalfMirror = 0x141, kRowMirror = 0x140;                // lane i -> 7-i / 15-i inside its 8 / 16 lanes
-
-// all-reduce inside aligned groups of G lanes: xor-butterfly on DPP (quads, half rows, rows)
-#define SCV_GROUP_ALLREDUCE(NAME, OP)                                                              \
-    template <int G>                                                                               \
-    __device__ __forceinline__ uint32_t NAME(uint32_t v) {                                         \
-        uint32_t t;                                                                                \
-        t = dpp_mov<kQuadXor1>(v); v = OP(v, t);                                                   \
-        t = dpp_mov<kQuadXor2>(v); v = OP(v, t);                                                   \
-        t = dpp_mov<kHalfMirror>(v); v = OP(v, t);                                                 \
-        if (G >= 16) { t = dpp_mov<kRowMirror>(v); v = OP(v, t); }                                 \
-        if (G >= 32) { t = swap_rows(v); v = OP(v, t); }                                           \
-        return v;                                                                                  \
-    }
-#define SCV_OP_MAX(a, b) ((a) > (b) ? (a) : (b))
-#define SCV_OP_MIN(a, b) ((a) < (b) ? (a) : (b))
-#define SCV_OP_ADD(a, b) ((a) + (b))
-SCV_GROUP_ALLREDUCE(group_max_u32, SCV_OP_MAX)
-SCV_GROUP_ALLREDUCE(group_min_u32, SCV_OP_MIN)
-SCV_GROUP_ALLREDUCE(group_sum_u32, SCV_OP_ADD)
-
-template <int G>
-__device__ __forceinline__ long long group_sum_i64(long long v) {    // limbs as in wave_sum_i64
-    const unsigned long long u = (unsigned long long)v;
-    const unsigned long long s0 = group_sum_u32<G>((uint32_t)(u & 0x3fffffu));
-    const unsigned long long s1 = group_sum_u32<G>((uint32_t)((u >> 22) & 0x1fffffu));
-    const unsigned long long s2 = group_sum_u32<G>((uint32_t)((u >> 43) & 0x1fffffu));
-    return (long long)(s0 + (s1 << 22) + (s2 << 43));
-}
-
-// #{ other lanes of my row whose value equals mine }, rotating the row with row_ror:1..15
-template <int R>
-__device__ __forceinline__ uint32_t count_row_matches(uint32_t mine, uint32_t theirs) {
-    if constexpr (R == 0) return 0;
-    else return (dpp_mov<0x120 + R>(theirs) == mine ? 1u : 0u) + count_row_matches<R - 1>(mine, theirs);
-}
-
-// count_i = #{ j in my G-lane cell : bin_j == bin_i } (inactive lanes carry 0xffffffff and get 0)
-template <int G>
-__device__ __forceinline__ uint32_t count_equal_in_group(uint32_t bin, bool active) {
-    uint32_t cnt;
-    if constexpr (G == 8) {
-        const uint32_t m = dpp_mov<kHalfMirror>(bin);                       // i ^ 7
-        cnt = 1u + (dpp_mov<kQuadXor1>(bin) == bin) + (dpp_mov<kQuadXor2>(bin) == bin) + (dpp_mov<kQuadXor3>(bin) == bin)
-                 + (m == bin) + (dpp_mov<kQuadXor1>(m) == bin) + (dpp_mov<kQuadXor2>(m) == bin) + (dpp_mov<kQuadXor3>(m) == bin);
-    } else if constexpr (G == 16) {
-        cnt = 1u + count_row_matches<15>(bin, bin);
-    } else {
-        const uint32_t other = swap_rows(bin);                               // the cell's second 16-lane row
-        cnt = 1u + count_row_matches<15>(bin, bin) + (other == bin ? 1u : 0u) + count_row_matches<15>(bin, other);
-    }
-    return active ? cnt : 0u;
-}
-
-template <int G, bool TOK>
-__global__ __launch_bounds__(256) void scv_tiny_cells(const AggArgs a) {
-    constexpr int CPW = 64 / G;                       // cells per wave per slice
-    constexpr int K = 4;                              // independent slices in flight per wave: a wave's single
-                                                      // 256-byte load cannot cover HBM latency (Little's law)
-    const int lane = threadIdx.x & 63;
-    const int sub = lane / G, l = lane % G;
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t step = nwaves * CPW;                // cells between consecutive slices of this wave
-    int64_t cell = wave * CPW + sub;
-    int64_t p = cell / a.B;
-    int32_t b = (int32_t)(cell - p * a.B);
-    const int64_t dp = step / a.B;
-    const int32_t db = (int32_t)(step - dp * a.B);
-    uint32_t bad = 0;
-    for (; cell - sub < a.ncells; ) {                  // wave-uniform trip count (DPP needs all lanes)
-        // ---- issue the loads of K slices first -------------------------------------------------
-        int64_t cells_k[K], p_k[K];
-        int32_t b_k[K], truth_k[K];
-        uint32_t bin_k[K];
-        long long tok_k[K];
-        bool active_k[K], live_k[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            cells_k[k] = cell; p_k[k] = p; b_k[k] = b;
-            live_k[k] = cell < a.ncells;
-            const int64_t n = live_k[k] ? valid_len(a, b) : 0;
-            active_k[k] = l < n;
-            bin_k[k] = 0xffffffffu;                    // inactive lanes never match anything
-            tok_k[k] = 0;
-            truth_k[k] = live_k[k] ? a.truth[p] : -1;
-            if (active_k[k]) {
-                bin_k[k] = (uint32_t)a.answers[cell * a.N + l];
-                if (TOK) tok_k[k] = a.tokens[cell * a.N + l];
-            }
-            cell += step; p += dp; b += db;
-            if (b >= a.B) { b -= a.B; p += 1; }
-        }
-        // ---- then count, slice by slice (registers only) ---------------------------------------
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const bool active = active_k[k];
-            uint32_t bin = bin_k[k];
-            if (active) { bad |= bin; bin = bin < 1023u ? bin : 1023u; }
-            const uint32_t cnt = count_equal_in_group<G>(bin, active);
-            // one max over (count << 10 | 1023 - bin): the winner carries max_count AND the smallest modal bin
-            const uint32_t key = group_max_u32<G>(active ? ((cnt << 10) | (1023u - bin)) : 0u);
-            const uint32_t maxc = key >> 10;
-            const uint32_t mm = 1023u - (key & 1023u);
-            // one sum over (votes at max | votes for truth << 16): both are <= 32
-            const bool at_max = active && cnt == maxc;
-            const uint32_t sums = group_sum_u32<G>((at_max ? 1u : 0u) | ((active && (int32_t)bin == truth_k[k]) ? 0x10000u : 0u));
-            const uint32_t votes_at_max = sums & 0xffffu, tc = sums >> 16;
-            long long tok = 0;
-            if (TOK) tok = group_sum_i64<G>(tok_k[k]);
-            if (l == 0 && live_k[k]) {
-                const bool any = maxc > 0;
-                const uint32_t n_modes = any ? exact_quotient(votes_at_max, maxc) : 0u;
-                const uint32_t hit = (any && tc == maxc) ? 1u : 0u;               // o1.py:206
-                if (a.cells) {
-                    uint4 rec;
-                    rec.x = maxc;
-                    rec.y = tc;
-                    rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
-                    rec.w = hit;
-                    reinterpret_cast<uint4*>(a.cells)[cells_k[k]] = rec;
-                }
-                if (a.cell_tokens) a.cell_tokens[cells_k[k]] = tok;
-                if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b_k[k] * SCV_TIE_CLASSES + n_modes], 1ull);
-                if (TOK && a.token_sum) atomicAdd(&a.token_sum[b_k[k]], (unsigned long long)tok);
-                if (a.truth_sum) atomicAdd(&a.truth_sum[b_k[k]], (unsigned long long)tc);
-            }
-        }
-    }
-    if (bad > 1023u) atomicOr(a.err_flag, 1u);
-}
 
 // ---- kernel 1f': tiny cells, ONE LANE PER CELL (N <= 32; the reference's own N = 1, 2, 4, 8 .. 32) ----
 //
@@ -1912,17 +1438,13 @@ __device__ __forceinline__ long long cellgroup_sum_i64(long long v) {    // limb
 // key = count << kKeyShift | LDS byte address: a workgroup may hold all 160 KiB of a CU's LDS (18 address bits); counts are <= 4096 (13 bits)
 constexpr int kKeyShift = 18;
 constexpr uint32_t kKeyMask = (1u << kKeyShift) - 1u;
-constexpr int kRegCellBins = 1025;                   // 1024 bins + one spare
-constexpr int kRegHistWords = 4 * kRegCellBins;      // per wave: C cells x 1025 bins x R copies, C * R = 4
 constexpr int kRegLaneWords = 64 + 128 + 64;         // + per lane: the first pivot's word, 8 bytes of trash (inactive vote slots add there: a
                                                      // shared trash bin serialised them 32-64 deep), the second pivot's word
-constexpr int kRegWaveWords = kRegHistWords + kRegLaneWords;
 // The waves of a workgroup are independent; a workgroup is ALL the waves a CU holds of the shape (launch bounds =
 // the occupancy the shape is meant to run at: 16 / 12 / 8 / 4 waves), so a launch is one workgroup per CU: the
 // end-of-launch counter flush then costs 256 device atomics per counter (12 ns each on one address), not 1024.
-template <int G, int V, bool TOK, bool DENSE, bool VEC = true>
+template <int G, int V, bool TOK, bool VEC = true>
 constexpr int reg_cells_waves() {
-    if (DENSE) return 8;
     if (!VEC && V == 1) return 12;             // unaligned rows, K = 4 batches in flight: 12-28 B of scratch at 128 VGPRs
     // (with tokens the one-vector shapes run K = 4 batches per iteration, each with its token loads in flight: they
     // spill at 128 VGPRs -- tools/kernel_resources.py -- and get 12 waves = 168 VGPRs like the four-vector shapes)
@@ -1970,15 +1492,6 @@ typedef uint32_t scv_v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) scv_v2u lds_v2u;
 typedef __attribute__((address_space(3))) scv_v4u lds_v4u;
 
-template <int R>
-__device__ __forceinline__ uint32_t lds_count(uint32_t A) {
-    if (R == 4) { const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)A); return q.x + q.y + q.z + q.w; }
-    if (R == 2) { const scv_v2u q = *reinterpret_cast<lds_v2u*>((uintptr_t)A); return q.x + q.y; }
-    return *reinterpret_cast<lds_u32*>((uintptr_t)A);
-}
-__device__ __forceinline__ void lds_add1(uint32_t addr) {
-    __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>((uintptr_t)addr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 __device__ __forceinline__ void lds_add(uint32_t addr, uint32_t inc) {
     __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>((uintptr_t)addr), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -2051,9 +1564,8 @@ __device__ __forceinline__ uint32_t pivot_select_h16(uint32_t A, uint32_t ap0, u
 // dwordx4 loads -- vector 0 starts `sh` = 0..3 elements before the row -- and masks both ends (votes are order-independent, so
 // the shift only moves the validity window: slot e of the superset is vote e - sh).  The superset of n votes has up to n + 3
 // slots; the host sizes the shape for N + 3.  (Round 2 used dword loads here: 3.45 vs 4.72 TB/s at N = 1001 / 1024.)
-template <int G, int V, int K, bool TOK, bool VEC, bool DENSE>
-__global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE, VEC>())) void scv_reg_cells(const AggArgs a) {
-    static_assert(!DENSE || G == 64, "the dense scan owns a whole wave per cell");
+template <int G, int V, int K, bool TOK, bool VEC>
+__global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_reg_cells(const AggArgs a) {
     constexpr int C = 64 / G;                 // cells per wave per batch
     constexpr int R = G / 16;                 // histogram copies per cell
     // 16-bit counters for every sparse shape (a cell slot holds <= 1024 votes): 8 KiB of LDS per wave instead of
@@ -2063,12 +1575,11 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE, VEC>())) vo
     //  P16 (G = 32 / 64, 2 / 4 copies): the copies of a bin sit side by side (one / two words per bin); a lane's
     //      increment (1 or 1 << 16) and word are constants of the lane, the read is one b32 / b64 + v_dot2_u32_u16.
     //      Two copies share a word, so all-equal votes serialise 32 deep instead of 16 (truth votes never do).
-    // The dense scan keeps 32-bit counters, [bin][copy].
-    constexpr bool H16 = !DENSE && G == 16;
-    constexpr bool P16 = !DENSE && G > 16;
-    constexpr int S = H16 ? 1 : (P16 ? (R == 4 ? 3 : 2) : (R == 4 ? 4 : (R == 2 ? 3 : 2)));   // log2(bytes between consecutive bins)
-    constexpr int WW = (H16 || P16) ? kRegWaveWords16 : kRegWaveWords;
-    constexpr uint32_t CELLBYTES = (H16 || P16) ? (uint32_t)(kRegCopyBytes16 * R) : (uint32_t)(kRegCellBins * R * 4);
+    constexpr bool H16 = G == 16;
+    constexpr bool P16 = G > 16;
+    constexpr int S = H16 ? 1 : (R == 4 ? 3 : 2);   // log2(bytes between consecutive bins)
+    constexpr int WW = kRegWaveWords16;
+    constexpr uint32_t CELLBYTES = (uint32_t)(kRegCopyBytes16 * R);
     constexpr int E = 4 * V;                  // votes per lane per batch
     constexpr uint32_t CAP = 4u * G * V;      // votes per cell slot
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_wg[];
@@ -2089,7 +1600,7 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE, VEC>())) vo
     const uint32_t LW = base + (uint32_t)(WW - kRegLaneWords) * 4u;          // first byte behind this wave's histograms
     const uint32_t ATR = LW + 256u + (uint32_t)lane * 8u;                    // this lane's trash (above every bin address)
     const uint32_t copy = (uint32_t)l & (R - 1);
-    const uint32_t copy4 = P16 ? (copy >> 1) * 4u : copy * (H16 ? (uint32_t)kRegCopyBytes16 : 4u);   // word of this lane's copy, bytes
+    const uint32_t copy4 = P16 ? (copy >> 1) * 4u : copy * (uint32_t)kRegCopyBytes16;   // word of this lane's copy, bytes
     const uint32_t copy_inc = 1u << (16u * (copy & 1u));                 // P16: this lane's half of that word
     const uint32_t copy2 = copy * 2u;                                    // P16: byte offset of this lane's 16-bit counter
     const uint32_t TW = LW + (uint32_t)lane * 4u;                            // this lane's pivot words (first / second pivot)
@@ -2188,9 +1699,8 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE, VEC>())) vo
         }
         if (!FULL) {
             // SENT: the (negative) "vote" whose bin address KB - (SENT << S) is ATR, the lane's trash.  KB - ATR is a multiple of the
-            // bin stride in every 16-bit layout (regions are 8-byte multiples); the 32-bit dense variant (16 bytes per bin, votes
-            // dead after this pass) rounds the trash address down to its stride.
-            const uint32_t SENT = (uint32_t)((int32_t)(KB - (DENSE ? (ATR & ~15u) : ATR)) >> S);
+            // bin stride in every 16-bit layout (regions are 8-byte multiples).
+            const uint32_t SENT = (uint32_t)((int32_t)(KB - ATR) >> S);
 #pragma unroll
             for (int k = 0; k < EL / 4; ++k) {
                 if (k < kfull && (VEC || k > 0)) continue;          // (wave-uniform) every slot of this vector is a vote in every lane
@@ -2209,11 +1719,10 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE, VEC>())) vo
 #pragma unroll
         for (int i = 0; i < EL; ++i) {
             A[i] = bin_address<S>(KB, c.v[i]);
-            if (!DENSE) c.v[i] = A[i];                              // (a pivot vote keeps its bin address: the bin holds the total when it is read)
+            c.v[i] = A[i];                                          // (a pivot vote keeps its bin address: the bin holds the total when it is read)
         }
         const uint32_t ap0 = A[0];                                  // an inactive lane's pivot is its trash address
         uint32_t ap1 = A[1] != ap0 ? A[1] : (A[2] != ap0 ? A[2] : A[3]);
-        if (a.reg_pivots == 1) ap1 = ap0;                           // (second pivot off: never selected, the first test wins)
 #pragma unroll
         for (int i = 0; i < EL; ++i) {
             if (H16) {
@@ -2223,7 +1732,7 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE, VEC>())) vo
                 lds_add(W, inc);
             } else {
                 const uint32_t W = i == 0 ? TW : pivot_select(A[i], copy4, ap0, ap1, TW, TW2);
-                if (P16) lds_add(W, copy_inc); else lds_add1(W);
+                lds_add(W, copy_inc);
             }
         }
         // move the pivot words into the pivots' bins (LDS operations of a wave execute in order: the reads of pass 2 see them)
@@ -2237,7 +1746,7 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE, VEC>())) vo
             lds_add(H16 ? (t1 + copy4) & ~3u : (t1 | copy4), w1);
         }
         // the lane's trash has collected the non-votes (and empty pivots): zero it, so that pass 2 reads count 0 there and needs no masks
-        if (!FULL && !DENSE) *reinterpret_cast<lds_v2u*>((uintptr_t)ATR) = scv_v2u{0u, 0u};
+        if (!FULL) *reinterpret_cast<lds_v2u*>((uintptr_t)ATR) = scv_v2u{0u, 0u};
         __builtin_amdgcn_wave_barrier();
     };
     // passes 2-4, sparse: read back the counts of the bins this lane voted for
@@ -2248,14 +1757,14 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE, VEC>())) vo
         // h[truth] (o1.py:206): every lane of the cell reads the truth's bin (same address: a broadcast).  Issued first, so it
         // has returned when the counts of pass 2 have (LDS answers in order); pinned before the clears of pass 4 below.
         const uint32_t ATt = (c.truth >= 0 && c.truth < kBins) ? KB - ((uint32_t)c.truth << S) : ATR;   // no such bin: the lane's trash
-        tc = H16 ? lds_count16<R>(ATt) : (P16 ? lds_count_packed<R>(ATt) : lds_count<R>(ATt));
+        tc = H16 ? lds_count16<R>(ATt) : lds_count_packed<R>(ATt);
 #pragma unroll
         for (int i0 = 0; i0 < EL; i0 += CH) {
             // all CH reads are issued before the first count is consumed (left alone, the scheduler keeps only
             // two ds_reads in flight and the pass becomes a chain of LDS latencies: measured 48 % wave-wait)
             uint32_t cn[CH];
 #pragma unroll
-            for (int i = i0; i < i0 + CH; ++i) cn[i - i0] = H16 ? lds_count16<R>(c.v[i]) : (P16 ? lds_count_packed<R>(c.v[i]) : lds_count<R>(c.v[i]));
+            for (int i = i0; i < i0 + CH; ++i) cn[i - i0] = H16 ? lds_count16<R>(c.v[i]) : lds_count_packed<R>(c.v[i]);
             __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, CH, 0);
             __builtin_amdgcn_sched_group_barrier(0x2 /* VALU */, CH * 6, 0);
 #pragma unroll
@@ -2282,50 +1791,19 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE, VEC>())) vo
         for (int i = 0; i < EL; ++i) {
             at_max += c.v[i] >= thr ? 1u : 0u;                      // inactive keys have count 0: they only count when max_count == 0
             if (H16) *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) + copy4)) = (uint16_t)0;
-            else if (P16) *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) | copy2)) = (uint16_t)0;
-            else *reinterpret_cast<lds_u32*>((uintptr_t)((c.v[i] & kKeyMask) | copy4)) = 0u;
+            else *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) | copy2)) = (uint16_t)0;
         }
         __builtin_amdgcn_wave_barrier();
     };
-    // passes 2-4, dense (G = 64): lane scans histogram indices x = lane + 64 j
-    auto dense_passes = [&](Batch& c, uint32_t& gkey, uint32_t& at_max, uint32_t& tc) {
-        const uint32_t A0 = base + (uint32_t)lane * 16u;
-        uint32_t key[16];
-        uint32_t lmax = 0;
-#pragma unroll
-        for (int j0 = 0; j0 < 16; j0 += 8) {                        // 8 b128 reads (32 registers) in flight at a time
-#pragma unroll
-            for (int j = j0; j < j0 + 8; ++j) key[j] = lds_count<4>(A0 + 1024u * j);
-            __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x2 /* VALU */, 8 * 5, 0);
-#pragma unroll
-            for (int j = j0; j < j0 + 8; ++j) {
-                key[j] = (key[j] << kKeyShift) | (A0 + 1024u * j);
-                lmax = key[j] > lmax ? key[j] : lmax;
-            }
-        }
-        tc = (c.truth >= 0 && c.truth < kBins) ? lds_count<4>(KB - ((uint32_t)c.truth << S)) : 0u;     // h[truth], before the zeroing
-        asm volatile("" : "+v"(tc) : : "memory");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) *reinterpret_cast<lds_v4u*>((uintptr_t)(A0 + 1024u * j)) = scv_v4u{0u, 0u, 0u, 0u};
-        __builtin_amdgcn_wave_barrier();
-        gkey = cellgroup_max<64>(lmax);
-        const uint32_t thr = gkey & ~kKeyMask;
-        at_max = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) at_max += key[j] >= thr ? 1u : 0u;    // BINS at max (all 1024 when the cell is empty)
-    };
-
     auto finish_cell = [&](const Batch& c, uint32_t gkey, uint32_t at_max, uint32_t tc, long long tsum) {
         const uint32_t maxc = gkey >> kKeyShift;                            // max count over every value of the cell
-        const uint32_t sum_at_max = cellgroup_sum<G>(at_max);               // votes (dense: bins) at the maximum, over the cell
+        const uint32_t sum_at_max = cellgroup_sum<G>(at_max);               // votes at the maximum, over the cell
         long long tok = 0;
         if (TOK) tok = cellgroup_sum_i64<G>(tsum);
         if (l == 0 && c.cell < a.ncells) {
             // statistics.multimode + o1.py:202-206
             const bool any = maxc > 0;
-            const uint32_t n_modes = any ? (DENSE ? sum_at_max : exact_quotient(sum_at_max, maxc)) : 0u;
+            const uint32_t n_modes = any ? exact_quotient(sum_at_max, maxc) : 0u;
             const uint32_t mm = 1023u - (((gkey & kKeyMask) - cellbase) >> S);
             const uint32_t hit = (any && tc == maxc) ? 1u : 0u;             // o1.py:206
             if (a.cells) {
@@ -2377,11 +1855,11 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, DENSE, VEC>())) vo
             int kfull = 0;
             auto partial = [&](auto live_tag) {
                 vote_pass(c, std::false_type{}, live_tag, kfull);
-                if (DENSE) dense_passes(c, gkey, at_max, tc); else sparse_passes(c, live_tag, gkey, at_max, tc);
+                sparse_passes(c, live_tag, gkey, at_max, tc);
             };
             if (__all(n == CAP && (VEC || c.sh == 0u))) {
                 vote_pass(c, std::true_type{}, std::integral_constant<int, V>{}, V);
-                if (DENSE) dense_passes(c, gkey, at_max, tc); else sparse_passes(c, std::integral_constant<int, V>{}, gkey, at_max, tc);
+                sparse_passes(c, std::integral_constant<int, V>{}, gkey, at_max, tc);
             } else {
                 // longest and shortest cell of the batch (wave-uniform: lane s * G holds cell slot s) -> live vectors, and the
                 // vectors [0, kfull) whose every slot is a vote in every lane
@@ -2547,8 +2025,7 @@ __global__ __launch_bounds__((64 * reg_dense_waves<V, H, TOK, VEC>())) void scv_
             }
             ap0 = A4[0];
             ap1 = A4[1] != ap0 ? A4[1] : (A4[2] != ap0 ? A4[2] : A4[3]);
-            if (a.reg_pivots == 1) ap1 = ap0;
-        }
+            }
         // a part is FULL when every slot of it is a vote (and a token): no masks
         bool full = (int32_t)c.nrel >= (int32_t)PART;
         if (!VEC) full = full && (!TOK || (int32_t)c.tnrel >= (int32_t)PART) && (!FIRST || (c.sh == 0u && c.tsh == 0u));
@@ -2770,83 +2247,6 @@ __global__ __launch_bounds__(T) void scv_prefix_hist(const AggArgs a) {
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
 }
 
-// Small pools: one wave per problem; after each boundary the passes 2-3 of scv_small_cells run over
-// the whole prefix [0, n) (L1-resident), the sparse clear runs once at the end.
-template <int T, bool TOK>
-__global__ __launch_bounds__(T) void scv_small_prefix(const AggArgs a) {
-    constexpr int NW = T / 64;
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    uint32_t* h = smem + wid * kBins;
-    int32_t* ord = reinterpret_cast<int32_t*>(smem + NW * kBins);
-    for (int i = lane; i < kBins; i += 64) h[i] = 0;
-    build_budget_order(a, ord, tid, T);
-    __syncthreads();
-    uint32_t bad = 0;
-    const int64_t wave0 = (int64_t)blockIdx.x * NW + wid, nwaves = (int64_t)gridDim.x * NW;
-    for (int64_t p = wave0; p < a.P; p += nwaves) {
-        const int32_t* row = a.answers + p * a.N;
-        const int32_t truth = a.truth[p];
-        long long tsum = 0;
-        int64_t done = 0;
-        for (int32_t k = a.B - 1; k >= 0; --k) {
-            const int32_t b = ord[k];
-            const int64_t n = valid_len(a, b);
-            for (int64_t i = done + lane; i < n; i += 64) {
-                const uint32_t v = (uint32_t)row[i];
-                bad |= v;
-                atomicAdd(&h[v < 1023u ? v : 1023u], 1u);
-                if (TOK) tsum += a.tokens[p * a.N + i];
-            }
-            if (n > done) done = n;
-            __builtin_amdgcn_wave_barrier();
-            uint32_t lmax = 0;
-            for (int64_t i = lane; i < n; i += 64) {
-                const uint32_t v = (uint32_t)row[i];
-                const uint32_t c = h[v < 1023u ? v : 1023u];
-                lmax = c > lmax ? c : lmax;
-            }
-            const uint32_t maxc = wave_max_u32(lmax);
-            uint32_t votes_at_max = 0, mm = 1024u;
-            for (int64_t i = lane; i < n; i += 64) {
-                const uint32_t v = (uint32_t)row[i];
-                const uint32_t bin = v < 1023u ? v : 1023u;
-                if (h[bin] == maxc) { votes_at_max += 1; mm = bin < mm ? bin : mm; }
-            }
-            votes_at_max = wave_sum_u32(votes_at_max);
-            mm = wave_min_u32(mm);
-            const uint32_t tc = (truth >= 0 && truth < kBins) ? h[truth] : 0u;
-            long long tok = 0;
-            if (TOK) tok = wave_sum_i64(tsum);
-            if (lane == 0) {
-                const int64_t cell = p * a.B + b;
-                const bool any = maxc > 0;
-                const uint32_t n_modes = any ? exact_quotient(votes_at_max, maxc) : 0u;
-                const uint32_t hit = (any && tc == maxc) ? 1u : 0u;
-                if (a.cells) {
-                    uint4 rec;
-                    rec.x = maxc;
-                    rec.y = tc;
-                    rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
-                    rec.w = hit;
-                    reinterpret_cast<uint4*>(a.cells)[cell] = rec;
-                }
-                if (a.cell_tokens) a.cell_tokens[cell] = tok;
-                if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
-                if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
-                if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        for (int64_t i = lane; i < done; i += 64) {             // sparse clear, once per problem
-            const uint32_t v = (uint32_t)row[i];
-            h[v < 1023u ? v : 1023u] = 0;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (bad > 1023u) atomicOr(a.err_flag, 1u);
-}
-
 // ---- synthetic generator ------------------------------------------------------------------------
 
 struct ProblemParams { uint32_t truth, q_num, d[4]; };
@@ -2918,7 +2318,7 @@ __global__ __launch_bounds__(256) void scv_synth_fill_k(int32_t* answers, int32_
 
 // The device error word as an int64 in caller memory, in stream order (scv_export_error_word): lets a multi-rank
 // caller put it behind the counters of the SAME all-reduce without a host round trip.
-__global__ void scv_export_err_k(const uint32_t* err_flag, long long* dst) { *dst = (long long)*err_flag; }
+__global__ void scv_export_err_k(const uint32_t* err_flag, uint32_t mask, long long* dst) { *dst = (long long)(*err_flag & mask); }
 
 // ---- problem-level bootstrap --------------------------------------------------------------------
 

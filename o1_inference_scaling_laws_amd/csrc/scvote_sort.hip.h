@@ -69,30 +69,64 @@ template <int NP, typename Tick, int... I>
 __device__ __forceinline__ void sv_sort_halves(uint32_t (&R)[NP], Tick& tick, std::integer_sequence<int, I...>) {
     ((sv_ce(R[SvNet<NP>::net.a[I]], R[SvNet<NP>::net.b[I]]), tick(R[SvNet<NP>::net.a[I]])), ...);      // (every index is a constant expression: R stays in registers)
 }
+constexpr bool sv_pow2(int n) { return n >= 2 && (n & (n - 1)) == 0; }
+template <int N>
+struct SvValley { static constexpr SvNetwork<N> net = sv_make_valley_merge<N>(); };
 // compare-exchanges (= calls of `tick`) of one sv_sort<NP>
 template <int NP>
 constexpr int sv_sort_ticks() {
+    if (!sv_pow2(NP)) return SvNet<NP>::net.n + NP + SvValley<NP>::net.n;
     int stages = 0;
     for (int j = NP >> 1; j > 0; j >>= 1) ++stages;
     return SvNet<NP>::net.n + NP / 2 + stages * (NP / 2);
+}
+template <int NP, typename Tick, int... I>
+__device__ __forceinline__ void sv_merge_valleys(uint32_t (&R)[NP], Tick& tick, std::integer_sequence<int, I...>) {
+    ((sv_ce(R[SvValley<NP>::net.a[I]], R[SvValley<NP>::net.b[I]]), tick(R[SvValley<NP>::net.a[I]])), ...);
+}
+// lo = ~min(a, b), hi = max(a, b) of a register that holds lo = ~a, hi = b: swap the halves, complement, one packed maximum
+__device__ __forceinline__ void sv_ce_halves(uint32_t& r) { r = pk_max_c(r, ~__builtin_amdgcn_alignbit(r, r, 16)); }
+template <int NP, typename Tick, int... I>
+__device__ __forceinline__ void sv_meet_halves(uint32_t (&R)[NP], Tick& tick, std::integer_sequence<int, I...>) {
+    ((sv_ce_halves(R[I]), tick(R[I])), ...);
 }
 
 // Ascending sort of the 2 * NP 16-bit elements of R; element i = half i / NP of R[i % NP].  Both halves are sorted in lockstep by
 // the odd-even mergesort network on the NP registers (any network whose exchanges all put the minimum on the lower wire runs on both
 // halves at once), then merged by one bitonic merge: the flip stage is the only one where the halves meet.  `tick(reg)` is called after
 // every compare-exchange with a register it has just written (the kernel spreads the next step's LDS-DMA pieces over the sort with it).
+//
+// NP not a power of two (round 4: the 48-vote shape, NP = 24 -- cells of 33 ... 48 votes used to sort 64 slots).  A bitonic merge on n
+// wires can leave out the wires of a +inf padding only when the padded sequence is still bitonic, i.e. when the n wires hold a VALLEY
+// (falling, then rising); the flip stage leaves a peak in the lower half.  So half 0 travels COMPLEMENTED (x ^ 0xffff: the lockstep
+// minimum / maximum then sort it descending): after the lockstep network the 2 * NP elements are A falling, B rising -- one valley --, the
+// first merge stage compares the two halves of each REGISTER (swap halves, complement, one packed maximum: lo = ~min(a, b),
+// hi = max(a, b): three instructions per register instead of five per pair), and both halves are valleys in their stored form, so
+// Lang's merge for arbitrary n (the power-of-two network minus every exchange that touches a pad wire: 52 instead of 80 exchanges at
+// NP = 24) sorts them in lockstep.  Result after the final un-complement: half 0 FALLING in r (the NP smallest elements), half 1
+// rising (the NP largest): in value order the elements run (0, NP-1) ... (0, 0), (1, 0) ... (1, NP-1) -- the halves meet at r = 0.
 template <int NP, typename Tick>
 __device__ __forceinline__ void sv_sort(uint32_t (&R)[NP], Tick& tick) {
-    static_assert(NP >= 2 && (NP & (NP - 1)) == 0, "packed registers");
-    sv_sort_halves<NP>(R, tick, std::make_integer_sequence<int, SvNet<NP>::net.n>{});
+    static_assert(NP >= 2, "packed registers");
+    if constexpr (!sv_pow2(NP)) {
 #pragma unroll
-    for (int r = 0; r < NP / 2; ++r) { sv_ce_cross(R[r], R[NP - 1 - r]); tick(R[r]); }   // element (0, r) against (1, NP - 1 - r)
+        for (int r = 0; r < NP; ++r) R[r] ^= 0xffffu;
+        sv_sort_halves<NP>(R, tick, std::make_integer_sequence<int, SvNet<NP>::net.n>{});
+        sv_meet_halves<NP>(R, tick, std::make_integer_sequence<int, NP>{});
+        sv_merge_valleys<NP>(R, tick, std::make_integer_sequence<int, SvValley<NP>::net.n>{});
 #pragma unroll
-    for (int j = NP >> 1; j > 0; j >>= 1) {
+        for (int r = 0; r < NP; ++r) R[r] ^= 0xffffu;
+    } else {
+        sv_sort_halves<NP>(R, tick, std::make_integer_sequence<int, SvNet<NP>::net.n>{});
 #pragma unroll
-        for (int r = 0; r < NP; ++r) {
-            const int l = r ^ j;
-            if (l > r) { sv_ce(R[r], R[l]); tick(R[r]); }
+        for (int r = 0; r < NP / 2; ++r) { sv_ce_cross(R[r], R[NP - 1 - r]); tick(R[r]); }   // element (0, r) against (1, NP - 1 - r)
+#pragma unroll
+        for (int j = NP >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int r = 0; r < NP; ++r) {
+                const int l = r ^ j;
+                if (l > r) { sv_ce(R[r], R[l]); tick(R[r]); }
+            }
         }
     }
 }
@@ -103,13 +137,15 @@ struct SortedStats { uint32_t max_run, at_max, min_at_max, truth_votes; };
 template <int NP>
 __device__ __forceinline__ SortedStats sv_scan(const uint32_t (&R)[NP], uint32_t tcmp2) {
     static_assert(NP % 4 == 0, "the scan steps take four registers per asm statement");
+    constexpr bool MEET = !sv_pow2(NP);
     uint32_t run[NP];
     uint32_t s = 0;
 #define SV_IDX(r, d) ((uint32_t)((r) + (d)) | ((uint32_t)((r) + NP + (d)) << 16))   /* (index of element (0, r)) + d | the same for (1, r) */
 #pragma unroll
     for (int r = 0; r < NP; r += 4) {
-        // predecessor of element (h, r): (h, r - 1); of (0, 0): none (0xffff differs from every element); of (1, 0): (0, NP - 1)
-        const uint32_t prev = r ? R[r - 1] : ((R[NP - 1] << 16) | 0xffffu);
+        // predecessor of element (h, r): (h, r - 1); of (0, 0): none (0xffff differs from every element); of (1, 0): (0, NP - 1) --
+        // MEET (NP not a power of two: the halves meet at r = 0, see sv_sort): (0, 0), whose run -- the FIRST of half 0 -- it continues
+        const uint32_t prev = r ? R[r - 1] : ((R[MEET ? 0 : NP - 1] << 16) | 0xffffu);
         // 1 where a run starts, times the 1-based index of the element; running maximum = index of the latest start
         uint32_t t0, t1, t2, t3, o0, o1, o2, o3;
         asm("v_xor_b32 %0, %8, %12\n\t"
@@ -134,7 +170,28 @@ __device__ __forceinline__ SortedStats sv_scan(const uint32_t (&R)[NP], uint32_t
         run[r] = o0; run[r + 1] = o1; run[r + 2] = o2; run[r + 3] = o3;
         s = o3;
     }
-    const uint32_t carry = s << 16;                     // a run that crosses from half 0 into half 1 started in half 0
+    uint32_t carry = s << 16;                           // a run that crosses from half 0 into half 1 started in half 0
+    if constexpr (MEET) {
+        // ... here it is half 0's FIRST run (f0 elements: those whose latest start is still index 1) that continues into half 1: an
+        // element of half 1 that has seen no start of its own belongs to a run that started f0 elements before index NP + 1
+        uint32_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < NP; r += 4) {
+            uint32_t t0, t1, t2, t3, ao;
+            asm("v_pk_min_u16 %0, %5, 2 op_sel_hi:[1,0]\n\t"
+                "v_pk_min_u16 %1, %6, 2 op_sel_hi:[1,0]\n\t"
+                "v_pk_min_u16 %2, %7, 2 op_sel_hi:[1,0]\n\t"
+                "v_pk_min_u16 %3, %8, 2 op_sel_hi:[1,0]\n\t"
+                "v_pk_add_u16 %0, %0, %1\n\t"
+                "v_pk_add_u16 %2, %2, %3\n\t"
+                "v_pk_add_u16 %4, %9, %0\n\t"
+                "v_pk_add_u16 %4, %4, %2"
+                : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(ao)
+                : "v"(run[r]), "v"(run[r + 1]), "v"(run[r + 2]), "v"(run[r + 3]), "v"(acc));
+            acc = ao;
+        }
+        carry = ((acc & 0xffffu) + 1u - (uint32_t)NP) << 16;     // (acc.lo = 2 NP - f0) -> NP + 1 - f0
+    }
     uint32_t mx = 0;
 #pragma unroll
     for (int r = 0; r < NP; r += 4) {
@@ -211,28 +268,20 @@ __device__ __forceinline__ uint32_t sv_sentinel(uint32_t x, uint32_t n2, uint32_
 
 // one LDS-DMA piece: 64 lanes x 16 bytes, lane l's bytes (from gbase + goff_l) land at lds_dst + 16 l; the source is a scalar base +
 // a 32-bit lane offset (no 64-bit address arithmetic on the VALU); M0 is written in the statement that reads it
-__device__ __forceinline__ void sv_dma16(const void* gbase, uint32_t goff, uint32_t lds_dst, bool nt) {
-    uint32_t keep;
-    if (nt)          // read-once stream: non-temporal (the line is not kept for a reuse that never comes)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
+__device__ __forceinline__ void sv_dma16(const void* gbase, uint32_t goff, uint32_t lds_dst) {
+    uint32_t keep;         // read-once stream: non-temporal (the line is not kept for a reuse that never comes; ordinary loads: 5-10 % slower at N = 8 ... 32)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
 }
-// ... and 64 lanes x 4 bytes (lane l's dword lands at lds_dst + 4 l): the per-lane gather of the cells' truth values
 // ... the same, pinned in the data flow of the sort: `dep` (a register the preceding compare-exchange wrote and a later one reads) is
 // an in/out operand the statement does not touch, so the exchanges before it stay before and the ones after it stay after -- without it
 // the compiler sinks the whole sort below the pieces (asm statements only keep their order among themselves)
-__device__ __forceinline__ void sv_dma16_pinned(const void* gbase, uint32_t goff, uint32_t lds_dst, bool nt, uint32_t& dep) {
+__device__ __forceinline__ void sv_dma16_pinned(const void* gbase, uint32_t goff, uint32_t lds_dst, uint32_t& dep) {
     uint32_t keep;
-    if (nt)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep), "+v"(dep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep), "+v"(dep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "+v"(dep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
 }
+// ... and 64 lanes x 4 bytes (lane l's dword lands at lds_dst + 4 l): the per-lane gather of the cells' truth values
 __device__ __forceinline__ void sv_dma4(const void* gbase, uint32_t goff, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
@@ -244,45 +293,25 @@ __device__ __forceinline__ int64_t sv_uniform64(int64_t v) {      // tell the co
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-// s_waitcnt vmcnt(k) for a wave-uniform k (the immediate must be a constant): the largest available value <= k
-__device__ __forceinline__ void sv_wait_vmcnt_le(uint32_t k) {
-#define SV_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-    switch (k > 12u ? 12u : k) {
-        SV_W(0) SV_W(1) SV_W(2) SV_W(3) SV_W(4) SV_W(5) SV_W(6) SV_W(7) SV_W(8) SV_W(9) SV_W(10) SV_W(11) SV_W(12)
-    }
-#undef SV_W
-}
-
 constexpr int sort_cells_threads(int nv) { return nv >= 64 ? 512 : 1024; }
 
-// NV: votes per lane (capacity of the shape; 8 / 16 / 32 / 64), KB: blocks of 64 cells per step.  Host contract: N % 4 == 0,
-// 4 <= N <= NV, 16-byte aligned bases, no pool rows; a.wave_lds_words = words of one wave's LDS region (KB * 64 * PS * 4, twice
-// that with tokens; PS = (N / 4) | 1 slots per padded row); the workgroup's LDS = regions | n_valid cache | tie classes | sums.
+// NV: votes per lane (capacity of the shape: 8 / 16 / 32 / 48 / 64).  Host contract: N % 4 == 0, 4 <= N <= NV, 16-byte aligned
+// bases, no pool rows; a.wave_lds_words = words of one wave's LDS region (64 * PS * 4, twice that with tokens, + 64 for the cells'
+// truth values; PS = (N / 4) | 1 slots per padded row); the workgroup's LDS = regions | n_valid cache | tie classes | sums.
 //
 // LIN (rows that are not all 16-byte aligned: N % 4 != 0 or unaligned bases; the reference's N is arbitrary, o1.py:276): a block
 // of 64 rows is still ONE contiguous run of bytes (64 * N * 4 is a multiple of 16, so every block has the base's misalignment):
 // the image is the 16-byte aligned superset of the block, linear, and a lane reads its row with N ds_read_b32 at lane stride N
 // words (conflict-free for odd N, 2-way for N = 2 mod 4).  Host contract: 1 <= N <= NV, a.wave_lds_words covers
-// KB * 64 * N * 4 + 16 bytes rounded up to whole KiB (twice with tokens: the token base has its own misalignment).
+// 64 * N * 4 + 16 bytes rounded up to whole KiB (twice with tokens: the token base has its own misalignment).
 //
-// DB (short rows, N <= 16; option "sort_db", OFF): TWO image buffers per wave, the copy runs two steps ahead.  A wave of the 8-vote
-// shape has 3 KB in flight behind ~170 instructions of counting and waits on memory 0.53 of its cycles (r03_sort_cells_pmc.md) --
-// but twice the bytes in flight made it SLOWER (N = 8: 87.6 vs 83.2 us, N = 16: 81.7 vs 72.4): the shapes are not latency-bound (and
-// not copy-bound: waves that only copy stream 6.9-7.2 TB/s, tools/hbm_probe.bin --dma).  The wait at the top of a step is then
-// vmcnt(<pieces of the next step's copy>): loads complete in order, so while a piece of THIS step's copy is outstanding all of those are too.
-//
-// NV = 128 (64 < N <= 128, aligned rows, no tokens: HALF): a whole 64-row block of 512-byte rows would take 33.8 KB of LDS per wave
-// -- one wave per SIMD, measured 3.0 TB/s against 3.8 for the register-resident kernels.  The rows are staged in two HALVES of 16
-// slots through ONE 17 KB image instead: slots 0..15 of every row, read into the first 32 packed registers, then slots 16.. into the
-// same image (that copy's latency is exposed to this wave and covered by the other wave of the SIMD), then the next step's first
-// half flies while the 128 votes are counted.  The initial placement of the votes in the registers is irrelevant to the sort; only
-// the sentinels name original positions.  8 waves per CU as for 64 votes.
-template <int NV, int KB, bool TOK, bool LIN = false, bool DB = false>
+// Measured and not kept (profiles/r03_sort_cells_ab.log, r03_ab_n128.log): two blocks of 64 cells per step, two image
+// buffers per wave with the copy two steps ahead, 32 resident waves per CU for the 8-vote shape, a 128-vote shape staged in two
+// half-rows, the copy's pieces issued back to back instead of between the compare-exchanges.
+template <int NV, bool TOK, bool LIN = false>
 __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const AggArgs a) {
-    constexpr bool HALF = NV == 128;
-    static_assert(!HALF || (KB == 1 && !TOK && !LIN && !DB), "the 128-vote shape: aligned rows, votes only");
     constexpr int NP = NV / 2, RSM = NV / 4;
-    constexpr int QMAX = KB * (RSM + 1);                             // DMA pieces per step at the widest row (LIN: 16 N KB + 16 bytes)
+    constexpr int QMAX = RSM + 1;                                    // DMA pieces per step at the widest row (LIN: 64 * 4 N + 16 bytes)
     constexpr int TC = NV + 1;                                       // tie classes 0..NV
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, T = (int)blockDim.x, NW = T >> 6;
@@ -291,7 +320,7 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
     const uint32_t rowbytes = (uint32_t)N * 4u;
     const uint32_t shv = LIN ? (uint32_t)(uintptr_t)a.answers & 15u : 0u;            // LIN: bytes between the aligned superset and the block
     const uint32_t sht = (LIN && TOK) ? (uint32_t)(uintptr_t)a.tokens & 15u : 0u;
-    const uint32_t nq = LIN ? ((uint32_t)KB * 64u * rowbytes + 16u + 1023u) >> 10 : (uint32_t)KB * PS;   // DMA pieces per step and stream
+    const uint32_t nq = LIN ? (64u * rowbytes + 16u + 1023u) >> 10 : PS;             // DMA pieces per step and stream
     uint32_t* nv_lds = lds + (int64_t)NW * a.wave_lds_words;
     const bool nv_cached = a.n_valid && B <= kMaxSortedB;
     uint32_t* tie = nv_lds + (nv_cached ? ((B + 3) & ~3) : 0);       // [B][TC]
@@ -305,17 +334,14 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
     }
     __syncthreads();
 
-    // this wave's region: votes image [KB * 64 rows][PS slots], then (TOK) the tokens image
-    const uint32_t rbase0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32*)(lds + (int64_t)wid * a.wave_lds_words));
-    const uint32_t img_bytes = HALF ? 64u * 17u * 16u : (LIN ? nq * 1024u : (uint32_t)KB * 64u * PS * 16u);
-    const uint32_t tru_off = img_bytes * (TOK ? 2u : 1u);            // one buffer: votes image | tokens image | the cells' truth values
-    const uint32_t buf_bytes = tru_off + (uint32_t)KB * 256u;        // (DB: two buffers)
+    // this wave's region: votes image [64 rows][PS slots], then (TOK) the tokens image, then the cells' truth values
+    const uint32_t rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32*)(lds + (int64_t)wid * a.wave_lds_words));
+    const uint32_t img_bytes = LIN ? nq * 1024u : 64u * PS * 16u;
+    const uint32_t tru_off = img_bytes * (TOK ? 2u : 1u);
     // source offset of every slot this lane copies: slot s = 64 q + lane is chunk k = s % PS of row c = s / PS (the pad slot,
     // k == RS, repeats the row's last chunk)
-    uint32_t off[HALF ? 1 : QMAX];
-    if (HALF) {
-        off[0] = 0;
-    } else if (LIN) {
+    uint32_t off[QMAX];
+    if (LIN) {
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) off[q] = (uint32_t)q * 1024u + (uint32_t)lane * 16u;
     } else {
@@ -330,11 +356,10 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
     }
     const int64_t nwaves = (int64_t)gridDim.x * NW;
     const int64_t wave = sv_uniform64((int64_t)blockIdx.x * NW + wid);
-    constexpr int64_t SC = (int64_t)KB * 64;                         // cells per step
+    constexpr int64_t SC = 64;                                       // cells per step
     const int64_t nsteps = (a.ncells + SC - 1) / SC;
     const int64_t total_bytes = a.ncells * (int64_t)rowbytes;
-    const bool nt = a.plain_loads == 0;                              // (option "plain_loads": ordinary loads, for A/B runs)
-    auto issue = [&](int64_t st, uint32_t rbase) {                   // (wave-uniform) start the copy of step st into the buffer at rbase
+    auto issue = [&](int64_t st) {                                   // (wave-uniform) start the copy of step st into this wave's image
         const int64_t byte0 = st * SC * (int64_t)rowbytes;
         // last 16-byte chunk that holds bytes of the tensor, relative to the (aligned superset of the) block
         const int64_t rem = LIN ? ((total_bytes - byte0 + shv - 1) & ~(int64_t)15) : total_bytes - byte0 - 16;
@@ -347,328 +372,218 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) {
             if ((uint32_t)q < nq) {
-                const uint32_t o = off[HALF ? 0 : q] < lim ? off[HALF ? 0 : q] : lim;      // (slots past the last cell re-read the tensor's last chunk)
-                sv_dma16(g, o, rbase + (uint32_t)q * 1024u, nt);
+                const uint32_t o = off[q] < lim ? off[q] : lim;      // (slots past the last cell re-read the tensor's last chunk)
+                sv_dma16(g, o, rbase + (uint32_t)q * 1024u);
                 if (TOK) {
-                    const uint32_t ot = off[HALF ? 0 : q] < limt ? off[HALF ? 0 : q] : limt;
-                    sv_dma16(gt, ot, rbase + img_bytes + (uint32_t)q * 1024u, nt);
+                    const uint32_t ot = off[q] < limt ? off[q] : limt;
+                    sv_dma16(gt, ot, rbase + img_bytes + (uint32_t)q * 1024u);
                 }
             }
         }
     };
 
-    // HALF: the copy of one half of the step's rows (which = 0: slots 0..15, 1: slots 16..RS-1) into the image at rbase; the source
-    // offsets are computed piece by piece (slot s = 64 q + lane is chunk s % PSh of row s / PSh; the pad slot repeats the last chunk)
-    const uint32_t RS2 = HALF ? RS - 16u : 0u, PSB = RS2 | 1u;        // second half: slots, padded slots (first half: 16, 17)
-    const uint32_t cB0 = HALF ? (uint32_t)lane / PSB : 0u, kB0 = HALF ? (uint32_t)lane - cB0 * PSB : 0u;
-    auto issue_half = [&](int64_t st, uint32_t rbase, int which) {
-        const int64_t byte0 = st * SC * (int64_t)rowbytes;
-        const int64_t rem = total_bytes - byte0 - 16;
-        const uint32_t lim = rem > 0x7fffffffll ? 0x7fffffffu : (uint32_t)rem;
-        const char* g = reinterpret_cast<const char*>(a.answers) + byte0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the previous half has left the image
-        const uint32_t PSh = which ? PSB : 17u, RSh = which ? RS2 : 16u, kbase = which ? 16u : 0u;
-        uint32_t c = which ? cB0 : (uint32_t)lane / 17u, k = which ? kB0 : (uint32_t)lane % 17u;
-        const uint32_t dc = 64u / PSh, dk = 64u - dc * PSh;
-#pragma unroll
-        for (int q = 0; q < 17; ++q) {
-            if ((uint32_t)q < PSh) {
-                const uint32_t o0 = c * rowbytes + (kbase + (k < RSh ? k : RSh - 1u)) * 16u;
-                sv_dma16(g, o0 < lim ? o0 : lim, rbase + (uint32_t)q * 1024u, nt);
-                c += dc; k += dk;
-                if (k >= PSh) { k -= PSh; c += 1; }
-            }
-        }
-    };
-
-    // Walkers.  The step's first cell c0 (problem p0, budget b0) advances on the scalar unit; slot j of this lane is cell c0 + 64 j +
-    // lane = c0 + lq[j] * B + lr[j]: its budget and its problem relative to p0 cost three 32-bit VALU operations per step.
+    // Walkers.  The step's first cell c0 (problem p0, budget b0) advances on the scalar unit; this lane's cell is c0 + lane =
+    // c0 + lq * B + lr: its budget and its problem relative to p0 cost three 32-bit VALU operations per step.
     const int64_t stride = nwaves * SC;
     const int64_t dp = sv_uniform64(stride / B);                     // (64-bit divisions run on the VALU: back to SGPRs)
     const int32_t db = (int32_t)(stride - dp * B);
     int64_t c0 = wave * SC;
     int64_t p0 = sv_uniform64(c0 / B);
     int32_t b0 = (int32_t)(c0 - p0 * B);
-    uint32_t lq[KB], lr[KB];
-#pragma unroll
-    for (int j = 0; j < KB; ++j) {
-        lq[j] = (uint32_t)(j * 64 + lane) / (uint32_t)B;
-        lr[j] = (uint32_t)(j * 64 + lane) - lq[j] * (uint32_t)B;
-    }
-    auto slot_budget = [&](int j, uint32_t& prel) -> int32_t {       // budget of slot j in the current step; prel = its problem - p0
-        const uint32_t bs = (uint32_t)b0 + lr[j];
+    const uint32_t lq = (uint32_t)lane / (uint32_t)B, lr = (uint32_t)lane - lq * (uint32_t)B;
+    auto slot_budget = [&](uint32_t& prel) -> int32_t {              // budget of this lane's cell in the current step; prel = its problem - p0
+        const uint32_t bs = (uint32_t)b0 + lr;
         const bool carry = bs >= (uint32_t)B;
-        prel = lq[j] + (carry ? 1u : 0u);
+        prel = lq + (carry ? 1u : 0u);
         return (int32_t)(carry ? bs - (uint32_t)B : bs);
     };
-    // stride % B == 0 (the host rounds the grid): slot j of this lane sees ONE budget -- its valid length is a constant of the
-    // launch and its counters stay in registers
+    // stride % B == 0 (the host rounds the grid): this lane sees ONE budget -- its valid length is a constant of the launch and its
+    // counters stay in registers
     const bool same_b = db == 0;
     const bool fixed_b = counters && same_b;
-    uint32_t h1[KB];
-    unsigned long long tcs[KB];
-    long long toks[KB];
-    int32_t my_b[KB];
-    uint32_t my_n[KB];
+    uint32_t h1 = 0;
+    unsigned long long tcs = 0;
+    long long toks = 0;
     auto budget_len = [&](int32_t b) -> uint32_t { return nv_cached ? nv_lds[b] : (uint32_t)valid_len(a, b); };
-#pragma unroll
-    for (int j = 0; j < KB; ++j) {
-        uint32_t prel;
-        h1[j] = 0; tcs[j] = 0; toks[j] = 0;
-        my_b[j] = slot_budget(j, prel);
-        my_n[j] = budget_len(my_b[j]);
-    }
+    uint32_t prel0;
+    const int32_t my_b = slot_budget(prel0);
+    const uint32_t my_n = budget_len(my_b);
 
     uint32_t bad = 0;
-    // The prefetch runs D steps ahead of the counting (D = 2 with two buffers) with a scalar walker of its own (cf, pf, bf).
-    constexpr int D = DB ? 2 : 1;
+    // The prefetch runs one step ahead of the counting with a scalar walker of its own (cf, pf, bf).
     int64_t cf = c0, pf = p0;
     int32_t bf = b0;
     // The truth of a step's cells travels with its images (a per-lane 4-byte LDS-DMA gather): the loop then holds no load the
     // compiler counts, so it cannot put a vmcnt(0) of its own in front of a use and drain the prefetch.
-    auto issue_truth = [&](uint32_t rbase) {                         // for the step at (cf, pf, bf); then the walker moves on
+    auto issue_truth = [&]() {                                       // for the step at (cf, pf, bf); then the walker moves on
         const int64_t left = a.ncells - cf;
         const uint32_t live_cells = left > (int64_t)SC ? (uint32_t)SC : (uint32_t)left;
         // (scalar base + 32-bit lane offset; the walker is uniform but the compiler may keep it in VGPRs: an "s" operand it cannot
         //  satisfy is silently replaced by a VGPR pair, which does not assemble)
         const int32_t* tp = reinterpret_cast<const int32_t*>(sv_uniform64((int64_t)(uintptr_t)(a.truth + pf)));
-#pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const uint32_t bs = (uint32_t)bf + lr[j];
-            const uint32_t prel = lq[j] + (bs >= (uint32_t)B ? 1u : 0u);
-            sv_dma4(tp, ((uint32_t)(j * 64 + lane) < live_cells ? prel : 0u) * 4u, rbase + tru_off + (uint32_t)j * 256u);
-        }
+        const uint32_t bs = (uint32_t)bf + lr;
+        const uint32_t prel = lq + (bs >= (uint32_t)B ? 1u : 0u);
+        sv_dma4(tp, ((uint32_t)lane < live_cells ? prel : 0u) * 4u, rbase + tru_off);
         cf += stride; pf += dp; bf += db;
         if (bf >= B) { bf -= B; pf += 1; }
     };
     auto advance = [&]() { c0 += stride; p0 += dp; b0 += db; if (b0 >= B) { b0 -= B; p0 += 1; } };
     int64_t st = wave;
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (st + d * nwaves < nsteps) {
-            if (HALF) issue_half(st + d * nwaves, rbase0, 0); else issue(st + d * nwaves, rbase0 + (uint32_t)d * buf_bytes);
-            issue_truth(rbase0 + (uint32_t)d * buf_bytes);
-        }
-    uint32_t parity = 0;
-    for (; st < nsteps; st += nwaves, parity ^= 1u) {
-        const uint32_t rbase = DB ? rbase0 + parity * buf_bytes : rbase0;
+    if (st < nsteps) { issue(st); issue_truth(); }
+    for (; st < nsteps; st += nwaves) {
         // this step's images have landed (LDS-DMA is counted by vmcnt; hipcc does not count asm loads)
-        if (DB && st + nwaves < nsteps) sv_wait_vmcnt_le(nq * (TOK ? 2u : 1u) + (uint32_t)KB);       // (the pieces of the next step's copy)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t R[KB][NP];
-        long long tok[KB];
-        uint32_t nvj[KB];
-        int32_t trj[KB];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t R[NP];
+        long long tok = 0;
         const int64_t left = a.ncells - c0;                          // (wave-uniform) cells from this step's first to the last
         const bool all_live = left >= (int64_t)SC;
         const uint32_t live_cells = all_live ? (uint32_t)SC : (uint32_t)left;
-        int32_t eb[KB];
-        if constexpr (HALF) {
-            const bool live = (uint32_t)lane < live_cells;
-            uint32_t prel;
-            eb[0] = same_b ? my_b[0] : slot_budget(0, prel);
-            const uint32_t n = live ? (same_b ? my_n[0] : budget_len(eb[0])) : 0u;
-            nvj[0] = n;
-            tok[0] = 0;
-            trj[0] = (int32_t)*reinterpret_cast<lds_u32*>((uintptr_t)(rbase + tru_off + (uint32_t)lane * 4u));
-            const bool full = all_live && __all(n == (uint32_t)NV);
-            const uint32_t n2 = n | (n << 16);
-            // one half: 16 slots of this lane's row (padded stride PSh) -> 32 packed registers Rh[0..31]: slot k holds the half's elements
-            // 4k..4k+3, paired with the elements 32 further on (slot k + 8); ebase: the half's first element in the row
-            auto read_half = [&](uint32_t (&Rall)[NP], int rb, uint32_t PSh, uint32_t RSh, uint32_t ebase) {
-                const uint32_t ra = rbase + (uint32_t)lane * (PSh * 16u);
-                uint32_t w[64];
+        const bool live = (uint32_t)lane < live_cells;
+        uint32_t prel;
+        const int32_t eb = same_b ? my_b : slot_budget(prel);
+        const uint32_t n = live ? (same_b ? my_n : budget_len(eb)) : 0u;
+        const int32_t trj = (int32_t)*reinterpret_cast<lds_u32*>((uintptr_t)(rbase + tru_off + (uint32_t)lane * 4u));
+        const uint32_t ra = LIN ? rbase + shv + (uint32_t)lane * rowbytes : rbase + (uint32_t)lane * (PS * 16u);
+        uint32_t w[NV];
+        if (LIN) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t k0 = (uint32_t)k < RSh ? (uint32_t)k : RSh - 1u, k1 = (uint32_t)(k + 8) < RSh ? (uint32_t)(k + 8) : RSh - 1u;
-                    const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k0));
-                    const scv_v4u h = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k1));
-                    w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
-                    w[32 + 4 * k] = h.x; w[32 + 4 * k + 1] = h.y; w[32 + 4 * k + 2] = h.z; w[32 + 4 * k + 3] = h.w;
-                }
-                uint32_t orv = 0;
-#pragma unroll
-                for (int i = 0; i < 64; ++i) orv |= w[i];
-                if (__any(orv > 1023u)) {
-#pragma unroll
-                    for (int i = 0; i < 64; ++i) {
-                        bad |= w[i] & (uint32_t)(((int32_t)(ebase + (uint32_t)i) - (int32_t)n) >> 31);
-                        w[i] = w[i] < 1023u ? w[i] : 1023u;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 32; ++r) Rall[rb + r] = w[r] | (w[r + 32] << 16);
-                if (!full) {
-#pragma unroll
-                    for (int r = 0; r < 32; ++r) {
-                        const uint32_t e0 = ebase + (uint32_t)r, e1 = e0 + 32u;     // original positions of the register's two votes
-                        Rall[rb + r] = sv_sentinel(Rall[rb + r], n2, (e0 + 1u) | ((e1 + 1u) << 16), (0x8000u | e0) | ((0x8000u | e1) << 16));
-                    }
-                }
-            };
-            read_half(R[0], 0, 17u, 16u, 0u);
-            issue_half(st, rbase, 1);                                 // the second half of this step's rows, into the same image
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            read_half(R[0], 32, PSB, RS2, 64u);
+            for (int i = 0; i < NV; ++i) w[i] = *reinterpret_cast<lds_u32*>((uintptr_t)(ra + 4u * i));   // (past the row: the neighbour's votes, never valid)
         } else {
 #pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const bool live = (uint32_t)(j * 64 + lane) < live_cells;
-            uint32_t prel;
-            eb[j] = same_b ? my_b[j] : slot_budget(j, prel);
-            const uint32_t n = live ? (same_b ? my_n[j] : budget_len(eb[j])) : 0u;
-            nvj[j] = n;
-            trj[j] = (int32_t)*reinterpret_cast<lds_u32*>((uintptr_t)(rbase + tru_off + (uint32_t)(j * 64 + lane) * 4u));
-            const uint32_t ra = LIN ? rbase + shv + (uint32_t)(j * 64 + lane) * rowbytes : rbase + (uint32_t)(j * 64 + lane) * (PS * 16u);
-            uint32_t w[NV];
-            if (LIN) {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) w[i] = *reinterpret_cast<lds_u32*>((uintptr_t)(ra + 4u * i));   // (past the row: the neighbour's votes, never valid)
-            } else {
-#pragma unroll
-                for (int k = 0; k < RSM / 2; ++k) {
-                    // elements 4k .. 4k + 3 and their partners NP elements further on: both halves of four packed registers
-                    // (slots past the row re-read its last slot: in-domain values that are never valid votes)
-                    const uint32_t k0 = (uint32_t)k < RS ? (uint32_t)k : RS - 1u, k1 = (uint32_t)(k + RSM / 2) < RS ? (uint32_t)(k + RSM / 2) : RS - 1u;
-                    const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k0));
-                    const scv_v4u h = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k1));
-                    w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
-                    w[NP + 4 * k] = h.x; w[NP + 4 * k + 1] = h.y; w[NP + 4 * k + 2] = h.z; w[NP + 4 * k + 3] = h.w;
-                }
-            }
-            tok[j] = 0;
-            if (TOK && LIN) {
-                const uint32_t rt = rbase + img_bytes + sht + (uint32_t)(j * 64 + lane) * rowbytes;
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    if (i < N) {
-                        const int32_t y = (int32_t)*reinterpret_cast<lds_u32*>((uintptr_t)(rt + 4u * i));
-                        tok[j] += (long long)(y & ((i - (int32_t)n) >> 31));      // validity as a mask: all ones when i < n
-                    }
-                }
-            }
-            if (TOK && !LIN) {
-#pragma unroll
-                for (int k = 0; k < RSM; ++k) {
-                    if ((uint32_t)k < RS) {
-                        const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + img_bytes + 16u * k));
-                        // validity as a MASK (a predicate per element would keep 64 SGPR pairs alive): all ones when element < n
-                        const int32_t nn = (int32_t)n - 4 * k;
-                        tok[j] += (long long)((int32_t)q.x & ((0 - nn) >> 31)) + (long long)((int32_t)q.y & ((1 - nn) >> 31))
-                                + (long long)((int32_t)q.z & ((2 - nn) >> 31)) + (long long)((int32_t)q.w & ((3 - nn) >> 31));
-                    }
-                }
-            }
-            // o1.py:140 int(extracted_answer) is unbounded; the extractor maps it into bins 0..1023: the clamp runs only in the
-            // (wave-uniform, rare) case that some slot -- a vote or not -- holds a larger value
-            uint32_t orv = 0;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) orv |= w[i];
-            const bool full = all_live && __all(n == (uint32_t)NV);
-            if (__any(orv > 1023u)) {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    bad |= w[i] & (uint32_t)((i - (int32_t)n) >> 31);
-                    w[i] = w[i] < 1023u ? w[i] : 1023u;
-                }
-            }
-            // every slot is <= 1023 now (votes, neighbours, pads): two per register
-#pragma unroll
-            for (int r = 0; r < NP; ++r) R[j][r] = w[r] | (w[r + NP] << 16);
-            if (!full) {
-                const uint32_t n2 = n | (n << 16);
-#pragma unroll
-                for (int r = 0; r < NP; ++r)
-                    R[j][r] = sv_sentinel(R[j][r], n2, (uint32_t)(r + 1) | ((uint32_t)(r + NP + 1) << 16),
-                                          (0x8000u | (uint32_t)r) | ((0x8000u | (uint32_t)(r + NP)) << 16));
+            for (int k = 0; k < RSM / 2; ++k) {
+                // elements 4k .. 4k + 3 and their partners NP elements further on: both halves of four packed registers
+                // (slots past the row re-read its last slot: in-domain values that are never valid votes)
+                const uint32_t k0 = (uint32_t)k < RS ? (uint32_t)k : RS - 1u, k1 = (uint32_t)(k + RSM / 2) < RS ? (uint32_t)(k + RSM / 2) : RS - 1u;
+                const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k0));
+                const scv_v4u h = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k1));
+                w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+                w[NP + 4 * k] = h.x; w[NP + 4 * k + 1] = h.y; w[NP + 4 * k + 2] = h.z; w[NP + 4 * k + 3] = h.w;
             }
         }
+        if (TOK && LIN) {
+            const uint32_t rt = rbase + img_bytes + sht + (uint32_t)lane * rowbytes;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                if (i < N) {
+                    const int32_t y = (int32_t)*reinterpret_cast<lds_u32*>((uintptr_t)(rt + 4u * i));
+                    tok += (long long)(y & ((i - (int32_t)n) >> 31));      // validity as a mask: all ones when i < n
+                }
+            }
+        }
+        if (TOK && !LIN) {
+#pragma unroll
+            for (int k = 0; k < RSM; ++k) {
+                if ((uint32_t)k < RS) {
+                    const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + img_bytes + 16u * k));
+                    // validity as a MASK (a predicate per element would keep 64 SGPR pairs alive): all ones when element < n
+                    const int32_t nn = (int32_t)n - 4 * k;
+                    tok += (long long)((int32_t)q.x & ((0 - nn) >> 31)) + (long long)((int32_t)q.y & ((1 - nn) >> 31))
+                         + (long long)((int32_t)q.z & ((2 - nn) >> 31)) + (long long)((int32_t)q.w & ((3 - nn) >> 31));
+                }
+            }
+        }
+        // o1.py:140 int(extracted_answer) is unbounded; the extractor maps it into bins 0..1023: the clamp runs only in the
+        // (wave-uniform, rare) case that some slot -- a vote or not -- holds a larger value
+        uint32_t orv = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) orv |= w[i];
+        const bool full = all_live && __all(n == (uint32_t)NV);
+        if (__any(orv > 1023u)) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                bad |= w[i] & (uint32_t)((i - (int32_t)n) >> 31);
+                w[i] = w[i] < 1023u ? w[i] : 1023u;
+            }
+        }
+        // every slot is <= 1023 now (votes, neighbours, pads): two per register
+#pragma unroll
+        for (int r = 0; r < NP; ++r) R[r] = w[r] | (w[r + NP] << 16);
+        if (!full) {
+            const uint32_t n2 = n | (n << 16);
+#pragma unroll
+            for (int r = 0; r < NP; ++r)
+                R[r] = sv_sentinel(R[r], n2, (uint32_t)(r + 1) | ((uint32_t)(r + NP + 1) << 16),
+                                   (0x8000u | (uint32_t)r) | ((0x8000u | (uint32_t)(r + NP)) << 16));
         }
         // the next step's copy flies while this step is counted
         uint4* const cells_out = a.cells ? reinterpret_cast<uint4*>(a.cells) + c0 : nullptr;     // (scalar bases of this step's outputs)
         int64_t* const ctok_out = (TOK && a.cell_tokens) ? a.cell_tokens + c0 : nullptr;
         advance();
-        // The next step's copy goes into the buffer just read.  SPREAD (votes only, one block per step, 16 votes or more; option
-        // "sort_spread"): its pieces are issued one every few compare-exchanges of the sort -- pinned there through a register operand,
-        // or the compiler sinks the sort below them -- instead of back to back: 3-5 % (N = 64: 96.3 -> 92.1 us, N = 30: 86.2 -> 81.7).
-        const bool have_next = st + (int64_t)D * nwaves < nsteps;
-        constexpr bool CAN_SPREAD = KB == 1 && !HALF && !TOK && NV >= 16;
-        const bool spread = CAN_SPREAD && a.sort_spread != 0 && have_next;
+        // The next step's copy goes into the image just read.  Votes only, 16 votes or more: its pieces are issued one every few
+        // compare-exchanges of the sort -- pinned there through a register operand, or the compiler sinks the sort below them --
+        // instead of back to back: 3-5 % (N = 64: 96.3 -> 92.1 us, N = 30: 86.2 -> 81.7).
+        const bool have_next = st + nwaves < nsteps;
+        constexpr bool CAN_SPREAD = !TOK && NV >= 16;
+        const bool spread = CAN_SPREAD && have_next;
         // (source base and limit of the next step's copy: wave-uniform values of this iteration)
-        const int64_t nbyte0 = (st + (int64_t)D * nwaves) * SC * (int64_t)rowbytes;
+        const int64_t nbyte0 = (st + nwaves) * SC * (int64_t)rowbytes;
         const int64_t nrem = LIN ? ((total_bytes - nbyte0 + shv - 1) & ~(int64_t)15) : total_bytes - nbyte0 - 16;
         const uint32_t nlim = nrem > 0x7fffffffll ? 0x7fffffffu : (nrem < 0 ? 0u : (uint32_t)nrem);
         const char* const ng = reinterpret_cast<const char*>(a.answers) + nbyte0 - shv;
         if (have_next) {
-            if (HALF) { issue_half(st + (int64_t)D * nwaves, rbase, 0); issue_truth(rbase); }
-            else if (spread) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_truth(rbase); }
-            else { issue(st + (int64_t)D * nwaves, rbase); issue_truth(rbase); }
+            if (spread) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_truth(); }
+            else { issue(st + nwaves); issue_truth(); }
         }
         constexpr int STEP = sv_sort_ticks<NP>() / QMAX > 0 ? sv_sort_ticks<NP>() / QMAX : 1;
         int ticks = 0;                                               // (a constant at every call site after unrolling)
-        auto piece = [&](int q, uint32_t& dep) {
+        auto piece = [&](int q, uint32_t& dep) __attribute__((always_inline)) {
             if constexpr (CAN_SPREAD) {
-                if ((uint32_t)q < nq) sv_dma16_pinned(ng, off[q] < nlim ? off[q] : nlim, rbase + (uint32_t)q * 1024u, nt, dep);
+                // (readfirstlane: under register pressure the compiler may hold the uniform address in a VGPR, and an "s" operand it cannot
+                //  satisfy is silently replaced by a VGPR, which does not assemble)
+                if ((uint32_t)q < nq) sv_dma16_pinned(ng, off[q] < nlim ? off[q] : nlim, (uint32_t)__builtin_amdgcn_readfirstlane((int)(rbase + (uint32_t)q * 1024u)), dep);
             }
         };
-        auto tick = [&](uint32_t& reg) {
+        auto tick = [&](uint32_t& reg) __attribute__((always_inline)) {
             if constexpr (CAN_SPREAD) {
                 if (spread && ticks % STEP == 0 && ticks / STEP < QMAX) piece(ticks / STEP, reg);
             }
             ++ticks;
         };
+        if constexpr (CAN_SPREAD) {
+            sv_sort<NP>(R, tick);
+            if (spread) {
 #pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            if constexpr (CAN_SPREAD) {
-                sv_sort<NP>(R[j], tick);
-                if (spread) {
-#pragma unroll
-                    for (int q = (sv_sort_ticks<NP>() + STEP - 1) / STEP; q < QMAX; ++q) piece(q, R[j][0]);   // (pieces the sort did not reach)
-                }
-            } else {
-                SvNoTick none;
-                sv_sort<NP>(R[j], none);
+                for (int q = (sv_sort_ticks<NP>() + STEP - 1) / STEP; q < QMAX; ++q) piece(q, R[0]);   // (pieces the sort did not reach)
             }
-            const uint32_t tcmp = (trj[j] >= 0 && trj[j] < kBins) ? (uint32_t)trj[j] : 0x7fffu;
-            const SortedStats s = sv_scan<NP>(R[j], tcmp | (tcmp << 16));
-            if ((uint32_t)(j * 64 + lane) < live_cells) {
-                const uint32_t n = nvj[j];
-                const bool any = n > 0;
-                const uint32_t maxc = any ? s.max_run : 0u;
-                // sentinels are runs of length 1: they are modes only when every vote is distinct
-                const uint32_t n_modes = any ? s.at_max - (s.max_run == 1u ? (uint32_t)NV - n : 0u) : 0u;
-                const uint32_t tc = s.truth_votes;
-                const uint32_t hit = (any && tc == maxc) ? 1u : 0u;                  // o1.py:206
-                if (a.cells) {
-                    uint4 rec;
-                    rec.x = maxc;
-                    rec.y = tc;
-                    rec.z = (n_modes & 0xffffu) | ((any ? (s.min_at_max & 0xffffu) : 0xffffu) << 16);
-                    rec.w = hit;
-                    __builtin_nontemporal_store(scv_v4u{rec.x, rec.y, rec.z, rec.w}, reinterpret_cast<scv_v4u*>(cells_out) + (uint32_t)(j * 64 + lane));
-                }
-                if (TOK && a.cell_tokens) ctok_out[(uint32_t)(j * 64 + lane)] = tok[j];
-                if (fixed_b) {                                                        // o1.py:238-240 as integers
-                    h1[j] += (hit && n_modes == 1u) ? 1u : 0u;
-                    if (hit && n_modes != 1u) atomicAdd(&tie[eb[j] * TC + (int32_t)n_modes], 1u);
-                    tcs[j] += tc;
-                    if (TOK) toks[j] += tok[j];
-                } else if (counters) {                                                // ... per workgroup in LDS
-                    if (hit) atomicAdd(&tie[eb[j] * TC + (int32_t)n_modes], 1u);
-                    if (tc) atomicAdd(&acc[eb[j]], (unsigned long long)tc);
-                    if (TOK) atomicAdd(&acc[B + eb[j]], (unsigned long long)tok[j]);
-                }
+        } else {
+            SvNoTick none;
+            sv_sort<NP>(R, none);
+        }
+        const uint32_t tcmp = (trj >= 0 && trj < kBins) ? (uint32_t)trj : 0x7fffu;
+        const SortedStats s = sv_scan<NP>(R, tcmp | (tcmp << 16));
+        if (live) {
+            const bool any = n > 0;
+            const uint32_t maxc = any ? s.max_run : 0u;
+            // sentinels are runs of length 1: they are modes only when every vote is distinct
+            const uint32_t n_modes = any ? s.at_max - (s.max_run == 1u ? (uint32_t)NV - n : 0u) : 0u;
+            const uint32_t tc = s.truth_votes;
+            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;                  // o1.py:206
+            if (a.cells) {
+                uint4 rec;
+                rec.x = maxc;
+                rec.y = tc;
+                rec.z = (n_modes & 0xffffu) | ((any ? (s.min_at_max & 0xffffu) : 0xffffu) << 16);
+                rec.w = hit;
+                __builtin_nontemporal_store(scv_v4u{rec.x, rec.y, rec.z, rec.w}, reinterpret_cast<scv_v4u*>(cells_out) + (uint32_t)lane);
+            }
+            if (TOK && a.cell_tokens) ctok_out[(uint32_t)lane] = tok;
+            if (fixed_b) {                                                        // o1.py:238-240 as integers
+                h1 += (hit && n_modes == 1u) ? 1u : 0u;
+                if (hit && n_modes != 1u) atomicAdd(&tie[eb * TC + (int32_t)n_modes], 1u);
+                tcs += tc;
+                if (TOK) toks += tok;
+            } else if (counters) {                                                // ... per workgroup in LDS
+                if (hit) atomicAdd(&tie[eb * TC + (int32_t)n_modes], 1u);
+                if (tc) atomicAdd(&acc[eb], (unsigned long long)tc);
+                if (TOK) atomicAdd(&acc[B + eb], (unsigned long long)tok);
             }
         }
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
     if (fixed_b) {
-#pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            if (h1[j]) atomicAdd(&tie[my_b[j] * TC + 1], h1[j]);
-            if (tcs[j]) atomicAdd(&acc[my_b[j]], tcs[j]);
-            if (TOK && toks[j]) atomicAdd(&acc[B + my_b[j]], (unsigned long long)toks[j]);
-        }
+        if (h1) atomicAdd(&tie[my_b * TC + 1], h1);
+        if (tcs) atomicAdd(&acc[my_b], tcs);
+        if (TOK && toks) atomicAdd(&acc[B + my_b], (unsigned long long)toks);
     }
     if (counters) {
         __syncthreads();

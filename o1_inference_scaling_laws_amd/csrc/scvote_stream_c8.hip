@@ -1,6 +1,10 @@
-// Streaming kernel scv_hist_argmax with R = 8 LDS copies of the histogram: 3 workgroup sizes x (3 unrolls + the
-// single-launch-epilogue variant) x tokens.  One table per translation unit (scvote_dispatch.h).
+// Streaming kernel scv_hist_argmax with R = 8 LDS copies of the histogram: 256 threads (+ the single-launch epilogues), 512 threads.
 #include "scvote_dispatch.h"
 namespace scv {
-KernelFn pick_stream_c8(int threads, int unroll, bool tok, bool xtra) { return stream_t<3>(threads, unroll, tok, xtra); }
+KernelFn pick_stream_c8(int threads, int unroll, bool tok, bool xtra) {
+    if (unroll != 4) return nullptr;
+    if (threads == 256) return stream_tok<3, 256, 4>(tok, xtra);
+    if (threads == 512 && !xtra) return stream_plain<3, 512, 4>(tok);
+    return nullptr;
+}
 }  // namespace scv

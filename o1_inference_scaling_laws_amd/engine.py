@@ -405,6 +405,85 @@ class MultiDeviceEngine:
         check(self._L.scv_allreduce_counters(self._comm, ptrs, n))
         return counters
 
+    def stat(self, key: str) -> int:
+        """Communicator counters (scv_comm_get_stat): "selftest_words" (verified per rank by the create-time self-test), "staging_bytes"."""
+        v = C.c_int64()
+        check(self._L.scv_comm_get_stat(self._comm, key.encode(), C.byref(v)))
+        return int(v.value)
+
+    def all_gather_cells(self, tables, rows):
+        """``tables[g]``: uint8 CUDA tensor [P, B, 16] on engine g's device -- the WHOLE cell table, in which engine g has written
+        its own block of ``rows[g]`` problems at row ``sum(rows[:g])``.  In place: afterwards every table holds every block
+        (scv_allgather_cells; asynchronous, ordered behind the engines' queued work)."""
+        P, B = int(tables[0].shape[0]), int(tables[0].shape[1])
+        if sum(int(r) for r in rows) != P or len(rows) != len(self.engines):
+            raise ValueError("rows must hold one block size per engine and add up to the table's problems")
+        for e, t in zip(self.engines, tables):
+            if tuple(t.shape) != (P, B, 16) or not t.is_contiguous():
+                raise ValueError("tables must be contiguous uint8 [P, B, 16] tensors of one shape")
+            e._check_device(t, "tables")
+        ptrs = (C.c_void_p * len(tables))(*[t.data_ptr() for t in tables])
+        check(self._L.scv_allgather_cells(self._comm, ptrs, (C.c_int64 * len(rows))(*[int(r) for r in rows]), B))
+        return tables
+
+    def all_gather_i64(self, buffers, counts):
+        """In-place all-gather of int64 blocks: engine g's block of ``counts[g]`` words sits at word ``sum(counts[:g])`` of
+        ``buffers[g]`` (scv_allgather_i64)."""
+        tot = sum(int(c) for c in counts)
+        for e, b in zip(self.engines, buffers):
+            if int(b.numel()) < tot or not b.is_contiguous():
+                raise ValueError("buffers must be contiguous int64 tensors of at least sum(counts) words")
+            e._check_device(b, "buffers")
+        ptrs = (C.c_void_p * len(buffers))(*[b.data_ptr() for b in buffers])
+        check(self._L.scv_allgather_i64(self._comm, ptrs, (C.c_int64 * len(counts))(*[int(c) for c in counts])))
+        return buffers
+
+    def evaluate_c5(self, shards, resamples: int, seed: int, M: int | None = None, n_valid=None):
+        """BASELINE config 5 from ONE process over this communicator's GPUs, no torch.distributed (the
+        multi-process form is passk.evaluate_device): ``shards[g] = (answers_g, truth_g, tokens_g | None)`` resident on engine g's
+        device (``scatter`` makes them).  Per engine: vote over its block (cells written into its block of the whole table) ->
+        ONE all-reduce of the packed counters + error word -> all-gather of the 16-byte cells -> bootstrap of its slice of the
+        resamples -> all-gather of the slices.  ``M=None`` reads the class bound from the counters (one host sync).
+        Returns (counters int64 [counters_size(B) + 1] -- the last word is the summed device error word --, cells uint8 [P, B, 16],
+        boot int64 [resamples, B, M], M), all on the first engine's device and complete on EVERY engine; asynchronous: ``sync()``
+        before reading (it raises what any engine has to report)."""
+        import torch
+        if len(shards) != len(self.engines):
+            raise ValueError("one shard per engine")
+        G = len(self.engines)
+        rows = [int(sh[0].shape[0]) for sh in shards]
+        P, B = sum(rows), int(shards[0][0].shape[1])
+        ncount = counters_size(B)
+        counters, tables = [], []
+        lo = 0
+        for e, (ans, tr, tok), n in zip(self.engines, shards, rows):
+            dev = ans.device
+            with torch.cuda.device(dev):
+                cnt = torch.zeros(ncount + 1, dtype=torch.int64, device=dev)
+                table = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
+                nv = None if n_valid is None else torch.as_tensor(np.asarray(n_valid, dtype=np.int32), device=dev)
+                if n:
+                    e.aggregate_device(ans, tr, tokens=tok, n_valid=nv, counters=cnt[:ncount], cells=table[lo:lo + n])
+                e.export_error_word(cnt[ncount:])
+            counters.append(cnt)
+            tables.append(table)
+            lo += n
+        self.all_reduce_counters(counters)
+        self.all_gather_cells(tables, rows)
+        if M is None:
+            from .passk import class_bound
+            M = class_bound(counters[0][:ncount], B)             # host sync (the classes present do not depend on the resample seed)
+        bounds = [((g * resamples) // G, ((g + 1) * resamples) // G) for g in range(G)]
+        boots = []
+        for e, table, (r0, r1) in zip(self.engines, tables, bounds):
+            with torch.cuda.device(table.device):
+                full = torch.empty((resamples, B, M), dtype=torch.int64, device=table.device)
+                if r1 > r0:
+                    e.bootstrap_device(table, r0, r1, seed, M, out=full[r0:r1])
+            boots.append(full)
+        self.all_gather_i64(boots, [(r1 - r0) * B * M for r0, r1 in bounds])
+        return counters[0], tables[0], boots[0], M
+
     def _run(self, fn_name, rows, truth, per_shard_kwargs, shared_kwargs):
         from concurrent.futures import ThreadPoolExecutor
         from .dist import shard_bounds
@@ -479,8 +558,8 @@ class MultiDeviceEngine:
         return total, [o[1] for o in outs], [o[2] for o in outs]
 
     def sync(self):
-        for e in self.engines:
-            e.sync()
+        """scv_comm_sync: every engine's stream drained, every engine's device error word judged (first error raised)."""
+        check(self._L.scv_comm_sync(self._comm))
 
     def aggregate_prefix(self, pool, truth, n_valid, tokens=None, want_cells=True) -> AggregateResult:
         pool = np.ascontiguousarray(pool, dtype=np.int32)

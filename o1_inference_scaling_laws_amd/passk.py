@@ -107,12 +107,15 @@ def evaluate_device(engine, answers_local, truth_local, num_problems: int, resam
     return C5Device(cnt, all_cells, boot, r0, r1, M, flag)
 
 
-def _raise_collectively(global_word: int, engine, what: str):
-    """Every rank raises when the all-reduced error word is non-zero: the rank(s) that saw the error with the
-    engine's own exception (``engine.sync()`` reads and clears the local word), the others with a remote notice."""
+def _raise_collectively(global_word: int, engine, what: str, group=None) -> bool:
+    """Every rank raises when the all-reduced error word says some rank's results are invalid: the rank(s) that saw the error
+    with the engine's own exception (``engine.sync()`` reads, judges and clears the local word), the others with a remote notice.
+    Returns True when the word was non-zero but nothing is wrong: ``engine.sync()`` accepted this rank's word (a fused-barrier
+    timeout it has just repaired with a separate bootstrap launch -- bit 2 of scv_export_error_word, one rank only) and there is
+    no other rank that could have contributed."""
     from ._lib import ERR_DOMAIN, DomainError, ScvError
     if global_word == 0:
-        return                                  # the branch is taken on the EXCHANGED word only: all ranks agree
+        return False                            # the branch is taken on the EXCHANGED word only: all ranks agree
     local = None
     if engine is not None and hasattr(engine, "sync"):
         try:
@@ -121,6 +124,8 @@ def _raise_collectively(global_word: int, engine, what: str):
             local = e
     if local is not None:
         raise local
+    if not scv_dist.collectives_active(group) and engine is not None and hasattr(engine, "sync"):
+        return True                             # one rank, and its own sync found nothing to report (it repaired what there was)
     raise DomainError(ERR_DOMAIN, f"another rank reported a device error during {what}; the exchanged results are invalid")
 
 
@@ -128,7 +133,8 @@ def check(dev: C5Device, engine=None, group=None):
     """Host side of the collective error word after the VOTE (one host sync; every rank takes the same branch because
     the word was summed over the ranks inside the counters' all-reduce).  Call before ``finish_host``."""
     word = int(dev.flag.cpu()[0]) if dev.flag is not None else 0
-    _raise_collectively(word, engine, "the vote")
+    if _raise_collectively(word, engine, "the vote", group):
+        dev.flag.zero_()                        # judged and cleared by the sync: gather_bootstrap must not count it again
 
 
 def gather_bootstrap(dev: C5Device, resamples: int, group=None, engine=None):
@@ -146,7 +152,7 @@ def gather_bootstrap(dev: C5Device, resamples: int, group=None, engine=None):
             engine.export_error_word(after)
             word += after
         scv_dist.all_reduce_counters(word, group)
-        _raise_collectively(int(word.cpu()[0]), engine, "the vote or the bootstrap")
+        _raise_collectively(int(word.cpu()[0]), engine, "the vote or the bootstrap", group)
     if not scv_dist.collectives_active(group):
         return dev.boot
     world = dist.get_world_size(group)

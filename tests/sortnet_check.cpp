@@ -1,10 +1,10 @@
 // CPU proof of the counting core of scv_sort_cells (csrc/scvote_sort.hip.h): built and run by tests/test_sort_network.py.
-//  1. the compile-time compare-exchange list of csrc/scvote_sortnet.h sorts (0-1 principle: exhaustively for N <= 16 wires,
-//     2^20 random 0-1 inputs for N = 32, 64);
+//  1. the compile-time compare-exchange list of csrc/scvote_sortnet.h sorts (0-1 principle: exhaustively for N <= 24 wires,
+//     SAMPLED -- 2^20 random 0-1 inputs -- for N = 32), and the valley merge of the 48-vote shape sorts every 0-1 valley;
 //  2. a scalar emulation of the device code's packed form -- two 16-bit elements per register, both halves through the same
 //     network in lockstep, ONE bitonic merge whose first stage crosses the halves, then the run-length scan with the carry
 //     between the halves, distinct sentinels behind the valid prefix -- gives statistics.multimode's (max count, number of modes,
-//     smallest mode) and the truth count, against a brute-force count, for every shape NV = 8 ... 128.
+//     smallest mode) and the truth count, against a brute-force count, for every shape NV = 8 ... 64 (48: the halves meet at r = 0).
 // The packed operations are restated here with the semantics of v_pk_min_u16 / v_pk_max_u16 / v_pk_add_u16 / v_pk_sub_u16 (clamp) /
 // v_pk_mul_lo_u16 / v_alignbit_b32 / v_bfi_b32; the order of operations is the device code's.
 #include <cstdint>
@@ -15,6 +15,7 @@
 #include "../o1_inference_scaling_laws_amd/csrc/scvote_sortnet.h"
 
 using scv::sv_make_network;
+using scv::sv_make_valley_merge;
 using scv::SvNetwork;
 
 template <typename F>
@@ -32,11 +33,11 @@ static uint32_t alignbit(uint32_t hi, uint32_t lo, int s) { return (uint32_t)(((
 template <int N>
 static bool network_sorts_all_01() {
     static constexpr SvNetwork<N> net = sv_make_network<N>();
-    const uint64_t total = N <= 16 ? (1ull << N) : (1ull << 20);
+    const uint64_t total = N <= 24 ? (1ull << N) : (1ull << 20);      // exhaustive up to 24 wires, SAMPLED (2^20 random 0-1 inputs) beyond
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     for (uint64_t t = 0; t < total; ++t) {
         uint64_t bits = t;
-        if (N > 16) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; bits = rng; }
+        if (N > 24) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; bits = rng; }
         int x[N];
         for (int i = 0; i < N; ++i) x[i] = (int)((bits >> i) & 1);
         for (int c = 0; c < net.n; ++c)
@@ -46,10 +47,28 @@ static bool network_sorts_all_01() {
     return true;
 }
 
+// the valley merge of csrc/scvote_sortnet.h (Lang's bitonic merge for arbitrary N: the pad exchanges left out) sorts EVERY 0-1 valley
+// 1^a 0^b 1^c of N wires (0-1 principle restricted to the inputs the merge is applied to: falling, then rising) -- exhaustive
+template <int N>
+static bool valley_merge_sorts_all_01_valleys() {
+    static constexpr SvNetwork<N> net = sv_make_valley_merge<N>();
+    for (int a = 0; a <= N; ++a)
+        for (int b = 0; a + b <= N; ++b) {
+            int x[N];
+            for (int i = 0; i < N; ++i) x[i] = (i < a || i >= a + b) ? 1 : 0;
+            for (int c = 0; c < net.n; ++c)
+                if (x[net.a[c]] > x[net.b[c]]) { const int tmp = x[net.a[c]]; x[net.a[c]] = x[net.b[c]]; x[net.b[c]] = tmp; }
+            for (int i = 1; i < N; ++i) if (x[i - 1] > x[i]) return false;
+        }
+    return true;
+}
+
 template <int NV>
 static bool packed_count_matches_bruteforce(int rounds) {
     constexpr int NP = NV / 2;
+    constexpr bool MEET = (NP & (NP - 1)) != 0;                  // NP not a power of two: the halves meet at r = 0 (sv_sort, sv_scan)
     static constexpr SvNetwork<NP> net = sv_make_network<NP>();
+    static constexpr SvNetwork<NP> valley = sv_make_valley_merge<NP>();
     uint64_t rng = 88172645463325252ull + NV;
     auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
     for (int it = 0; it < rounds; ++it) {
@@ -69,22 +88,37 @@ static bool packed_count_matches_bruteforce(int rounds) {
                 R[r] = pk_max(R[r], pk_mul(pk_min(pk_sub_sat(idx1, n2), 0x00010001u), sent));
             }
         }
+        if (MEET) for (int r = 0; r < NP; ++r) R[r] ^= 0xffffu;                      // half 0 travels complemented
         for (int c = 0; c < net.n; ++c) { const uint32_t lo = R[net.a[c]], hi = R[net.b[c]]; R[net.a[c]] = pk_min(lo, hi); R[net.b[c]] = pk_max(lo, hi); }
-        for (int r = 0; r < NP / 2; ++r) {
-            uint32_t &a = R[r], &b = R[NP - 1 - r];
-            const uint32_t t = alignbit(b, b, 16), mn = pk_min(a, t), mx = pk_max(a, t);
-            a = (mn & 0xffffu) | (mx & 0xffff0000u);
-            b = alignbit(mx, mn, 16);
+        if (MEET) {
+            for (int r = 0; r < NP; ++r) R[r] = pk_max(R[r], ~alignbit(R[r], R[r], 16));   // lo = ~min(a, b), hi = max(a, b)
+            for (int c = 0; c < valley.n; ++c) { const uint32_t lo = R[valley.a[c]], hi = R[valley.b[c]]; R[valley.a[c]] = pk_min(lo, hi); R[valley.b[c]] = pk_max(lo, hi); }
+            for (int r = 0; r < NP; ++r) R[r] ^= 0xffffu;
+            // value order now: (0, NP-1) ... (0, 0), (1, 0) ... (1, NP-1)
+            for (int r = 1; r < NP; ++r) if ((R[r - 1] & 0xffffu) < (R[r] & 0xffffu) || (R[r - 1] >> 16) > (R[r] >> 16)) { printf("NV=%d: halves not sorted\n", NV); return false; }
+            if ((R[0] & 0xffffu) > (R[0] >> 16)) { printf("NV=%d: halves overlap\n", NV); return false; }
+        } else {
+            for (int r = 0; r < NP / 2; ++r) {
+                uint32_t &a = R[r], &b = R[NP - 1 - r];
+                const uint32_t t = alignbit(b, b, 16), mn = pk_min(a, t), mx = pk_max(a, t);
+                a = (mn & 0xffffu) | (mx & 0xffff0000u);
+                b = alignbit(mx, mn, 16);
+            }
+            for (int j = NP >> 1; j > 0; j >>= 1)
+                for (int r = 0; r < NP; ++r) { const int l = r ^ j; if (l > r) { const uint32_t lo = R[r], hi = R[l]; R[r] = pk_min(lo, hi); R[l] = pk_max(lo, hi); } }
         }
-        for (int j = NP >> 1; j > 0; j >>= 1)
-            for (int r = 0; r < NP; ++r) { const int l = r ^ j; if (l > r) { const uint32_t lo = R[r], hi = R[l]; R[r] = pk_min(lo, hi); R[l] = pk_max(lo, hi); } }
         uint32_t run[NP], s = 0;
         for (int r = 0; r < NP; ++r) {
-            const uint32_t prev = r ? R[r - 1] : ((R[NP - 1] << 16) | 0xffffu);
+            const uint32_t prev = r ? R[r - 1] : ((R[MEET ? 0 : NP - 1] << 16) | 0xffffu);
             s = pk_max(s, pk_mul(pk_min(R[r] ^ prev, 0x00010001u), (uint32_t)(r + 1) | ((uint32_t)(r + NP + 1) << 16)));
             run[r] = s;
         }
-        const uint32_t carry = s << 16;
+        uint32_t carry = s << 16;
+        if (MEET) {                                                                   // half 0's FIRST run continues into half 1
+            uint32_t acc = 0;
+            for (int r = 0; r < NP; ++r) acc = pk_add(acc, pk_min(run[r], 0x00020002u));
+            carry = ((acc & 0xffffu) + 1u - (uint32_t)NP) << 16;
+        }
         uint32_t mx = 0;
         for (int r = 0; r < NP; ++r) { run[r] = pk_sub((uint32_t)(r + 2) | ((uint32_t)(r + NP + 2) << 16), pk_max(run[r], carry)); mx = pk_max(mx, run[r]); }
         const uint32_t max_run = (mx & 0xffffu) > (mx >> 16) ? (mx & 0xffffu) : (mx >> 16), mr2 = max_run | (max_run << 16);
@@ -117,11 +151,16 @@ static bool packed_count_matches_bruteforce(int rounds) {
 int main() {
     bool ok = true;
     ok &= network_sorts_all_01<2>() && network_sorts_all_01<4>() && network_sorts_all_01<8>() && network_sorts_all_01<16>();
-    ok &= network_sorts_all_01<32>() && network_sorts_all_01<64>();
-    printf("network: %s (exchanges on 4 / 8 / 16 / 32 / 64 wires: %d %d %d %d %d)\n", ok ? "sorts" : "FAILS", sv_make_network<4>().n, sv_make_network<8>().n,
-           sv_make_network<16>().n, sv_make_network<32>().n, sv_make_network<64>().n);
+    ok &= network_sorts_all_01<24>();                                   // the 48-vote shape's lockstep network: exhaustive (2^24 inputs)
+    ok &= network_sorts_all_01<32>();                                   // (sampled: 2^20 random 0-1 inputs; Batcher's network, and the GPU parity tests cover it)
+    printf("network: %s (exchanges on 4 / 8 / 16 / 24 / 32 wires: %d %d %d %d %d; exhaustive up to 24 wires, 32 sampled)\n", ok ? "sorts" : "FAILS", sv_make_network<4>().n,
+           sv_make_network<8>().n, sv_make_network<16>().n, sv_make_network<24>().n, sv_make_network<32>().n);
+    const bool okv = valley_merge_sorts_all_01_valleys<6>() && valley_merge_sorts_all_01_valleys<12>() && valley_merge_sorts_all_01_valleys<24>() &&
+                     valley_merge_sorts_all_01_valleys<16>() && valley_merge_sorts_all_01_valleys<48>();
+    printf("valley merge: %s (exchanges on 24 wires: %d)\n", okv ? "sorts every 0-1 valley" : "FAILS", sv_make_valley_merge<24>().n);
+    ok &= okv;
     bool ok2 = packed_count_matches_bruteforce<8>(20000) && packed_count_matches_bruteforce<16>(20000) && packed_count_matches_bruteforce<32>(20000) &&
-               packed_count_matches_bruteforce<64>(20000) && packed_count_matches_bruteforce<128>(10000);
+               packed_count_matches_bruteforce<48>(60000) && packed_count_matches_bruteforce<64>(20000) && packed_count_matches_bruteforce<24>(20000);
     printf("packed sort + scan: %s\n", ok2 ? "equals statistics.multimode" : "DIFFERS");
     return ok && ok2 ? 0 : 1;
 }

@@ -83,7 +83,7 @@ def test_every_option_and_stat_key_is_documented_in_the_header():
         body = src[src.index(f"int {fn}("):]
         body = body[: body.index("\n}\n")]
         keys = re.findall(r'!strcmp\(key, "([a-z0-9_]+)"\)', body)
-        assert len(keys) >= 5, fn
+        assert 5 <= len(keys) <= 15, (fn, len(keys))                 # round 4: at most 15 option keys are part of the boundary
         missing = [k for k in keys if f'"{k}"' not in hdr]
         assert not missing, f"{fn}: keys not documented in include/scvote.h: {missing}"
 
@@ -97,7 +97,7 @@ def test_no_kernel_spills_to_scratch():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     rows = mod.collect()
-    assert len(rows) > 150
+    assert 100 <= len(rows) <= 130, len(rows)                        # round 4: pruned from 231 (at most 130)
     allowed = {"scv_lane_cells<32, 512, true>"}                      # 12 B, N = 17..32 with tokens: known, measured
     spilled = {r[0]: r[4] for r in rows if r[4] and r[0] not in allowed}
     assert not spilled, spilled

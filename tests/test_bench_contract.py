@@ -172,3 +172,42 @@ def test_more_ranks_than_gpus_is_one_json_error_line():
     assert out.returncode != 0
     d = _last_json(out.stdout)
     assert "error" in d and f"--gpus {n}" in d["error"] and d["n_gpus"] == n and d["value"] is None
+
+
+def test_single_process_communicator_runs_equal_the_torch_run_word_for_word(tmp_path):
+    """one bench, both multi-GPU stacks.  `--comm peer --gpus 2 --share-device` (ONE process, the library's
+    one-shot all-reduce over peer access; two contexts on cuda:0) and `--comm rccl` on one device (single-process RCCL: the
+    ncclAllReduce call path itself) give the torch run's all-reduced counters word for word, with the same JSON contract plus
+    per-rank kernel times and the exposed all-reduce time; the create-time self-test ran."""
+    common = ["--samples", str(1 << 15), "--steps", "3", "--warmup", "1", "--resident", "4", "--no-cpu-baseline"]
+    one = _bench(["--problems-per-step", "96", *common, "--dump", str(tmp_path / "one.npz")])
+    peer = _bench(["--comm", "peer", "--gpus", "2", "--share-device", "--problems-per-step", "48", *common, "--dump", str(tmp_path / "peer.npz")])
+    a, b = np.load(tmp_path / "peer.npz")["counters"], np.load(tmp_path / "one.npz")["counters"]
+    assert a.shape == b.shape == (8 * 1027,) and np.array_equal(a, b) and a.sum() > 0
+    assert KEYS <= set(peer) and peer["n_gpus"] == 2 and peer["config"]["comm"] == "peer" and one["config"]["comm"] == "torch"
+    assert peer["config"]["comm_ranks"] == 2 and peer["config"]["comm_selftest_words_per_rank"] > 0 and peer["config"]["devices"] == [0, 0]
+    r = peer["roofline"]
+    assert r["kernel_avg_ms_per_rank_min"] <= r["kernel_avg_ms_per_rank_max"] == r["kernel_avg_ms"] and r["exposed_allreduce_us"] > 0
+    assert peer["accuracy_last_step"] == one["accuracy_last_step"]
+    assert abs(peer["value"] - 2 * 48 * 8 * (1 << 15) * 3 / (peer["ms_per_step"] * 3e-3)) / peer["value"] < 1e-9
+    rccl = _bench(["--comm", "rccl", "--gpus", "1", "--problems-per-step", "96", *common, "--dump", str(tmp_path / "rccl.npz")])
+    assert np.array_equal(np.load(tmp_path / "rccl.npz")["counters"], b)
+    assert rccl["config"]["comm"] == "rccl" and rccl["config"]["rccl_ranks"] == 1 and rccl["config"]["comm_selftest_words_per_rank"] > 0
+    # parity leg of the single-process line, and C5 through the communicator (cells + whole resample table vs the oracle inside bench.py)
+    c5 = ["--workload", "c5", "--problems", "300", "--samples", str(1 << 14), "--resamples", "101", "--steps", "2", "--warmup", "1", "--dist", "3"]
+    p5 = _bench(["--comm", "peer", "--gpus", "3", "--share-device", *c5, "--dump", str(tmp_path / "p5.npz")])
+    t5 = _bench([*c5, "--dump", str(tmp_path / "t5.npz"), "--no-cpu-baseline"])
+    assert p5["parity"].startswith("bit-exact: rank 0") and "bootstrap_parity" in p5["c5"] and p5["c5"]["device_error_word"] == 0
+    x, y = np.load(tmp_path / "p5.npz"), np.load(tmp_path / "t5.npz")
+    for k in ("counters", "cells", "boot"):
+        assert x[k].shape == y[k].shape and np.array_equal(x[k], y[k]), k
+
+
+def test_single_process_communicator_with_too_few_gpus_is_one_json_error_line():
+    import torch
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--comm", "peer", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert out.returncode != 0
+    d = _last_json(out.stdout)
+    assert "error" in d and f"--gpus {n}" in d["error"] and d["value"] is None

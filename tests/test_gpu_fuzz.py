@@ -11,11 +11,9 @@ from tests._adapters import OracleEngine, assert_results_equal
 
 pytestmark = pytest.mark.gpu
 
-DEFAULTS = (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1), ("small_n_max", 512),
-            ("tiny_n_max", 32), ("small_reg", 1), ("prefetch", 1), ("stagger_vecs", 0), ("plain_loads", 0),
-            ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_pivots", 0),
-            ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1),
-            ("sort_cells", 1), ("sort_n_min", 8), ("sort_n_max", 64), ("sort_kb", 0), ("sort_db", 0), ("sort_spread", 1), ("sort_waves", 0))
+DEFAULTS = (("path", 0), ("segs", 0), ("grid", 0), ("auto_geometry", 1), ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0),
+            ("prefix_path", 0), ("sort_n_min", 8), ("sort_n_max", 64))
+GEOMETRIES = ((4, 256, 2), (8, 256, 4), (8, 512, 4), (16, 256, 4), (16, 512, 4), (16, 1024, 4))       # (copies, threads, unroll) instantiated
 
 
 def _draw(rng):
@@ -30,7 +28,7 @@ def _draw(rng):
         P, B, N = int(rng.integers(1, 12)), int(rng.integers(1, 4)), int(rng.integers(9000, 80000))
     else:
         P, B, N = int(rng.integers(1, 4)), int(rng.integers(1, 3)), int(rng.integers(200000, 600000))
-    dist = int(rng.integers(0, 4))
+    dist = int(rng.integers(0, 6))                               # D0 ... D5 (the fuzz never saw D4 / D5)
     narrow = int(rng.choice([0, 0, 3, 40]))                      # fold values into few bins -> heavy ties
     tokens = bool(rng.integers(0, 2))
     nv_kind = rng.choice(["none", "random", "prefix", "zeros"], p=[0.35, 0.35, 0.2, 0.1])
@@ -44,61 +42,33 @@ def _draw(rng):
         nv = np.where(rng.integers(0, 2, size=B) == 1, N, 0)
     opts = {}
     if rng.random() < 0.6:
-        opts["path"] = int(rng.integers(0, 5))                    # (path 5, the sorted-cells kernel, is drawn below: earlier seeds keep their configurations)
+        opts["path"] = int(rng.choice([0, 1, 2, 4, 5]))
         if opts["path"] == 2:
             opts["segs"] = int(rng.choice([0, 2, 3, 5, 16, 40]))
-            opts["ticket_merge"] = int(rng.integers(0, 2))        # merge kernel / last-arriver merge inside the launch
     if rng.random() < 0.3:
-        opts["sorted"] = int(rng.integers(0, 2))
-    if rng.random() < 0.3:
-        opts["fused_counters_max"] = int(rng.choice([0, 1, 4096]))
-    if rng.random() < 0.25:
-        opts["prefetch"] = 0
-    if rng.random() < 0.2:
-        opts["balance"] = 0
+        opts["fused_counters_max"] = int(rng.choice([0, 1, 4096]))   # 0: every kernel leaves the counters to scv_reduce_cells
     if rng.random() < 0.2:
         opts["grid"] = int(rng.integers(1, 40))
     if rng.random() < 0.25:
-        opts["tiny_lane"] = 0                                     # the round-1 several-lanes-per-cell kernel
-    if rng.random() < 0.2:
-        opts["tiny_n_max"] = 0
-    if rng.random() < 0.2:
-        opts["small_reg"] = int(rng.integers(0, 3))
-    if rng.random() < 0.25:
-        opts["reg_n_max"] = int(rng.choice([0, 600]))            # round-1 dispatch below / above the register-resident range
+        opts["reg_n_max"] = int(rng.choice([0, 600]))            # streaming kernel below / above the register-resident range
     if rng.random() < 0.4:                                       # forced register-kernel shape (ignored when its capacity is < N)
-        opts["reg_shape"] = int(rng.choice([1601, 1602, 1604, 3201, 3202, 3204, 6401, 6402, 6404, 1041, 1042, 1044, 1081, 1082]))
-        opts["reg_dense4"] = int(rng.integers(0, 2))
+        opts["reg_shape"] = int(rng.choice([1601, 1602, 1604, 3204, 6404, 1041, 1042, 1044, 1048]))
     tuning = None
     if rng.random() < 0.3:
-        tuning = (int(rng.choice([4, 8, 16, 32])), int(rng.choice([256, 512, 1024])), int(rng.integers(1, 5)),
-                  int(rng.choice([2, 4, 8])))
+        c, t, u = GEOMETRIES[int(rng.integers(0, len(GEOMETRIES)))]
+        tuning = (c, t, int(rng.integers(1, 5)), u)
     prefix = bool(rng.random() < 0.25) and nv is not None
-    if rng.random() < 0.3:                                       # (drawn last: earlier seeds keep their configurations)
-        opts["reg_lds_counters"] = 0                              # register kernels: cell table + scv_reduce_cells / per-cell atomics
-    if rng.random() < 0.3:
-        opts["prefix_cells"] = 0                                  # prefix mode on short pools: the one-pass kernels
-    if rng.random() < 0.3:
-        opts["prefix_lane"] = 0                                   # prefix mode on pools of <= 64: cell kernels / one-pass kernels
-    if rng.random() < 0.3:
-        opts["prefix_stage"] = 0                                  # one-lane-per-problem kernel without the LDS snapshots
-    if rng.random() < 0.4:
-        opts["reg_pivots"] = int(rng.integers(1, 3))              # register kernels: one / two pivots per lane forced (default: per batch)
-    # round 3: the sorted-cells kernel (default for 5 <= N <= 64) switched off / forced / two blocks per step / the 128-vote shape
+    if prefix and rng.random() < 0.6:
+        opts["prefix_path"] = int(rng.integers(1, 4))            # one lane per problem / cell kernels on pool rows / one streaming pass
+    # the sorted-cells kernel (default for 5 / 8 <= N <= 64) switched off / forced / with other bounds
     r = rng.random()
     if r < 0.3:
-        opts["sort_cells"] = 0
+        opts["sort_n_max"] = 0
     elif r < 0.45:
         opts["path"] = 5
-    if rng.random() < 0.3:
-        opts["sort_kb"] = int(rng.integers(1, 3))
-    if rng.random() < 0.3:
-        opts["sort_db"] = 1
-    if rng.random() < 0.3:
-        opts["sort_spread"] = 0
-    if rng.random() < 0.3:
-        opts["sort_n_max"] = int(rng.choice([16, 128]))
-        opts["sort_n_min"] = int(rng.choice([4, 8, 40]))
+    elif r < 0.6:
+        opts["sort_n_max"] = int(rng.choice([16, 40, 64]))
+        opts["sort_n_min"] = int(rng.choice([1, 4, 8, 40]))
     return P, B, N, dist, narrow, tokens, nv, opts, tuning, prefix
 
 

@@ -98,17 +98,16 @@ def test_host_mode_streams_problem_chunks(hip_engine, monkeypatch):
     assert n >= 10 and total > 0
 
 
-@pytest.mark.parametrize("pipeline,threads", [(0, 1), (1, 1), (1, 5)])
-def test_host_mode_pipeline_and_pinned_sources(hip_engine, monkeypatch, pipeline, threads):
+@pytest.mark.parametrize("threads", [1, 5])
+def test_host_mode_pipeline_and_pinned_sources(hip_engine, threads):
     """the three-stage HOST ingestion pipeline (worker threads -> pinned bounce slots -> DMA ->
-    kernel, two slots in flight) against the serial loop and the oracle: many chunks, a chunk size that does not
+    kernel, two slots in flight) against the oracle: many chunks, a chunk size that does not
     divide P, tokens, ragged budgets, pageable and pinned (DMA in place) sources, every output."""
     from o1_inference_scaling_laws_amd.engine import pinned_empty
-    monkeypatch.setenv("SCV_STAGE_MB", "1")
+    hip_engine.set_option("stage_mb", 1)
     a, t, tr = coracle.synth_fill(203, 2, 9001, 77, 1, want_tokens=True)    # 14.6 MB of votes + tokens -> ~15 chunks
     nv = np.array([9001, 77], dtype=np.int32)
     want = oracle(a, tr, tokens=t, n_valid=nv)
-    hip_engine.set_option("host_pipeline", pipeline)
     hip_engine.set_option("copy_threads", threads)
     try:
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
@@ -128,7 +127,7 @@ def test_host_mode_pipeline_and_pinned_sources(hip_engine, monkeypatch, pipeline
             hip_engine.aggregate(bad, tr)
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)         # the ctx recovers
     finally:
-        hip_engine.set_option("host_pipeline", 1)
+        hip_engine.set_option("stage_mb", 128)
         hip_engine.set_option("copy_threads", 6)
 
 
@@ -166,10 +165,10 @@ def test_argument_errors(hip_engine):
     assert L.scv_set_tuning(ctx, 5, 0, 0, 0) == _lib.ERR_ARG and L.scv_set_tuning(ctx, 2, 0, 0, 0) == _lib.ERR_ARG
 
 
-@pytest.mark.parametrize("copies", [4, 8, 16, 32])
-@pytest.mark.parametrize("threads", [256, 512, 1024])
-@pytest.mark.parametrize("unroll", [2, 4, 8])
+@pytest.mark.parametrize("copies,threads,unroll", [(4, 256, 2), (8, 256, 4), (8, 512, 4), (16, 256, 4), (16, 512, 4), (16, 1024, 4)])
 def test_every_kernel_variant_is_bit_exact(hip_engine, copies, threads, unroll):
+    """Every instantiated geometry of the streaming kernel (include/scvote.h, scv_set_tuning); anything else is refused."""
+    assert hip_engine._L.scv_set_tuning(hip_engine._ctx, 32, 256, 0, 4) == _lib.ERR_ARG and hip_engine._L.scv_set_tuning(hip_engine._ctx, 16, 1024, 0, 8) == _lib.ERR_ARG
     a, t, tr = coracle.synth_fill(9, 3, 30001, 99, 1, want_tokens=True)
     nv = np.array([30001, 12345, 2], dtype=np.int32)
     want = oracle(a, tr, tokens=t, n_valid=nv)
@@ -184,18 +183,16 @@ def test_every_kernel_variant_is_bit_exact(hip_engine, copies, threads, unroll):
         hip_engine.set_option("path", 0)
 
 
-@pytest.mark.parametrize("stagger,plain,balance,grid", [(4099, 0, 1, 0), (1 << 16, 1, 0, 0), (0, 1, 1, 7), (12345, 0, 0, 3)])
-def test_launch_geometry_options_are_bit_exact(hip_engine, stagger, plain, balance, grid):
+@pytest.mark.parametrize("grid", [0, 7, 3, 300])
+def test_launch_geometry_options_are_bit_exact(hip_engine, grid):
     a, _, tr = coracle.synth_fill(37, 3, 100003, 5, 1)
     nv = np.array([100003, 4097, 5], dtype=np.int32)
     want = oracle(a, tr, n_valid=nv)
     try:
-        for k, v in (("stagger_vecs", stagger), ("plain_loads", plain), ("balance", balance), ("grid", grid)):
-            hip_engine.set_option(k, v)
+        hip_engine.set_option("grid", grid)
         assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), want, check_tokens=False)
     finally:
-        for k, v in (("stagger_vecs", 0), ("plain_loads", 0), ("balance", 1), ("grid", 0)):
-            hip_engine.set_option(k, v)
+        hip_engine.set_option("grid", 0)
 
 
 # ---- every regime of the kernel family, forced ------------------------------------------------------
@@ -206,10 +203,8 @@ def _with_options(eng, opts):
             for k, v in opts.items():
                 eng.set_option(k, v)
         def __exit__(self_, *exc):
-            for k, v in (("path", 0), ("segs", 0), ("sorted", 1), ("grid", 0), ("balance", 1), ("auto_geometry", 1),
-                         ("small_n_max", 512), ("tiny_n_max", 32), ("small_reg", 1), ("stagger_vecs", 0), ("plain_loads", 0), ("fused_counters_max", 4096),
-                         ("reg_n_max", 8192), ("reg_shape", 0), ("reg_dense4", 0), ("ticket_merge", 0), ("tiny_lane", 1), ("reg_lds_counters", 1), ("prefix_cells", 1), ("prefix_lane", 1), ("prefix_stage", 1), ("reg_pivots", 0),
-                         ("sort_cells", 1), ("sort_n_min", 8), ("sort_n_max", 64), ("sort_kb", 0), ("sort_db", 0), ("sort_spread", 1), ("sort_waves", 0)):
+            for k, v in (("path", 0), ("segs", 0), ("grid", 0), ("auto_geometry", 1), ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0),
+                         ("prefix_path", 0), ("boot_path", 0), ("sort_n_min", 8), ("sort_n_max", 64)):
                 eng.set_option(k, v)
     return _Ctx()
 
@@ -230,12 +225,12 @@ def test_register_resident_cells_path(hip_engine, dist, shape):
     a, t, tr = coracle.synth_fill(P, B, N, 900 + dist, dist, want_tokens=True)
     nv = np.array([max(0, N - 3 * b) if b % 2 else N >> (b // 2) for b in range(B)], dtype=np.int32)
     # every kernel shape whose capacity covers N: sparse g*100+v (4*g*v votes), dense 1000+10*v+h (256*v*h votes)
-    shapes = [g * 100 + v for g in (16, 32, 64) for v in (1, 2, 4) if 4 * g * v >= N]
+    shapes = [g * 100 + v for g, v in ((16, 1), (16, 2), (16, 4), (32, 4), (64, 4)) if 4 * g * v >= N]
     shapes += [1000 + 10 * v + h for v, h in ((4, 1), (4, 2), (4, 4), (4, 8)) if 256 * v * h >= N]
     pick = [shapes[(P + dist + i * 3) % len(shapes)] for i in range(3)]
-    for opts in ({"path": 4}, {"path": 4, "grid": 7, "fused_counters_max": 0, "reg_shape": pick[0], "reg_lds_counters": 0, "reg_pivots": 2},
-                 {"path": 4, "grid": 64, "fused_counters_max": 1 << 30, "reg_shape": pick[1], "reg_lds_counters": 0, "reg_pivots": 1},
-                 {"path": 4, "reg_shape": pick[2], "reg_dense4": 1, "grid": 5}):
+    for opts in ({"path": 4}, {"path": 4, "grid": 7, "fused_counters_max": 0, "reg_shape": pick[0]},
+                 {"path": 4, "grid": 64, "fused_counters_max": 1 << 30, "reg_shape": pick[1]},
+                 {"path": 4, "reg_shape": pick[2], "grid": 5}):
         with _with_options(hip_engine, opts):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
             assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
@@ -279,9 +274,9 @@ def test_register_kernels_accumulate_counters_in_lds(hip_engine, shape):
     nv = np.array([N if b % 3 else max(1, N // (1 + b % 7)) for b in range(B)], dtype=np.int32)
     want = oracle(a, tr, tokens=t, n_valid=nv)
     with _with_options(hip_engine, {"path": 4}):
-        before = hip_engine.stat("reg_lds_counters")
+        before = hip_engine.stat("lds_counters")
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
-        fits = hip_engine.stat("reg_lds_counters") > before
+        fits = hip_engine.stat("lds_counters") > before
         if B <= 150:
             assert fits                                               # few budgets: the tables always fit the spare LDS
         if B >= 1000:
@@ -302,11 +297,13 @@ def test_register_kernels_accumulate_counters_in_lds(hip_engine, shape):
 @pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("shape", [(50, 3, 1), (40, 2, 2), (33, 4, 3), (70, 8, 64), (20, 3, 100), (900, 2, 128), (9, 2, 257),
                                    (300, 3, 512), (5, 11, 2048), (3, 2, 5001), (2000, 2, 17), (4000, 1, 33)])
-def test_small_n_wave_per_cell_path(hip_engine, dist, shape):
+def test_short_and_mid_cells_on_every_kernel_that_serves_them(hip_engine, dist, shape):
+    """The same cells through the auto dispatch, with the register-resident kernels forced (any N >= 1), and with the sorted-cells
+    kernel switched off (N <= 32 then run one lane per cell, longer cells on the register-resident kernels)."""
     P, B, N = shape
     a, t, tr = coracle.synth_fill(P, B, N, 300 + dist, dist, want_tokens=True)
     nv = np.array([max(0, N - 3 * b) if b % 2 else N >> (b // 2) for b in range(B)], dtype=np.int32)
-    for opts in ({"path": 3}, {"path": 3, "small_reg": 0, "tiny_n_max": 0}, {"path": 3, "small_reg": 2, "tiny_n_max": 0}):
+    for opts in ({}, {"path": 4}, {"sort_n_max": 0}):
         with _with_options(hip_engine, opts):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
             assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
@@ -317,7 +314,7 @@ def test_small_n_wave_per_cell_path(hip_engine, dist, shape):
 @pytest.mark.parametrize("shape", [(1, 1, 1), (50, 3, 1), (41, 11, 8), (333, 5, 7), (64, 8, 9), (100, 3, 16), (77, 2, 17),
                                    (30, 7, 32), (5000, 3, 4), (3, 1, 0)])
 def test_tiny_cells_register_path(hip_engine, dist, shape):
-    """N <= 32: several cells per wave (G = 8/16/32 lanes per cell), the reference's own budget sizes."""
+    """N <= 32, the reference's own budget sizes: auto dispatch, sorted cells off / forced, counters left to the reduction kernel."""
     P, B, N = shape
     if N == 0:
         a, t, tr = np.zeros((P, B, 0), np.int32), np.zeros((P, B, 0), np.int32), np.zeros(P, np.int32)
@@ -325,7 +322,7 @@ def test_tiny_cells_register_path(hip_engine, dist, shape):
         a, t, tr = coracle.synth_fill(P, B, N, 40 + dist, dist, want_tokens=True)
         a = a % (3 + dist * 300)                                   # few distinct values -> many ties
     nv = np.array([(N >> (b % 4)) if b % 3 else N for b in range(B)], dtype=np.int32)
-    for opts in ({"path": 3}, {"path": 0}, {"path": 0, "sort_cells": 0}, {"path": 3, "tiny_n_max": 0}, {"path": 3, "fused_counters_max": 0}):
+    for opts in ({"path": 0}, {"sort_n_max": 0}, {"path": 5}, {"path": 4}, {"fused_counters_max": 0}, {"fused_counters_max": 0, "sort_n_max": 0}):
         with _with_options(hip_engine, opts):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
             assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
@@ -337,14 +334,14 @@ def test_tiny_cells_register_path(hip_engine, dist, shape):
 def test_tiny_cells_one_lane_per_cell(hip_engine, dist, shape):
     """scv_lane_cells (N <= 32): pair counting (NV = 4, 8) and the sorting-network path (NV = 16, 32), aligned and
     unaligned rows, tokens, ragged n_valid incl. 0, narrow value ranges (heavy ties), counters fused through LDS with
-    many budgets, small forced grids (many cells per lane), cells requested or not -- and the round-1 kernel still agrees."""
+    many budgets, small forced grids (many cells per lane), cells requested or not."""
     P, B, N = shape
     a, t, tr = coracle.synth_fill(P, B, N, 500 + dist, dist, want_tokens=True)
     a2 = (a % 5).astype(np.int32)                                       # 5 distinct values: ties everywhere
     tr2 = (tr % 5).astype(np.int32)
     rng = np.random.default_rng(3)
     nv = rng.integers(0, N + 1, size=(B,), dtype=np.int32)
-    for opts in ({"sort_cells": 0}, {"grid": 3, "sort_cells": 0}, {"tiny_lane": 0, "sort_cells": 0}):     # (sort_cells = 1, the default: next test)
+    for opts in ({"sort_n_max": 0}, {"grid": 3, "sort_n_max": 0}):     # (sorted cells, the default from 5 / 8 votes: next test)
         with _with_options(hip_engine, opts):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
             assert_results_equal(hip_engine.aggregate(a2, tr2, n_valid=nv), oracle(a2, tr2, n_valid=nv), check_tokens=False)
@@ -353,22 +350,24 @@ def test_tiny_cells_one_lane_per_cell(hip_engine, dist, shape):
             want = oracle(a, tr, tokens=t)
             assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum)
             assert np.array_equal(got.truth_count_sum, want.truth_count_sum)
-    hip_engine.set_option("tiny_lane", 1)
 
 
 SORT_SHAPES = [(700, 3, 4), (41, 11, 8), (3333, 5, 7), (1000, 3, 16), (777, 2, 17), (300, 7, 32), (20000, 2, 12), (9000, 1, 31), (100, 200, 8),
                (5000, 4, 5), (4000, 3, 20), (2500, 4, 30), (2000, 2, 33), (1500, 3, 48), (1200, 4, 61), (1100, 2, 63), (3000, 4, 64), (1, 1, 64),
-               (65, 1, 36), (40, 600, 24), (900, 64, 64)]
+               (65, 1, 36), (40, 600, 24), (900, 64, 64),
+               # round 4: the 48-vote shape (33 ... 48 votes: 24 packed registers, the halves meet at r = 0), aligned and unaligned rows
+               (2000, 2, 36), (1800, 3, 40), (1700, 2, 44), (900, 3, 45), (1300, 2, 47), (700, 5, 34), (77, 1, 48), (300, 40, 48)]
 
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("shape", SORT_SHAPES, ids=lambda s: "x".join(map(str, s)))
 def test_sorted_cells_one_lane_per_cell(hip_engine, dist, shape):
     """scv_sort_cells (round 3; the reference's own range, o1.py:267,276): one lane per cell, the wave's 64 rows staged through
-    LDS by LDS-DMA, packed 16-bit bitonic sort + run-length scan in registers.  Every shape of the kernel (8 / 16 / 32 / 64 votes
+    LDS by LDS-DMA, packed 16-bit sort + run-length scan in registers.  Every shape of the kernel (8 / 16 / 32 / 48 / 64 votes
     per lane), rows 16-byte aligned (padded image, b128 reads) and not (linear image, dword reads), a cell count that is not a
-    multiple of 64, tokens, ragged n_valid incl. 0, narrow value ranges (ties everywhere), many budgets (counters in LDS; more
-    budgets than the n_valid cache holds), small forced grids (many steps per wave), two blocks per step, two image buffers per wave (option sort_db), cells wanted or not."""
+    multiple of 64, tokens, ragged n_valid incl. 0, narrow value ranges (ties everywhere: runs that cross the halves of the packed
+    registers), many budgets (counters in LDS; more budgets than the n_valid cache holds), small forced grids (many steps per
+    wave), cells wanted or not."""
     P, B, N = shape
     a, t, tr = coracle.synth_fill(P, B, N, 700 + dist, dist, want_tokens=True)
     a2 = (a % 5).astype(np.int32)                                       # 5 distinct values: ties everywhere
@@ -376,7 +375,7 @@ def test_sorted_cells_one_lane_per_cell(hip_engine, dist, shape):
     rng = np.random.default_rng(5 + N)
     nv = rng.integers(0, N + 1, size=(B,), dtype=np.int32)
     before = hip_engine.stat("sort_cells")
-    for opts in ({}, {"grid": 3, "sort_db": 1, "sort_spread": 0}, {"path": 5, "sort_kb": 2}):
+    for opts in ({}, {"grid": 3}, {"path": 5}):
         with _with_options(hip_engine, opts):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
             assert_results_equal(hip_engine.aggregate(a2, tr2, n_valid=nv), oracle(a2, tr2, n_valid=nv), check_tokens=False)
@@ -391,7 +390,8 @@ def test_sorted_cells_one_lane_per_cell(hip_engine, dist, shape):
 
 def test_sorted_cells_edges(hip_engine):
     """Domain errors surface (and only for votes inside the valid prefix), spare bins, a truth outside the histogram, all votes
-    distinct (every vote a mode: the sentinels of a short prefix must not count), the 128-vote shape (option sort_n_max)."""
+    distinct (every vote a mode: the sentinels of a short prefix must not count), and for the 48-vote shape -- whose sorted halves
+    meet in the middle of the value order -- runs that cross from one half into the other, hand-built."""
     a = np.zeros((100, 2, 32), dtype=np.int32)
     a[57, 1, 5] = 5000
     with pytest.raises(_lib.DomainError):
@@ -408,11 +408,22 @@ def test_sorted_cells_edges(hip_engine):
         got = hip_engine.aggregate(a, tr, n_valid=nv)
         assert_results_equal(got, oracle(a, tr, n_valid=nv), check_tokens=False)
     assert got.cells["n_modes"][0, 0] == 1 and got.cells["n_modes"][0, 1] == 0
-    with _with_options(hip_engine, {"sort_n_max": 128}):
-        for N in (68, 100, 128):
-            a, t, tr = coracle.synth_fill(300, 3, N, N, 3, want_tokens=True)
-            nv = np.array([N, N // 2, 3], dtype=np.int32)
-            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+    a = np.tile(np.arange(48, dtype=np.int32)[::-1] * 21, (130, 2, 1))          # 48 distinct values on the 48-vote shape
+    tr = np.full(130, 21 * 40, dtype=np.int32)
+    for nv in (None, np.array([48, 33], dtype=np.int32), np.array([47, 0], dtype=np.int32)):
+        assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
+    # runs across the halves: sorted position 24 falls inside a run (lengths 10 | 20 | 18, 20 | 8 | 20, 24 | 24, 1 | 46 | 1, 48), votes shuffled
+    rng = np.random.default_rng(48)
+    rows = []
+    for lens in ((10, 20, 18), (20, 8, 20), (24, 24), (1, 46, 1), (48,), (23, 2, 23), (12, 12, 12, 12), (5, 19, 1, 23)):
+        v = np.concatenate([np.full(n, 100 + 7 * i, dtype=np.int32) for i, n in enumerate(lens)])
+        for _ in range(8):
+            rows.append(rng.permutation(v))
+    a = np.stack(rows).reshape(len(rows), 1, 48)
+    tr = np.array([100 + 7 * (i % 3) for i in range(len(rows))], dtype=np.int32)
+    for nv in (None, np.array([41], dtype=np.int32), np.array([25], dtype=np.int32)):
+        assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
+    assert hip_engine.stat("sort_cells") > 0
 
 
 def test_tiny_cells_reference_family_and_domain(hip_engine, golden):
@@ -439,7 +450,8 @@ def test_small_n_path_spare_bins_ties_and_truth_edges(hip_engine):
     a = rng.integers(1000, 1024, size=(300, 3, 37), dtype=np.int32)
     a[:100] = rng.integers(0, 4, size=(100, 3, 37), dtype=np.int32)         # heavy ties among few values
     tr = rng.integers(-3, 1027, size=(300,), dtype=np.int32)
-    with _with_options(hip_engine, {"path": 3}):
+    for opts in ({}, {"path": 4}, {"sort_n_max": 0}):
+      with _with_options(hip_engine, opts):
         assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
         bad = a.copy()
         bad[7, 1, 5] = 5000
@@ -459,19 +471,17 @@ def test_split_n_path(hip_engine, segs, shape, dist):
         assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
 
 
-@pytest.mark.parametrize("ticket_merge", [0, 1])
 @pytest.mark.parametrize("segs,shape,dist", [(17, (2, 2, 200003), 1), (40, (3, 1, 300000), 3), (256, (1, 1, 1 << 20), 1), (255, (2, 1, 700001), 0),
                                              (300, (1, 2, 400000), 1), (16, (5, 3, 99999), 2), (33, (1, 1, 66), 1)])
-def test_split_n_merge_inside_the_launch(hip_engine, ticket_merge, segs, shape, dist):
-    """Split cells merged by the last-arriving segment (group tree, fan-in 16; > 256 segments fall back to the merge
-    kernel) vs the two-launch path vs the oracle: one and two levels, ragged last groups, tokens, repeated calls on
-    the same context (every arrival counter must be back at zero), also under the overwrite-counters mode."""
+def test_split_n_with_many_segments_and_overwrite_mode(hip_engine, segs, shape, dist):
+    """Split cells (S workgroups per cell + the merge kernel) vs the oracle: many segments, ragged last segments, tokens, repeated
+    calls on the same context, also under the overwrite-counters mode (a memset node in front: the merge kernel finishes the cells)."""
     import torch
     P, B, N = shape
     a, t, tr = coracle.synth_fill(P, B, N, 800 + segs, dist, want_tokens=True)
     nv = np.array([N - 5 * b for b in range(B)], dtype=np.int32)
-    with _with_options(hip_engine, {"path": 2, "segs": segs, "ticket_merge": ticket_merge}):
-        for rep in range(3):
+    with _with_options(hip_engine, {"path": 2, "segs": segs}):
+        for rep in range(2):
             assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
             assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
         dev = torch.device("cuda:0")
@@ -482,7 +492,6 @@ def test_split_n_merge_inside_the_launch(hip_engine, ticket_merge, segs, shape, 
             hip_engine.sync()
             got = AggregateResult.from_counters(c.cpu().numpy(), P, B, cells_from_torch(cells), ctok.cpu().numpy())
             assert_results_equal(got, oracle(a, tr, tokens=t))
-    hip_engine.set_option("ticket_merge", 0)
 
 
 @pytest.mark.parametrize("shape,opts", [((30, 8, 1 << 17), {}), ((30, 8, 1 << 17), {"path": 2, "segs": 3}), ((7, 3, 5000), {"path": 1}),
@@ -524,37 +533,35 @@ def test_overwrite_counters_mode(hip_engine, shape, opts):
         assert np.array_equal(AggregateResult.from_counters(counters.cpu().numpy(), P, B).tie_class_hits, 2 * want.tie_class_hits)
 
 
-@pytest.mark.parametrize("prefetch", [0, 1])
 @pytest.mark.parametrize("shape", [(700, 3, 1000), (300, 2, 4099), (90, 5, 16385), (600, 1, 513), (40, 2, 70001)])
-def test_streaming_path_with_and_without_cross_item_prefetch(hip_engine, prefetch, shape):
+def test_streaming_path_with_cross_item_prefetch(hip_engine, shape):
     P, B, N = shape
     a, t, tr = coracle.synth_fill(P, B, N, 77 + N, 1, want_tokens=True)
     nv = np.array([N if b % 2 == 0 else max(0, N // 3 - b) for b in range(B)], dtype=np.int32)
-    with _with_options(hip_engine, {"path": 1, "prefetch": prefetch}):
+    with _with_options(hip_engine, {"path": 1}):
         assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
         assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
-    with _with_options(hip_engine, {"path": 2, "segs": 5, "prefetch": prefetch}):
+    with _with_options(hip_engine, {"path": 2, "segs": 5}):
         assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
 
 
-@pytest.mark.parametrize("sorted_", [0, 1])
-def test_streaming_path_sorted_and_natural_traversal(hip_engine, sorted_):
+def test_streaming_path_sorted_and_natural_traversal(hip_engine):
     a, t, tr = coracle.synth_fill(41, 11, 3000, 8, 1, want_tokens=True)
     nv = np.array([1, 1, 1, 1, 1, 1, 1, 1, 2, 4, 3000], dtype=np.int32)      # the reference's ragged family, scaled
-    with _with_options(hip_engine, {"path": 1, "sorted": sorted_}):
+    with _with_options(hip_engine, {"path": 1}):
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
     a = np.ascontiguousarray(np.broadcast_to(a[:1, :1, :600], (2, 600, 600)))    # B > 512: sorted order unavailable
     tr2 = tr[:2]
     nv2 = np.arange(600, dtype=np.int32)
-    with _with_options(hip_engine, {"path": 1, "sorted": sorted_}):
+    with _with_options(hip_engine, {"path": 1}):
         assert_results_equal(hip_engine.aggregate(a, tr2, n_valid=nv2), oracle(a, tr2, n_valid=nv2), check_tokens=False)
-    with _with_options(hip_engine, {"path": 3, "sorted": sorted_}):
+    with _with_options(hip_engine, {"path": 4}):
         assert_results_equal(hip_engine.aggregate(a, tr2, n_valid=nv2), oracle(a, tr2, n_valid=nv2), check_tokens=False)
 
 
 @pytest.mark.parametrize("fused_max", [0, 1 << 30])
-@pytest.mark.parametrize("path", [1, 2, 3])
+@pytest.mark.parametrize("path", [1, 2, 4, 0])
 def test_counters_fused_and_reduced_agree(hip_engine, fused_max, path):
     """Per-budget counters via per-cell atomics (few cells) and via scv_reduce_cells (many cells)."""
     import torch
@@ -631,9 +638,9 @@ def test_prefix_mode_equals_dense_oracle(hip_engine, case):
     if N <= 4096:
         with _with_options(hip_engine, {"path": 1}):       # force the streaming kernel on a small pool
             assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
-        with _with_options(hip_engine, {"path": 3}):
+        with _with_options(hip_engine, {"prefix_path": 2}):       # the cell kernels on pool rows
             assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
-        with _with_options(hip_engine, {"prefix_cells": 0, "prefix_lane": 0}):   # the one-pass snapshot kernels
+        with _with_options(hip_engine, {"prefix_path": 3}):       # one streaming pass, a snapshot per boundary
             assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
 
 
@@ -658,13 +665,13 @@ def test_prefix_budgets_over_short_pools_run_on_the_cell_kernels(hip_engine, dis
         assert hip_engine.stat(stat) == before + 1
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
         if N <= 64:
-            with _with_options(hip_engine, {"prefix_lane": 0}):
+            with _with_options(hip_engine, {"prefix_path": 2}):
                 before = hip_engine.stat("prefix_cells")
                 assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
                 assert hip_engine.stat("prefix_cells") == before + 1
             with _with_options(hip_engine, {"grid": 3}):               # many problems per lane
                 assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
-            with _with_options(hip_engine, {"prefix_stage": 0, "grid": 5}):   # reductions at every boundary, direct cell writes
+            with _with_options(hip_engine, {"prefix_path": 3, "grid": 5}):   # one streaming pass, a histogram snapshot per boundary
                 assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
                 got = hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool, want_cells=False)
                 assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum)
@@ -1060,7 +1067,7 @@ def test_bootstrap_kernels_bit_exact(hip_engine, boot_lds, shape):
     a, _, tr = coracle.synth_fill(P, B, N, 31, dist)
     cells = coracle.aggregate(a, tr)["cells"]
     mmax = int(cells["n_modes"][cells["hit"] == 1].max(initial=0))
-    hip_engine.set_option("boot_lds", boot_lds)
+    hip_engine.set_option("boot_path", 0 if boot_lds else 3)
     try:
         for (r0, r1, M) in ((0, 300, mmax + 1), (5, 18, 1025 if B <= 2 else mmax + 2), (7, 7, 4)):
             rc, want = coracle.bootstrap(cells, r0, r1, 0xC0FFEE, M)
@@ -1071,7 +1078,7 @@ def test_bootstrap_kernels_bit_exact(hip_engine, boot_lds, shape):
             with pytest.raises(_lib.ScvError):
                 hip_engine.bootstrap(cells, 0, 50, 0xC0FFEE, mmax)        # largest class present does not fit
     finally:
-        hip_engine.set_option("boot_lds", 1)
+        hip_engine.set_option("boot_path", 0)
 
 
 def test_config_C5_pipeline_full_cell_size_bit_exact(hip_engine):
@@ -1112,7 +1119,7 @@ def test_config_C5_pipeline_full_cell_size_bit_exact(hip_engine):
 def test_vote_and_bootstrap_in_one_call(hip_engine, shape, dist, fused):
     """scv_aggregate_bootstrap_i32: the vote and the bootstrap of its own cell table in one call -- ONE kernel launch
     (grid barrier + resamples inside the vote kernel) when the shape allows it, two queued launches otherwise (short
-    cells, table too large for the LDS, option boot_fused = 0).  Counters, cells and the whole resample table vs the
+    cells, table too large for the LDS, option boot_path = 2).  Counters, cells and the whole resample table vs the
     oracle; repeated calls (the barrier's counter / generation state must stay consistent); tokens."""
     import torch
     P, B, N = shape
@@ -1126,7 +1133,7 @@ def test_vote_and_bootstrap_in_one_call(hip_engine, shape, dist, fused):
     M = int(want["cells"]["n_modes"][want["cells"]["hit"] == 1].max(initial=0)) + 1
     rc, want_boot = coracle.bootstrap(want["cells"], 2, 131, 99, M)
     assert rc == 0
-    hip_engine.set_option("boot_fused", fused)
+    hip_engine.set_option("boot_path", 0 if fused else 2)
     one0, two0 = hip_engine.stat("boot_fused"), hip_engine.stat("boot_separate")
     # the fused form needs whole-cell streaming (N > 4096) and the [P, B] code table in the workgroup's LDS
     expect_fused = bool(fused) and N > 4096 and P * B <= 30000 and not (2 * P * B <= 256 and 4 * N >= (1 << 20))   # (few huge cells are split)
@@ -1157,7 +1164,7 @@ def test_vote_and_bootstrap_in_one_call(hip_engine, shape, dist, fused):
             with pytest.raises(_lib.ScvError):
                 hip_engine.sync()
     finally:
-        hip_engine.set_option("boot_fused", 1)
+        hip_engine.set_option("boot_path", 0)
 
 
 def test_bootstrap_device_fused_no_host_roundtrip(hip_engine):
@@ -1257,7 +1264,7 @@ def test_fused_bootstrap_barrier_timeout_is_repaired_not_reported(hip_engine):
     resample table: scv_sync resets the barrier, re-runs the bootstrap as a separate launch and clears the error bit.
     Afterwards the fused form works again (barrier state clean), and a too-small class bound is still reported."""
     ans, tr, want, M, want_boot = _boot_case(hip_engine)
-    hip_engine.set_option("boot_cooperative", 0)
+    hip_engine.set_option("boot_path", 1)
     hip_engine.set_option("boot_spin_limit", 1)
     try:
         r0 = hip_engine.stat("boot_recovered")
@@ -1278,7 +1285,7 @@ def test_fused_bootstrap_barrier_timeout_is_repaired_not_reported(hip_engine):
                 hip_engine.sync()
     finally:
         hip_engine.set_option("boot_spin_limit", 1 << 20)
-        hip_engine.set_option("boot_cooperative", 1)
+        hip_engine.set_option("boot_path", 0)
     counters, cells, _, boot = hip_engine.aggregate_bootstrap_device(ans, tr, 0, 150, 77, M)
     hip_engine.sync()
     assert np.array_equal(boot.cpu().numpy(), want_boot)
@@ -1295,7 +1302,7 @@ def test_fused_bootstrap_with_a_competing_kernel_on_another_stream(hip_engine, c
     dev = torch.device("cuda:0")
     side = torch.cuda.Stream(device=dev)
     x = torch.ones(1 << 28, dtype=torch.float32, device=dev)              # 1 GiB
-    hip_engine.set_option("boot_cooperative", cooperative)
+    hip_engine.set_option("boot_path", 0 if cooperative else 1)
     try:
         for _ in range(2):
             with torch.cuda.stream(side):
@@ -1307,7 +1314,7 @@ def test_fused_bootstrap_with_a_competing_kernel_on_another_stream(hip_engine, c
             assert np.array_equal(cells_from_torch(cells)["n_modes"], want["cells"]["n_modes"])
             side.synchronize()
     finally:
-        hip_engine.set_option("boot_cooperative", 1)
+        hip_engine.set_option("boot_path", 0)
         torch.cuda.synchronize()
 
 
@@ -1366,6 +1373,47 @@ def test_c5_pipeline_reports_device_errors(hip_engine):
     d4 = passk.evaluate_device(hip_engine, ans, trd, P, 64, 5, M=d.M)             # and the engine is clean again
     passk.check(d4, hip_engine)
     assert np.array_equal(passk.gather_bootstrap(d4, 64, engine=hip_engine).cpu().numpy(), boot.cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_c5_error_word_is_judged_like_scv_sync_judges_it():
+    """the collective error word must be the word as the HOST judges it.  (a) An engine created with
+    clamp_to_invalid_bin counts an out-of-domain vote for bin 1023 and reports nothing: passk.check / gather_bootstrap must not
+    raise 'another rank reported a device error' on it.  (b) A fused vote + bootstrap whose (non-cooperative) grid barrier timed
+    out is REPAIRED by the sync inside the check, which then returns -- with the repaired table."""
+    import torch
+    from o1_inference_scaling_laws_amd import passk
+    from o1_inference_scaling_laws_amd.engine import Engine
+    dev = torch.device("cuda:0")
+    P, N = 300, 9000
+    a, _, tr = coracle.synth_fill(P, 1, N, 12, 1)
+    bad = a.copy()
+    bad[5, 0, 77] = 1 << 21
+    clamped = a.copy()
+    clamped[5, 0, 77] = 1023
+    want = coracle.aggregate(clamped, tr)
+    with Engine(clamp_to_invalid_bin=True) as eng:
+        ans, trd = torch.from_numpy(bad).to(dev), torch.from_numpy(tr).to(dev)
+        for fused in (True, False):
+            d = passk.evaluate_device(eng, ans, trd, P, 32, 5, M=2, fused=fused)
+            passk.check(d, eng)
+            boot = passk.gather_bootstrap(d, 32, engine=eng)
+            assert int(d.flag.cpu()[0]) == 0
+            got = cells_from_torch(d.cells)
+            for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+                assert np.array_equal(got[f], want["cells"][f]), f
+            rc, want_boot = coracle.bootstrap(want["cells"], 0, 32, 5, 2)
+            assert rc == 0 and np.array_equal(boot.cpu().numpy(), want_boot)
+    with Engine() as eng:                                             # (b) barrier timeout: ordinary launch, one poll, a grid that cannot be co-resident
+        eng.set_option("boot_path", 1)
+        eng.set_option("boot_spin_limit", 1)
+        ans, trd = torch.from_numpy(a).to(dev), torch.from_numpy(tr).to(dev)
+        want = coracle.aggregate(a, tr)
+        rc, want_boot = coracle.bootstrap(want["cells"], 0, 32, 5, 2)
+        d = passk.evaluate_device(eng, ans, trd, P, 32, 5, M=2)
+        passk.check(d, eng)                                           # raw word may carry bit 2: repaired, not raised
+        boot = passk.gather_bootstrap(d, 32, engine=eng)
+        assert np.array_equal(boot.cpu().numpy(), want_boot)
 
 
 # ---- round 3: the exchange step behind the C ABI (scv_comm_*, scv_allreduce_counters) -------------------------------------
@@ -1439,6 +1487,103 @@ def test_c_abi_communicator_rccl_on_one_device():
     P, B = want.cells.shape
     got = AggregateResult.from_counters(bufs[0][:-1], P, B, cells)
     assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and bufs[0][-1] == 0
+
+
+@pytest.mark.parametrize("devices,flags", [([0, 0, 0], 0), ([0, 0], 0), ([0], 1)])
+def test_communicator_self_test_at_create_and_in_place_all_gathers(devices, flags):
+    """Round 4.  scv_comm_create ends with a self-test (known patterns through every peer path, one whole all-reduce, one
+    all-gather; verified on every device, two rounds): stat "selftest_words" says how much was verified.  Then the in-place
+    all-gathers behind the C ABI -- scv_allgather_cells (16-byte cell blocks at their row offsets) and scv_allgather_i64 (the
+    resample slices) -- with ragged block sizes, one of them empty."""
+    import ctypes as C
+    import torch
+    L = _lib.load()
+    comm = C.c_void_p()
+    G = len(devices)
+    _lib.check(L.scv_comm_create(C.byref(comm), (C.c_int * G)(*devices), G, 0, flags))
+    try:
+        v = C.c_int64()
+        _lib.check(L.scv_comm_get_stat(comm, b"selftest_words", C.byref(v)))
+        assert v.value >= 2 * 8217, v.value
+        _lib.check(L.scv_comm_get_stat(comm, b"staging_bytes", C.byref(v)))
+        assert v.value == 1 << 20
+        assert L.scv_comm_get_stat(comm, b"nope", C.byref(v)) == _lib.ERR_ARG
+        rng = np.random.default_rng(5)
+        B = 3
+        rows = [7, 0, 12][:G] if G > 1 else [9]
+        P = sum(rows)
+        want = rng.integers(0, 255, size=(P, B, 16), dtype=np.uint8)
+        tables, lo = [], 0
+        for r in range(G):
+            t = torch.full((P, B, 16), 0xEE, dtype=torch.uint8, device="cuda:0")
+            t[lo:lo + rows[r]] = torch.from_numpy(want[lo:lo + rows[r]]).to("cuda:0")
+            tables.append(t)
+            lo += rows[r]
+        torch.cuda.synchronize()
+        _lib.check(L.scv_allgather_cells(comm, (C.c_void_p * G)(*[t.data_ptr() for t in tables]), (C.c_int64 * G)(*rows), B))
+        counts = [5, 1000, 0][:G] if G > 1 else [77]
+        wantw = rng.integers(-2 ** 62, 2 ** 62, size=(sum(counts),), dtype=np.int64)
+        bufs, lo = [], 0
+        for r in range(G):
+            b = torch.full((sum(counts) + 3,), -1, dtype=torch.int64, device="cuda:0")
+            b[lo:lo + counts[r]] = torch.from_numpy(wantw[lo:lo + counts[r]]).to("cuda:0")
+            bufs.append(b)
+            lo += counts[r]
+        torch.cuda.synchronize()
+        _lib.check(L.scv_allgather_i64(comm, (C.c_void_p * G)(*[b.data_ptr() for b in bufs]), (C.c_int64 * G)(*counts)))
+        _lib.check(L.scv_comm_sync(comm))
+        for t in tables:
+            assert np.array_equal(t.cpu().numpy(), want)
+        for b in bufs:
+            assert np.array_equal(b.cpu().numpy()[:-3], wantw) and b.cpu().numpy()[-3:].tolist() == [-1, -1, -1]
+        assert L.scv_allgather_cells(comm, None, (C.c_int64 * G)(*rows), B) == _lib.ERR_ARG
+        assert L.scv_allgather_i64(comm, (C.c_void_p * G)(*[b.data_ptr() for b in bufs]), (C.c_int64 * G)(*([-1] * G))) == _lib.ERR_ARG
+    finally:
+        L.scv_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("devices,rccl", [([0, 0, 0], False), ([0, 0], False), ([0], True)])
+def test_multi_device_c5_without_torch_distributed_equals_one_context_and_oracle(devices, rccl):
+    """VERDICT r3 missing #4 / next #6: BASELINE config 5 for G > 1 from ONE process through the C ABI's communicator
+    (MultiDeviceEngine.evaluate_c5: vote per rank into its block of the whole cell table, ONE all-reduce of counters + error
+    word, scv_allgather_cells, per-rank scv_bootstrap over its slice of the resamples, scv_allgather_i64).  Counters, the
+    gathered cell table and the whole R x B x M resample table equal the 1-context run and the oracle."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine, MultiDeviceEngine
+    P, B, N, R, seed = 203, 2, 9000, 101, 4242
+    a, _, tr = coracle.synth_fill(P, B, N, 77, 3)
+    want = coracle.aggregate(a, tr)
+    M = int(want["cells"]["n_modes"][want["cells"]["hit"] == 1].max(initial=0)) + 1
+    rc, want_boot = coracle.bootstrap(want["cells"], 0, R, seed, M)
+    assert rc == 0
+    with MultiDeviceEngine(devices=devices, rccl=rccl) as me:
+        assert me.stat("selftest_words") > 0
+        shards = me.scatter(a, tr)
+        for M_arg in (None, M):                                        # class bound from the counters (host sync) / given
+            counters, table, boot, M_got = me.evaluate_c5([(s[0], s[1], None) for s in shards], R, seed, M=M_arg)
+            me.sync()
+            assert M_got == M
+            got = AggregateResult.from_counters(counters.cpu().numpy()[:-1], P, B)
+            assert np.array_equal(got.tie_class_hits, want["tie_class_hits"]) and np.array_equal(got.truth_count_sum, want["truth_count_sum"])
+            assert int(counters.cpu()[-1]) == 0
+            gc = cells_from_torch(table)
+            for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+                assert np.array_equal(gc[f], want["cells"][f]), f
+            assert np.array_equal(boot.cpu().numpy(), want_boot)
+        # one context, same numbers
+        with Engine() as one:
+            dev = torch.device("cuda:0")
+            _, cells1, _, boot1 = one.aggregate_bootstrap_device(torch.from_numpy(a).to(dev), torch.from_numpy(tr).to(dev), 0, R, seed, M)
+            one.sync()
+            assert np.array_equal(boot1.cpu().numpy(), boot.cpu().numpy()) and np.array_equal(cells1.cpu().numpy(), table.cpu().numpy())
+        # an out-of-domain vote on one rank: the summed error word is non-zero and sync raises
+        bad = a.copy()
+        bad[P - 1, 0, 17] = 1 << 20
+        shards = me.scatter(bad, tr)
+        counters, _, _, _ = me.evaluate_c5([(s[0], s[1], None) for s in shards], R, seed, M=M)
+        with pytest.raises(_lib.DomainError):
+            me.sync()
+        assert int(counters.cpu()[-1]) != 0
 
 
 def test_c_abi_communicator_argument_errors():

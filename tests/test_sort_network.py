@@ -1,5 +1,5 @@
 """CPU proof of the counting core of the sorted-cells kernel (csrc/scvote_sort.hip.h): the compile-time compare-exchange
-network (csrc/scvote_sortnet.h, plain C++) sorts -- 0-1 principle -- and a scalar emulation of the device code's packed form
+network (csrc/scvote_sortnet.h, plain C++) sorts -- 0-1 principle, exhaustive up to 24 wires, sampled at 32 -- and a scalar emulation of the device code's packed form
 (lockstep halves, one cross merge, run-length scan with the carry between the halves, sentinels) equals a brute-force
 statistics.multimode for every shape.  tests/sortnet_check.cpp is compiled with g++ and run here; no GPU."""
 import os
@@ -15,5 +15,6 @@ def test_sorting_network_and_packed_scan_on_cpu(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     sys.stdout.write(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "network: sorts (exchanges on 4 / 8 / 16 / 32 / 64 wires: 5 19 63 191 543)" in out.stdout
+    assert "network: sorts (exchanges on 4 / 8 / 16 / 24 / 32 wires: 5 19 63 132 191" in out.stdout
+    assert "valley merge: sorts every 0-1 valley (exchanges on 24 wires: 52)" in out.stdout
     assert "packed sort + scan: equals statistics.multimode" in out.stdout

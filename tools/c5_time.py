@@ -12,7 +12,7 @@ eng.synth_fill_device(ans, None, tr, P=P, B=B, N=N, seed=55, dist=1)
 counters, cells, _ = eng.aggregate_device(ans, tr)
 eng.sync()
 for lds in (0, 1):
-    eng.set_option("boot_lds", lds)
+    eng.set_option("boot_path", 0 if lds else 3)      # LDS-resident code table / global gathers
     out = eng.bootstrap_device(cells, 0, 1000, 7, 4); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []

@@ -32,11 +32,10 @@ def run(label, src, **opts):
     print(f"{label:54s} {best*1e3:8.1f} ms  = {a.nbytes/best/1e9:6.1f} GB/s = {a.size/best:.3e} votes/s   acc={res.accuracy(0):.4f}", flush=True)
 
 
-run("serial staging (round 1), pageable source", a, host_pipeline=0)
 for th in (1, 4, 8, 16, 32):
-    run(f"pipeline, pageable source, {th:2d} copy threads, 128 MB", a, host_pipeline=1, copy_threads=th, stage_mb=128)
+    run(f"pipeline, pageable source, {th:2d} copy threads, 128 MB", a, copy_threads=th, stage_mb=128)
 for mb in (32, 64, 256, 512):
-    run(f"pipeline, pageable source, 16 copy threads, {mb} MB", a, host_pipeline=1, copy_threads=16, stage_mb=mb)
-run("pipeline, PINNED source (DMA in place), 128 MB", ap, host_pipeline=1, copy_threads=8, stage_mb=128)
+    run(f"pipeline, pageable source, 16 copy threads, {mb} MB", a, copy_threads=16, stage_mb=mb)
+run("pipeline, PINNED source (DMA in place), 128 MB", ap, copy_threads=8, stage_mb=128)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(rows, open("gpurun_out/host_mode.json", "w"), indent=1)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """scv_sort_cells (one lane per cell, rows staged by LDS-DMA, sorted in registers) on the GPU box: a parity sweep against the
 C oracle (every N = 4 ... 64 that is a multiple of 4, several B, ragged n_valid, tokens, every distribution, out-of-domain votes)
-and an A/B timing against the kernels it replaces (option sort_cells = 0).  One JSON file under gpurun_out/."""
+and an A/B timing against the kernels it replaces (option sort_n_max = 0).  One JSON file under gpurun_out/."""
 from __future__ import annotations
 
 import json
@@ -20,7 +20,7 @@ def parity(eng, big=False):
     bad = []
     n = 0
     rng = np.random.default_rng(3)
-    for N in list(range(1, 65)) + ([68, 96, 100, 124, 128] if big else []):
+    for N in list(range(1, 65)) + []:
         for (P, B) in ((1, 1), (7, 3), (300, 4), (1000, 11), (5000, 8), (70000, 2)):
             if P * B * N > 6_000_000:
                 continue
@@ -109,7 +109,7 @@ def main():
                 if tok and not cells:
                     continue
                 rec = {"shape": [P, B, N], "tokens": tok, "cell_table": cells}
-                for label, opts in (("old", {"sort_cells": 0}), ("sort", {"sort_cells": 1})):
+                for label, opts in (("lane/reg", {"sort_n_max": 0}), ("sort", {"sort_n_max": 64})):
                     eng = Engine(device=0, timing=True)
                     for k, v in opts.items():
                         eng.set_option(k, v)
