@@ -48,6 +48,7 @@ def main():
     from o1_inference_scaling_laws_amd.engine import Engine
     eng = Engine(device=0, timing=True)
     out = []
+    only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]      # substrings of case names
     cases = [
         ("headline slab", 256, 8, 1 << 20, False, None),
         ("tokens stream", 128, 8, 1 << 20, True, None),
@@ -104,6 +105,28 @@ def main():
         ("N=64 D3 tie", 400000, 4, 64, False, None, 3),
         ("N=64 D5 degenerate-wrong", 400000, 4, 64, False, None, 5),
         ("N=96 P=200k", 200000, 4, 96, False, None),
+        # round 4: the 48-vote shape of the sorted-cells kernel (33 ... 48 votes used to sort 64 slots)
+        ("small N=36 P=500k", 500000, 4, 36, False, None),
+        ("small N=40 P=500k", 500000, 4, 40, False, None),
+        ("small N=44 P=400k", 400000, 4, 44, False, None),
+        ("small N=48 P=400k counters only", 400000, 4, 48, False, None, 1, False),
+        ("small N=48 P=400k + tokens", 400000, 4, 48, True, None),
+        ("N=45 P=400k (unaligned rows)", 400000, 4, 45, False, None),
+        ("N=48 D0 uniform", 400000, 4, 48, False, None, 0),
+        ("N=48 D3 tie", 400000, 4, 48, False, None, 3),
+        ("N=48 D5 degenerate-wrong", 400000, 4, 48, False, None, 5),
+        # round 4: the reference's MOST COMMON cell sizes -- N = 1 for all 8-20 ask-nicely budgets (o1.py:302), N = 1 x 8, 2, 4 (o1.py:276)
+        ("N=1 P=12.8M", 12800000, 8, 1, False, None),
+        ("N=1 P=12.8M counters only", 12800000, 8, 1, False, None, 1, False),
+        ("N=1 P=12.8M + tokens", 12800000, 8, 1, True, None),
+        ("N=1 P=12.8M + tokens counters only", 12800000, 8, 1, True, None, 1, False),
+        ("N=2 P=12.8M", 12800000, 4, 2, False, None),
+        ("N=2 P=12.8M counters only", 12800000, 4, 2, False, None, 1, False),
+        ("N=2 P=12.8M + tokens", 12800000, 4, 2, True, None),
+        ("N=4 P=6.4M", 6400000, 4, 4, False, None),
+        ("N=4 P=6.4M counters only", 6400000, 4, 4, False, None, 1, False),
+        ("N=4 P=6.4M + tokens", 6400000, 4, 4, True, None),
+        ("N=4 P=6.4M + tokens counters only", 6400000, 4, 4, True, None, 1, False),
     ]
     # the hot value is NOT the truth (D3 exact ties, D4 a confidently wrong majority, D5 all votes one wrong value) and D0
     for (P, B, N) in ((100000, 4, 256), (50000, 4, 1024), (20000, 8, 4096)):
@@ -111,11 +134,15 @@ def main():
             cases.append((f"N={N} {nm}", P, B, N, False, None, d))
     for case in cases:
         name, P, B, N, tok, nv = case[:6]
+        if only and not any(o in name for o in only):
+            continue
         r = run(eng, torch, P, B, N, tok, n_valid=nv, dist=case[6] if len(case) > 6 else 1, want_cells=case[7] if len(case) > 7 else True)
         r["name"] = name
         out.append(r)
         print(f"{name:28s} {str(r['shape']):22s} tok={int(tok)}  {r['median_us']:10.1f} us  {r['GBps']:8.1f} GB/s  {r['votes_per_s']:.3e} votes/s", flush=True)
         torch.cuda.empty_cache()
+    if only:
+        return
     # prefix budgets over one pool: one pass vs the dense expansion (reported separately: different bytes)
     from o1_inference_scaling_laws_amd.engine import counters_size
     import statistics as st
