@@ -317,7 +317,7 @@ int scv_host_free(void* p);
  * (scv_aggregate_bootstrap_i32: one launch / two), "boot_cooperative" (one-launch forms started as cooperative launches),
  * "boot_recovered" (grid-barrier timeouts repaired by scv_sync with a separate bootstrap launch), "overwrite_fused" (counters
  * overwritten by the vote kernel's last workgroup), "lds_counters" (register-resident launches that produced their counters
- * themselves), "sort_cells" (sorted-cells launches), "prefix_cells" / "prefix_lane" (prefix calls served by the cell kernels / by
+ * themselves), "sort_cells" (sorted-cells launches), "few_votes" (launches of the kernel for cells of exactly 1, 2 or 4 votes), "prefix_cells" / "prefix_lane" (prefix calls served by the cell kernels / by
  * the one-lane-per-problem kernel). */
 int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out);
 

@@ -62,9 +62,11 @@ def load():
     L.scv_comm_ctx.restype = p
     L.scv_allreduce_counters.argtypes = [p, C.POINTER(p), i64]
     L.scv_comm_sync.argtypes = [p]
-    L.scv_allgather_cells.argtypes = [p, C.POINTER(p), C.POINTER(i64), i32]
-    L.scv_allgather_i64.argtypes = [p, C.POINTER(p), C.POINTER(i64)]
-    L.scv_comm_get_stat.argtypes = [p, C.c_char_p, C.POINTER(i64)]
+    ab_build = bool(os.environ.get("SCV_LIB_PATH"))              # an older build loaded for an A/B run (tools/ only) may lack the newest entry points
+    if not ab_build or hasattr(L, "scv_allgather_cells"):
+        L.scv_allgather_cells.argtypes = [p, C.POINTER(p), C.POINTER(i64), i32]
+        L.scv_allgather_i64.argtypes = [p, C.POINTER(p), C.POINTER(i64)]
+        L.scv_comm_get_stat.argtypes = [p, C.c_char_p, C.POINTER(i64)]
     L.scv_last_kernel_ns.argtypes = [p, C.POINTER(u64)]
     L.scv_drain_kernel_ns.argtypes = [p, C.POINTER(u64), C.POINTER(u64)]
     L.scv_get_stat.argtypes = [p, C.c_char_p, C.POINTER(i64)]
@@ -81,6 +83,8 @@ def load():
                  "scv_device_count", "scv_device_info", "scv_host_alloc", "scv_host_free", "scv_get_stat", "scv_export_error_word",
                  "scv_comm_create", "scv_comm_destroy", "scv_comm_size", "scv_allreduce_counters", "scv_comm_sync",
                  "scv_allgather_cells", "scv_allgather_i64", "scv_comm_get_stat"):
+        if ab_build and not hasattr(L, name):
+            continue
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -158,7 +158,7 @@ struct scv_ctx {
     struct BootReq { int32_t r0, r1, M; uint64_t seed; int64_t* out; bool fused; }* boot_req = nullptr;   // set for the duration of one call
     // the last fused request, kept so that a grid-barrier timeout can be repaired at scv_sync by a separate bootstrap launch
     struct BootLast { const scv_cell* cells = nullptr; int64_t P = 0; int32_t B = 0, r0 = 0, r1 = 0, M = 0; uint64_t seed = 0; int64_t* out = nullptr; bool valid = false; } boot_last;
-    int64_t stat_boot_recovered = 0, stat_boot_cooperative = 0, stat_sort_cells = 0;
+    int64_t stat_boot_recovered = 0, stat_boot_cooperative = 0, stat_sort_cells = 0, stat_few_votes = 0;
     // split-N scratch (grown on demand)
     void* d_partial = nullptr;
     size_t d_partial_bytes = 0;
@@ -475,6 +475,29 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         return finish(ev);
     }
 
+    if (kind == LANE && (N == 1 || N == 2 || N == 4) && !pool_rows && ncells < 0x7fffffffll / 4 && (ncells * N) % 4 == 0 &&
+        (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0) && lane_kernel_lds(B, (int)N) <= (size_t)60 * 1024) {
+        // ---- cells of exactly 1, 2 or 4 votes (the reference's most common sizes, o1.py:276,302): one 16-byte vector = 4 / 2 / 1 cells per lane
+        const int64_t nvecs = ncells * N / 4;
+        const int threads = 1024;
+        const size_t lds = lane_kernel_lds(B, (int)N);
+        int64_t grid = (nvecs + threads - 1) / threads;
+        const int64_t cap = (int64_t)ctx->num_cus * 2;             // two workgroups per CU: 32 waves, each with two vectors in flight
+        if (grid > cap) grid = cap;
+        // cells per grid step a multiple of B: every cell slot of a lane then keeps its budget and its counters stay in registers
+        const int64_t cpl = 4 / N;
+        if ((grid * threads * cpl) % B != 0 && grid > B) grid -= grid % B;
+        if (ctx->grid_override > 0) grid = ctx->grid_override;
+        ctx->stat_few_votes += 1;
+        if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+#define SCV_FEW(NVV) do { if (tok) hipLaunchKernelGGL((scv::scv_few_votes<NVV, true>), dim3((unsigned)grid), dim3(threads), lds, ctx->stream, a); \
+                          else hipLaunchKernelGGL((scv::scv_few_votes<NVV, false>), dim3((unsigned)grid), dim3(threads), lds, ctx->stream, a); } while (0)
+        if (N == 1) SCV_FEW(1); else if (N == 2) SCV_FEW(2); else SCV_FEW(4);
+#undef SCV_FEW
+        SCV_HIP(hipGetLastError());
+        return finish(ev);
+    }
+
     if (kind == LANE) {
         // ---- tiny cells, one lane per cell; counters accumulated in LDS and flushed by the same launch
         const int nv = N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : 32));
@@ -509,7 +532,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         // fewer cells than CUs: one cell per CU whatever the band, so give each the widest workgroup
         if (ncells <= ctx->num_cus && N >= 4096) { copies = 16; threads = 1024; wg_per_cu = 1; unroll = 4; }
     }
-    const size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords + scv::kMaxSortedB) * sizeof(uint32_t);
+    // histogram copies | cross-wave scratch | budget order | (tokens) one U KiB LDS-DMA staging block per wave
+    const size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords + scv::kMaxSortedB) * sizeof(uint32_t) + (tok ? (size_t)(threads / 64) * unroll * 1024 : 0);
     if ((int64_t)lds > ctx->lds_max) return fail(SCV_ERR_ARG, "LDS request %zu exceeds device limit %lld", lds, (long long)ctx->lds_max);
     const int by_lds = (int)((160 * 1024) / lds);
     const int by_waves = 2048 / threads;
@@ -1306,6 +1330,7 @@ int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
     else if (!strcmp(key, "prefix_cells")) *out = ctx->stat_prefix_cells;
     else if (!strcmp(key, "prefix_lane")) *out = ctx->stat_prefix_lane;
     else if (!strcmp(key, "sort_cells")) *out = ctx->stat_sort_cells;
+    else if (!strcmp(key, "few_votes")) *out = ctx->stat_few_votes;
     else return fail(SCV_ERR_ARG, "unknown stat '%s'", key);
     return SCV_OK;
 }

@@ -266,13 +266,8 @@ __device__ __forceinline__ uint32_t sv_sentinel(uint32_t x, uint32_t n2, uint32_
     return o;
 }
 
-// one LDS-DMA piece: 64 lanes x 16 bytes, lane l's bytes (from gbase + goff_l) land at lds_dst + 16 l; the source is a scalar base +
-// a 32-bit lane offset (no 64-bit address arithmetic on the VALU); M0 is written in the statement that reads it
-__device__ __forceinline__ void sv_dma16(const void* gbase, uint32_t goff, uint32_t lds_dst) {
-    uint32_t keep;         // read-once stream: non-temporal (the line is not kept for a reuse that never comes; ordinary loads: 5-10 % slower at N = 8 ... 32)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
-}
+// (one LDS-DMA piece: lds_dma16 of scvote_kernels.hip.h)
+__device__ __forceinline__ void sv_dma16(const void* gbase, uint32_t goff, uint32_t lds_dst) { lds_dma16(gbase, goff, lds_dst); }
 // ... the same, pinned in the data flow of the sort: `dep` (a register the preceding compare-exchange wrote and a later one reads) is
 // an in/out operand the statement does not touch, so the exchanges before it stay before and the ones after it stay after -- without it
 // the compiler sinks the whole sort below the pieces (asm statements only keep their order among themselves)
@@ -287,11 +282,7 @@ __device__ __forceinline__ void sv_dma4(const void* gbase, uint32_t goff, uint32
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(goff), "s"(gbase), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ int64_t sv_uniform64(int64_t v) {      // tell the compiler a value is wave-uniform (it lives in SGPRs from here on)
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v & 0xffffffffu));
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)hi << 32) | lo);
-}
+__device__ __forceinline__ int64_t sv_uniform64(int64_t v) { return uniform64(v); }
 
 constexpr int sort_cells_threads(int nv) { return nv >= 64 ? 512 : 1024; }
 

@@ -11,6 +11,7 @@
 //                                        workgroups of 1024 threads, each streaming its own 256 KiB / 512 KiB / 4 MiB segment ONCE
 //                                        (the few-huge-cells shapes: split-N segments, C2's 512 KiB cells) -- GB/s per workgroup
 //                                        and in total, and the time one segment takes (the floor of those shapes)
+//   hbm_probe.bin [cells] --c2           the floor of BASELINE config 2: a pure read of its 125.8 MB in ONE launch, cut into 240 ... 1920 segments
 //   hbm_probe.bin [cells] --dma          the ceiling of the LDS-DMA input path of scv_sort_cells: waves that only copy 2-16 KiB blocks HBM -> LDS
 //   hbm_probe.bin [cells] --calib        3 launches of ONE variant (read_cells_pipe<4>, grid 250 x 1024) and nothing
 //                                        else: run under `rocprofv3 --pmc FETCH_SIZE` to get FETCH_SIZE per launch
@@ -153,13 +154,14 @@ double time_ms(F f, int reps = 5) {
 
 int main(int argc, char** argv) {
     long ncells = 10000;
-    bool calib = false, shortcells = false, quick = false, percu = false, dma = false;
+    bool calib = false, shortcells = false, quick = false, percu = false, dma = false, c2 = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--calib")) calib = true;
         else if (!strcmp(argv[i], "--short")) shortcells = true;
         else if (!strcmp(argv[i], "--quick")) quick = true;
         else if (!strcmp(argv[i], "--percu")) percu = true;
         else if (!strcmp(argv[i], "--dma")) dma = true;
+        else if (!strcmp(argv[i], "--c2")) c2 = true;
         else ncells = atol(argv[i]);
     }
     const long cell_bytes = 4l << 20;
@@ -193,6 +195,37 @@ int main(int argc, char** argv) {
                     }
                 }
             }
+        }
+        return 0;
+    }
+    if (c2) {
+        // BASELINE config 2 is 30 x 8 cells of 512 KiB = 125.8 MB in ONE launch: what is the floor of a pure read of those bytes, and does it
+        // depend on how the launch is cut?  240 / 480 / 960 / 1920 segments x workgroup sizes; U loads of 16 bytes in flight per lane;
+        // distinct regions per repetition (nothing served by the 256 MiB Infinity Cache); launch time by hipEvents, median of 40+.
+        printf("c2: pure read of 125.8 MB in one launch, by segments x threads per workgroup (us per launch | GB/s)\n");
+        const long total_vecs = 240l * 512 * 1024 / 16;
+        struct G { int segs, threads, u; };
+        for (G g : {G{240, 1024, 4}, G{240, 1024, 8}, G{240, 512, 4}, G{240, 512, 8}, G{480, 1024, 4}, G{480, 512, 4}, G{480, 512, 8}, G{480, 256, 4}, G{960, 512, 4}, G{960, 256, 4},
+                    G{960, 256, 8}, G{1920, 256, 4}, G{1920, 128, 4}, G{256, 1024, 4}, G{512, 512, 4}, G{1024, 256, 4}}) {
+            const long seg_vecs = total_vecs / g.segs / ((long)g.u * g.threads) * ((long)g.u * g.threads);     // whole steps only (<= 0.6 % fewer bytes)
+            const long span = (long)g.segs * seg_vecs;
+            const long regions = nvec / span < 64 ? nvec / span : 64;
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            std::vector<float> ts;
+            for (long r = 0; r < regions; ++r) {
+                CK(hipEventRecord(e0));
+                if (g.u == 4) read_cells<4, true><<<g.segs, g.threads>>>(buf + r * span, seg_vecs, g.segs, sink);
+                else read_cells<8, true><<<g.segs, g.threads>>>(buf + r * span, seg_vecs, g.segs, sink);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (r >= 2) ts.push_back(ms);
+            }
+            std::sort(ts.begin(), ts.end());
+            const double ms = ts.empty() ? 0 : ts[ts.size() / 2], best = ts.empty() ? 0 : ts[0];
+            printf("c2      %4d segments of %6.1f KiB x %4d threads, U = %d : median %6.1f us (best %6.1f) | %6.0f GB/s\n", g.segs, seg_vecs * 16 / 1024.0, g.threads, g.u,
+                   ms * 1e3, best * 1e3, span * 16.0 / ms / 1e6);
         }
         return 0;
     }
