@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--graph-steps", type=int, default=1,
                     help="with --graph: consecutive steps captured into ONE graph (the launch-bound inner loop of C2 as a single "
                          "graph launch); --steps and --warmup are rounded up to multiples of it")
+    ap.add_argument("--c2-one-launch", action="store_true", help="c2: overwrite-counters mode (one kernel launch per evaluation, no memset node)")
+    ap.add_argument("--no-timing", action="store_true", help="no hipEvent records around the launches (they cost ~7 us per step on a 26 us step: c2); kernel time = wall clock")
     ap.add_argument("--graph", action="store_true",
                     help="single GPU: capture memset + hot-path launch of every resident chunk into a hipGraph and replay it "
                          "(launch-bound workloads such as --workload c2); kernel time is then taken from the wall clock")
@@ -420,7 +422,7 @@ def main_single_process(args):
     ctok = [torch.empty((rows[g], B), dtype=torch.int64, device=torch.device("cuda", devices[g])) if args.tokens else None for g in range(world)]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps + args.warmup + 1)]
     c5_state = {"M": None, "last": None, "boot_seed": args.seed ^ 0xB007}
-    ow = args.workload == "c2"
+    ow = args.workload == "c2" and args.c2_one_launch
 
     def step(i, timed_slot=None):
         if c5:
@@ -586,7 +588,12 @@ def main():
         args.problems_per_step, args.resident = hi - lo, 1
     Pc, B, N = args.problems_per_step, args.budgets, args.samples
     use_graph = bool(args.graph) and world == 1 and not c5
-    eng = Engine(device=local_rank, timing=not use_graph)     # hipEvent records cannot live inside a captured graph
+    # C2 steps take ~26 us and a pair of hipEvent records around every launch adds ~8 us to each (profiles/r04_c2_sweep.json: 34.0 vs 26.4 us):
+    # the timed region of c2 runs WITHOUT the records (that is `value`), and the kernel's own duration comes from a second, instrumented
+    # loop over the same chunks right after it (roofline.kernel_avg_ms; `kernel_timed_in` says so)
+    split_timing = args.workload == "c2" and not use_graph and not args.no_timing and world == 1
+    no_events = use_graph or args.no_timing or split_timing   # hipEvent records cannot live inside a captured graph
+    eng = Engine(device=local_rank, timing=not no_events)
     eng.set_tuning(args.copies, args.threads, args.wg_per_cu, args.unroll)
 
     # ---- resident inputs: `resident` distinct chunks, generated on device ------------------------
@@ -626,17 +633,20 @@ def main():
 
     c5_state = {"M": None, "last": None, "boot_seed": args.seed ^ 0xB007}
 
-    def step(i):
+    def step(i, engine=None):
+        engine = engine or eng
         ans, tok, tr, _ = slots[i % R]
         if c5:
             out = passk.evaluate_device(eng, ans, tr, args.problems, args.resamples, c5_state["boot_seed"], M=c5_state["M"],
                                         tokens_local=tok, counters=pipe.buffers[i % 2], cells_local=cells)
             c5_state["M"], c5_state["last"] = out.M, out      # the class bound is found once (host sync), then reused
             return out.counters
-        # c2 (few long cells): the kernel's last workgroup overwrites the counters -- one launch per step, no memset
-        ow = args.workload == "c2"
+        # c2 (few long cells): zeroing memset + accumulate.  The one-launch form (overwrite=True: the kernel's last workgroup turns the cell table
+        # into the counters) is 0.8-1.0 us per step SLOWER in every geometry of profiles/r04_c2_sweep.json (26.4 vs 25.6 us eager): the
+        # 65.7 KB counter rewrite by one workgroup costs more than a memset node that overlaps the previous step's tail.  --c2-one-launch selects it.
+        ow = args.workload == "c2" and args.c2_one_launch
         counters = pipe.acquire(i, zero=not ow)   # waits for this buffer's previous all-reduce (and zeroes it)
-        eng.aggregate_device(ans, tr, tokens=tok, counters=counters, cells=cells, cell_tokens=ctok, overwrite=ow)
+        engine.aggregate_device(ans, tr, tokens=tok, counters=counters, cells=cells, cell_tokens=ctok, overwrite=ow)
         return pipe.publish(i)               # async all-reduce (no-op with one rank)
 
     graphs = {}
@@ -686,14 +696,14 @@ def main():
               and ((c["truth_count"] == c["max_count"]) == (c["hit"] == 1)).all() and (c["n_modes"] >= 1).all())
         if not ok:
             sys.exit("cell table violates its invariants")
-    if not use_graph:
+    if not no_events:
         eng.drain_kernel_ns()
 
     # ---- warmup + timed region -------------------------------------------------------------------
     for i in range(args.warmup):
         step(i)
     fence()
-    if not use_graph:
+    if not no_events:
         eng.drain_kernel_ns()
     t0 = time.perf_counter()
     last = None
@@ -701,8 +711,25 @@ def main():
         last = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    if use_graph:
-        kern_ns, launches = int(elapsed * 1e9), args.steps    # no events inside a graph: wall clock per step (upper bound)
+    kernel_timed_in = "the timed region (hipEvents recorded by the library around every launch)"
+    # the cell table now holds the LAST TIMED step's chunk (c5: this rank's shard)
+    last_cells = cells_from_torch(cells) if rank == 0 else None
+    if split_timing:
+        eng_t = Engine(device=local_rank, timing=True)
+        eng_t.set_tuning(args.copies, args.threads, args.wg_per_cu, args.unroll)
+        nt = max(10, min(args.steps, 100))
+        for i in range(nt + 5):
+            if i == 5:
+                eng_t.sync()
+                eng_t.drain_kernel_ns()
+            step(args.warmup + args.steps + i, eng_t)
+        fence()
+        kern_ns, launches = eng_t.drain_kernel_ns()
+        eng_t.close()
+        kernel_timed_in = f"a second loop of {nt} steps over the same chunks with hipEvent records (the timed region ran without them: they add ~8 us to a ~26 us step)"
+    elif no_events:
+        kern_ns, launches = int(elapsed * 1e9), args.steps    # no events (inside a graph / --no-timing): wall clock per step (upper bound)
+        kernel_timed_in = "nothing: wall clock of the timed region per step (upper bound)"
     else:
         kern_ns, launches = eng.drain_kernel_ns()
     if world > 1 or force:
@@ -714,9 +741,7 @@ def main():
         kern_avg_ns = float(kmax.item())
     else:
         kern_avg_ns = kern_ns / max(launches, 1)
-    # the cell table now holds the LAST TIMED step's chunk (c5: this rank's shard)
     last_slot = slots[(args.warmup + args.steps - 1) % R] if args.steps > 0 else slots[0]
-    last_cells = cells_from_torch(cells) if rank == 0 else None
 
     slots_span = f"{min(sl[3] for sl in slots)}..{max(sl[3] for sl in slots) + Pc - 1}" + (" interleaved over the ranks" if world > 1 else "")
     votes_per_step_per_gpu = Pc * B * N
@@ -772,7 +797,7 @@ def main():
             "tokens_stream": bool(args.tokens),
             "parallelism": f"problems sharded over {world} GPU(s), one int64 all-reduce of {counters_size(B)} counters per step",
             "seed": args.seed,
-            "launch": (f"hipGraph replay ({gs} step(s) per graph launch)" if use_graph else "eager"),
+            "launch": (f"hipGraph replay ({gs} step(s) per graph launch)" if use_graph else ("eager, no hipEvent records" if no_events else "eager")),
             "comm": "torch",
             "backend": args.backend if (world > 1 or force) else None,
             "collectives_forced_on_one_rank": bool(force),
@@ -794,6 +819,7 @@ def main():
             "traffic_source": ev.get("traffic_source"),
             "kernel": "scv_hist_argmax",
             "kernel_avg_ms": kern_avg_ns / 1e6,
+            "kernel_timed_in": kernel_timed_in,
             "launches_timed": launches,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "measured_read_ceiling_gbs": ev.get("read_ceiling_gbs"),

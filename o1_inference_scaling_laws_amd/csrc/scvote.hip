@@ -475,18 +475,17 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         return finish(ev);
     }
 
-    if (kind == LANE && (N == 1 || N == 2 || N == 4) && !pool_rows && ncells < 0x7fffffffll / 4 && (ncells * N) % 4 == 0 &&
+    if (kind == LANE && (N == 1 || N == 2 || N == 4) && !pool_rows && ncells < (1ll << 29) && ncells % (256 / N) == 0 &&
         (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0) && lane_kernel_lds(B, (int)N) <= (size_t)60 * 1024) {
-        // ---- cells of exactly 1, 2 or 4 votes (the reference's most common sizes, o1.py:276,302): one 16-byte vector = 4 / 2 / 1 cells per lane
-        const int64_t nvecs = ncells * N / 4;
+        // ---- cells of exactly 1, 2 or 4 votes (the reference's most common sizes, o1.py:276,302): a block of 256 / 128 / 64 cells per wave and step
+        const int64_t nblocks = ncells / (256 / N);
         const int threads = 1024;
         const size_t lds = lane_kernel_lds(B, (int)N);
-        int64_t grid = (nvecs + threads - 1) / threads;
-        const int64_t cap = (int64_t)ctx->num_cus * 2;             // two workgroups per CU: 32 waves, each with two vectors in flight
+        int64_t grid = (nblocks + threads / 64 - 1) / (threads / 64);
+        const int64_t cap = (int64_t)ctx->num_cus * 2;             // two workgroups per CU: 32 waves, each with a block in flight behind the one it counts
         if (grid > cap) grid = cap;
         // cells per grid step a multiple of B: every cell slot of a lane then keeps its budget and its counters stay in registers
-        const int64_t cpl = 4 / N;
-        if ((grid * threads * cpl) % B != 0 && grid > B) grid -= grid % B;
+        if ((grid * (threads / 64) * 256) % B != 0 && grid > B) grid -= grid % B;
         if (ctx->grid_override > 0) grid = ctx->grid_override;
         ctx->stat_few_votes += 1;
         if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
@@ -532,8 +531,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         // fewer cells than CUs: one cell per CU whatever the band, so give each the widest workgroup
         if (ncells <= ctx->num_cus && N >= 4096) { copies = 16; threads = 1024; wg_per_cu = 1; unroll = 4; }
     }
-    // histogram copies | cross-wave scratch | budget order | (tokens) one U KiB LDS-DMA staging block per wave
-    const size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords + scv::kMaxSortedB) * sizeof(uint32_t) + (tok ? (size_t)(threads / 64) * unroll * 1024 : 0);
+    const size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords + scv::kMaxSortedB) * sizeof(uint32_t);
     if ((int64_t)lds > ctx->lds_max) return fail(SCV_ERR_ARG, "LDS request %zu exceeds device limit %lld", lds, (long long)ctx->lds_max);
     const int by_lds = (int)((160 * 1024) / lds);
     const int by_waves = 2048 / threads;

@@ -378,89 +378,10 @@ __device__ __forceinline__ void stream_votes_tokens(uint32_t* hist, uint32_t cop
     }
 }
 
-// votes + tokens with the TOKEN row moved by LDS-DMA (round 4).  The token row only feeds a sum, yet held in registers it halved the
-// loads in flight per lane (UT = U / 2 of each stream: 114 VGPRs at U = 4, no room for more) and the two-stream kernel ran at
-// 6.0-6.5 TB/s against 7.0 votes-only.  Here the vote stream keeps its U register loads per lane and every wave copies the U KiB
-// of tokens that belong to them HBM -> LDS with global_load_lds_dwordx4 (no VGPR is staged): twice the bytes in flight.
-// One 1 KiB x U staging block per wave, single-buffered, software-pipelined one step deep:
-//     step k:  issue the U vote loads of step k            (outstanding: L(k-1) D(k-1) L(k))
-//              wait until only those U are outstanding      -> votes and tokens of step k-1 have landed (loads complete in order)
-//              read the tokens of step k-1 out of the block     (lgkmcnt(0): the block is free again)
-//              issue the U token pieces of step k into the block
-//              vote step k-1, sum its tokens
-// The steps cover the vectors [lo, lo + steps * U * T) of the run, the same for every lane of the workgroup; the caller streams the rest
-// (fewer than U * T vectors) through registers.  tokbuf: LDS byte address of this wave's block (wave-uniform).
-// begin: issue step 0 of the run [lo, hi) -- its U vote loads into xp, its U token pieces into the block (which must be free).
-template <int T, int U>
-__device__ __forceinline__ void dma_run_begin(const int4* v4, const int4* t4, int64_t lo, int tid, uint32_t tokbuf, int4 (&xp)[U]) {
-    const int lane = tid & 63;
-    const char* tb = reinterpret_cast<const char*>(uniform64((int64_t)(uintptr_t)(t4 + lo + (tid - lane))));
-    const int4* vp = v4 + lo + tid;
-#pragma unroll
-    for (int u = 0; u < U; ++u) xp[u] = stream_load(vp + (int64_t)u * T);
-#pragma unroll
-    for (int u = 0; u < U; ++u) lds_dma16(tb + (int64_t)u * T * 16, (uint32_t)lane * 16u, tokbuf + (uint32_t)u * 1024u);
-}
-// run: the steps after step 0 (already issued: xp), -> first vector not covered
-template <int RL2, int T, int U>
-__device__ __forceinline__ int64_t stream_votes_tokens_dma(uint32_t* hist, uint32_t copy, const int4* v4, const int4* t4, int64_t lo, int64_t hi,
-                                                          int tid, uint32_t tokbuf, int4 (&xp)[U], uint32_t& bad, long long& tsum) {
-    const int64_t steps = (hi - lo) / ((int64_t)U * T);          // (>= 1: the caller began the run)
-    const int lane = tid & 63;
-    const uint32_t lane16 = (uint32_t)lane * 16u;
-    // this wave's first token vector of step 0 (wave-uniform): lane l copies the vector the lane loads as its vote vector
-    const char* tb = reinterpret_cast<const char*>(uniform64((int64_t)(uintptr_t)(t4 + lo + (tid - lane))));
-    const int4* vp = v4 + lo + tid;
-    // tokens of the step out of the block FIRST (U reads, nothing else in the LDS queue behind them), so that the block is free -- and the
-    // next step's pieces are issued -- before the 16 U histogram adds of the step, not after them
-    auto read_tokens = [&](scv_v4u (&y)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) y[u] = *reinterpret_cast<lds_v4u*>((uintptr_t)(tokbuf + (uint32_t)u * 1024u + lane16));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    auto votes_and_sum = [&](const int4 (&x)[U], const scv_v4u (&y)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            vote4<RL2>(hist, copy, x[u], bad);
-            tsum += (long long)(int32_t)y[u].x + (long long)(int32_t)y[u].y + (long long)(int32_t)y[u].z + (long long)(int32_t)y[u].w;
-        }
-    };
-    // two register sets ping-pong (a copy xp = x at the end of a step would need x loaded: vmcnt(0) on the back edge)
-    auto step = [&](int4 (&nxt)[U], const int4 (&prv)[U]) {
-        vp += (int64_t)U * T;
-        tb += (int64_t)U * T * 16;
-#pragma unroll
-        for (int u = 0; u < U; ++u) nxt[u] = stream_load(vp + (int64_t)u * T);
-        // (the compiler waits with vmcnt(U) for prv on its own: it counts the U loads above and not the DMA pieces, which are older;
-        //  said explicitly so that the token reads below never depend on its schedule)
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(U) : "memory");
-        scv_v4u y[U];
-        read_tokens(y);
-#pragma unroll
-        for (int u = 0; u < U; ++u) lds_dma16(tb + (int64_t)u * T * 16, lane16, tokbuf + (uint32_t)u * 1024u);
-        votes_and_sum(prv, y);
-    };
-    int4 xq[U];
-    int64_t k = 1;
-    for (; k + 1 < steps; k += 2) {
-        step(xq, xp);
-        step(xp, xq);
-    }
-    asm volatile("" ::: "memory");
-    scv_v4u y[U];
-    if (k < steps) {
-        step(xq, xp);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        read_tokens(y);
-        votes_and_sum(xq, y);
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        read_tokens(y);
-        votes_and_sum(xp, y);
-    }
-    return lo + steps * (int64_t)U * T;
-}
-
+// (Round 4, measured and not kept: the TOKEN row moved by LDS-DMA -- global_load_lds_dwordx4, one U KiB staging block per wave, no
+//  VGPR staged -- so that the vote stream keeps its U register loads per lane: twice the bytes in flight per lane.  On the same box,
+//  interleaved with the round-3 library: 6.81 / 6.79 against 6.75 / 6.79 TB/s on 4 MiB rows, and C2 with tokens 47.8 against 45.0 us --
+//  the register form with its cross-item prefetch is as fast on long rows and faster on short ones: profiles/r04_tokens_dma_ab.log.)
 // Stream one contiguous run of votes (a whole cell, a split-N segment, or the run between two
 // prefix boundaries) into the replicated histogram; accumulates the token sum when TOK.
 template <int RL2, int T, int U, bool TOK>
@@ -706,30 +627,37 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
     // registers before the current item's epilogue (B1 / fold / reductions), so a short cell's load
     // latency overlaps the previous cell's epilogue instead of following it.
     const bool pf = !TOK && a.prefetch;
-    // ... with the tokens stream the token row goes through LDS-DMA (stream_votes_tokens_dma): one U KiB staging block per wave behind
-    // the budget order; items whose token row is not 16-byte congruent with the vote row take stream_row.
-    const uint32_t tokbuf = TOK ? (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)(lds_u32*)(reinterpret_cast<uint32_t*>(ord) + kMaxSortedB)
-                                                                                + (uint32_t)(tid >> 6) * (uint32_t)U * 1024u)) : 0u;
+    // ... and with the tokens stream: the first UT vectors of BOTH rows of the next item (round 2 had no prefetch here: 6.4-6.6
+    // against 6.9-7.1 TB/s votes-only).  Items whose token row is not 16-byte congruent with the vote row take stream_row.
+    constexpr int UT = U > 1 ? U / 2 : 1;
+    const bool pft = TOK && a.prefetch;
+    int4 pret[TOK ? UT : 1];
+    const int4* cur_t4 = nullptr;             // first aligned vector of the current item's token row (NULL: not congruent)
     auto token_vectors = [&](const StreamItem& it, int64_t lo) -> const int4* {
         const int32_t* t = a.tokens + it.cell * a.N + lo + it.head;
         return (((uintptr_t)t) & 15u) == 0 ? reinterpret_cast<const int4*>(t) : nullptr;
     };
-    int4 pre[U];                              // votes only: first tile of the item | tokens: step 0 of the item's LDS-DMA run
-    const int4* cur_t4 = nullptr;             // tokens: non-NULL = the item's run was begun (congruent rows of at least one step)
-    auto dma_eligible = [&](const StreamItem& it, int64_t lo) -> const int4* {
-        if (!TOK || it.nvec < (int64_t)U * T) return nullptr;
-        return token_vectors(it, lo);
-    };
+    int4 pre[U];
     StreamItem cur;
     int64_t cur_lo = 0;
     if ((int64_t)blockIdx.x < nitems) {
         describe_item(a, use_ord, ord, blockIdx.x, cur, cur_lo);
-        if (TOK) cur_t4 = dma_eligible(cur, cur_lo);
         if (pf) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t idx = tid + (int64_t)u * T;
                 pre[u] = idx < cur.nvec ? stream_load(cur.v4 + idx) : make_int4(0, 0, 0, 0);
+            }
+        }
+        if (TOK && pft) {
+            cur_t4 = token_vectors(cur, cur_lo);
+            if (cur_t4) {
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+                    const int64_t idx = tid + (int64_t)u * T;
+                    pre[u] = idx < cur.nvec ? stream_load(cur.v4 + idx) : make_int4(0, 0, 0, 0);
+                    pret[u] = idx < cur.nvec ? stream_load(cur_t4 + idx) : make_int4(0, 0, 0, 0);
+                }
             }
         }
     }
@@ -746,15 +674,17 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
             if (cur.nvec > (int64_t)U * T) stream_votes<RL2, T, U>(hist, copy, cur.v4, (int64_t)U * T, cur.nvec, tid, bad);
             const int64_t t0 = cur.head + (cur.nvec << 2);
             if (tid < cur.n - t0) vote<RL2>(hist, copy, (uint32_t)cur.row[t0 + tid], bad);
-        } else if (TOK && cur_t4) {
-            // votes through registers, tokens through LDS-DMA; head / remainder / tail of the run through registers.  (Measured and not kept:
-            // step 0 of the NEXT item issued before this item's epilogue, as the votes-only variant does with its first tile -- its 16
-            // registers live across the epilogue took the 1024-thread variant from 115 to 128 VGPRs + 20 spilled.)
+        } else if (TOK && pft && cur_t4) {
+            // votes + tokens with the first tile of both rows already in registers
             const int32_t* trow = a.tokens + cell * a.N + cur_lo;
-            dma_run_begin<T, U>(cur.v4, cur_t4, 0, tid, tokbuf, pre);
             if (tid < cur.head) { vote<RL2>(hist, copy, (uint32_t)cur.row[tid], bad); tsum += trow[tid]; }
-            const int64_t done = stream_votes_tokens_dma<RL2, T, U>(hist, copy, cur.v4, cur_t4, 0, cur.nvec, tid, tokbuf, pre, bad, tsum);
-            if (done < cur.nvec) stream_votes_tokens<RL2, T, (U > 1 ? U / 2 : 1)>(hist, copy, cur.v4, cur_t4, done, cur.nvec, tid, bad, tsum);
+#pragma unroll
+            for (int u = 0; u < UT; ++u)
+                if (tid + (int64_t)u * T < cur.nvec) {
+                    vote4<RL2>(hist, copy, pre[u], bad);
+                    tsum += (long long)pret[u].x + (long long)pret[u].y + (long long)pret[u].z + (long long)pret[u].w;
+                }
+            if (cur.nvec > (int64_t)UT * T) stream_votes_tokens<RL2, T, UT>(hist, copy, cur.v4, cur_t4, (int64_t)UT * T, cur.nvec, tid, bad, tsum);
             const int64_t t0 = cur.head + (cur.nvec << 2);
             if (tid < cur.n - t0) { vote<RL2>(hist, copy, (uint32_t)cur.row[t0 + tid], bad); tsum += trow[t0 + tid]; }
         } else {
@@ -767,12 +697,22 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
         const int4* nxt_t4 = nullptr;
         if (more) {
             describe_item(a, use_ord, ord, item + gridDim.x, nxt, nxt_lo);
-            if (TOK) nxt_t4 = dma_eligible(nxt, nxt_lo);
             if (pf) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int64_t idx = tid + (int64_t)u * T;
                     pre[u] = idx < nxt.nvec ? stream_load(nxt.v4 + idx) : make_int4(0, 0, 0, 0);
+                }
+            }
+            if (TOK && pft) {
+                nxt_t4 = token_vectors(nxt, nxt_lo);
+                if (nxt_t4) {
+#pragma unroll
+                    for (int u = 0; u < UT; ++u) {
+                        const int64_t idx = tid + (int64_t)u * T;
+                        pre[u] = idx < nxt.nvec ? stream_load(nxt.v4 + idx) : make_int4(0, 0, 0, 0);
+                        pret[u] = idx < nxt.nvec ? stream_load(nxt_t4 + idx) : make_int4(0, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1184,23 +1124,25 @@ __global__ __launch_bounds__(T) void scv_lane_cells(const AggArgs a) {
 // ---- kernel 1f0: cells of EXACTLY 1, 2 or 4 votes -- the reference's most common sizes ---------------------------------------
 //
 // o1.py:302 runs every ask-nicely budget with N = 1 (8 ... 20 budgets), o1.py:276 the first eight majority budgets with N = 1 and then
-// N = 2, 4.  scv_lane_cells<4> serves them with its general machinery (a row per lane, walker per cell, KC cells in flight):
-// 157 lane-instructions per cell at N = 1 (profiles/r04_regimes.log: 0.6 TB/s of votes with the cell table, 1.0 without).  A cell
-// of N in {1, 2, 4} votes is 4 / 8 / 16 bytes: here a lane takes ONE 16-byte vector = 4 / 2 / 1 CONSECUTIVE cells per step (one
-// global_load_dwordx4 per lane and stream, 1 KiB per wave instruction), counts each cell with a handful of compares (no sort, no
-// sentinels: validity is a bit per vote), and writes the cells' records as one 64 / 32 / 16-byte run.  With the grid rounded so that
-// a step covers a multiple of B cells, a lane's 4 / N cells keep their budgets for the whole launch: n_valid is read once and the
-// class-1 hits and sums stay in registers.  Host contract: N == NV, 16-byte aligned bases, ncells * N % 4 == 0, no pool rows,
-// ncells < 2^31.
+// N = 2, 4.  scv_lane_cells<4> serves them with its general machinery (a row per lane, a walker per cell, KC cells in flight):
+// 157 lane-instructions per cell at N = 1 (profiles/r04_regimes.log: 1.0 TB/s of votes without the cell table).  A cell of N in
+// {1, 2, 4} votes is 4 / 8 / 16 bytes: here a wave takes a BLOCK of 256 / 128 / 64 consecutive cells per step and lane l owns the cells
+// block + l, block + 64 + l, ... (4 / N of them): every load and every store instruction of the wave touches CONSECUTIVE bytes (256 B
+// ... 1 KiB of votes, 1 KiB of cell records) -- with 4 consecutive cells per lane the 16-byte records left in 64-byte strides and the
+// launch took 1.6x the general kernel's time.  A cell is counted with a handful of compares (no sort, no sentinels: validity is a bit
+// per vote).  With the grid rounded so that a step covers a multiple of B cells, a lane's cell slots keep their budgets for the whole
+// launch: n_valid is read once and the class-1 hits and sums stay in registers.  Host contract: N == NV, 16-byte aligned bases,
+// ncells % (256 / NV) == 0 (whole blocks), no pool rows, ncells < 2^29.
 template <int NV, bool TOK>
 __global__ __launch_bounds__(1024) void scv_few_votes(const AggArgs a) {
     static_assert(NV == 1 || NV == 2 || NV == 4, "cells of 1, 2 or 4 votes");
     constexpr int CPL = 4 / NV;                                      // cells per lane and step
+    constexpr uint32_t BLK = 64u * CPL;                              // cells per wave and step
     constexpr int TC = NV + 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* tie = lds;                                             // [B][TC]
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + (((int64_t)a.B * TC + 1) & ~(int64_t)1));   // [B] truth sums | [B] token sums
-    const int tid = threadIdx.x, T = (int)blockDim.x;
+    const int tid = threadIdx.x, T = (int)blockDim.x, lane = tid & 63;
     const bool counters = a.tie_hits || a.truth_sum || (TOK && a.token_sum);
     if (counters) {
         for (int64_t i = tid; i < (int64_t)a.B * TC; i += T) tie[i] = 0;
@@ -1208,24 +1150,20 @@ __global__ __launch_bounds__(1024) void scv_few_votes(const AggArgs a) {
         __syncthreads();
     }
     const uint32_t B = (uint32_t)a.B;
-    const uint32_t nvecs = (uint32_t)((a.ncells * NV) >> 2);         // 16-byte vectors of the whole tensor
-    const uint32_t stride = (uint32_t)gridDim.x * (uint32_t)T;       // vectors per step of the grid
-    uint32_t v = (uint32_t)blockIdx.x * (uint32_t)T + (uint32_t)tid; // this lane's vector
-    // (p, b) of the lane's first cell, then add-and-carry: the step stride in cells is (dp, db) per cell slot
-    const uint32_t c0 = v * CPL;
-    uint32_t p0 = c0 / B, b0 = c0 - p0 * B;
-    const uint32_t dcell = stride * CPL, dp = dcell / B, db = dcell - dp * B;
+    const uint32_t nblocks = (uint32_t)(a.ncells / BLK);
+    const uint32_t nwaves = (uint32_t)gridDim.x * (uint32_t)(T >> 6);
+    uint32_t blk = (uint32_t)blockIdx.x * (uint32_t)(T >> 6) + (uint32_t)(tid >> 6);          // this wave's block
+    // (p, b) of each cell slot of the lane, then add-and-carry: a step moves every slot by nwaves * BLK cells = (dp, db)
+    const uint32_t dcell = nwaves * BLK, dp = dcell / B, db = dcell - dp * B;
     const bool fixed_b = db == 0;                                    // the host rounds the grid: a lane's cells keep their budgets
-    uint32_t bj[CPL], nj[CPL];                                       // budgets and valid lengths of the lane's cell slots (fixed_b)
-    {
-        uint32_t b = b0;
+    uint32_t pj[CPL], bj[CPL], nj[CPL];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            bj[j] = b;
-            const int64_t n = valid_len(a, (int32_t)b);
-            nj[j] = (uint32_t)(n < NV ? n : NV);
-            b = b + 1u == B ? 0u : b + 1u;
-        }
+    for (int j = 0; j < CPL; ++j) {
+        const uint32_t c = blk * BLK + 64u * j + (uint32_t)lane;
+        pj[j] = c / B;
+        bj[j] = c - pj[j] * B;
+        const int64_t n = valid_len(a, (int32_t)bj[j]);
+        nj[j] = (uint32_t)(n < NV ? n : NV);
     }
     uint32_t h1[CPL];
     unsigned long long tcs[CPL];
@@ -1233,60 +1171,78 @@ __global__ __launch_bounds__(1024) void scv_few_votes(const AggArgs a) {
 #pragma unroll
     for (int j = 0; j < CPL; ++j) { h1[j] = 0; tcs[j] = 0; toks[j] = 0; }
     uint32_t bad = 0;
-    const int4* av = reinterpret_cast<const int4*>(a.answers);
-    const int4* tv = TOK ? reinterpret_cast<const int4*>(a.tokens) : nullptr;
-    // one step ahead: the vector(s) of the next step are loaded before the current ones are counted
-    int4 x = make_int4(0, 0, 0, 0), y = make_int4(0, 0, 0, 0);
-    if (v < nvecs) { x = stream_load(av + v); if (TOK) y = stream_load(tv + v); }
-    for (; v < nvecs; v += stride) {
-        const uint32_t vn = v + stride;
-        int4 xn = make_int4(0, 0, 0, 0), yn = make_int4(0, 0, 0, 0);
-        if (vn < nvecs) { xn = stream_load(av + vn); if (TOK) yn = stream_load(tv + vn); }
-        const uint32_t w[4] = {(uint32_t)x.x, (uint32_t)x.y, (uint32_t)x.z, (uint32_t)x.w};
-        const int32_t tk[4] = {y.x, y.y, y.z, y.w};
-        uint32_t p = p0, b = b0;
-        uint4 rec[CPL];
-        long long ctok[CPL];
+    typedef uint32_t vnv __attribute__((ext_vector_type(NV == 1 ? 1 : NV)));
+    struct Votes { uint32_t w[CPL][NV]; int32_t tk[CPL][NV]; };
+    auto load = [&](uint32_t bk, Votes& o) {                        // every instruction: 64 lanes x 4 NV consecutive bytes
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
+            const uint64_t c = (uint64_t)bk * BLK + 64u * j + (uint32_t)lane;
+            if constexpr (NV == 1) {
+                o.w[j][0] = (uint32_t)__builtin_nontemporal_load(a.answers + c);
+                if (TOK) o.tk[j][0] = __builtin_nontemporal_load(a.tokens + c);
+            } else if constexpr (NV == 2) {
+                typedef int v2i32 __attribute__((ext_vector_type(2)));
+                const v2i32 q = __builtin_nontemporal_load(reinterpret_cast<const v2i32*>(a.answers) + c);
+                o.w[j][0] = (uint32_t)q.x; o.w[j][1] = (uint32_t)q.y;
+                if (TOK) { const v2i32 y = __builtin_nontemporal_load(reinterpret_cast<const v2i32*>(a.tokens) + c); o.tk[j][0] = y.x; o.tk[j][1] = y.y; }
+            } else {
+                const int4 q = stream_load(reinterpret_cast<const int4*>(a.answers) + c);
+                o.w[j][0] = (uint32_t)q.x; o.w[j][1] = (uint32_t)q.y; o.w[j][2] = (uint32_t)q.z; o.w[j][3] = (uint32_t)q.w;
+                if (TOK) { const int4 y = stream_load(reinterpret_cast<const int4*>(a.tokens) + c); o.tk[j][0] = y.x; o.tk[j][1] = y.y; o.tk[j][2] = y.z; o.tk[j][3] = y.w; }
+            }
+        }
+    };
+    Votes cur{}, nxt{};
+    if (blk < nblocks) load(blk, cur);
+    for (; blk < nblocks; blk += nwaves) {
+        if (blk + nwaves < nblocks) load(blk + nwaves, nxt);         // one step ahead
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const uint32_t b = bj[j];
             const uint32_t n = fixed_b ? nj[j] : (uint32_t)(valid_len(a, (int32_t)b) < NV ? valid_len(a, (int32_t)b) : NV);
-            const int32_t truth = a.truth[p];
+            const int32_t truth = a.truth[pj[j]];
             const uint32_t tcmp = (truth >= 0 && truth < kBins) ? (uint32_t)truth : 0xffffffffu;
-            // statistics.multimode on <= 4 votes: count_i = #{ j valid : x_j == x_i }; a mode is counted at its FIRST occurrence
+            // every vote is a bin: an out-of-domain vote (o1.py:140 int(extracted_answer) is unbounded; the extractor maps it into bins 0..1023)
+            // counts for bin 1023 -- and raises the error word when it is inside the valid prefix
+            uint32_t w[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                bad |= (uint32_t)i < n ? cur.w[j][i] : 0u;
+                w[i] = cur.w[j][i] < 1023u ? cur.w[j][i] : 1023u;
+            }
+            // statistics.multimode on <= 4 votes: count_i = #{ k valid : x_k == x_i }; a mode is counted at its FIRST occurrence
             uint32_t cnt[NV], maxc = 0, tc = 0;
             long long tok = 0;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const uint32_t xi = w[j * NV + i];
                 const bool vi = (uint32_t)i < n;
-                bad |= vi ? xi : 0u;
                 uint32_t c = 0;
 #pragma unroll
-                for (int k = 0; k < NV; ++k) c += ((uint32_t)k < n && w[j * NV + k] == xi) ? 1u : 0u;
+                for (int k = 0; k < NV; ++k) c += ((uint32_t)k < n && w[k] == w[i]) ? 1u : 0u;
                 cnt[i] = vi ? c : 0u;
                 maxc = cnt[i] > maxc ? cnt[i] : maxc;
-                tc += (vi && xi == tcmp) ? 1u : 0u;
-                if (TOK) tok += vi ? (long long)tk[j * NV + i] : 0ll;
+                tc += (vi && w[i] == tcmp) ? 1u : 0u;
+                if (TOK) tok += vi ? (long long)cur.tk[j][i] : 0ll;
             }
             uint32_t n_modes = 0, mm = 0xffffu;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const uint32_t xi = w[j * NV + i];
                 bool first = true;
 #pragma unroll
-                for (int k = 0; k < i; ++k) first = first && !((uint32_t)k < n && w[j * NV + k] == xi);
+                for (int k = 0; k < i; ++k) first = first && !((uint32_t)k < n && w[k] == w[i]);
                 const bool mode = cnt[i] == maxc && maxc > 0 && first;
                 n_modes += mode ? 1u : 0u;
-                const uint32_t xc = xi < 1023u ? xi : 1023u;                 // (an out-of-domain vote counts for bin 1023 and raises the error word)
-                mm = (mode && xc < mm) ? xc : mm;
+                mm = (mode && w[i] < mm) ? w[i] : mm;
             }
             const bool any = maxc > 0;
             const uint32_t hit = (any && tc == maxc) ? 1u : 0u;                   // o1.py:206
-            rec[j].x = maxc; rec[j].y = tc; rec[j].z = (n_modes & 0xffffu) | ((any ? mm : 0xffffu) << 16); rec[j].w = hit;
-            ctok[j] = tok;
+            const uint64_t c = (uint64_t)blk * BLK + 64u * j + (uint32_t)lane;
+            if (a.cells)
+                __builtin_nontemporal_store(scv_v4u{maxc, tc, (n_modes & 0xffffu) | ((any ? mm : 0xffffu) << 16), hit}, reinterpret_cast<scv_v4u*>(a.cells) + c);
+            if (TOK && a.cell_tokens) a.cell_tokens[c] = tok;
             if (fixed_b) {                                                        // o1.py:238-240 as integers, in registers
                 h1[j] += (hit && n_modes == 1u) ? 1u : 0u;
-                if (counters && hit && n_modes != 1u) atomicAdd(&tie[bj[j] * TC + n_modes], 1u);
+                if (counters && hit && n_modes != 1u) atomicAdd(&tie[b * TC + n_modes], 1u);
                 tcs[j] += tc;
                 if (TOK) toks[j] += tok;
             } else if (counters) {
@@ -1294,22 +1250,10 @@ __global__ __launch_bounds__(1024) void scv_few_votes(const AggArgs a) {
                 if (tc) atomicAdd(&acc[b], (unsigned long long)tc);
                 if (TOK) atomicAdd(&acc[B + b], (unsigned long long)tok);
             }
-            b += 1u;
-            if (b == B) { b = 0u; p += 1u; }
+            pj[j] += dp; bj[j] += db;
+            if (bj[j] >= B) { bj[j] -= B; pj[j] += 1u; }
         }
-        if (a.cells) {
-            scv_v4u* out = reinterpret_cast<scv_v4u*>(a.cells) + (uint64_t)v * CPL;
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) __builtin_nontemporal_store(scv_v4u{rec[j].x, rec[j].y, rec[j].z, rec[j].w}, out + j);
-        }
-        if (TOK && a.cell_tokens) {
-            long long* out = reinterpret_cast<long long*>(a.cell_tokens) + (uint64_t)v * CPL;
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) out[j] = ctok[j];
-        }
-        x = xn; y = yn;
-        p0 += dp; b0 += db;
-        if (b0 >= B) { b0 -= B; p0 += 1u; }
+        cur = nxt;
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
     if (counters && fixed_b) {

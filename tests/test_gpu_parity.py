@@ -426,6 +426,54 @@ def test_sorted_cells_edges(hip_engine):
     assert hip_engine.stat("sort_cells") > 0
 
 
+@pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("shape", [(256, 1, 1), (32, 8, 1), (4000, 8, 1), (4096, 3, 1), (1024, 2, 2), (128, 11, 2), (5120, 3, 4), (6400, 8, 4), (64, 1, 4), (320, 5, 4),
+                                   (100000, 4, 1), (1, 1, 4), (51200, 7, 2), (64, 600, 4), (2, 2, 1), (30, 8, 1), (333, 5, 4)])
+def test_cells_of_exactly_1_2_4_votes(hip_engine, dist, shape):
+    """Round 4: scv_few_votes -- the reference's MOST COMMON cell sizes (N = 1 for every ask-nicely budget, o1.py:302; N = 1 x 8, 2, 4 for
+    the majority family, o1.py:276).  A lane takes one 16-byte vector = 4 / 2 / 1 consecutive cells: budgets of every residue, ragged
+    n_valid incl. 0, tokens, few distinct values (ties: 2 + 2, 1 + 1 + 1 + 1, 3 + 1), truth outside the domain, counters with and
+    without the cell table, small forced grids (many steps per lane, budgets that move from step to step), cell counts that do not fill
+    whole vectors (those go to scv_lane_cells), out-of-domain votes."""
+    import torch
+    P, B, N = shape
+    a, t, tr = coracle.synth_fill(P, B, N, 4100 + dist, dist, want_tokens=True)
+    a2 = (a % 3).astype(np.int32)
+    tr2 = (tr % 4).astype(np.int32)
+    tr2[::7] = 1023
+    tr2[::11] = -5
+    rng = np.random.default_rng(N + B)
+    nv = rng.integers(0, N + 1, size=(B,), dtype=np.int32)
+    before = hip_engine.stat("few_votes")
+    for opts in ({}, {"grid": 3}, {"grid": 5}, {"fused_counters_max": 0}):
+        with _with_options(hip_engine, opts):
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), oracle(a, tr, tokens=t))
+            assert_results_equal(hip_engine.aggregate(a2, tr2, n_valid=nv), oracle(a2, tr2, n_valid=nv), check_tokens=False)
+            assert_results_equal(hip_engine.aggregate(a2, tr2, tokens=t, n_valid=nv), oracle(a2, tr2, tokens=t, n_valid=nv))
+            got = hip_engine.aggregate(a2, tr2, tokens=t, want_cells=False)
+            want = oracle(a2, tr2, tokens=t)
+            assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum)
+            assert np.array_equal(got.truth_count_sum, want.truth_count_sum)
+    if (P * B * N) % 256 == 0:
+        assert hip_engine.stat("few_votes") > before
+    else:
+        assert hip_engine.stat("few_votes") == before                  # not whole blocks of 64 lanes x 16 bytes: the general one-lane-per-cell kernel
+    bad = a.copy()
+    bad[P - 1, B - 1, N - 1] = 1 << 20
+    with pytest.raises(_lib.DomainError):
+        hip_engine.aggregate(bad, tr)
+    if N > 1:
+        hip_engine.aggregate(bad, tr, n_valid=np.full(B, N - 1, dtype=np.int32))       # beyond the valid prefix: not an error
+    from o1_inference_scaling_laws_amd.engine import Engine
+    with Engine(clamp_to_invalid_bin=True) as ce:                      # two different out-of-domain values are the SAME bin 1023
+        c = a2.copy()
+        c[0, 0, 0] = 5000
+        if N > 1:
+            c[0, 0, 1] = 7000
+        cw = np.minimum(c, 1023)
+        assert_results_equal(ce.aggregate(c, tr2), oracle(cw, tr2), check_tokens=False)
+
+
 def test_tiny_cells_reference_family_and_domain(hip_engine, golden):
     """The reference's real shape: [30, 11, 8] with n_valid = 1 x8, 2, 4, 8 goes through the tiny path."""
     pipe = golden["pipeline"]
