@@ -21,7 +21,7 @@ def newest(pattern):
     return max(files, key=os.path.getmtime) if files else None
 
 
-lines = [f"# rocprofv3 summary {tag} (MI355X, `python bench.py --no-cpu-baseline`)", ""]
+lines = [f"# rocprofv3 summary {tag} (MI355X, `python bench.py --steps 8 --warmup 2 --no-cpu-baseline`; same box and session as {tag}_bench.json: tools/gpu_round.sh)", ""]
 ks = newest("prof_trace/*/*_kernel_stats.csv")
 if ks:
     shutil.copy(ks, os.path.join(P, f"{tag}_kernel_stats.csv"))
@@ -68,9 +68,15 @@ if pmc:
                      f"active cycles per 64-vote ds_add_u32 = {avg['SQ_LDS_IDX_ACTIVE']/(algo/4/64):.2f}.")
     json.dump({"pmc_avg": avg, "hbm_traffic_bytes": (avg.get("FETCH_SIZE", 0) * 2048 + avg.get("WRITE_SIZE", 0) * 1024)},
               open(os.path.join(P, f"{tag}_pmc.json"), "w"), indent=1)
-for name in ("bench.json", "hbm_probe.log"):
+# every other file of the same session that the documents quote (one box, one invocation: tools/gpu_round.sh)
+for name in ("bench.json", "hbm_probe.log", "hbm_probe_percu.log", "hbm_probe_dma.log", "bench_c5.json", "bench_c2.json", "bench_c2_one_launch.json", "bench_c2_graph.json",
+             "bench_c2_graph10.json", "bench_dists.jsonl", "bench_tokens.jsonl", "bench_comm_peer_2ctx.json", "bench_comm_rccl_1gpu.json", "bench_2ranks_shared_gpu.json",
+             "regimes.log", "regimes.json", "sort_check.log", "prefix_small.log", "host_mode.log", "pytest_gpu.log", "smoke.log"):
     src = os.path.join(G, name)
     if os.path.exists(src):
-        shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
+        shutil.copy(src, os.path.join(P, f"{tag}_{name.replace('bench_c5.json', 'bench_c5_1gpu.json')}"))
+summ = os.path.join(G, f"prof_regimes_{tag}", "summary.md")
+if os.path.exists(summ):
+    shutil.copy(summ, os.path.join(P, f"{tag}_regimes_pmc.md"))
 open(os.path.join(P, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
