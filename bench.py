@@ -371,18 +371,27 @@ def main_single_process(args):
     world = args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     ndev = torch.cuda.device_count()
+    # ONE JSON line on stdout: librccl prints a version banner on the process's stdout when its first communicator is created -- everything but
+    # the line goes to stderr (fd 1 is pointed at fd 2 for the run; the line is written to the saved descriptor)
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit(obj):
+        real_stdout.write(json.dumps(obj) + "\n")
+        real_stdout.flush()
     if not args.share_device and ndev < world:
-        print(json.dumps({"error": f"bench.py --gpus {world} --comm {args.comm}: only {ndev} HIP device(s) visible; one rank per GPU is required "
-                                   f"(--share-device exists for the 1-GPU test box only)",
-                          "metric": "sample-votes/sec (problems x samples)", "value": None, "n_gpus": world, "hip_devices_visible": ndev}), flush=True)
+        emit({"error": f"bench.py --gpus {world} --comm {args.comm}: only {ndev} HIP device(s) visible; one rank per GPU is required "
+                       f"(--share-device exists for the 1-GPU test box only)",
+              "metric": "sample-votes/sec (problems x samples)", "value": None, "n_gpus": world, "hip_devices_visible": ndev})
         sys.exit(2)
     devices = [0] * world if args.share_device else list(range(world))
     t_create = time.perf_counter()
     try:
         mde = MultiDeviceEngine(devices, rccl=args.comm == "rccl", timing=True)      # create ends with the communicator's self-test
     except ScvError as e:
-        print(json.dumps({"error": f"scv_comm_create({devices}, {args.comm}) failed: {e}", "metric": "sample-votes/sec (problems x samples)",
-                          "value": None, "n_gpus": world, "hip_devices_visible": ndev}), flush=True)
+        emit({"error": f"scv_comm_create({devices}, {args.comm}) failed: {e}", "metric": "sample-votes/sec (problems x samples)",
+              "value": None, "n_gpus": world, "hip_devices_visible": ndev})
         sys.exit(2)
     t_create = time.perf_counter() - t_create
     c5 = args.workload == "c5"
@@ -524,8 +533,8 @@ def main_single_process(args):
             np.savez(args.dump, counters=cnt.cpu().numpy()[:ncount], cells=table.cpu().numpy(), boot=boot.cpu().numpy())
     elif args.dump:
         np.savez(args.dump, counters=last.cpu().numpy())
-    print(json.dumps(out), flush=True)
     mde.close()
+    emit(out)
 
 
 def main():
