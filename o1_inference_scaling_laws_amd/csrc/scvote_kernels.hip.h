@@ -1973,32 +1973,39 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_
         }
         __builtin_amdgcn_wave_barrier();
     };
-    auto finish_cell = [&](const Batch& c, uint32_t gkey, uint32_t at_max, uint32_t tc, long long tsum) {
-        const uint32_t maxc = gkey >> kKeyShift;                            // max count over every value of the cell
-        const uint32_t sum_at_max = cellgroup_sum<G>(at_max);               // votes at the maximum, over the cell
-        long long tok = 0;
-        if (TOK) tok = cellgroup_sum_i64<G>(tsum);
-        if (l == 0 && c.cell < a.ncells) {
-            // statistics.multimode + o1.py:202-206
-            const bool any = maxc > 0;
-            const uint32_t n_modes = any ? exact_quotient(sum_at_max, maxc) : 0u;
-            const uint32_t mm = 1023u - (((gkey & kKeyMask) - cellbase) >> S);
-            const uint32_t hit = (any && tc == maxc) ? 1u : 0u;             // o1.py:206
-            if (a.cells) {
-                uint4 rec;
-                rec.x = maxc;
-                rec.y = tc;
-                rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
-                rec.w = hit;
-                reinterpret_cast<uint4*>(a.cells)[c.cell] = rec;
-            }
-            if (a.cell_tokens) a.cell_tokens[c.cell] = tok;
-            if (wgc.tcl > 0) wg_counters_add<TOK>(a, wgc, c.b, hit, n_modes, tc, tok);
-            else {
-                if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)c.b * SCV_TIE_CLASSES + n_modes], 1ull);
-                if (TOK && a.token_sum) atomicAdd(&a.token_sum[c.b], (unsigned long long)tok);
-                if (a.truth_sum) atomicAdd(&a.truth_sum[c.b], (unsigned long long)tc);
-            }
+    // The outcome of one batch for this lane's cell: everything the record and the counters need, the same in every lane of the cell.
+    struct Outcome { uint32_t gkey, sum_at_max, tc; long long tok; int64_t cell; int32_t b; };
+    auto reduce_cell = [&](const Batch& c, uint32_t gkey, uint32_t at_max, uint32_t tc, long long tsum) -> Outcome {
+        Outcome o;
+        o.gkey = gkey;
+        o.sum_at_max = cellgroup_sum<G>(at_max);                             // votes at the maximum, over the cell
+        o.tc = tc;
+        o.tok = 0;
+        if (TOK) o.tok = cellgroup_sum_i64<G>(tsum);
+        o.cell = c.cell; o.b = c.b;
+        return o;
+    };
+    // statistics.multimode + o1.py:202-206: the record and the counters of one cell, by ONE lane of the cell
+    auto emit_cell = [&](const Outcome& o) {
+        const uint32_t maxc = o.gkey >> kKeyShift;                          // max count over every value of the cell
+        const bool any = maxc > 0;
+        const uint32_t n_modes = any ? exact_quotient(o.sum_at_max, maxc) : 0u;
+        const uint32_t mm = 1023u - (((o.gkey & kKeyMask) - cellbase) >> S);
+        const uint32_t hit = (any && o.tc == maxc) ? 1u : 0u;               // o1.py:206
+        if (a.cells) {
+            uint4 rec;
+            rec.x = maxc;
+            rec.y = o.tc;
+            rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
+            rec.w = hit;
+            reinterpret_cast<uint4*>(a.cells)[o.cell] = rec;
+        }
+        if (a.cell_tokens) a.cell_tokens[o.cell] = o.tok;
+        if (wgc.tcl > 0) wg_counters_add<TOK>(a, wgc, o.b, hit, n_modes, o.tc, o.tok);
+        else {
+            if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)o.b * SCV_TIE_CLASSES + n_modes], 1ull);
+            if (TOK && a.token_sum) atomicAdd(&a.token_sum[o.b], (unsigned long long)o.tok);
+            if (a.truth_sum) atomicAdd(&a.truth_sum[o.b], (unsigned long long)o.tc);
         }
     };
 
@@ -2008,6 +2015,9 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_
 #pragma unroll
             for (int j = 0; j < K; ++j) load(nxt[j]);
         }
+        // (with tokens the K outcomes held across the step cost spills at the 128-register cap of the K >= 2 shapes: one block per batch there)
+        constexpr bool kOneMask = K > 1 && !TOK;
+        Outcome out[kOneMask ? K : 1];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             Batch& c = cur[j];
@@ -2056,8 +2066,18 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_
                 else if (V >= 2 && live > 1) partial(std::integral_constant<int, V >= 2 ? 2 : V>{});
                 else partial(std::integral_constant<int, 1>{});
             }
-            finish_cell(c, gkey, at_max, tc, tsum);
+            out[kOneMask ? j : 0] = reduce_cell(c, gkey, at_max, tc, tsum);
+            if (!kOneMask && l == 0 && c.cell < a.ncells) emit_cell(out[0]);
         }
+        if (!kOneMask) return;
+        // The records and counters of the step's K batches under ONE mask: lane j of a cell takes batch j (every lane of a cell holds its
+        // cell's outcome of every batch).  With one masked block per batch the ~40 wave-instructions of the block -- quotient, record, LDS
+        // counters, all for 64 / G active lanes -- were issued K times per step (N <= 128: K = 2 or 4, 8 % of the step at N = 128).
+        Outcome mine = out[0];
+#pragma unroll
+        for (int j = 1; j < K; ++j)
+            if (l == j) mine = out[j];
+        if (l < K && mine.cell < a.ncells) emit_cell(mine);
     };
 
     Batch bufa[K], bufb[K];

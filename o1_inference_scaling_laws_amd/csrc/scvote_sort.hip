@@ -27,3 +27,15 @@ RegKernel pick_sort_kernel(int nv, bool tok, bool lin) {
     }
 }
 }  // namespace scv
+#ifdef SCV_SORT_TIMELINE
+// measurement build only: read (and clear) the phase sums of scv_sort_cells
+extern "C" int scv_debug_sort_timeline(unsigned long long* out8, int clear) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(scv::scv_sort_timeline), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (clear) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(scv::scv_sort_timeline), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+

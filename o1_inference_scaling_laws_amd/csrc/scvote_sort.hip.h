@@ -299,6 +299,17 @@ constexpr int sort_cells_threads(int nv) { return nv >= 64 ? 512 : 1024; }
 // Measured and not kept (profiles/r03_sort_cells_ab.log, r03_ab_n128.log): two blocks of 64 cells per step, two image
 // buffers per wave with the copy two steps ahead, 32 resident waves per CU for the 8-vote shape, a 128-vote shape staged in two
 // half-rows, the copy's pieces issued back to back instead of between the compare-exchanges.
+#ifdef SCV_SORT_TIMELINE
+// Measurement build only (tools/sort_timeline.py; never defined for the product library): shader cycles every wave spent in the phases of
+// a step -- wait for the copy | rows LDS -> registers, packed | sort (+ the next copy's pieces) | scan | records and counters --, summed
+// over all waves, plus the number of steps.  (s_memtime returns through lgkmcnt: each stamp also drains the wave's LDS queue.)
+__device__ unsigned long long scv_sort_timeline[8];
+#define SV_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_now = __builtin_readcyclecounter(); \
+                         __builtin_amdgcn_sched_barrier(0); tl[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define SV_STAMP(i) do { } while (0)
+#endif
+
 template <int NV, bool TOK, bool LIN = false>
 __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const AggArgs a) {
     constexpr int NP = NV / 2, RSM = NV / 4;
@@ -421,9 +432,24 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
     auto advance = [&]() { c0 += stride; p0 += dp; b0 += db; if (b0 >= B) { b0 -= B; p0 += 1; } };
     int64_t st = wave;
     if (st < nsteps) { issue(st); issue_truth(); }
+    // Stores a step issues AFTER the pieces of the next step's copy: the cell record and the cell's token sum (wave-uniform; one
+    // instruction each -- a step has at least one live lane).  vmcnt retires in issue order on gfx9 (loads and stores share the counter;
+    // hipcc's own waits rely on it), so "all but the last `late` operations" = every piece has landed, while the stores -- a full
+    // write round trip, which a vmcnt(0) here exposed to the wave at every step -- stay in flight across the next step.
+    const int late = (a.cells ? 1 : 0) + ((TOK && a.cell_tokens) ? 1 : 0);
+    bool first = true;
+#ifdef SCV_SORT_TIMELINE
+    unsigned long long tl[6] = {0, 0, 0, 0, 0, 0}, tl_steps = 0;
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
     for (; st < nsteps; st += nwaves) {
+        SV_STAMP(5);                                                 // (loop control; the first stamp: everything before the loop)
         // this step's images have landed (LDS-DMA is counted by vmcnt; hipcc does not count asm loads)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (first || late == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (late == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        first = false;
+        SV_STAMP(0);
         uint32_t R[NP];
         long long tok = 0;
         const int64_t left = a.ncells - c0;                          // (wave-uniform) cells from this step's first to the last
@@ -496,6 +522,7 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
                 R[r] = sv_sentinel(R[r], n2, (uint32_t)(r + 1) | ((uint32_t)(r + NP + 1) << 16),
                                    (0x8000u | (uint32_t)r) | ((0x8000u | (uint32_t)(r + NP)) << 16));
         }
+        SV_STAMP(1);
         // the next step's copy flies while this step is counted
         uint4* const cells_out = a.cells ? reinterpret_cast<uint4*>(a.cells) + c0 : nullptr;     // (scalar bases of this step's outputs)
         int64_t* const ctok_out = (TOK && a.cell_tokens) ? a.cell_tokens + c0 : nullptr;
@@ -504,7 +531,11 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
         // compare-exchanges of the sort -- pinned there through a register operand, or the compiler sinks the sort below them --
         // instead of back to back: 3-5 % (N = 64: 96.3 -> 92.1 us, N = 30: 86.2 -> 81.7).
         const bool have_next = st + nwaves < nsteps;
+#ifdef SCV_SORT_NOSPREAD
+        constexpr bool CAN_SPREAD = false;                           // (measurement build: the copy's pieces back to back, stamped on their own)
+#else
         constexpr bool CAN_SPREAD = !TOK && NV >= 16;
+#endif
         const bool spread = CAN_SPREAD && have_next;
         // (source base and limit of the next step's copy: wave-uniform values of this iteration)
         const int64_t nbyte0 = (st + nwaves) * SC * (int64_t)rowbytes;
@@ -515,6 +546,9 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
             if (spread) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_truth(); }
             else { issue(st + nwaves); issue_truth(); }
         }
+#ifdef SCV_SORT_NOSPREAD
+        SV_STAMP(5);
+#endif
         constexpr int STEP = sv_sort_ticks<NP>() / QMAX > 0 ? sv_sort_ticks<NP>() / QMAX : 1;
         int ticks = 0;                                               // (a constant at every call site after unrolling)
         auto piece = [&](int q, uint32_t& dep) __attribute__((always_inline)) {
@@ -540,8 +574,13 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
             SvNoTick none;
             sv_sort<NP>(R, none);
         }
+        SV_STAMP(2);
         const uint32_t tcmp = (trj >= 0 && trj < kBins) ? (uint32_t)trj : 0x7fffu;
         const SortedStats s = sv_scan<NP>(R, tcmp | (tcmp << 16));
+#ifdef SCV_SORT_TIMELINE
+        asm volatile("" : : "v"(s.max_run), "v"(s.at_max), "v"(s.min_at_max), "v"(s.truth_votes));
+#endif
+        SV_STAMP(3);
         if (live) {
             const bool any = n > 0;
             const uint32_t maxc = any ? s.max_run : 0u;
@@ -569,7 +608,18 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
                 if (TOK) atomicAdd(&acc[B + eb], (unsigned long long)tok);
             }
         }
+        SV_STAMP(4);
+#ifdef SCV_SORT_TIMELINE
+        ++tl_steps;
+#endif
     }
+#ifdef SCV_SORT_TIMELINE
+    if (lane == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&scv_sort_timeline[i], tl[i]);
+        atomicAdd(&scv_sort_timeline[6], tl_steps);
+        atomicAdd(&scv_sort_timeline[7], 1ull);
+    }
+#endif
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
     if (fixed_b) {
         if (h1) atomicAdd(&tie[my_b * TC + 1], h1);

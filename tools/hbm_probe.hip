@@ -13,6 +13,8 @@
 //                                        and in total, and the time one segment takes (the floor of those shapes)
 //   hbm_probe.bin [cells] --c2           the floor of BASELINE config 2: a pure read of its 125.8 MB in ONE launch, cut into 240 ... 1920 segments
 //   hbm_probe.bin [cells] --dma          the ceiling of the LDS-DMA input path of scv_sort_cells: waves that only copy 2-16 KiB blocks HBM -> LDS
+//   hbm_probe.bin [cells] --dmawork      ... with the VALU work of a sorted-cells step behind the copy: every wave copying for itself against one
+//                                        producer wave per workgroup (the design question of scv_sort_cells, round 4)
 //   hbm_probe.bin [cells] --calib        3 launches of ONE variant (read_cells_pipe<4>, grid 250 x 1024) and nothing
 //                                        else: run under `rocprofv3 --pmc FETCH_SIZE` to get FETCH_SIZE per launch
 //                                        for exactly cells * 4 MiB of algorithmic reads
@@ -128,6 +130,141 @@ __global__ void dma_blocks(const char* __restrict__ src, long nblocks, int piece
     if (acc == 0x12345678) *sink = acc;
 }
 
+// ---- LDS-DMA stream WITH the work of a sorted-cells step behind it (--dmawork): who should issue the copy? ------------------------------
+// A wave of scv_sort_cells stages a block of PIECES KiB, reads it into 4 * PIECES registers per lane, and runs ~21 VALU instructions per
+// vote on them.  Its copy is "asynchronous" only after the memory pipe has ACCEPTED a piece: with every wave of a CU issuing, a piece waits
+// in the pipe's queue and the wave with it (profiles/r04_sort_timeline*.log: 40-58 % of a wave's cycles).  Two forms of the same work:
+//   mode 0  every wave copies for itself: wait for the block | rows -> registers | issue the next block's pieces | compute
+//   mode 1  NC consumer waves + ONE producer wave per workgroup: the producer issues every piece (it alone waits in the queue) and
+//           publishes "block landed" through an LDS flag per consumer once vmcnt says so (vmcnt retires in order: with D requests of
+//           np pieces in flight, vmcnt((D - 1) np) means the oldest has landed); a consumer publishes "rows read" the same way
+typedef unsigned __attribute__((address_space(3))) lds_uint;
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+#define W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+        W(0) W(1) W(2) W(3) W(4) W(5) W(6) W(7) W(8) W(9) W(10) W(11) W(12) W(13) W(14) W(15) W(16) W(17) W(18) W(19) W(20) W(21)
+        W(22) W(23) W(24) W(25) W(26) W(27) W(28) W(29) W(30) W(31) W(32) W(33) W(34) W(35) W(36) W(37) W(38) W(39) W(40) W(41)
+        W(42) W(43) W(44) W(45) W(46) W(47) W(48) W(49) W(50) W(51) W(52) W(53) W(54) W(55) W(56) W(57) W(58) W(59) W(60) W(61)
+        W(62)
+#undef W
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+}
+__device__ __forceinline__ unsigned flag_load(unsigned addr) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void flag_store(unsigned addr, unsigned v) {
+    asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void dma_piece(const char* g, unsigned off, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
+}
+
+template <int PIECES>
+__global__ void __launch_bounds__(1024) dma_work(const char* __restrict__ src, long nblocks, int k_iter, int mode, int depth, int nb, int npd, int* sink) {
+    constexpr int NR = 4 * PIECES;                                   // registers of a lane's row
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int nc = mode ? nw - npd : nw;                             // consumer waves (mode 1: the last npd waves are producers)
+    const unsigned region = (unsigned)PIECES * 1024u + 1024u;        // one buffer (+ one pad piece, as the 64-vote image)
+    const unsigned lds0 = (unsigned)(unsigned long)(lds_uint*)lds_dyn;
+    const unsigned flags = lds0 + (unsigned)(nc * nb) * region;      // landed[nc] | consumed[nc]: blocks of consumer c that have landed / been read
+    if (threadIdx.x < 2 * nc) lds_dyn[(flags - lds0) / 4 + threadIdx.x] = 0;
+    __syncthreads();
+    const long nwaves = (long)gridDim.x * nc;
+    constexpr int np = PIECES + 1;
+    auto issue = [&](int c, long k) {                                // block k of consumer c into buffer k % nb
+        const long b = (long)blockIdx.x * nc + c + k * nwaves;
+        const char* g = src + b * (long)PIECES * 1024;
+        const unsigned rb = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(c * nb + (int)(k % nb)) * region));
+#pragma unroll
+        for (int q = 0; q < np; ++q) {
+            unsigned off = ((unsigned)q * 64u + (unsigned)lane) * 16u;
+            if (off > (unsigned)PIECES * 1024u - 16u) off = (unsigned)PIECES * 1024u - 16u;
+            dma_piece(g, off, rb + (unsigned)q * 1024u);
+        }
+    };
+    auto blocks_of = [&](int c) -> long {                            // how many blocks consumer c processes
+        const long first = (long)blockIdx.x * nc + c;
+        return first < nblocks ? (nblocks - first + nwaves - 1) / nwaves : 0;
+    };
+    if (mode && wid >= nc) {
+        // ---- a producer: serves the consumers c = pid, pid + npd, ...; lane c holds consumer c's counters.  One ds_read shows every
+        // consumer's progress; whoever has a free buffer and blocks left gets its next block issued; requests land in issue order.
+        __builtin_amdgcn_s_setprio(3);
+        const int pid = wid - nc;
+        const bool mine = lane < nc && lane % npd == pid;
+        const unsigned total = mine ? (unsigned)blocks_of(lane) : 0u;
+        unsigned issued = 0, landed = 0;                             // (per lane = per consumer)
+        unsigned ring = 0;                                           // lane i: consumer of the i-th request in flight (mod 64)
+        int head = 0, inflight = 0;
+        auto retire = [&]() {
+            wait_vmcnt((inflight - 1) * np);
+            const int c = __builtin_amdgcn_readlane((int)ring, head);
+            head = (head + 1) & 63; --inflight;
+            if (lane == c) { ++landed; flag_store(flags + 4u * (unsigned)c, landed); }
+        };
+        for (;;) {
+            unsigned consumed = 0;
+            if (mine) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(consumed) : "v"(flags + 4u * (unsigned)(nc + lane)) : "memory");
+            const bool more = mine && issued < total;
+            unsigned long long ready = __ballot(more && issued < consumed + (unsigned)nb);
+            if (!__ballot(more) && !inflight) break;
+            if (!ready) { if (inflight) retire(); else __builtin_amdgcn_s_sleep(1); continue; }
+            while (ready) {
+                const int c = __builtin_ctzll(ready);
+                ready &= ready - 1;
+                if (inflight == depth) retire();
+                const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)issued, c);
+                issue(c, (long)k);
+                if (lane == c) ++issued;
+                if (lane == ((head + inflight) & 63)) ring = (unsigned)c;
+                ++inflight;
+            }
+        }
+        return;
+    }
+    // ---- a consumer (mode 0: it also copies for itself, one buffer)
+    const int c = wid;
+    unsigned acc = 0;
+    const long nk = blocks_of(c);
+    if (!mode && nk > 0) issue(c, 0);
+    for (long k = 0; k < nk; ++k) {
+        if (mode) { while (flag_load(flags + 4u * (unsigned)c) < (unsigned)k + 1u) __builtin_amdgcn_s_sleep(1); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned rb = lds0 + (unsigned)(c * nb + (int)(k % nb)) * region;
+        unsigned r[NR];
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            // lane l's row: PIECES slots at slot stride PIECES + 1 (odd: conflict-free)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(*(v4i*)&r[4 * i]) : "v"(rb + ((unsigned)lane * (unsigned)(PIECES | 1) + (unsigned)i) * 16u) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (mode) flag_store(flags + 4u * (unsigned)(nc + c), (unsigned)k + 1u);
+        else if (k + 1 < nk) issue(c, k + 1);
+        for (int it = 0; it < k_iter; ++it) {
+#pragma unroll
+            for (int i = 0; i < NR / 2; ++i) {
+                unsigned t;
+                asm volatile("v_pk_min_u16 %0, %1, %2\n\tv_pk_max_u16 %2, %1, %2" : "=&v"(t), "+v"(r[i]), "+v"(r[NR - 1 - i]));
+                r[i] = t;
+            }
+#pragma unroll
+            for (int i = 0; i + 1 < NR; i += 2) {
+                unsigned t;
+                asm volatile("v_pk_min_u16 %0, %1, %2\n\tv_pk_max_u16 %2, %1, %2" : "=&v"(t), "+v"(r[i]), "+v"(r[i + 1]));
+                r[i] = t;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) acc ^= r[i];
+    }
+    if (acc == 0x12345678u) *sink = (int)acc;
+}
+
 __global__ void fill(v4i* dst, long nvec) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -154,13 +291,14 @@ double time_ms(F f, int reps = 5) {
 
 int main(int argc, char** argv) {
     long ncells = 10000;
-    bool calib = false, shortcells = false, quick = false, percu = false, dma = false, c2 = false;
+    bool calib = false, shortcells = false, quick = false, percu = false, dma = false, c2 = false, dmawork = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--calib")) calib = true;
         else if (!strcmp(argv[i], "--short")) shortcells = true;
         else if (!strcmp(argv[i], "--quick")) quick = true;
         else if (!strcmp(argv[i], "--percu")) percu = true;
         else if (!strcmp(argv[i], "--dma")) dma = true;
+        else if (!strcmp(argv[i], "--dmawork")) dmawork = true;
         else if (!strcmp(argv[i], "--c2")) c2 = true;
         else ncells = atol(argv[i]);
     }
@@ -176,6 +314,52 @@ int main(int argc, char** argv) {
             CK(hipDeviceSynchronize());
         }
         printf("calib: 3 launches of read_cells_pipe<4,nt> grid 250 x 1024, %ld bytes each\n", bytes);
+        return 0;
+    }
+    if (dmawork) {
+        printf("dmawork: the copy + the VALU work of a sorted-cells step (k VALU instructions per block and lane); mode 0 = every wave copies for itself, "
+               "mode 1 = one producer wave per workgroup copies for nc consumers (depth requests in flight)\n");
+        auto run = [&](auto kern, int pieces, int nc, int k_valu, int mode, int depth, int nb, int npd) {
+            const int nr = 4 * pieces, k_iter = k_valu / (2 * nr);   // one iteration = 2 nr instructions
+            const size_t lds = (size_t)nc * nb * ((size_t)pieces * 1024 + 1024) + 8 * (size_t)nc;
+            if (lds > 160 * 1024) return;
+            CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const long nblocks = bytes / ((long)pieces * 1024);
+            const int threads = (nc + (mode ? npd : 0)) * 64;
+            if (threads > 1024) return;
+            const double ms = time_ms([&] { kern<<<256, threads, lds>>>((const char*)buf, nblocks, k_iter, mode, depth, nb, npd, sink); CK(hipGetLastError()); }, 3);
+            if (mode) printf("dmawork %2d KiB blocks x %2d consumer waves x %d buffers  %4d VALU per block  %d producer wave(s), %2d requests in flight each : %7.3f ms = %6.0f GB/s\n",
+                             pieces, nc, nb, k_iter * 2 * nr, npd, depth, ms, bytes / ms / 1e6);
+            else printf("dmawork %2d KiB blocks x %2d consumer waves x %d buffers  %4d VALU per block  self-issued                                   : %7.3f ms = %6.0f GB/s\n",
+                        pieces, nc, nb, k_iter * 2 * nr, ms, bytes / ms / 1e6);
+        };
+        for (int k_valu : {0, 1024, 1344}) {
+            run(dma_work<16>, 16, 8, k_valu, 0, 0, 1, 0);
+            run(dma_work<16>, 16, 8, k_valu, 1, 3, 1, 1);
+            run(dma_work<16>, 16, 8, k_valu, 1, 3, 1, 2);
+            run(dma_work<16>, 16, 4, k_valu, 1, 3, 2, 1);
+            run(dma_work<16>, 16, 4, k_valu, 1, 3, 2, 2);
+            run(dma_work<16>, 16, 4, k_valu, 1, 2, 2, 2);
+        }
+        for (int k_valu : {0, 512, 640}) {
+            run(dma_work<8>, 8, 16, k_valu, 0, 0, 1, 0);
+            run(dma_work<8>, 8, 14, k_valu, 1, 6, 1, 2);
+            run(dma_work<8>, 8, 8, k_valu, 1, 6, 2, 1);
+            run(dma_work<8>, 8, 8, k_valu, 1, 6, 2, 2);
+            run(dma_work<8>, 8, 8, k_valu, 1, 3, 2, 2);
+            run(dma_work<8>, 8, 12, k_valu, 1, 3, 1, 2);
+        }
+        for (int k_valu : {0, 256, 320}) {
+            run(dma_work<4>, 4, 16, k_valu, 0, 0, 1, 0);
+            run(dma_work<4>, 4, 14, k_valu, 1, 6, 2, 2);
+            run(dma_work<4>, 4, 8, k_valu, 1, 6, 4, 2);
+            run(dma_work<4>, 4, 8, k_valu, 1, 12, 4, 1);
+        }
+        for (int k_valu : {0, 128, 160}) {
+            run(dma_work<2>, 2, 16, k_valu, 0, 0, 1, 0);
+            run(dma_work<2>, 2, 14, k_valu, 1, 10, 3, 2);
+            run(dma_work<2>, 2, 8, k_valu, 1, 10, 6, 2);
+        }
         return 0;
     }
     if (dma) {
