@@ -15,14 +15,26 @@
 //
 // Counting (o1.py:181-195 + statistics.multimode + o1.py:204-213) without LDS, without cross-lane traffic, without compares:
 // votes are 10-bit values, so two fit a register and v_pk_min_u16 / v_pk_max_u16 run TWO compare-exchanges per instruction
-// pair.  Element i of the cell sits in half i / NP of register i % NP (NP = NV / 2): a bitonic network in its all-ascending
-// ("flip") form sorts both halves in lockstep and needs the halves to meet in one stage only (5 instructions per register
-// pair there).  NV = 64: 720 instructions for 64 votes.  A scan over the sorted registers then gives, again two elements per
-// instruction, run_i = length of the run of equal values ending at i (running maximum of the 1-based indices of run starts),
-// max_count = max run, len(multimode) = #{ i : run_i == max_count } (a maximal run reaches max_count exactly once, at its last
-// element: no division), min_mode = min x_i over those, truth_count = #{ x_i == truth }: 16 instructions per register.
-// Votes past the valid prefix (n_valid[b] < NV) become DISTINCT sentinels 0x8000 | i: they sort behind every vote, form runs of
-// length 1, and are subtracted from the mode count when max_count == 1.
+// pair.  Element i of the cell sits in half i / NP of register i % NP (NP = NV / 2): an odd-even mergesort network on the NP
+// registers sorts both halves in lockstep and one bitonic merge joins them; the halves meet in one stage only (5 instructions
+// per register pair there).  NV = 64: 622 instructions for 64 votes.  A scan over the sorted registers then gives, again two
+// elements per instruction, the 1-based index of the run start each element belongs to (running maximum of
+// [x_i != x_i-1] * index), hence key_i = (NV - length of the run ending at i) << 10 | x_i: the SMALLEST key is the last element
+// of the longest run with the smallest value -- max_count and min(multimode) from one packed minimum per register --,
+// len(multimode) = #{ i : key_i <= smallest key | 0x3ff } (a maximal run reaches max_count exactly once, at its last element:
+// no division), truth_count = #{ x_i == truth }: 13 instructions per register (round 3: 16, with a pass of its own for the
+// candidates of min_mode).  Votes past the valid prefix (n_valid[b] < NV) become DISTINCT sentinels 0x8000 | i: they sort
+// behind every vote, form runs of length 1, and their keys saturate (v_pk_mad_u16 clamp) above every vote's key -- except in
+// the 64-vote shape when every vote is distinct (run length 1 is key field 63, and 63 << 10 | 1023 is the saturated key),
+// where all of them are counted and taken off again.
+//
+// What bounds it (round 4: tools/valu_probe.hip, tools/sort_timeline.py, hbm_probe --dmawork; profiles/r04_valu_probe.log,
+// r04_sort_timeline*.log, r04_hbm_probe_dmawork.log): packed 16-bit and three-operand VALU instructions issue every 4.4 cycles
+// per SIMD (plain 32-bit add / xor: 2.2), so ~20 of them per vote cap the shapes near 7 TB/s; a wave spends 40-58 % of its cycles
+// blocked ISSUING its LDS-DMA pieces (the CU's memory pipe serves every wave's pieces in turn) or waiting for them, which two to
+// four waves per SIMD cover to ~70 % VALU occupancy.  One producer wave per workgroup that issues every piece (consumers wait
+// on LDS flags, one or two buffers each) does not beat the waves copying for themselves on the same work (4.0-4.5 against 4.7
+// TB/s at 16 KiB blocks, worse for smaller blocks): measured in the probe, not built here.
 #pragma once
 
 #include <utility>
@@ -192,63 +204,68 @@ __device__ __forceinline__ SortedStats sv_scan(const uint32_t (&R)[NP], uint32_t
         }
         carry = ((acc & 0xffffu) + 1u - (uint32_t)NP) << 16;     // (acc.lo = 2 NP - f0) -> NP + 1 - f0
     }
-    uint32_t mx = 0;
+    // key of an element = (NV - length of the run ending at it) << 10 | value, NV = 2 NP: the SMALLEST key belongs to the last element of
+    // the longest run with the smallest value -- max_count and min(multimode) from one packed minimum per register, no second pass for
+    // the candidates.  NV - length = start + (NV - 1 - index1) with the 1-based start of the run (its own half's, or the carry);
+    // a sentinel (>= 0x8000) saturates its key (clamp).
+    constexpr int NV = 2 * NP;
+    uint32_t key[NP];
+    uint32_t km = 0xffffffffu;
+#define SV_KOFF(r) (((uint32_t)(NV - 2 - (r)) & 0xffffu) | (((uint32_t)(NV - 2 - (r) - NP) & 0xffffu) << 16))   /* NV - 1 - index1 of (0, r) | of (1, r) */
 #pragma unroll
     for (int r = 0; r < NP; r += 4) {
-        // run length ending here = (index + 1) - start; running maximum
-        uint32_t n0, n1, n2, n3, mo;
+        uint32_t k0, k1, k2, k3, mo;
         asm("v_pk_max_u16 %0, %5, %9\n\t"
             "v_pk_max_u16 %1, %6, %9\n\t"
             "v_pk_max_u16 %2, %7, %9\n\t"
             "v_pk_max_u16 %3, %8, %9\n\t"
-            "v_pk_sub_u16 %0, %11, %0\n\t"
-            "v_pk_sub_u16 %1, %12, %1\n\t"
-            "v_pk_sub_u16 %2, %13, %2\n\t"
-            "v_pk_sub_u16 %3, %14, %3\n\t"
-            "v_pk_max_u16 %4, %10, %0\n\t"
-            "v_pk_max_u16 %4, %4, %1\n\t"
-            "v_pk_max_u16 %4, %4, %2\n\t"
-            "v_pk_max_u16 %4, %4, %3"
-            : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "=&v"(mo)
-            : "v"(run[r]), "v"(run[r + 1]), "v"(run[r + 2]), "v"(run[r + 3]), "v"(carry), "v"(mx),
-              "s"(SV_IDX(r, 2)), "s"(SV_IDX(r + 1, 2)), "s"(SV_IDX(r + 2, 2)), "s"(SV_IDX(r + 3, 2)));
-        run[r] = n0; run[r + 1] = n1; run[r + 2] = n2; run[r + 3] = n3;
-        mx = mo;
+            "v_pk_add_u16 %0, %0, %11\n\t"
+            "v_pk_add_u16 %1, %1, %12\n\t"
+            "v_pk_add_u16 %2, %2, %13\n\t"
+            "v_pk_add_u16 %3, %3, %14\n\t"
+            "v_pk_mad_u16 %0, %0, %15, %16 clamp\n\t"
+            "v_pk_mad_u16 %1, %1, %15, %17 clamp\n\t"
+            "v_pk_mad_u16 %2, %2, %15, %18 clamp\n\t"
+            "v_pk_mad_u16 %3, %3, %15, %19 clamp\n\t"
+            "v_pk_min_u16 %4, %10, %0\n\t"
+            "v_pk_min_u16 %4, %4, %1\n\t"
+            "v_pk_min_u16 %4, %4, %2\n\t"
+            "v_pk_min_u16 %4, %4, %3"
+            : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3), "=&v"(mo)
+            : "v"(run[r]), "v"(run[r + 1]), "v"(run[r + 2]), "v"(run[r + 3]), "v"(carry), "v"(km),
+              "s"(SV_KOFF(r)), "s"(SV_KOFF(r + 1)), "s"(SV_KOFF(r + 2)), "s"(SV_KOFF(r + 3)), "v"(0x04000400u),
+              "v"(R[r]), "v"(R[r + 1]), "v"(R[r + 2]), "v"(R[r + 3]));
+        key[r] = k0; key[r + 1] = k1; key[r + 2] = k2; key[r + 3] = k3;
+        km = mo;
     }
+#undef SV_KOFF
 #undef SV_IDX
     SortedStats o;
-    o.max_run = (mx & 0xffffu) > (mx >> 16) ? (mx & 0xffffu) : (mx >> 16);
-    const uint32_t mr2 = o.max_run | (o.max_run << 16);
-    uint32_t below = 0, minc = 0xffffffffu, tc = 0;
+    const uint32_t k1 = (km & 0xffffu) < (km >> 16) ? (km & 0xffffu) : (km >> 16);
+    o.max_run = (uint32_t)NV - (k1 >> 10);
+    o.min_at_max = k1 & 0x3ffu;
+    const uint32_t thr = k1 | 0x3ffu, thr2 = thr | (thr << 16);
+    uint32_t above = 0, tc = 0;
 #pragma unroll
     for (int r = 0; r < NP; r += 2) {
-        // m = 1 where the run ending here is shorter than the longest; candidates for min_mode: the element where it is a mode,
-        // 0xffff elsewhere; 1 where the element equals the truth
-        uint32_t m0, m1, t0, t1, b2, c2, t2;
-        asm("v_pk_sub_u16 %0, %7, %8\n\t"
-            "v_pk_sub_u16 %1, %7, %9\n\t"
-            "v_xor_b32 %2, %10, %12\n\t"
-            "v_xor_b32 %3, %11, %12\n\t"
+        // 1 where the run ending here is shorter than the longest (key above every key of that length); 1 where the element equals
+        // the truth; both summed as packed 0 / 1 by 32-bit three-operand adds (no carry between the halves: sums <= NP)
+        uint32_t e0, e1, d0, d1, ao, to;
+        asm("v_pk_sub_u16 %0, %6, %8 clamp\n\t"
+            "v_pk_sub_u16 %1, %7, %8 clamp\n\t"
+            "v_xor_b32 %2, %9, %11\n\t"
+            "v_xor_b32 %3, %10, %11\n\t"
             "v_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]\n\t"
             "v_pk_min_u16 %1, %1, 1 op_sel_hi:[1,0]\n\t"
             "v_pk_sub_u16 %2, 1, %2 op_sel_hi:[0,1] clamp\n\t"
             "v_pk_sub_u16 %3, 1, %3 op_sel_hi:[0,1] clamp\n\t"
-            "v_pk_add_u16 %4, %13, %0\n\t"
-            "v_pk_add_u16 %6, %15, %2\n\t"
-            "v_pk_sub_u16 %0, 0, %0 op_sel_hi:[0,1]\n\t"
-            "v_pk_add_u16 %4, %4, %1\n\t"
-            "v_pk_sub_u16 %1, 0, %1 op_sel_hi:[0,1]\n\t"
-            "v_pk_add_u16 %6, %6, %3\n\t"
-            "v_or_b32 %0, %10, %0\n\t"
-            "v_or_b32 %1, %11, %1\n\t"
-            "v_pk_min_u16 %5, %14, %0\n\t"
-            "v_pk_min_u16 %5, %5, %1"
-            : "=&v"(m0), "=&v"(m1), "=&v"(t0), "=&v"(t1), "=&v"(b2), "=&v"(c2), "=&v"(t2)
-            : "v"(mr2), "v"(run[r]), "v"(run[r + 1]), "v"(R[r]), "v"(R[r + 1]), "v"(tcmp2), "v"(below), "v"(minc), "v"(tc));
-        below = b2; minc = c2; tc = t2;
+            "v_add3_u32 %4, %12, %0, %1\n\t"
+            "v_add3_u32 %5, %13, %2, %3"
+            : "=&v"(e0), "=&v"(e1), "=&v"(d0), "=&v"(d1), "=&v"(ao), "=&v"(to)
+            : "v"(key[r]), "v"(key[r + 1]), "v"(thr2), "v"(R[r]), "v"(R[r + 1]), "v"(tcmp2), "v"(above), "v"(tc));
+        above = ao; tc = to;
     }
-    o.at_max = 2u * NP - ((below & 0xffffu) + (below >> 16));
-    o.min_at_max = (minc & 0xffffu) < (minc >> 16) ? (minc & 0xffffu) : (minc >> 16);
+    o.at_max = 2u * NP - ((above & 0xffffu) + (above >> 16));
     o.truth_votes = (tc & 0xffffu) + (tc >> 16);
     return o;
 }
@@ -499,22 +516,25 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
                 }
             }
         }
-        // o1.py:140 int(extracted_answer) is unbounded; the extractor maps it into bins 0..1023: the clamp runs only in the
-        // (wave-uniform, rare) case that some slot -- a vote or not -- holds a larger value
+        // Two votes per register.  v_cvt_pk_u16_u32 saturates, so a slot outside 16 bits stays outside the domain and the domain check runs
+        // on the packed registers (one v_or3 per four votes).  o1.py:140 int(extracted_answer) is unbounded; the extractor maps it into
+        // bins 0..1023: the clamp runs only in the (wave-uniform, rare) case that some slot -- a vote or not -- holds a larger value
+#pragma unroll
+        for (int r = 0; r < NP; ++r) R[r] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(w[r], w[r + NP]));
         uint32_t orv = 0;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) orv |= w[i];
+        for (int r = 0; r < NP; ++r) orv |= R[r];
         const bool full = all_live && __all(n == (uint32_t)NV);
-        if (__any(orv > 1023u)) {
+        if (__any((orv & 0xfc00fc00u) != 0u)) {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                bad |= w[i] & (uint32_t)((i - (int32_t)n) >> 31);
-                w[i] = w[i] < 1023u ? w[i] : 1023u;
+            for (int r = 0; r < NP; ++r) {
+                // (validity as masks: all ones in a half whose slot index is below n)
+                const uint32_t valid2 = ((uint32_t)((r - (int32_t)n) >> 31) & 0xffffu) | ((uint32_t)((r + NP - (int32_t)n) >> 31) << 16);
+                bad |= R[r] & valid2;
+                R[r] = pk_min_c(R[r], 0x03ff03ffu);
             }
         }
-        // every slot is <= 1023 now (votes, neighbours, pads): two per register
-#pragma unroll
-        for (int r = 0; r < NP; ++r) R[r] = w[r] | (w[r + NP] << 16);
+        // every slot is <= 1023 now (votes, neighbours, pads)
         if (!full) {
             const uint32_t n2 = n | (n << 16);
 #pragma unroll
@@ -584,8 +604,9 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
         if (live) {
             const bool any = n > 0;
             const uint32_t maxc = any ? s.max_run : 0u;
-            // sentinels are runs of length 1: they are modes only when every vote is distinct
-            const uint32_t n_modes = any ? s.at_max - (s.max_run == 1u ? (uint32_t)NV - n : 0u) : 0u;
+            // a sentinel's key is above every vote's -- except in the 64-vote shape when every vote is distinct (run length 1 is key field 63
+            // there: 63 << 10 | 1023 is the saturated key), where ALL sentinels were counted and come off again
+            const uint32_t n_modes = any ? s.at_max - ((NV == 64 && s.max_run == 1u) ? (uint32_t)NV - n : 0u) : 0u;
             const uint32_t tc = s.truth_votes;
             const uint32_t hit = (any && tc == maxc) ? 1u : 0u;                  // o1.py:206
             if (a.cells) {
@@ -620,7 +641,7 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
         atomicAdd(&scv_sort_timeline[7], 1ull);
     }
 #endif
-    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+    if (bad & 0xfc00fc00u) atomicOr(a.err_flag, 1u);
     if (fixed_b) {
         if (h1) atomicAdd(&tie[my_b * TC + 1], h1);
         if (tcs) atomicAdd(&acc[my_b], tcs);

@@ -2,11 +2,12 @@
 //  1. the compile-time compare-exchange list of csrc/scvote_sortnet.h sorts (0-1 principle: exhaustively for N <= 24 wires,
 //     SAMPLED -- 2^20 random 0-1 inputs -- for N = 32), and the valley merge of the 48-vote shape sorts every 0-1 valley;
 //  2. a scalar emulation of the device code's packed form -- two 16-bit elements per register, both halves through the same
-//     network in lockstep, ONE bitonic merge whose first stage crosses the halves, then the run-length scan with the carry
-//     between the halves, distinct sentinels behind the valid prefix -- gives statistics.multimode's (max count, number of modes,
-//     smallest mode) and the truth count, against a brute-force count, for every shape NV = 8 ... 64 (48: the halves meet at r = 0).
+//     network in lockstep, ONE bitonic merge whose first stage crosses the halves, then the run-start scan with the carry
+//     between the halves, the keys (NV - run length) << 10 | value with their saturation, distinct sentinels behind the valid
+//     prefix -- gives statistics.multimode's (max count, number of modes, smallest mode) and the truth count, against a
+//     brute-force count, for every shape NV = 8 ... 64 (48: the halves meet at r = 0).
 // The packed operations are restated here with the semantics of v_pk_min_u16 / v_pk_max_u16 / v_pk_add_u16 / v_pk_sub_u16 (clamp) /
-// v_pk_mul_lo_u16 / v_alignbit_b32 / v_bfi_b32; the order of operations is the device code's.
+// v_pk_mul_lo_u16 / v_pk_mad_u16 (clamp) / v_alignbit_b32 / v_bfi_b32; the order of operations is the device code's.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +29,10 @@ static uint32_t pk_add(uint32_t a, uint32_t b) { return pk(a, b, [](uint32_t x, 
 static uint32_t pk_sub(uint32_t a, uint32_t b) { return pk(a, b, [](uint32_t x, uint32_t y) { return x - y; }); }
 static uint32_t pk_sub_sat(uint32_t a, uint32_t b) { return pk(a, b, [](uint32_t x, uint32_t y) { return x > y ? x - y : 0u; }); }
 static uint32_t pk_mul(uint32_t a, uint32_t b) { return pk(a, b, [](uint32_t x, uint32_t y) { return x * y; }); }
+static uint32_t pk_mad_sat(uint32_t a, uint32_t b, uint32_t c) {     // v_pk_mad_u16 ... clamp
+    auto one = [](uint32_t x, uint32_t y, uint32_t z) { const uint32_t v = x * y + z; return v > 0xffffu ? 0xffffu : v; };
+    return one(a & 0xffffu, b & 0xffffu, c & 0xffffu) | (one(a >> 16, b >> 16, c >> 16) << 16);
+}
 static uint32_t alignbit(uint32_t hi, uint32_t lo, int s) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> s); }
 
 template <int N>
@@ -73,10 +78,12 @@ static bool packed_count_matches_bruteforce(int rounds) {
     auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
     for (int it = 0; it < rounds; ++it) {
         const int dom = (int[]){2, 3, 5, 50, 1024}[next() % 5];
+        const bool corner = it % 16 == 7;                              // every vote distinct, 1023 among them: the key 63 << 10 | 1023 (NV = 64) is the saturated one
         const int pick = (int)(next() % 6);
         const uint32_t n = pick == 0 ? 0u : pick == 1 ? 1u : pick <= 3 ? (uint32_t)NV : (uint32_t)(next() % (NV + 1));
         uint32_t w[NV];
-        for (int i = 0; i < NV; ++i) w[i] = (uint32_t)(next() % dom);
+        for (int i = 0; i < NV; ++i) w[i] = corner ? (uint32_t)(1023 - i) : (uint32_t)(next() % dom);
+        if (corner) for (int i = NV - 1; i > 0; --i) { const int j = (int)(next() % (uint64_t)(i + 1)); const uint32_t t = w[i]; w[i] = w[j]; w[j] = t; }
         const uint32_t truth = (next() & 1) ? w[next() % NV] : (uint32_t)(next() % 1024);
         // ---- device order: pack, sentinels, sort halves, cross merge, scan
         uint32_t R[NP];
@@ -119,21 +126,28 @@ static bool packed_count_matches_bruteforce(int rounds) {
             for (int r = 0; r < NP; ++r) acc = pk_add(acc, pk_min(run[r], 0x00020002u));
             carry = ((acc & 0xffffu) + 1u - (uint32_t)NP) << 16;
         }
-        uint32_t mx = 0;
-        for (int r = 0; r < NP; ++r) { run[r] = pk_sub((uint32_t)(r + 2) | ((uint32_t)(r + NP + 2) << 16), pk_max(run[r], carry)); mx = pk_max(mx, run[r]); }
-        const uint32_t max_run = (mx & 0xffffu) > (mx >> 16) ? (mx & 0xffffu) : (mx >> 16), mr2 = max_run | (max_run << 16);
-        const uint32_t tcmp = truth < 1024u ? truth : 0x7fffu, t2 = tcmp | (tcmp << 16);
-        uint32_t below = 0, minc = 0xffffffffu, tc = 0;
+        // key of an element = (NV - length of the run ending at it) << 10 | value: the smallest key is the longest run's last element with
+        // the smallest value (max_count and min(multimode) in one packed minimum per register); a sentinel's key saturates (v_pk_mad_u16 clamp)
+        uint32_t key[NP], kmin = 0xffffffffu;
         for (int r = 0; r < NP; ++r) {
-            const uint32_t m = pk_min(pk_sub(mr2, run[r]), 0x00010001u);
-            below = pk_add(below, m);
-            minc = pk_min(minc, R[r] | pk_sub(0u, m));
-            tc = pk_add(tc, pk_sub_sat(0x00010001u, R[r] ^ t2));
+            const uint32_t c2 = ((uint32_t)(NV - 1 - (r + 1)) & 0xffffu) | (((uint32_t)(NV - 1 - (r + NP + 1)) & 0xffffu) << 16);
+            key[r] = pk_mad_sat(pk_add(pk_max(run[r], carry), c2), 0x04000400u, R[r]);
+            kmin = pk_min(kmin, key[r]);
         }
-        const uint32_t at_max = 2u * NP - ((below & 0xffffu) + (below >> 16));
+        const uint32_t k1 = (kmin & 0xffffu) < (kmin >> 16) ? (kmin & 0xffffu) : (kmin >> 16);
+        const uint32_t max_run = (uint32_t)NV - (k1 >> 10), thr = k1 | 0x3ffu, thr2 = thr | (thr << 16);
+        const uint32_t tcmp = truth < 1024u ? truth : 0x7fffu, t2 = tcmp | (tcmp << 16);
+        uint32_t above = 0, tc = 0;                                                   // (32-bit adds of packed 0 / 1: no carry between the halves)
+        for (int r = 0; r < NP; r += 2) {
+            above = above + pk_min(pk_sub_sat(key[r], thr2), 0x00010001u) + pk_min(pk_sub_sat(key[r + 1], thr2), 0x00010001u);
+            tc = tc + pk_sub_sat(0x00010001u, R[r] ^ t2) + pk_sub_sat(0x00010001u, R[r + 1] ^ t2);
+        }
+        const uint32_t at_max = 2u * NP - ((above & 0xffffu) + (above >> 16));
         const bool any = n > 0;
-        const uint32_t got_max = any ? max_run : 0u, got_modes = any ? at_max - (max_run == 1u ? (uint32_t)NV - n : 0u) : 0u;
-        const uint32_t got_min = any ? ((minc & 0xffffu) < (minc >> 16) ? (minc & 0xffffu) : (minc >> 16)) : 0xffffu;
+        // (a sentinel is a run of one whose key saturates: above every vote's key except in the 64-vote shape when every vote is distinct --
+        //  run length 1 is key field 63 there, 63 << 10 | 1023 = 0xffff -- where ALL sentinels count and are taken off again)
+        const uint32_t got_max = any ? max_run : 0u, got_modes = any ? at_max - ((NV == 64 && max_run == 1u) ? (uint32_t)NV - n : 0u) : 0u;
+        const uint32_t got_min = any ? (k1 & 0x3ffu) : 0xffffu;
         const uint32_t got_tc = (tc & 0xffffu) + (tc >> 16);
         // ---- brute force (statistics.multimode on the valid prefix)
         uint32_t cnt[1024] = {0}, want_max = 0, want_modes = 0, want_min = 0xffffu, want_tc = 0;

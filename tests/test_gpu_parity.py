@@ -408,6 +408,13 @@ def test_sorted_cells_edges(hip_engine):
         got = hip_engine.aggregate(a, tr, n_valid=nv)
         assert_results_equal(got, oracle(a, tr, n_valid=nv), check_tokens=False)
     assert got.cells["n_modes"][0, 0] == 1 and got.cells["n_modes"][0, 1] == 0
+    # the saturated key of the 64-vote shape: all votes distinct (run length 1 = key field 63) and 1023 among them -- 63 << 10 | 1023 is also
+    # what a sentinel's key saturates to; prefixes that end before / at / after the 1023, truth = 1023 and not
+    rng = np.random.default_rng(64)
+    a = np.stack([rng.permutation(1023 - np.arange(64, dtype=np.int32)) for _ in range(260)]).reshape(130, 2, 64)
+    tr = np.where(np.arange(130) % 2 == 0, 1023, 990).astype(np.int32)
+    for nv in (None, np.array([64, 40], dtype=np.int32), np.array([63, 1], dtype=np.int32), np.array([2, 33], dtype=np.int32)):
+        assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), oracle(a, tr, n_valid=nv), check_tokens=False)
     a = np.tile(np.arange(48, dtype=np.int32)[::-1] * 21, (130, 2, 1))          # 48 distinct values on the 48-vote shape
     tr = np.full(130, 21 * 40, dtype=np.int32)
     for nv in (None, np.array([48, 33], dtype=np.int32), np.array([47, 0], dtype=np.int32)):
