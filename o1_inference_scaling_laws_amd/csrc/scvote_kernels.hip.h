@@ -1172,11 +1172,18 @@ __global__ __launch_bounds__(1024) void scv_few_votes(const AggArgs a) {
     for (int j = 0; j < CPL; ++j) { h1[j] = 0; tcs[j] = 0; toks[j] = 0; }
     uint32_t bad = 0;
     typedef uint32_t vnv __attribute__((ext_vector_type(NV == 1 ? 1 : NV)));
-    struct Votes { uint32_t w[CPL][NV]; int32_t tk[CPL][NV]; };
-    auto load = [&](uint32_t bk, Votes& o) {                        // every instruction: 64 lanes x 4 NV consecutive bytes
+    struct Votes { uint32_t w[CPL][NV]; int32_t tk[CPL][NV]; int32_t truth[CPL]; };
+    // `ahead`: the slots' problems are those of the step after the current one (the slots' walkers plus one stride): the truth of a step
+    // travels with its votes -- loaded inside the step, every step waited a memory latency for it (PMC round 4, N = 1: wave-wait 0.85;
+    // counters only, N = 1: 183 -> 129 us, with tokens 217 -> 158; N = 2: 100 -> 97).  Not when the launch writes the cell table: that launch is bound by
+    // its 16-byte records (5.3 TB/s of reads + writes at N = 1) and ran 7-9 % SLOWER with the extra loads in flight (r04_ab_few_truth.log).
+    // Nor for cells of 4 votes (one truth per 16 bytes of votes: 91 -> 94 us with it).
+    const bool pre = NV < 4 && !a.cells;
+    auto load = [&](uint32_t bk, Votes& o, bool ahead) {            // every instruction: 64 lanes x 4 NV consecutive bytes
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             const uint64_t c = (uint64_t)bk * BLK + 64u * j + (uint32_t)lane;
+            if (pre) o.truth[j] = a.truth[ahead ? pj[j] + dp + (bj[j] + db >= B ? 1u : 0u) : pj[j]];
             if constexpr (NV == 1) {
                 o.w[j][0] = (uint32_t)__builtin_nontemporal_load(a.answers + c);
                 if (TOK) o.tk[j][0] = __builtin_nontemporal_load(a.tokens + c);
@@ -1193,14 +1200,14 @@ __global__ __launch_bounds__(1024) void scv_few_votes(const AggArgs a) {
         }
     };
     Votes cur{}, nxt{};
-    if (blk < nblocks) load(blk, cur);
+    if (blk < nblocks) load(blk, cur, false);
     for (; blk < nblocks; blk += nwaves) {
-        if (blk + nwaves < nblocks) load(blk + nwaves, nxt);         // one step ahead
+        if (blk + nwaves < nblocks) load(blk + nwaves, nxt, true);   // one step ahead
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             const uint32_t b = bj[j];
             const uint32_t n = fixed_b ? nj[j] : (uint32_t)(valid_len(a, (int32_t)b) < NV ? valid_len(a, (int32_t)b) : NV);
-            const int32_t truth = a.truth[pj[j]];
+            const int32_t truth = pre ? cur.truth[j] : a.truth[pj[j]];
             const uint32_t tcmp = (truth >= 0 && truth < kBins) ? (uint32_t)truth : 0xffffffffu;
             // every vote is a bin: an out-of-domain vote (o1.py:140 int(extracted_answer) is unbounded; the extractor maps it into bins 0..1023)
             // counts for bin 1023 -- and raises the error word when it is inside the valid prefix
