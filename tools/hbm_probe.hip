@@ -317,8 +317,8 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (dmawork) {
-        printf("dmawork: the copy + the VALU work of a sorted-cells step (k VALU instructions per block and lane); mode 0 = every wave copies for itself, "
-               "mode 1 = one producer wave per workgroup copies for nc consumers (depth requests in flight)\n");
+        printf("dmawork: the copy + the VALU work of a sorted-cells step (k packed min / max per block and lane, plus up to k / 2 v_mov the compiler keeps: x 1.5 for the "
+               "instruction count); self-issued = every wave copies for itself, else producer wave(s) copy for the consumer waves\n");
         auto run = [&](auto kern, int pieces, int nc, int k_valu, int mode, int depth, int nb, int npd) {
             const int nr = 4 * pieces, k_iter = k_valu / (2 * nr);   // one iteration = 2 nr instructions
             const size_t lds = (size_t)nc * nb * ((size_t)pieces * 1024 + 1024) + 8 * (size_t)nc;
@@ -328,9 +328,9 @@ int main(int argc, char** argv) {
             const int threads = (nc + (mode ? npd : 0)) * 64;
             if (threads > 1024) return;
             const double ms = time_ms([&] { kern<<<256, threads, lds>>>((const char*)buf, nblocks, k_iter, mode, depth, nb, npd, sink); CK(hipGetLastError()); }, 3);
-            if (mode) printf("dmawork %2d KiB blocks x %2d consumer waves x %d buffers  %4d VALU per block  %d producer wave(s), %2d requests in flight each : %7.3f ms = %6.0f GB/s\n",
+            if (mode) printf("dmawork %2d KiB blocks x %2d consumer waves x %d buffers  %4d pk_min/pk_max per block  %d producer wave(s), %2d requests in flight each : %7.3f ms = %6.0f GB/s\n",
                              pieces, nc, nb, k_iter * 2 * nr, npd, depth, ms, bytes / ms / 1e6);
-            else printf("dmawork %2d KiB blocks x %2d consumer waves x %d buffers  %4d VALU per block  self-issued                                   : %7.3f ms = %6.0f GB/s\n",
+            else printf("dmawork %2d KiB blocks x %2d consumer waves x %d buffers  %4d pk_min/pk_max per block  self-issued                                   : %7.3f ms = %6.0f GB/s\n",
                         pieces, nc, nb, k_iter * 2 * nr, ms, bytes / ms / 1e6);
         };
         for (int k_valu : {0, 1024, 1344}) {

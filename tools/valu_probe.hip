@@ -80,16 +80,17 @@ __global__ void __launch_bounds__(1024) probe(long long* cycles, uint32_t* sink,
             if (OP == LSHL_OR) { if (DEP) DEP16_3("v_lshl_or_b32", "%1"); else INDEP4_3("v_lshl_or_b32", "%16"); }
             if (OP == FMA_F32) { if (DEP) DEP16_3("v_fma_f32", "%1"); else INDEP4_3("v_fma_f32", "%16"); }
             if (OP == CNDMASK) {
-                // 16 selects on the same vcc (set once outside the timed work by the compare below)
-                asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(r[0]), "v"(k) : "vcc");
-                if (DEP) { asm volatile("v_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\n"
-                                        "v_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\n"
-                                        "v_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\n"
-                                        "v_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\n" : "+v"(r[0]) : "v"(k) : "vcc"); }
-                else {
-#pragma unroll
-                    for (int i = 1; i < 16; ++i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(k) : "vcc");
-                }
+                // 16 selects on one vcc, in ONE statement (hipcc pads every asm statement that clobbers vcc with an s_nop)
+                if (DEP) asm volatile("v_cmp_gt_u32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\n"
+                                      "v_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\n"
+                                      "v_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\n"
+                                      "v_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[0]) : "v"(k) : "vcc");
+                else asm volatile("v_cmp_gt_u32 vcc, %0, %16\n s_nop 1\n v_cndmask_b32 %0, %0, %16, vcc\nv_cndmask_b32 %1, %1, %16, vcc\nv_cndmask_b32 %2, %2, %16, vcc\nv_cndmask_b32 %3, %3, %16, vcc\n"
+                                  "v_cndmask_b32 %4, %4, %16, vcc\nv_cndmask_b32 %5, %5, %16, vcc\nv_cndmask_b32 %6, %6, %16, vcc\nv_cndmask_b32 %7, %7, %16, vcc\n"
+                                  "v_cndmask_b32 %8, %8, %16, vcc\nv_cndmask_b32 %9, %9, %16, vcc\nv_cndmask_b32 %10, %10, %16, vcc\nv_cndmask_b32 %11, %11, %16, vcc\n"
+                                  "v_cndmask_b32 %12, %12, %16, vcc\nv_cndmask_b32 %13, %13, %16, vcc\nv_cndmask_b32 %14, %14, %16, vcc\nv_cndmask_b32 %15, %15, %16, vcc"
+                                  : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]),
+                                    "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]) : "v"(k) : "vcc");
             }
             if (OP == PAIR_MINMAX) {
                 // one compare-exchange of the sorting network: (a, b) -> (min, max); 8 exchanges on 16 registers = 16 instructions
@@ -131,8 +132,8 @@ static void run(long long* d_cycles, uint32_t* d_sink, int cus, double clock_rat
             std::vector<long long> c(waves);
             CK(hipMemcpy(c.data(), d_cycles, sizeof(long long) * waves, hipMemcpyDeviceToHost));
             std::sort(c.begin(), c.end());
-            // PAIR_MINMAX issues 24 instructions per 8 exchanges (min, max, mov); CNDMASK 16 with its compare
-            const double per_rep = OP == PAIR_MINMAX ? 24.0 * 4 : (OP == CNDMASK ? 16.0 * 4 : 64.0);
+            // PAIR_MINMAX issues 24 instructions per 8 exchanges (min, max, mov); CNDMASK 16 selects + their compare
+            const double per_rep = OP == PAIR_MINMAX ? 24.0 * 4 : (OP == CNDMASK ? 17.0 * 4 : 64.0);
             const double cyc = (double)c[waves / 2] * clock_ratio / (kReps * per_rep * w);
             // cross-check against the wall clock of the launch (includes ~5 us of launch): cycles at the nominal shader clock
             const double ev = (double)ms * 1e-3 * clock_khz * 1e3 / (kReps * per_rep * w);
