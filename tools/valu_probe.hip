@@ -48,10 +48,12 @@ constexpr int kReps = 256;
                  : "+v"(r[0]) : "v"(k))
 
 enum Op { PK_MIN_U16, PK_MAX_U16, PK_ADD_U16, PK_SUB_CLAMP, MIN_U32, XOR_B32, ADD_U32, ALIGNBIT, BFI, PERM, OR3, MIN3_U32, PAIR_MINMAX, CNDMASK,
-          PK_MAD_U16, LSHL_OR, FMA_F32, kOps };
+          PK_MAD_U16, LSHL_OR, FMA_F32, CNDMASK_SGPR, CNDMASK_MIX, V_CMP, ADDC, CND_E32_SMOV, CND_E64_VCC, CND_E64_VCMP, kOps };
 static const char* kNames[kOps] = {"v_pk_min_u16", "v_pk_max_u16", "v_pk_add_u16", "v_pk_sub_u16 clamp", "v_min_u32", "v_xor_b32", "v_add_u32",
                                    "v_alignbit_b32", "v_bfi_b32", "v_perm_b32", "v_or3_b32", "v_min3_u32", "pk_min+pk_max pair (an exchange)",
-                                   "v_cndmask_b32 (vcc)", "v_pk_mad_u16", "v_lshl_or_b32", "v_fma_f32"};
+                                   "v_cndmask_b32 (vcc)", "v_pk_mad_u16", "v_lshl_or_b32", "v_fma_f32", "v_cndmask_b32 (SGPR pair, s_mov)",
+                                   "v_cndmask_b32 + v_xor_b32 alternating", "v_cmp_gt_u32 (vcc)", "v_addc_co_u32 (vcc in / out)",
+                                   "v_cndmask_b32_e32, vcc written by s_mov", "v_cndmask_b32_e64 ... vcc, vcc written by v_cmp", "v_cndmask_b32_e64 ... s[n:n+1] written by v_cmp"};
 
 template <int OP, bool DEP>
 __global__ void __launch_bounds__(1024) probe(long long* cycles, uint32_t* sink, uint32_t seed) {
@@ -91,6 +93,60 @@ __global__ void __launch_bounds__(1024) probe(long long* cycles, uint32_t* sink,
                                   "v_cndmask_b32 %12, %12, %16, vcc\nv_cndmask_b32 %13, %13, %16, vcc\nv_cndmask_b32 %14, %14, %16, vcc\nv_cndmask_b32 %15, %15, %16, vcc"
                                   : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]),
                                     "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]) : "v"(k) : "vcc");
+            }
+            if (OP == CNDMASK_SGPR) {
+                // the mask in an SGPR pair written by the scalar unit (no VALU -> SGPR hazard, no vcc)
+                unsigned long long m;
+                asm volatile("s_mov_b64 %0, 0x55555555" : "=s"(m));
+                if (DEP) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(r[0]) : "v"(k), "s"(m));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(k), "s"(m));
+                }
+            }
+            if (OP == CNDMASK_MIX) {
+                unsigned long long m;
+                asm volatile("s_mov_b64 %0, 0x55555555" : "=s"(m));
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    asm volatile("v_cndmask_b32 %0, %0, %2, %3\n v_xor_b32 %1, %1, %2" : "+v"(r[DEP ? 0 : 2 * i]), "+v"(r[DEP ? 1 : 2 * i + 1]) : "v"(k), "s"(m));
+            }
+            if (OP == V_CMP) {
+                asm volatile("v_cmp_gt_u32 vcc, %0, %1\n v_cmp_gt_u32 vcc, %2, %1\n v_cmp_gt_u32 vcc, %3, %1\n v_cmp_gt_u32 vcc, %4, %1\n"
+                             "v_cmp_gt_u32 vcc, %0, %1\n v_cmp_gt_u32 vcc, %2, %1\n v_cmp_gt_u32 vcc, %3, %1\n v_cmp_gt_u32 vcc, %4, %1\n"
+                             "v_cmp_gt_u32 vcc, %0, %1\n v_cmp_gt_u32 vcc, %2, %1\n v_cmp_gt_u32 vcc, %3, %1\n v_cmp_gt_u32 vcc, %4, %1\n"
+                             "v_cmp_gt_u32 vcc, %0, %1\n v_cmp_gt_u32 vcc, %2, %1\n v_cmp_gt_u32 vcc, %3, %1\n v_cmp_gt_u32 vcc, %4, %1"
+                             : : "v"(r[0]), "v"(k), "v"(r[1]), "v"(r[2]), "v"(r[3]) : "vcc");
+            }
+            if (OP == ADDC) {
+                if (DEP) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n"
+                                      "v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n"
+                                      "v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n"
+                                      "v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc"
+                                      : "+v"(r[0]) : "v"(k) : "vcc");
+                else asm volatile("v_addc_co_u32 %0, vcc, %0, %4, vcc\n v_addc_co_u32 %1, vcc, %1, %4, vcc\n v_addc_co_u32 %2, vcc, %2, %4, vcc\n v_addc_co_u32 %3, vcc, %3, %4, vcc\n"
+                                  "v_addc_co_u32 %0, vcc, %0, %4, vcc\n v_addc_co_u32 %1, vcc, %1, %4, vcc\n v_addc_co_u32 %2, vcc, %2, %4, vcc\n v_addc_co_u32 %3, vcc, %3, %4, vcc\n"
+                                  "v_addc_co_u32 %0, vcc, %0, %4, vcc\n v_addc_co_u32 %1, vcc, %1, %4, vcc\n v_addc_co_u32 %2, vcc, %2, %4, vcc\n v_addc_co_u32 %3, vcc, %3, %4, vcc\n"
+                                  "v_addc_co_u32 %0, vcc, %0, %4, vcc\n v_addc_co_u32 %1, vcc, %1, %4, vcc\n v_addc_co_u32 %2, vcc, %2, %4, vcc\n v_addc_co_u32 %3, vcc, %3, %4, vcc"
+                                  : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "v"(k) : "vcc");
+            }
+            if (OP == CND_E32_SMOV) {
+                asm volatile("s_mov_b64 vcc, 0x55555555" : : : "vcc");
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(r[DEP ? 0 : i]) : "v"(k) : "vcc");
+            }
+            if (OP == CND_E64_VCC) {
+                asm volatile("v_cmp_gt_u32 vcc, %0, %1\n s_nop 3" : : "v"(r[0]), "v"(k) : "vcc");
+#pragma unroll
+                for (int i = DEP ? 0 : 1; i < 16; ++i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(r[DEP ? 0 : i]) : "v"(k) : "vcc");
+            }
+            if (OP == CND_E64_VCMP) {
+                unsigned long long m;
+                asm volatile("v_cmp_gt_u32 %0, %1, %2\n s_nop 3" : "=s"(m) : "v"(r[0]), "v"(k));
+#pragma unroll
+                for (int i = DEP ? 0 : 1; i < 16; ++i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[DEP ? 0 : i]) : "v"(k), "s"(m));
             }
             if (OP == PAIR_MINMAX) {
                 // one compare-exchange of the sorting network: (a, b) -> (min, max); 8 exchanges on 16 registers = 16 instructions
@@ -133,7 +189,7 @@ static void run(long long* d_cycles, uint32_t* d_sink, int cus, double clock_rat
             CK(hipMemcpy(c.data(), d_cycles, sizeof(long long) * waves, hipMemcpyDeviceToHost));
             std::sort(c.begin(), c.end());
             // PAIR_MINMAX issues 24 instructions per 8 exchanges (min, max, mov); CNDMASK 16 selects + their compare
-            const double per_rep = OP == PAIR_MINMAX ? 24.0 * 4 : (OP == CNDMASK ? 17.0 * 4 : 64.0);
+            const double per_rep = OP == PAIR_MINMAX ? 24.0 * 4 : (OP == CNDMASK ? 17.0 * 4 : 64.0);   // (CNDMASK_SGPR: + one s_mov_b64 per 16, not counted)
             const double cyc = (double)c[waves / 2] * clock_ratio / (kReps * per_rep * w);
             // cross-check against the wall clock of the launch (includes ~5 us of launch): cycles at the nominal shader clock
             const double ev = (double)ms * 1e-3 * clock_khz * 1e3 / (kReps * per_rep * w);
@@ -175,5 +231,12 @@ int main() {
     run<PERM>(d_cycles, d_sink, cus, ratio, clk_khz);
     run<CNDMASK>(d_cycles, d_sink, cus, ratio, clk_khz);
     run<FMA_F32>(d_cycles, d_sink, cus, ratio, clk_khz);
+    run<CNDMASK_SGPR>(d_cycles, d_sink, cus, ratio, clk_khz);
+    run<CNDMASK_MIX>(d_cycles, d_sink, cus, ratio, clk_khz);
+    run<V_CMP>(d_cycles, d_sink, cus, ratio, clk_khz);
+    run<ADDC>(d_cycles, d_sink, cus, ratio, clk_khz);
+    run<CND_E32_SMOV>(d_cycles, d_sink, cus, ratio, clk_khz);
+    run<CND_E64_VCC>(d_cycles, d_sink, cus, ratio, clk_khz);
+    run<CND_E64_VCMP>(d_cycles, d_sink, cus, ratio, clk_khz);
     return 0;
 }
