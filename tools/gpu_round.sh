@@ -48,6 +48,7 @@ echo "== sorted cells: parity sweep"; timeout 900 python tools/sort_check.py 2>&
 echo "== LDS-DMA path ceiling"; timeout 300 ./tools/hbm_probe.bin 1000 --dma 2>&1 | tee gpurun_out/hbm_probe_dma.log | tail -4
 echo "== VALU issue rates"; timeout 300 ./tools/valu_probe.bin 2>&1 | tee gpurun_out/valu_probe.log | grep -E "pk_min|xor|alignbit" | head -6
 echo "== the copy + a sorted-cells step's VALU work: self-issued against a producer wave"; timeout 300 ./tools/hbm_probe.bin 1000 --dmawork > gpurun_out/hbm_probe_dmawork.log 2>&1; grep -E "16 KiB.*(1280|   0) pk_min" gpurun_out/hbm_probe_dmawork.log | head -8
+echo "== cycles to issue an LDS-DMA piece"; timeout 120 ./tools/hbm_probe.bin 1000 --vmemq > gpurun_out/hbm_probe_vmemq.log 2>&1; grep -E "lds +256 workgroup\(s\) x  8|stamps alone\) +1 workgroup\(s\) x  1" gpurun_out/hbm_probe_vmemq.log | cut -c1-200
 echo "== phase timeline of scv_sort_cells (measurement builds)"; timeout 600 python tools/sort_timeline.py 2>&1 | grep -v amdgpu.ids > gpurun_out/sort_timeline.log; timeout 600 python tools/sort_timeline.py --nospread 16 32 48 64 2>&1 | grep -v amdgpu.ids > gpurun_out/sort_timeline_nospread.log; tail -2 gpurun_out/sort_timeline.log | cut -c1-300
 echo "== prefix budgets over short pools"; timeout 600 python tools/prefix_small.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/prefix_small.log | tail -14
 echo "== host mode"; timeout 600 python tools/host_mode_bench.py 2>&1 | grep -v amdgpu | tee gpurun_out/host_mode.log | tail -12

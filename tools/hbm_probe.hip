@@ -15,6 +15,7 @@
 //   hbm_probe.bin [cells] --dma          the ceiling of the LDS-DMA input path of scv_sort_cells: waves that only copy 2-16 KiB blocks HBM -> LDS
 //   hbm_probe.bin [cells] --dmawork      ... with the VALU work of a sorted-cells step behind the copy: every wave copying for itself against one
 //                                        producer wave per workgroup (the design question of scv_sort_cells, round 4)
+//   hbm_probe.bin [cells] --vmemq        cycles a wave spends issuing its q-th LDS-DMA piece, back to back: where the memory pipe's queue is full
 //   hbm_probe.bin [cells] --calib        3 launches of ONE variant (read_cells_pipe<4>, grid 250 x 1024) and nothing
 //                                        else: run under `rocprofv3 --pmc FETCH_SIZE` to get FETCH_SIZE per launch
 //                                        for exactly cells * 4 MiB of algorithmic reads
@@ -265,6 +266,56 @@ __global__ void __launch_bounds__(1024) dma_work(const char* __restrict__ src, l
     if (acc == 0x12345678u) *sink = (int)acc;
 }
 
+// ---- how many LDS-DMA pieces does the memory pipe ACCEPT before a wave's next one blocks? (--vmemq) ----------------------------------------
+// Every wave issues P pieces back to back (1 KiB each, consecutive source addresses, all into the same 1 KiB of LDS: only the issue is
+// measured) and stamps s_memtime around each: cycles[wave][q] = time the q-th issue took.  With one wave on the chip the first pieces are
+// accepted in a few dozen cycles each; where the time per issue jumps to a memory latency, the queue in front of the wave is full.
+template <int KIND>   // 0: global_load_lds_dwordx4 (LDS-DMA) | 1: global_load_dwordx4 into VGPRs | 2: ... and a ds_write_b128 of an earlier quad after each | 3: the stamp alone | 4: buffer_load_dwordx4 ... lds
+__global__ void vmem_queue(const char* __restrict__ src, int pieces, long wave_stride, unsigned* cycles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const long wave = (long)blockIdx.x * nw + wid;
+    const unsigned lds0 = (unsigned)(unsigned long)(lds_uint*)lds_dyn + (unsigned)wid * 1024u;
+    const char* g = src + wave * wave_stride;
+    unsigned long long t = __builtin_readcyclecounter();
+    v4i r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = v4i{lane, i, 0, 0};
+    for (int q = 0; q < pieces; ++q) {
+        if (KIND == 0) dma_piece(g + (long)q * 1024, (unsigned)lane * 16u, (unsigned)__builtin_amdgcn_readfirstlane((int)lds0));
+        else if (KIND == 3) { }                                          // the stamp alone
+        else if (KIND == 4) {
+            // the MUBUF form: descriptor {base, stride 0, 2^32 - 1 bytes, raw 32-bit format} in four SGPRs, byte offset in a VGPR
+            const unsigned long long base = (unsigned long long)(g + (long)q * 1024);
+            const v4i rs = {(int)(unsigned)base, (int)(unsigned)(base >> 32) & 0xffff, -1, 0x00020000};
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"((unsigned)lane * 16u), "s"(rs), "s"((unsigned)__builtin_amdgcn_readfirstlane((int)lds0)) : "memory");
+        } else {
+            const char* gq = g + (long)q * 1024;
+            // (eight destination quads in rotation; the asm is opaque to hipcc: no waits of its own)
+            switch (q & 7) {
+#define LD(i) case i: asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(r[i]) : "v"((unsigned)lane * 16u), "s"(gq) : "memory"); \
+                      if (KIND == 2) asm volatile("ds_write_b128 %0, %1" : : "v"(lds0 + (unsigned)lane * 16u), "v"(r[(i + 4) & 7]) : "memory"); break;
+                LD(0) LD(1) LD(2) LD(3) LD(4) LD(5) LD(6) LD(7)
+#undef LD
+            }
+        }
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        if (lane == 0) cycles[wave * (pieces + 1) + q] = (unsigned)(t1 - t);
+        t = t1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (lane == 0) cycles[wave * (pieces + 1) + pieces] = (unsigned)(t1 - t);
+    if (KIND != 0) {
+        int acc = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc ^= r[i].x ^ r[i].y ^ r[i].z ^ r[i].w;
+        if (acc == 0x12345678) cycles[0] = (unsigned)acc;
+    }
+}
+
 __global__ void fill(v4i* dst, long nvec) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -291,7 +342,7 @@ double time_ms(F f, int reps = 5) {
 
 int main(int argc, char** argv) {
     long ncells = 10000;
-    bool calib = false, shortcells = false, quick = false, percu = false, dma = false, c2 = false, dmawork = false;
+    bool calib = false, shortcells = false, quick = false, percu = false, dma = false, c2 = false, dmawork = false, vmemq = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--calib")) calib = true;
         else if (!strcmp(argv[i], "--short")) shortcells = true;
@@ -299,6 +350,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--percu")) percu = true;
         else if (!strcmp(argv[i], "--dma")) dma = true;
         else if (!strcmp(argv[i], "--dmawork")) dmawork = true;
+        else if (!strcmp(argv[i], "--vmemq")) vmemq = true;
         else if (!strcmp(argv[i], "--c2")) c2 = true;
         else ncells = atol(argv[i]);
     }
@@ -314,6 +366,38 @@ int main(int argc, char** argv) {
             CK(hipDeviceSynchronize());
         }
         printf("calib: 3 launches of read_cells_pipe<4,nt> grid 250 x 1024, %ld bytes each\n", bytes);
+        return 0;
+    }
+    if (vmemq) {
+        printf("vmemq: cycles a wave spends ISSUING its q-th LDS-DMA piece (global_load_lds_dwordx4, 1 KiB), back to back; median over the waves; last column: the wait for all of them\n");
+        constexpr int P = 40;
+        unsigned* d_cyc;
+        CK(hipMalloc(&d_cyc, sizeof(unsigned) * 256 * 16 * (P + 1)));
+        for (int kind : {3, 0, 4, 1, 2})
+        for (int blocks : {1, 256}) {
+            for (int waves : {1, 4, 8, 16}) {
+                const int nwaves = blocks * waves;
+                for (int rep = 0; rep < 2; ++rep) {
+                    const char* src0 = (const char*)buf + (long)(rep + 2 * kind) * (256l << 20);
+                    if (kind == 0) vmem_queue<0><<<blocks, waves * 64, waves * 1024>>>(src0, P, (long)P * 1024, d_cyc);
+                    else if (kind == 1) vmem_queue<1><<<blocks, waves * 64, waves * 1024>>>(src0, P, (long)P * 1024, d_cyc);
+                    else if (kind == 2) vmem_queue<2><<<blocks, waves * 64, waves * 1024>>>(src0, P, (long)P * 1024, d_cyc);
+                    else if (kind == 3) vmem_queue<3><<<blocks, waves * 64, waves * 1024>>>(src0, P, (long)P * 1024, d_cyc);
+                    else vmem_queue<4><<<blocks, waves * 64, waves * 1024>>>(src0, P, (long)P * 1024, d_cyc);
+                    CK(hipDeviceSynchronize());
+                }
+                std::vector<unsigned> c((size_t)nwaves * (P + 1));
+                CK(hipMemcpy(c.data(), d_cyc, sizeof(unsigned) * c.size(), hipMemcpyDeviceToHost));
+                printf("vmemq %-22s %3d workgroup(s) x %2d waves:", kind == 0 ? "global_load_lds_dwordx4" : (kind == 1 ? "global_load_dwordx4" : (kind == 2 ? "load + ds_write_b128" : (kind == 3 ? "(the stamps alone)" : "buffer_load_dwordx4 lds"))), blocks, waves);
+                for (int q = 0; q <= P; ++q) {
+                    std::vector<unsigned> col(nwaves);
+                    for (int w = 0; w < nwaves; ++w) col[w] = c[(size_t)w * (P + 1) + q];
+                    std::sort(col.begin(), col.end());
+                    printf(q == P ? " | %u" : " %u", col[nwaves / 2]);
+                }
+                printf("\n");
+            }
+        }
         return 0;
     }
     if (dmawork) {
