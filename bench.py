@@ -104,12 +104,13 @@ def parse():
 
 # ---- the cpu_baseline leg: the only code here that touches oracle/ (test infrastructure) -------------------
 
-def check_cells_vs_c_oracle(gpu_cells, P_check, B, N, seed, dist, p_offset, tokens=None):
+def check_cells_vs_c_oracle(gpu_cells, P_check, B, N, seed, dist, p_offset, tokens=None, threads=0, fatal=True):
     """GPU cell table rows [0, P_check) of a chunk vs oracle/scv_oracle.c on the regenerated inputs, in slabs of
-    32 problems (1 GiB at N = 2^20) spread over the host cores.  Exits on the first differing field."""
+    32 problems (1 GiB at N = 2^20) spread over the host cores.  Exits on the first differing field (fatal=False: returns
+    (problems checked, message | None) instead, for the multi-rank lines where every rank reports before anyone leaves)."""
     import numpy as np
     from oracle import coracle
-    threads = min(os.cpu_count() or 1, 64)
+    threads = threads or min(os.cpu_count() or 1, 64)
     done = 0
     while done < P_check:
         n = min(32, P_check - done)
@@ -118,9 +119,77 @@ def check_cells_vs_c_oracle(gpu_cells, P_check, B, N, seed, dist, p_offset, toke
         assert want["rc"] == 0
         for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
             if not np.array_equal(gpu_cells[f][done:done + n], want["cells"][f]):
-                sys.exit(f"PARITY FAILURE field {f}: GPU cell table differs from the CPU oracle (problems {p_offset + done}..)")
+                row = int(np.flatnonzero((gpu_cells[f][done:done + n] != want["cells"][f]).any(axis=1))[0])
+                msg = f"PARITY FAILURE field {f}: GPU cell table differs from the CPU oracle (problem {p_offset + done + row}, chunk at {p_offset})"
+                if fatal:
+                    sys.exit(msg)
+                return done, msg
         done += n
-    return done
+    return (done, None) if not fatal else done
+
+
+# ---- the N > 1 line proves its own exchange step (BASELINE C4: "bit-exact at every GPU count"; o1.py:232-245) ----------------------
+
+RANK_PARITY_PROBLEMS = 32       # problems of EVERY rank's last timed chunk that go through the oracle (rank-local, in parallel)
+
+
+def injected_fault():
+    """TEST ONLY (tests/test_bench_contract.py): SCV_BENCH_FAULT="rank:word" flips one word of that rank's all-reduced buffer on the
+    host before the verification reads it -- what a stale peer read or a dropped rank would look like -- so the tests can see the
+    line refuse to print.  -> (rank, word) | None."""
+    spec = os.environ.get("SCV_BENCH_FAULT")
+    if not spec:
+        return None
+    r, w = spec.split(":")
+    return int(r), int(w)
+
+
+def first_difference(got, want):
+    """None when equal, else (flat index, got, want, number of differing words)."""
+    import numpy as np
+    got, want = np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)
+    if got.shape != want.shape:
+        return (-1, got.shape, want.shape, -1)
+    d = np.flatnonzero(got != want)
+    return None if d.size == 0 else (int(d[0]), int(got[d[0]]), int(want[d[0]]), int(d.size))
+
+
+def closed_form_check(counters_np, B, N, total_problems, dist_id):
+    """Distributions whose reduced counters are known in closed form, whatever the sharding: D2 (every vote of a problem is its
+    truth: each cell a strict win => tie_class_hits[b][1] = problems, truth_count_sum[b] = problems * N) and D5 (every vote is one
+    WRONG value: no hit anywhere, truth_count_sum = 0).  -> (description | None, message | None)."""
+    import numpy as np
+    if dist_id not in (2, 5):
+        return None, None
+    c = np.asarray(counters_np, dtype=np.int64)
+    tie = c[: B * 1025].reshape(B, 1025)
+    tcs = c[B * 1025 + B: B * 1025 + 2 * B]
+    if dist_id == 2:
+        want_tie1, want_tcs = total_problems, total_problems * N
+    else:
+        want_tie1, want_tcs = 0, 0
+    for b in range(B):
+        if int(tie[b, 1]) != want_tie1 or int(tie[b].sum()) != want_tie1 or int(tcs[b]) != want_tcs:
+            return None, (f"closed form of dist {dist_id} violated at budget {b}: tie_class_hits[b][1] = {int(tie[b, 1])} (want {want_tie1}), "
+                          f"row sum {int(tie[b].sum())}, truth_count_sum[b] = {int(tcs[b])} (want {want_tcs})")
+    return (f"D{dist_id}: tie_class_hits[b][1] == {want_tie1} (= ranks x problems per rank) and truth_count_sum[b] == {want_tcs} for all {B} budgets", None)
+
+
+def judge_exchange(rank, ncount, reduced_np, local_parts, gathered_cells_np=None, local_cell_parts=None):
+    """One rank's verdict on the exchange step: its all-reduced buffer vs the int64 numpy sum of every rank's PRE-reduce counters
+    (gathered by a path that is not the all-reduce under test), and for C5 its all-gathered cell table vs the ranks' own blocks."""
+    import numpy as np
+    msgs = []
+    want = np.sum(np.stack([np.asarray(p, dtype=np.int64)[:ncount] for p in local_parts]), axis=0, dtype=np.int64)
+    d = first_difference(np.asarray(reduced_np)[:ncount], want)
+    if d is not None:
+        msgs.append(f"rank {rank}: all-reduced counters != independently gathered sum: word {d[0]} holds {d[1]}, want {d[2]} ({d[3]} of {ncount} words differ)")
+    if gathered_cells_np is not None:
+        want_t = np.concatenate([np.asarray(c) for c in local_cell_parts], axis=0)
+        d = first_difference(np.asarray(gathered_cells_np).view(np.uint8), want_t.view(np.uint8))
+        if d is not None:
+            msgs.append(f"rank {rank}: all-gathered cell table != the ranks' own blocks: byte {d[0]} holds {d[1]}, want {d[2]} ({d[3]} bytes differ)")
+    return msgs, want
 
 
 def cpu_baseline(args, B, N, gpu_first_cells, first_off, gpu_last_cells, last_off, last_is_timed):
@@ -455,6 +524,7 @@ def main_single_process(args):
         if timed_slot is not None:
             with torch.cuda.device(cur[0].device):
                 ev[timed_slot][1].record()                      # ... and here its buffer holds the sum (waits for the slowest rank included)
+        c5_state["cur"] = cur                                   # every rank's buffer (each must hold the sum: verified after the timed region)
         return cur[0]
 
     def fence():
@@ -482,6 +552,69 @@ def main_single_process(args):
     exposed_us = None if c5 or args.steps == 0 else float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(args.steps)])) * 1e3
     last_off = slots[0][(args.warmup + args.steps - 1) % R][3] if args.steps > 0 else slots[0][0][3]
     last_cells = cells_from_torch(cells[0]) if not c5 else cells_from_torch(c5_state["last"][1])[: rows[0]]
+    # ---- the exchange step proves itself (outside the timed region): every rank's PRE-reduce counters of the last timed chunk are
+    # computed once more by a launch with no collective behind it, copied to the host rank by rank (plain D2H), summed in numpy
+    # int64, and compared word for word with the all-reduced buffer OF EVERY RANK; C5: every rank's gathered cell table and gathered
+    # resample table too.  Every rank's last chunk also goes through the oracle (RANK_PARITY_PROBLEMS problems each).
+    last_i = args.warmup + args.steps - 1
+    exchange, failures = None, []
+    if args.steps > 0:
+        locals_np, local_cells_np, rank_cells = [], [], []
+        for g, e in enumerate(mde.engines):
+            ans, tok, tr, _ = slots[g][0 if c5 else last_i % R]
+            with torch.cuda.device(ans.device):
+                lc = torch.zeros(ncount, dtype=torch.int64, device=ans.device)
+                lt = torch.empty((rows[g], B, 16), dtype=torch.uint8, device=ans.device)
+                if rows[g]:
+                    e.aggregate_device(ans, tr, tokens=tok, counters=lc, cells=lt, cell_tokens=ctok[g], overwrite=False)
+                e.sync()
+                locals_np.append(lc.cpu().numpy())
+                local_cells_np.append(lt.cpu().numpy())
+        if c5:
+            reduced = [c.cpu().numpy() for c in mde.last_c5["counters"]]
+            tables = [t.cpu().numpy() for t in mde.last_c5["tables"]]
+            boots = [b_.cpu().numpy() for b_ in mde.last_c5["boots"]]
+        else:
+            reduced = [c.cpu().numpy() for c in c5_state["cur"]]
+            tables = [None] * world
+        want_sum = None
+        fault = injected_fault()
+        if fault:
+            reduced[fault[0]] = reduced[fault[0]].copy()
+            reduced[fault[0]][fault[1]] += 1
+        for g in range(world):
+            msgs, want_sum = judge_exchange(g, ncount, reduced[g], locals_np, tables[g], local_cells_np if c5 else None)
+            failures += msgs
+            if c5 and first_difference(boots[g], boots[0]) is not None:
+                failures.append(f"rank {g}: gathered resample table differs from rank 0's")
+            if c5 and int(reduced[g][ncount]) != 0:
+                failures.append(f"rank {g}: summed device error word = {int(reduced[g][ncount])}")
+            rank_cells.append(cells_from_torch(torch.from_numpy(local_cells_np[g])))
+            if not c5 and first_difference(cells_from_torch(cells[g]).view(np.uint8), local_cells_np[g]) is not None:
+                failures.append(f"rank {g}: the cell table of the last timed step differs from the same chunk's re-run")
+        cf_what, cf_msg = closed_form_check(want_sum, B, N, args.problems if c5 else Pc * world, args.dist)
+        if cf_msg:
+            failures.append(cf_msg)
+        checked = 0
+        if not args.no_cpu_baseline:
+            for g in range(world):
+                p_off = slots[g][0 if c5 else last_i % R][3]
+                n, msg = check_cells_vs_c_oracle(rank_cells[g], min(RANK_PARITY_PROBLEMS, rows[g]), B, N, args.seed, args.dist, p_off, fatal=False)
+                checked += 1
+                if msg:
+                    failures.append(f"rank {g}: {msg}")
+        exchange = {
+            "allreduce_verified": not failures, "allreduce_words": ncount, "ranks_verified": world,
+            "how": "every rank's pre-reduce counters of the last timed chunk (a re-run of the chunk with no collective behind it), copied D2H rank by "
+                   "rank, summed in numpy int64 and compared word for word with the all-reduced buffer of EVERY rank"
+                   + ("; C5: every rank's all-gathered cell table vs the ranks' own blocks, every rank's gathered resample table vs rank 0's" if c5 else ""),
+            "parity_ranks_checked": checked, "parity_problems_per_rank": min(RANK_PARITY_PROBLEMS, min(rows)) if checked else 0,
+            "closed_form": cf_what,
+        }
+        if failures:
+            emit({"error": "EXCHANGE / PARITY FAILURE", "failures": failures[:8], "n_gpus": world, "value": None,
+                  "metric": "sample-votes/sec (problems x samples)", "allreduce_verified": False})
+            sys.exit(3)
     votes_per_step_per_gpu = Pc * B * N
     total_votes = (args.problems * B * N if c5 else votes_per_step_per_gpu * world) * args.steps
     bytes_per_launch = votes_per_step_per_gpu * BYTES_PER_VOTE * (2 if args.tokens else 1)
@@ -511,12 +644,16 @@ def main_single_process(args):
                      "exposed_allreduce_us": exposed_us,
                      "exposed_allreduce_what": "rank 0's stream, hipEvents: from the end of its vote kernel to its buffer holding the sum (waiting for the slowest rank included)"},
         "parity": None, "cpu_baseline": None,
+        "parity_ranks_checked": exchange["parity_ranks_checked"] if exchange else 0,
+        "allreduce_verified": bool(exchange and exchange["allreduce_verified"]),
+        "exchange_check": exchange,
         "accuracy_last_step": [round(final.accuracy(b), 6) for b in range(B)],
     }
-    if not args.no_cpu_baseline:
-        n = check_cells_vs_c_oracle(last_cells, min(16, last_cells.shape[0]), B, N, args.seed, args.dist, last_off)
+    if not args.no_cpu_baseline and exchange:
         n0 = check_cells_vs_c_oracle(first_cells, min(4, first_cells.shape[0]), B, N, args.seed, args.dist, slots[0][0][3])
-        out["parity"] = f"bit-exact: rank 0's first {n} problems x {B} budgets x {N} votes of the last timed chunk (+ {n0} of the sanity pass) vs oracle/scv_oracle.c"
+        out["parity"] = (f"bit-exact: EVERY rank's first {exchange['parity_problems_per_rank']} problems x {B} budgets x {N} votes of its last timed chunk "
+                         f"({world} ranks; + {n0} of rank 0's sanity pass) vs oracle/scv_oracle.c; all-reduced counters of every rank == the "
+                         f"independently gathered int64 sum ({ncount} words)")
         out["metric"] += ", bit-exact vs CPU (see parity)"
     else:
         out["metric"] += " (parity not checked in this run)"
@@ -582,6 +719,20 @@ def main():
             assert rccl_ranks == world, f"RCCL communicator has {rccl_ranks} ranks, expected {world}"
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # one collective of every kind the run will issue, BEFORE the resident chunks claim HBM: RCCL sizes its channel buffers and
+        # IPC mappings on first use, and the default c3 run leaves ~15 GB of 309 free (7 x 41.94 GB resident)
+        warm = torch.zeros(8 * 1027 + 1, dtype=torch.int64, device=dev)
+        dist.all_reduce(warm, op=dist.ReduceOp.SUM)
+        if args.backend == "nccl":
+            parts = [torch.empty(4096, dtype=torch.uint8, device=dev) for _ in range(world)]
+            dist.all_gather(parts, torch.zeros(4096, dtype=torch.uint8, device=dev))
+            parts = [torch.empty(512, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(parts, torch.zeros(512, dtype=torch.int64, device=dev))
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=dev), op=dist.ReduceOp.MAX)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        assert int(warm.abs().sum().item()) == 0
+        del warm
 
     from o1_inference_scaling_laws_amd import passk
     from o1_inference_scaling_laws_amd.dist import CounterPipeline, shard_bounds
@@ -721,8 +872,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_timed_in = "the timed region (hipEvents recorded by the library around every launch)"
-    # the cell table now holds the LAST TIMED step's chunk (c5: this rank's shard)
-    last_cells = cells_from_torch(cells) if rank == 0 else None
+    # the cell table now holds the LAST TIMED step's chunk (c5: this rank's shard); every rank keeps its own for the oracle
+    last_cells = cells_from_torch(cells)
+    last_host = None if last is None else last.cpu().numpy().copy()       # the reduced counters of the last TIMED step (the buffers are reused below)
     if split_timing:
         eng_t = Engine(device=local_rank, timing=True)
         eng_t.set_tuning(args.copies, args.threads, args.wg_per_cu, args.unroll)
@@ -752,6 +904,63 @@ def main():
         kern_avg_ns = kern_ns / max(launches, 1)
     last_slot = slots[(args.warmup + args.steps - 1) % R] if args.steps > 0 else slots[0]
 
+    # ---- the exchange step proves itself (outside the timed region; BASELINE C4 "bit-exact at every GPU count") -----------------
+    # Every rank (1) runs its last timed chunk once more into a fresh buffer with NO collective behind it = its PRE-reduce counters,
+    # (2) hands them to every other rank over a path that is not the all-reduce under test (a gloo group: pickled numpy over host TCP),
+    # (3) sums them in numpy int64 and compares word for word with ITS OWN all-reduced buffer of the last timed step, (4) sends
+    # RANK_PARITY_PROBLEMS problems of its last timed chunk through oracle/scv_oracle.c (rank-local, the ranks in parallel), and
+    # (5) the verdicts are exchanged so that every rank leaves with the same status; rank 0 names rank and word on a mismatch.
+    exchange = None
+    if (world > 1 or force) and args.steps > 0:
+        ncount = counters_size(B)
+        ans, tok, tr, p_off_last = last_slot
+        lc = torch.zeros(ncount, dtype=torch.int64, device=dev)
+        lt = torch.empty((Pc, B, 16), dtype=torch.uint8, device=dev)
+        if Pc:
+            eng.aggregate_device(ans, tr, tokens=tok, counters=lc, cells=lt, cell_tokens=ctok, overwrite=False)
+        eng.sync()
+        torch.cuda.synchronize(dev)
+        mine = {"rank": rank, "counters": lc.cpu().numpy(), "cells": lt.cpu().numpy() if c5 else None}
+        vg = None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+        parts = [None] * world
+        dist.all_gather_object(parts, mine, group=vg)
+        assert [p_["rank"] for p_ in parts] == list(range(world))
+        gathered_table = c5_state["last"].cells.cpu().numpy() if c5 else None
+        fault = injected_fault()
+        if fault and fault[0] == rank:
+            last_host = last_host.copy()
+            last_host[fault[1]] += 1
+        msgs, want_sum = judge_exchange(rank, ncount, last_host, [p_["counters"] for p_ in parts], gathered_table,
+                                        [p_["cells"] for p_ in parts] if c5 else None)
+        if first_difference(last_cells.view(np.uint8), mine["cells"] if c5 else lt.cpu().numpy()) is not None:
+            msgs.append(f"rank {rank}: the cell table of the last timed step differs from the same chunk's re-run")
+        cf_what, cf_msg = closed_form_check(want_sum, B, N, args.problems if c5 else Pc * world, args.dist)
+        if cf_msg:
+            msgs.append(f"rank {rank}: {cf_msg}")
+        n_checked = 0
+        if not args.no_cpu_baseline:
+            n_checked, msg = check_cells_vs_c_oracle(last_cells, min(RANK_PARITY_PROBLEMS, Pc), B, N, args.seed, args.dist, p_off_last,
+                                                     threads=max(1, min(64, (os.cpu_count() or 1) // world)), fatal=False)
+            if msg:
+                msgs.append(f"rank {rank}: {msg}")
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, {"rank": rank, "msgs": msgs, "checked": n_checked}, group=vg)
+        failures = [m for v in verdicts for m in v["msgs"]]
+        exchange = {
+            "allreduce_verified": not failures, "allreduce_words": ncount, "ranks_verified": world,
+            "how": "every rank: pre-reduce counters of its last timed chunk (a re-run of the chunk with no collective behind it) -> gloo "
+                   "all_gather_object (host TCP, not the all-reduce under test) -> numpy int64 sum == its own all-reduced buffer of the last "
+                   "TIMED step, word for word" + ("; C5: its all-gathered cell table == the ranks' own blocks" if c5 else ""),
+            "parity_ranks_checked": sum(1 for v in verdicts if v["checked"] > 0),
+            "parity_problems_per_rank": min(v["checked"] for v in verdicts),
+            "closed_form": cf_what,
+        }
+        if failures:
+            if rank == 0:
+                print(json.dumps({"error": "EXCHANGE / PARITY FAILURE", "failures": failures[:8], "n_gpus": world, "value": None,
+                                  "metric": "sample-votes/sec (problems x samples)", "allreduce_verified": False}), flush=True)
+            sys.exit(3)
+
     slots_span = f"{min(sl[3] for sl in slots)}..{max(sl[3] for sl in slots) + Pc - 1}" + (" interleaved over the ranks" if world > 1 else "")
     votes_per_step_per_gpu = Pc * B * N
     total_votes = (args.problems * B * N if c5 else votes_per_step_per_gpu * world) * args.steps
@@ -771,7 +980,7 @@ def main():
             ev["read_ceiling_gbs"] = live
             ev["read_ceiling_source"] = "tools/hbm_probe.bin --quick run by this process right after the timed region, same box (best of 4 read-only kernels)"
 
-    final = AggregateResult.from_counters(last.cpu().numpy(), Pc, B, num_problems=args.problems if c5 else Pc * world)
+    final = AggregateResult.from_counters(last_host[:counters_size(B)], Pc, B, num_problems=args.problems if c5 else Pc * world)
     if c5:
         workload = (f"C5: P={args.problems} x N={N} sharded by problem over {world} GPU(s) ({Pc} problems = {bytes_per_launch / 1e9:.2f} GB on rank 0); "
                     f"step = vote + counters all-reduce + cell all-gather + {args.resamples}-resample bootstrap (class bound M={c5_state['M']}; "
@@ -836,6 +1045,9 @@ def main():
             "read_ceiling_source": ev.get("read_ceiling_source"),
         },
         "parity": None,
+        "parity_ranks_checked": exchange["parity_ranks_checked"] if exchange else None,
+        "allreduce_verified": exchange["allreduce_verified"] if exchange else None,
+        "exchange_check": exchange,
         "accuracy_last_step": [round(final.accuracy(b), 6) for b in range(B)],
         "device": {"cus": eng.num_cus, "hbm_gb": round(eng.hbm_bytes / 1e9, 1)},
     }
@@ -843,9 +1055,10 @@ def main():
         if world == 1:
             out["parity"], out["cpu_baseline"] = cpu_baseline(args, B, N, first_cells, first_off, last_cells, last_slot[3], args.steps > 0)
         else:
-            # multi-rank lines carry no CPU baseline (contract: N = 1 only) but rank 0's shard is still checked
-            n = check_cells_vs_c_oracle(last_cells, min(16, last_cells.shape[0]), B, N, args.seed, args.dist, last_slot[3])
-            out["parity"] = f"bit-exact: rank 0's first {n} problems x {B} budgets x {N} votes of the last timed chunk vs oracle/scv_oracle.c"
+            # multi-rank lines carry no CPU baseline (contract: N = 1 only); EVERY rank's shard went through the oracle above
+            out["parity"] = (f"bit-exact: EVERY rank's first {exchange['parity_problems_per_rank']} problems x {B} budgets x {N} votes of its last timed "
+                             f"chunk ({exchange['parity_ranks_checked']} ranks, rank-local, in parallel) vs oracle/scv_oracle.c; all-reduced counters of "
+                             f"every rank == the independently gathered int64 sum ({counters_size(B)} words)") if exchange else None
             out["cpu_baseline"] = None
     elif rank == 0:
         out["cpu_baseline"] = None
@@ -858,6 +1071,17 @@ def main():
     if c5:
         d = c5_state["last"]
         boot_all = passk.gather_bootstrap(d, args.resamples, engine=eng)      # raises on every rank if any rank's device error word is set
+        if exchange is not None:
+            # the gathered resample table must be the same on every rank (rank 0's goes through the oracle below)
+            import hashlib
+            digests = [None] * world
+            dist.all_gather_object(digests, hashlib.sha256(boot_all.cpu().numpy().tobytes()).hexdigest(), group=vg)
+            if len(set(digests)) != 1:
+                if rank == 0:
+                    print(json.dumps({"error": "EXCHANGE FAILURE: the gathered resample table differs between ranks", "digests": digests,
+                                      "n_gpus": world, "value": None, "allreduce_verified": False}), flush=True)
+                sys.exit(3)
+            exchange["c5_resample_table_equal_on_every_rank"] = True
         if rank == 0:
             all_cells = cells_from_torch(d.cells)
             t1 = time.perf_counter()
@@ -878,7 +1102,7 @@ def main():
             if args.dump:
                 np.savez(args.dump, counters=d.counters.cpu().numpy(), cells=d.cells.cpu().numpy(), boot=boot_all.cpu().numpy())
     elif rank == 0 and args.dump:
-        np.savez(args.dump, counters=last.cpu().numpy())
+        np.savez(args.dump, counters=last_host)
     if rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()

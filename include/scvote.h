@@ -96,8 +96,8 @@ int scv_sync(scv_ctx* ctx);
 
 /*
  * Streaming-kernel geometry (for A/B measurement; 0 / negative = keep current).  By default the library picks the geometry
- * from the shape (measured bands); any explicit value here switches that off until
- * scv_set_option(ctx, "auto_geometry", 1).  Instantiated: (copies, threads) in (4, 256) with unroll 2; (8, 256) (8, 512)
+ * from the shape (measured bands); any explicit value here switches that off until ALL FOUR arguments are negative
+ * (scv_set_tuning(ctx, -1, -1, -1, -1): back to the library's own choice).  Instantiated: (copies, threads) in (4, 256) with unroll 2; (8, 256) (8, 512)
  * (16, 256) (16, 512) (16, 1024) with unroll 4 -- anything else is SCV_ERR_ARG.
  *   copies        LDS sub-histogram replication R        threads     workgroup size
  *   wg_per_cu     persistent workgroups per CU (clamped by LDS and wave capacity)
@@ -121,7 +121,6 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  *                         reduction (the cell kernels otherwise keep per-workgroup LDS tables and flush them in the same launch)
  *   "grid"                > 0: exact persistent grid (0: from the CU count, balanced so that all workgroups stream the same number of items)
  *   "segs"                split-N segments per cell (0 auto)
- *   "auto_geometry"       default 1; see scv_set_tuning
  *   "prefix_path"         scv_aggregate_prefix_i32: 0 auto | 1 one lane per problem, every budget out of one pass (pools <= 64) |
  *                         2 the cell kernels on pool rows (pools <= 4096) | 3 one streaming pass, a histogram snapshot per boundary
  *   "boot_path"           scv_aggregate_bootstrap_i32: 0 auto (ONE cooperative launch when the shape allows it) | 1 one ORDINARY launch |
@@ -129,6 +128,9 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  *   "boot_spin_limit"     default 2^20: polls at the grid barrier before a workgroup of an ordinary one-launch form gives up and leaves
  *                         the bootstrap to scv_sync; tests set 1
  *   "stage_mb"            HOST mode: chunk size of the staging pipeline (default 128)
+ *   "host_small_kb"       HOST mode: calls whose inputs + outputs fit in this many KiB (default 1024 -- every call the reference itself
+ *                         makes: P = 30, N <= 128, o1.py:277,302) skip the pipeline: one pinned block, one H2D, the kernel, one D2H, one
+ *                         stream sync, no threads and no per-call allocation; 0: every HOST call goes through the pipeline
  *   "copy_threads"        HOST mode: threads filling the pinned bounce slots (default 6)
  */
 int scv_set_option(scv_ctx* ctx, const char* key, int64_t value);
@@ -318,7 +320,9 @@ int scv_host_free(void* p);
  * "boot_recovered" (grid-barrier timeouts repaired by scv_sync with a separate bootstrap launch), "overwrite_fused" (counters
  * overwritten by the vote kernel's last workgroup), "lds_counters" (register-resident launches that produced their counters
  * themselves), "sort_cells" (sorted-cells launches), "few_votes" (launches of the kernel for cells of exactly 1, 2 or 4 votes), "prefix_cells" / "prefix_lane" (prefix calls served by the cell kernels / by
- * the one-lane-per-problem kernel). */
+ * the one-lane-per-problem kernel), "host_small_calls" / "host_pipelined_calls" (HOST-mode calls served by the one-block small path / by
+ * the staging pipeline), "host_thread_start_failures" (worker threads of the staging pipeline the system refused to start: the
+ * pipeline runs with the threads it has, the calling thread at least). */
 int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out);
 
 int scv_device_count(void);

@@ -17,6 +17,8 @@
 #include <functional>
 #include <mutex>
 #include <new>
+#include <stdexcept>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -30,6 +32,34 @@ int fail(int code, const char* fmt, ...) {
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
     return code;
+}
+
+// No C++ exception crosses the C ABI (include/scvote.h): every extern "C" body runs inside guarded().  What can throw
+// on the host side is the standard library (std::vector / std::function growth: std::bad_alloc; std::thread creation in a container
+// with a thread limit: std::system_error); all of it becomes an error code + message, never std::terminate in a ctypes caller.
+template <class F>
+int guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(SCV_ERR_ALLOC, "out of host memory (std::bad_alloc inside the library)");
+    } catch (const std::exception& e) {
+        return fail(SCV_ERR_ARG, "internal error: %s", e.what());
+    } catch (...) {
+        return fail(SCV_ERR_ARG, "internal error: unknown C++ exception");
+    }
+}
+
+// TEST HOOK (tests/test_gpu_parity.py): SCV_TEST_FAULT in the environment makes the HOST-mode staging path fail the way a
+// starved container would -- "thread": every worker-thread creation raises std::system_error (the pipeline must run on the calling
+// thread alone); "alloc": std::bad_alloc while the copy pieces are built; "throw": a std::runtime_error.  Read per HOST-mode call.
+int test_fault() {
+    const char* f = getenv("SCV_TEST_FAULT");
+    if (!f || !*f) return 0;
+    if (!strcmp(f, "thread")) return 1;
+    if (!strcmp(f, "alloc")) return 2;
+    if (!strcmp(f, "throw")) return 3;
+    return 0;
 }
 
 #define SCV_HIP(expr)                                                                              \
@@ -82,8 +112,19 @@ struct HostPipe {
             if (++jobs_done == jobs.size()) cv_done.notify_all();
         }
     }
-    void start(int nthreads) {
-        for (int i = (int)workers.size(); i < nthreads; ++i) workers.emplace_back([this] { worker_loop(); });
+    // Fewer threads than asked for is fine (run() makes the calling thread a worker too): a container at its thread limit raises
+    // std::system_error from std::thread's constructor; the pipeline then runs with the workers it already has, possibly none.
+    int start_failures = 0;
+    void start(int nthreads, bool fail_for_test = false) noexcept {
+        for (int i = (int)workers.size(); i < nthreads; ++i) {
+            try {
+                if (fail_for_test) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "test hook");
+                workers.emplace_back([this] { worker_loop(); });
+            } catch (const std::exception&) {
+                ++start_failures;
+                break;
+            }
+        }
     }
     // run the pieces on the workers (the caller takes pieces too) and return when all are done
     void run(std::vector<std::function<void()>>&& pieces) {
@@ -174,6 +215,13 @@ struct scv_ctx {
     void* d_stage = nullptr;
     size_t d_stage_bytes = 0;
     HostPipe* pipe = nullptr;       // HOST-mode ingestion pipeline (created on the first HOST call)
+    // HOST-mode small calls (everything the reference itself asks for: P = 30, N <= 128, o1.py:277,302): one pinned block and one
+    // HBM block owned by the ctx, allocated on the first small call
+    void* small_h = nullptr;
+    void* small_d = nullptr;
+    size_t small_bytes = 0;
+    int small_call_kb = 1024;       // option "host_small_kb": calls whose inputs + outputs fit in this many KiB take the small path (0: never)
+    int64_t stat_small_calls = 0, stat_pipelined_calls = 0;
 };
 
 namespace {
@@ -852,123 +900,144 @@ const char* scv_last_error(void) { return g_err; }
 const char* scv_version(void) { return "scvote 0.1 (gfx950)"; }
 
 int scv_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
+    return guarded([&]() -> int {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+        return n;
+    });
 }
 
 int scv_create(scv_ctx** out, int device, uint32_t flags) {
-    if (!out) return fail(SCV_ERR_ARG, "scv_create: out is NULL");
-    *out = nullptr;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SCV_ERR_NO_DEVICE, "no HIP device visible");
-    if (device < 0) { SCV_HIP(hipGetDevice(&device)); }
-    if (device >= n) return fail(SCV_ERR_ARG, "device %d out of range (%d visible)", device, n);
-    scv_ctx* ctx = new (std::nothrow) scv_ctx();
-    if (!ctx) return fail(SCV_ERR_ALLOC, "out of host memory");
-    ctx->device = device;
-    ctx->flags = flags;
-    DeviceGuard guard_;                       // restores the caller's current device on every return path
-    hipError_t e = guard_.enter(device) == SCV_OK ? hipSuccess : hipErrorInvalidDevice;
-    hipDeviceProp_t prop;
-    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) { ctx->own_stream = true; e = hipMalloc((void**)&ctx->d_err, 256); }
-    if (e == hipSuccess) e = hipMemset(ctx->d_err, 0, 256);
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_tickets, kTicketWords * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(ctx->d_tickets, 0, kTicketWords * sizeof(uint32_t));
-    if (e == hipSuccess) { ctx->d_tickets_words = kTicketWords; e = hipDeviceSynchronize(); }
-    if (e != hipSuccess) {
-        int code = fail(-(int)e, "scv_create: %s", hipGetErrorString(e));
-        if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
-        if (ctx->d_err) (void)hipFree(ctx->d_err);
-        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-        delete ctx;
-        return code;
-    }
-    ctx->num_cus = prop.multiProcessorCount;
-    ctx->lds_max = 160 * 1024;  // gfx950: a single workgroup may declare all 160 KiB
-    ctx->clock_khz = prop.clockRate;
-    ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
-    *out = ctx;
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!out) return fail(SCV_ERR_ARG, "scv_create: out is NULL");
+        *out = nullptr;
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SCV_ERR_NO_DEVICE, "no HIP device visible");
+        if (device < 0) { SCV_HIP(hipGetDevice(&device)); }
+        if (device >= n) return fail(SCV_ERR_ARG, "device %d out of range (%d visible)", device, n);
+        scv_ctx* ctx = new (std::nothrow) scv_ctx();
+        if (!ctx) return fail(SCV_ERR_ALLOC, "out of host memory");
+        ctx->device = device;
+        ctx->flags = flags;
+        DeviceGuard guard_;                       // restores the caller's current device on every return path
+        hipError_t e = guard_.enter(device) == SCV_OK ? hipSuccess : hipErrorInvalidDevice;
+        hipDeviceProp_t prop;
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) { ctx->own_stream = true; e = hipMalloc((void**)&ctx->d_err, 256); }
+        if (e == hipSuccess) e = hipMemset(ctx->d_err, 0, 256);
+        if (e == hipSuccess) e = hipMalloc(&ctx->d_tickets, kTicketWords * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(ctx->d_tickets, 0, kTicketWords * sizeof(uint32_t));
+        if (e == hipSuccess) { ctx->d_tickets_words = kTicketWords; e = hipDeviceSynchronize(); }
+        if (e != hipSuccess) {
+            int code = fail(-(int)e, "scv_create: %s", hipGetErrorString(e));
+            if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
+            if (ctx->d_err) (void)hipFree(ctx->d_err);
+            if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return code;
+        }
+        ctx->num_cus = prop.multiProcessorCount;
+        ctx->lds_max = 160 * 1024;  // gfx950: a single workgroup may declare all 160 KiB
+        ctx->clock_khz = prop.clockRate;
+        ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
+        *out = ctx;
+        return SCV_OK;
+    });
 }
 
 int scv_destroy(scv_ctx* ctx) {
-    if (!ctx) return SCV_OK;
-    DeviceGuard guard_;
-    (void)guard_.enter(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    if (ctx->pipe) { ctx->pipe->shutdown(); delete ctx->pipe; ctx->pipe = nullptr; }
-    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
-    if (ctx->d_partial) (void)hipFree(ctx->d_partial);
-    if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
-    if (ctx->d_cells) (void)hipFree(ctx->d_cells);
-    if (ctx->d_err) (void)hipFree(ctx->d_err);
-    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!ctx) return SCV_OK;
+        DeviceGuard guard_;
+        (void)guard_.enter(ctx->device);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+        if (ctx->pipe) { ctx->pipe->shutdown(); delete ctx->pipe; ctx->pipe = nullptr; }
+        if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+        if (ctx->small_h) (void)hipHostFree(ctx->small_h);
+        if (ctx->small_d) (void)hipFree(ctx->small_d);
+        if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+        if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
+        if (ctx->d_cells) (void)hipFree(ctx->d_cells);
+        if (ctx->d_err) (void)hipFree(ctx->d_err);
+        if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return SCV_OK;
+    });
 }
 
 int scv_set_stream(scv_ctx* ctx, void* hip_stream) {
-    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
-    SCV_ENTER(ctx);
-    // No synchronisation here (same contract as any set-stream call: ordering between the old and the
-    // new stream is the caller's): a sync would be illegal while the new stream is being captured
-    // into a hipGraph.  Only the ctx's own private stream is drained before it is destroyed.
-    if (ctx->own_stream) {
-        SCV_HIP(hipStreamSynchronize(ctx->stream));
-        SCV_HIP(hipStreamDestroy(ctx->stream));
-        ctx->own_stream = false;
-    }
-    ctx->stream = (hipStream_t)hip_stream;  // borrowed; NULL is the device's default stream
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+        SCV_ENTER(ctx);
+        // No synchronisation here (same contract as any set-stream call: ordering between the old and the
+        // new stream is the caller's): a sync would be illegal while the new stream is being captured
+        // into a hipGraph.  Only the ctx's own private stream is drained before it is destroyed.
+        if (ctx->own_stream) {
+            SCV_HIP(hipStreamSynchronize(ctx->stream));
+            SCV_HIP(hipStreamDestroy(ctx->stream));
+            ctx->own_stream = false;
+        }
+        ctx->stream = (hipStream_t)hip_stream;  // borrowed; NULL is the device's default stream
+        return SCV_OK;
+    });
 }
 
 int scv_sync(scv_ctx* ctx) {
-    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
-    SCV_ENTER(ctx);
-    SCV_HIP(hipStreamSynchronize(ctx->stream));
-    uint32_t w = 0;
-    // always read the word (4 bytes): a hot path captured into a hipGraph is replayed without passing
-    // through launch_aggregate, so the host-side dirty flag says nothing about replays
-    if (int rc = fetch_err(ctx, &w, true)) return rc;
-    return check_err_word(ctx, w);
+    return guarded([&]() -> int {
+        if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+        SCV_ENTER(ctx);
+        SCV_HIP(hipStreamSynchronize(ctx->stream));
+        uint32_t w = 0;
+        // always read the word (4 bytes): a hot path captured into a hipGraph is replayed without passing
+        // through launch_aggregate, so the host-side dirty flag says nothing about replays
+        if (int rc = fetch_err(ctx, &w, true)) return rc;
+        return check_err_word(ctx, w);
+    });
 }
 
 int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unroll) {
-    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
-    const int c = copies > 0 ? copies : ctx->copies, t = threads > 0 ? threads : ctx->threads, u = unroll > 0 ? unroll : ctx->unroll;
-    if (copies > 0 || threads > 0 || unroll > 0)
-        if (!scv::pick_kernel(c, t, u, false, false))
-            return fail(SCV_ERR_ARG, "streaming geometry copies=%d threads=%d unroll=%d is not instantiated: (copies, threads) in (4, 256) [unroll 2], "
-                        "(8, 256) (8, 512) (16, 256) (16, 512) (16, 1024) [unroll 4]", c, t, u);
-    ctx->copies = c; ctx->threads = t; ctx->unroll = u;
-    if (wg_per_cu > 0) ctx->wg_per_cu = wg_per_cu;
-    if (copies > 0 || threads > 0 || wg_per_cu > 0 || unroll > 0) ctx->user_tuned = true;   // explicit geometry wins over the auto choice
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+        if (copies < 0 && threads < 0 && wg_per_cu < 0 && unroll < 0) {      // all four negative: the library picks the geometry from the shape again
+            ctx->copies = 16; ctx->threads = 1024; ctx->wg_per_cu = 1; ctx->unroll = 4;
+            ctx->user_tuned = false;
+            return SCV_OK;
+        }
+        const int c = copies > 0 ? copies : ctx->copies, t = threads > 0 ? threads : ctx->threads, u = unroll > 0 ? unroll : ctx->unroll;
+        if (copies > 0 || threads > 0 || unroll > 0)
+            if (!scv::pick_kernel(c, t, u, false, false))
+                return fail(SCV_ERR_ARG, "streaming geometry copies=%d threads=%d unroll=%d is not instantiated: (copies, threads) in (4, 256) [unroll 2], "
+                            "(8, 256) (8, 512) (16, 256) (16, 512) (16, 1024) [unroll 4]", c, t, u);
+        ctx->copies = c; ctx->threads = t; ctx->unroll = u;
+        if (wg_per_cu > 0) ctx->wg_per_cu = wg_per_cu;
+        if (copies > 0 || threads > 0 || wg_per_cu > 0 || unroll > 0) ctx->user_tuned = true;   // explicit geometry wins over the auto choice
+        return SCV_OK;
+    });
 }
 
 int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
-    if (!ctx || !key) return fail(SCV_ERR_ARG, "NULL argument");
-    if (!strcmp(key, "overwrite_counters")) ctx->overwrite_counters = value != 0;
-    else if (!strcmp(key, "path")) { if (value < 0 || value > 5 || value == 3) return fail(SCV_ERR_ARG, "path must be 0, 1, 2, 4 or 5"); ctx->path = (int)value; }
-    else if (!strcmp(key, "sort_n_min")) { if (value < 1 || value > 65) return fail(SCV_ERR_ARG, "sort_n_min must be 1..65"); ctx->sort_n_min = (int)value; }
-    else if (!strcmp(key, "sort_n_max")) { if (value < 0 || value > 64) return fail(SCV_ERR_ARG, "sort_n_max must be 0..64"); ctx->sort_n_max = (int)value; }
-    else if (!strcmp(key, "reg_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "reg_n_max < 0"); ctx->reg_n_max = (int)(value > 8192 ? 8192 : value); }
-    else if (!strcmp(key, "reg_shape")) { if (value < 0 || value > 9999) return fail(SCV_ERR_ARG, "reg_shape out of range"); ctx->reg_shape = (int)value; }
-    else if (!strcmp(key, "fused_counters_max")) { if (value < 0) return fail(SCV_ERR_ARG, "fused_counters_max < 0"); ctx->fused_counters_max = (int)(value > (1 << 30) ? (1 << 30) : value); }
-    else if (!strcmp(key, "grid")) { if (value < 0 || value > (1 << 20)) return fail(SCV_ERR_ARG, "grid out of range"); ctx->grid_override = (int)value; }
-    else if (!strcmp(key, "segs")) { if (value < 0 || value > 4096) return fail(SCV_ERR_ARG, "segs out of range"); ctx->segs_override = (int)value; }
-    else if (!strcmp(key, "auto_geometry")) ctx->user_tuned = value == 0;
-    else if (!strcmp(key, "prefix_path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "prefix_path must be 0..3"); ctx->prefix_path = (int)value; }
-    else if (!strcmp(key, "boot_path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "boot_path must be 0..3"); ctx->boot_path = (int)value; }
-    else if (!strcmp(key, "boot_spin_limit")) { if (value < 1 || value > (1 << 30)) return fail(SCV_ERR_ARG, "boot_spin_limit out of range"); ctx->boot_spin_limit = (int)value; }
-    else if (!strcmp(key, "stage_mb")) { if (value < 1 || value > 65536) return fail(SCV_ERR_ARG, "stage_mb out of range"); ctx->stage_mb = (int)value; }
-    else if (!strcmp(key, "copy_threads")) { if (value < 1 || value > 256) return fail(SCV_ERR_ARG, "copy_threads out of range"); ctx->copy_threads = (int)value; }
-    else return fail(SCV_ERR_ARG, "unknown option '%s'", key);
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!ctx || !key) return fail(SCV_ERR_ARG, "NULL argument");
+        if (!strcmp(key, "overwrite_counters")) ctx->overwrite_counters = value != 0;
+        else if (!strcmp(key, "path")) { if (value < 0 || value > 5 || value == 3) return fail(SCV_ERR_ARG, "path must be 0, 1, 2, 4 or 5"); ctx->path = (int)value; }
+        else if (!strcmp(key, "sort_n_min")) { if (value < 1 || value > 65) return fail(SCV_ERR_ARG, "sort_n_min must be 1..65"); ctx->sort_n_min = (int)value; }
+        else if (!strcmp(key, "sort_n_max")) { if (value < 0 || value > 64) return fail(SCV_ERR_ARG, "sort_n_max must be 0..64"); ctx->sort_n_max = (int)value; }
+        else if (!strcmp(key, "reg_n_max")) { if (value < 0) return fail(SCV_ERR_ARG, "reg_n_max < 0"); ctx->reg_n_max = (int)(value > 8192 ? 8192 : value); }
+        else if (!strcmp(key, "reg_shape")) { if (value < 0 || value > 9999) return fail(SCV_ERR_ARG, "reg_shape out of range"); ctx->reg_shape = (int)value; }
+        else if (!strcmp(key, "fused_counters_max")) { if (value < 0) return fail(SCV_ERR_ARG, "fused_counters_max < 0"); ctx->fused_counters_max = (int)(value > (1 << 30) ? (1 << 30) : value); }
+        else if (!strcmp(key, "grid")) { if (value < 0 || value > (1 << 20)) return fail(SCV_ERR_ARG, "grid out of range"); ctx->grid_override = (int)value; }
+        else if (!strcmp(key, "segs")) { if (value < 0 || value > 4096) return fail(SCV_ERR_ARG, "segs out of range"); ctx->segs_override = (int)value; }
+        else if (!strcmp(key, "prefix_path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "prefix_path must be 0..3"); ctx->prefix_path = (int)value; }
+        else if (!strcmp(key, "boot_path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "boot_path must be 0..3"); ctx->boot_path = (int)value; }
+        else if (!strcmp(key, "boot_spin_limit")) { if (value < 1 || value > (1 << 30)) return fail(SCV_ERR_ARG, "boot_spin_limit out of range"); ctx->boot_spin_limit = (int)value; }
+        else if (!strcmp(key, "stage_mb")) { if (value < 1 || value > 65536) return fail(SCV_ERR_ARG, "stage_mb out of range"); ctx->stage_mb = (int)value; }
+        else if (!strcmp(key, "host_small_kb")) { if (value < 0 || value > (1 << 20)) return fail(SCV_ERR_ARG, "host_small_kb out of range"); ctx->small_call_kb = (int)value; }
+        else if (!strcmp(key, "copy_threads")) { if (value < 1 || value > 256) return fail(SCV_ERR_ARG, "copy_threads out of range"); ctx->copy_threads = (int)value; }
+        else return fail(SCV_ERR_ARG, "unknown option '%s'", key);
+        return SCV_OK;
+    });
 }
 
 }  // extern "C" (reopened below)
@@ -996,7 +1065,7 @@ int ensure_pipe(scv_ctx* ctx, size_t bounce_bytes, size_t dslot_bytes) {
     int nthreads = ctx->copy_threads - 1;                      // the calling thread copies too
     const int hw = (int)std::thread::hardware_concurrency();
     if (hw > 0 && nthreads > hw - 1) nthreads = hw - 1;
-    if (nthreads > 0) hp->start(nthreads);
+    if (nthreads > 0) hp->start(nthreads, test_fault() == 1);
     if (bounce_bytes > hp->bounce_bytes) {
         for (int k = 0; k < HostPipe::kSlots; ++k) {
             if (hp->bounce[k]) { SCV_HIP(hipHostFree(hp->bounce[k])); hp->bounce[k] = nullptr; }
@@ -1090,6 +1159,7 @@ int host_pipelined(scv_ctx* ctx, bool prefix, const int32_t* answers, const int3
         char* db = static_cast<char*>(hp->dslot[k]);
         // stage 1: caller memory -> pinned bounce slot (worker threads); overlaps the DMA of the previous chunk
         std::vector<std::function<void()>> pieces;
+        if (const int tf = test_fault(); tf >= 2) { if (tf == 2) throw std::bad_alloc(); throw std::runtime_error("test hook: SCV_TEST_FAULT=throw"); }
         if (!pin_a) add_copy_pieces(pieces, bb + o_ans, answers + (size_t)p0 * row_elems, (size_t)pc * row_bytes, parts);
         if (tokens && !pin_t) add_copy_pieces(pieces, bb + o_tok, tokens + (size_t)p0 * row_elems, (size_t)pc * row_bytes, parts);
         memcpy(bb + o_truth, truth + p0, (size_t)pc * sizeof(int32_t));
@@ -1131,6 +1201,80 @@ int host_pipelined(scv_ctx* ctx, bool prefix, const int32_t* answers, const int3
     return check_err_word(ctx, w);
 }
 
+// HOST mode, small calls.  Every call the reference itself makes is tiny (P = 30 problems, N <= 128 samples, o1.py:277,302: a 15 KB
+// tensor and a 10 us kernel), and the three-stage pipeline above -- built for GB-sized inputs -- cost it 0.25-0.4 ms of thread
+// hand-offs, events and per-chunk copies.  Here the whole call is ONE pinned block and ONE HBM block owned by the ctx:
+//     [ answers | tokens | truth | n_valid | counters = 0 | error word = 0 | cells | cell_tokens ]
+//       `---------------- one H2D -------------------------------------'
+//                                            `------------------- one D2H ------------------------'
+// host memcpy in, one hipMemcpyAsync, the kernel, one hipMemcpyAsync back, one stream sync, host memcpy out.  No worker threads,
+// no bounce slots, no per-call allocation; the kernels' error flag points into the block for the duration of the call, so the word
+// arrives with the results and is zero again on the next call without a memset.
+int host_small(scv_ctx* ctx, bool prefix, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
+               const int32_t* truth, int64_t P, int32_t B, int64_t N, scv_cell* cells_out, int64_t* cell_tokens_out,
+               int64_t* tie_class_hits_out, int64_t* token_sum_out, int64_t* truth_count_sum_out, bool* taken) {
+    *taken = false;
+    if (ctx->small_call_kb <= 0 || P <= 0 || B <= 0) return SCV_OK;
+    const size_t votes_bytes = (size_t)P * (prefix ? (size_t)1 : (size_t)B) * (size_t)N * sizeof(int32_t);
+    const size_t counters_bytes = ((size_t)B * SCV_TIE_CLASSES + 2 * (size_t)B) * sizeof(int64_t);
+    size_t off = 0;
+    const size_t o_ans = off; off = align_up(off + votes_bytes, 256);
+    const size_t o_tok = off; off = align_up(off + (tokens ? votes_bytes : 0), 256);
+    const size_t o_truth = off; off = align_up(off + (size_t)P * sizeof(int32_t), 256);
+    const size_t o_nv = off; off = align_up(off + (size_t)B * sizeof(int32_t), 256);
+    const size_t o_cnt = off; off = align_up(off + counters_bytes, 256);
+    const size_t o_err = off; off += 256;
+    const size_t h2d_bytes = off;
+    const size_t o_cells = off; off = align_up(off + (size_t)P * B * sizeof(scv_cell), 256);
+    const size_t o_ctok = off; off = align_up(off + (tokens ? (size_t)P * B * sizeof(int64_t) : 0), 256);
+    const size_t total = off;
+    if (total > (size_t)ctx->small_call_kb << 10) return SCV_OK;
+    if (total > ctx->small_bytes) {
+        const size_t want = ((size_t)ctx->small_call_kb << 10) > total ? ((size_t)ctx->small_call_kb << 10) : total;
+        if (ctx->small_h) { SCV_HIP(hipHostFree(ctx->small_h)); ctx->small_h = nullptr; }
+        if (ctx->small_d) { SCV_HIP(hipFree(ctx->small_d)); ctx->small_d = nullptr; }
+        ctx->small_bytes = 0;
+        SCV_HIP(hipHostMalloc(&ctx->small_h, want, hipHostMallocDefault));
+        SCV_HIP(hipMalloc(&ctx->small_d, want));
+        ctx->small_bytes = want;
+    }
+    *taken = true;
+    ctx->stat_small_calls += 1;
+    char* hb = static_cast<char*>(ctx->small_h);
+    char* db = static_cast<char*>(ctx->small_d);
+    if (votes_bytes) memcpy(hb + o_ans, answers, votes_bytes);
+    if (tokens && votes_bytes) memcpy(hb + o_tok, tokens, votes_bytes);
+    memcpy(hb + o_truth, truth, (size_t)P * sizeof(int32_t));
+    if (n_valid) memcpy(hb + o_nv, n_valid, (size_t)B * sizeof(int32_t));
+    memset(hb + o_cnt, 0, o_err + 256 - o_cnt);                       // counters + error word start at zero on the device too
+    hipStream_t s = ctx->stream;
+    SCV_HIP(hipMemcpyAsync(db, hb, h2d_bytes, hipMemcpyHostToDevice, s));
+    int64_t* d_tie = reinterpret_cast<int64_t*>(db + o_cnt);
+    int64_t* d_tok = d_tie + (size_t)B * SCV_TIE_CLASSES;
+    int64_t* d_ts = d_tok + B;
+    // the kernels report into the block's own error word for this call (restored on every path)
+    struct ErrSwap { scv_ctx* c; uint32_t* keep; bool dirty; ~ErrSwap() { c->d_err = keep; c->err_dirty = dirty; } } swap{ctx, ctx->d_err, ctx->err_dirty};
+    ctx->d_err = reinterpret_cast<uint32_t*>(db + o_err);
+    auto launch = prefix ? launch_prefix : launch_dense;
+    if (int rc = launch(ctx, reinterpret_cast<const int32_t*>(db + o_ans), tokens ? reinterpret_cast<const int32_t*>(db + o_tok) : nullptr,
+                        n_valid ? reinterpret_cast<const int32_t*>(db + o_nv) : nullptr, reinterpret_cast<const int32_t*>(db + o_truth), P, B, N,
+                        reinterpret_cast<scv_cell*>(db + o_cells), tokens ? reinterpret_cast<int64_t*>(db + o_ctok) : nullptr, d_tie, d_tok, d_ts)) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    const bool want_cells = cells_out || cell_tokens_out;
+    SCV_HIP(hipMemcpyAsync(hb + o_cnt, db + o_cnt, (want_cells ? total : o_cells) - o_cnt, hipMemcpyDeviceToHost, s));
+    SCV_HIP(hipStreamSynchronize(s));
+    uint32_t w = 0;
+    memcpy(&w, hb + o_err, sizeof w);
+    if (tie_class_hits_out) memcpy(tie_class_hits_out, hb + o_cnt, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t));
+    if (token_sum_out) memcpy(token_sum_out, hb + o_cnt + (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), (size_t)B * sizeof(int64_t));
+    if (truth_count_sum_out) memcpy(truth_count_sum_out, hb + o_cnt + ((size_t)B * SCV_TIE_CLASSES + B) * sizeof(int64_t), (size_t)B * sizeof(int64_t));
+    if (cells_out) memcpy(cells_out, hb + o_cells, (size_t)P * B * sizeof(scv_cell));
+    if (cell_tokens_out && tokens) memcpy(cell_tokens_out, hb + o_ctok, (size_t)P * B * sizeof(int64_t));
+    return check_err_word(ctx, w);
+}
+
 // Shared body of scv_aggregate_i32 (dense: rows of B*N votes per problem) and
 // scv_aggregate_prefix_i32 (prefix: one row of N votes per problem).
 int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
@@ -1155,6 +1299,11 @@ int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const in
     // HOST mode accumulates its own zeroed counters over the chunks: the DEVICE-mode overwrite option must not apply
     struct Restore { scv_ctx* c; int v; ~Restore() { c->overwrite_counters = v; } } restore{ctx, ctx->overwrite_counters};
     ctx->overwrite_counters = 0;
+    bool small = false;
+    if (int rc = host_small(ctx, prefix, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
+                            tie_class_hits_out, token_sum_out, truth_count_sum_out, &small)) return rc;
+    if (small) return SCV_OK;
+    ctx->stat_pipelined_calls += 1;
     return host_pipelined(ctx, prefix, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
                           tie_class_hits_out, token_sum_out, truth_count_sum_out);
 }
@@ -1167,61 +1316,67 @@ int scv_aggregate_i32(scv_ctx* ctx, const int32_t* answers, const int32_t* token
                       const int32_t* truth, int64_t P, int32_t B, int64_t N, int mem_kind, scv_cell* cells_out,
                       int64_t* cell_tokens_out, int64_t* tie_class_hits_out, int64_t* token_sum_out,
                       int64_t* truth_count_sum_out) {
-    return aggregate_common(ctx, false, answers, tokens, n_valid, truth, P, B, N, mem_kind, cells_out, cell_tokens_out,
-                            tie_class_hits_out, token_sum_out, truth_count_sum_out);
+    return guarded([&]() -> int {
+        return aggregate_common(ctx, false, answers, tokens, n_valid, truth, P, B, N, mem_kind, cells_out, cell_tokens_out,
+                                tie_class_hits_out, token_sum_out, truth_count_sum_out);
+    });
 }
 
 int scv_aggregate_prefix_i32(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, const int32_t* n_valid,
                              const int32_t* truth, int64_t P, int32_t B, int64_t N, int mem_kind, scv_cell* cells_out,
                              int64_t* cell_tokens_out, int64_t* tie_class_hits_out, int64_t* token_sum_out,
                              int64_t* truth_count_sum_out) {
-    return aggregate_common(ctx, true, pool, tokens, n_valid, truth, P, B, N, mem_kind, cells_out, cell_tokens_out,
-                            tie_class_hits_out, token_sum_out, truth_count_sum_out);
+    return guarded([&]() -> int {
+        return aggregate_common(ctx, true, pool, tokens, n_valid, truth, P, B, N, mem_kind, cells_out, cell_tokens_out,
+                                tie_class_hits_out, token_sum_out, truth_count_sum_out);
+    });
 }
 
 int scv_bootstrap(scv_ctx* ctx, const scv_cell* cells, int64_t P, int32_t B, int32_t r_begin, int32_t r_end,
                   uint64_t seed, int32_t M, int mem_kind, int64_t* counts_out) {
-    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
-    if (!cells || !counts_out) return fail(SCV_ERR_ARG, "bootstrap: NULL pointer");
-    if (P <= 0 || P > 0xFFFFFFFFll || B <= 0 || M <= 0 || r_end < r_begin || r_begin < 0)
-        return fail(SCV_ERR_ARG, "bootstrap: bad shape P=%lld B=%d M=%d r=[%d,%d)", (long long)P, B, M, r_begin, r_end);
-    const size_t lds = (size_t)B * M * sizeof(uint32_t);
-    if (lds > 64 * 1024) return fail(SCV_ERR_ARG, "bootstrap: B*M=%lld counters exceed 64 KiB of LDS", (long long)B * M);
-    if (mem_kind != SCV_MEM_HOST && mem_kind != SCV_MEM_DEVICE) return fail(SCV_ERR_ARG, "bad mem_kind %d", mem_kind);
-    SCV_ENTER(ctx);
-    const int32_t R = r_end - r_begin;
-    if (R == 0) return SCV_OK;
-    hipStream_t s = ctx->stream;
-    const size_t out_bytes = (size_t)R * B * M * sizeof(int64_t);
-    // LDS-resident kernel when the 2-byte code table + counters fit (P * B up to ~70 k cells); otherwise the
-    // global-gather kernel.  "boot_path" = 3 forces the latter (parity tests).
-    const size_t lds_fast = (((size_t)B * M + 3) & ~(size_t)3) * sizeof(uint32_t) + (((size_t)P * B + 7) & ~(size_t)7) * sizeof(uint16_t);
-    const bool fast = ctx->boot_path != 3 && lds_fast <= (size_t)144 * 1024;
-    auto launch_boot = [&](const scv_cell* d_cells, unsigned long long* d_out) -> int {
-        if (fast) {
-            int64_t grid = (int64_t)ctx->num_cus;                          // one 1024-thread workgroup per CU, R / grid resamples each
-            if (grid > R) grid = R;
-            SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scv::scv_bootstrap_lds_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast));
-            hipLaunchKernelGGL(scv::scv_bootstrap_lds_k, dim3((unsigned)grid), dim3(1024), lds_fast, s, d_cells, P, B, r_begin, r_end, seed, M, d_out, ctx->d_err);
-        } else {
-            hipLaunchKernelGGL(scv::scv_bootstrap_k, dim3((unsigned)R), dim3(256), lds, s, d_cells, P, B, r_begin, seed, M, d_out, ctx->d_err);
-        }
-        SCV_HIP(hipGetLastError());
-        ctx->err_dirty = true;
-        return SCV_OK;
-    };
-    if (mem_kind == SCV_MEM_DEVICE) return launch_boot(cells, reinterpret_cast<unsigned long long*>(counts_out));
-    const size_t cells_bytes = (size_t)P * B * sizeof(scv_cell);
-    const size_t o_out = align_up(cells_bytes, 256);
-    if (int rc = ensure_stage(ctx, o_out + out_bytes)) return rc;
-    char* base = static_cast<char*>(ctx->d_stage);
-    SCV_HIP(hipMemcpyAsync(base, cells, cells_bytes, hipMemcpyHostToDevice, s));
-    if (int rc = launch_boot(reinterpret_cast<const scv_cell*>(base), reinterpret_cast<unsigned long long*>(base + o_out))) return rc;
-    SCV_HIP(hipMemcpyAsync(counts_out, base + o_out, out_bytes, hipMemcpyDeviceToHost, s));
-    SCV_HIP(hipStreamSynchronize(s));
-    uint32_t w = 0;
-    if (int rc = fetch_err(ctx, &w)) return rc;
-    return check_err_word(ctx, w);
+    return guarded([&]() -> int {
+        if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+        if (!cells || !counts_out) return fail(SCV_ERR_ARG, "bootstrap: NULL pointer");
+        if (P <= 0 || P > 0xFFFFFFFFll || B <= 0 || M <= 0 || r_end < r_begin || r_begin < 0)
+            return fail(SCV_ERR_ARG, "bootstrap: bad shape P=%lld B=%d M=%d r=[%d,%d)", (long long)P, B, M, r_begin, r_end);
+        const size_t lds = (size_t)B * M * sizeof(uint32_t);
+        if (lds > 64 * 1024) return fail(SCV_ERR_ARG, "bootstrap: B*M=%lld counters exceed 64 KiB of LDS", (long long)B * M);
+        if (mem_kind != SCV_MEM_HOST && mem_kind != SCV_MEM_DEVICE) return fail(SCV_ERR_ARG, "bad mem_kind %d", mem_kind);
+        SCV_ENTER(ctx);
+        const int32_t R = r_end - r_begin;
+        if (R == 0) return SCV_OK;
+        hipStream_t s = ctx->stream;
+        const size_t out_bytes = (size_t)R * B * M * sizeof(int64_t);
+        // LDS-resident kernel when the 2-byte code table + counters fit (P * B up to ~70 k cells); otherwise the
+        // global-gather kernel.  "boot_path" = 3 forces the latter (parity tests).
+        const size_t lds_fast = (((size_t)B * M + 3) & ~(size_t)3) * sizeof(uint32_t) + (((size_t)P * B + 7) & ~(size_t)7) * sizeof(uint16_t);
+        const bool fast = ctx->boot_path != 3 && lds_fast <= (size_t)144 * 1024;
+        auto launch_boot = [&](const scv_cell* d_cells, unsigned long long* d_out) -> int {
+            if (fast) {
+                int64_t grid = (int64_t)ctx->num_cus;                          // one 1024-thread workgroup per CU, R / grid resamples each
+                if (grid > R) grid = R;
+                SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scv::scv_bootstrap_lds_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast));
+                hipLaunchKernelGGL(scv::scv_bootstrap_lds_k, dim3((unsigned)grid), dim3(1024), lds_fast, s, d_cells, P, B, r_begin, r_end, seed, M, d_out, ctx->d_err);
+            } else {
+                hipLaunchKernelGGL(scv::scv_bootstrap_k, dim3((unsigned)R), dim3(256), lds, s, d_cells, P, B, r_begin, seed, M, d_out, ctx->d_err);
+            }
+            SCV_HIP(hipGetLastError());
+            ctx->err_dirty = true;
+            return SCV_OK;
+        };
+        if (mem_kind == SCV_MEM_DEVICE) return launch_boot(cells, reinterpret_cast<unsigned long long*>(counts_out));
+        const size_t cells_bytes = (size_t)P * B * sizeof(scv_cell);
+        const size_t o_out = align_up(cells_bytes, 256);
+        if (int rc = ensure_stage(ctx, o_out + out_bytes)) return rc;
+        char* base = static_cast<char*>(ctx->d_stage);
+        SCV_HIP(hipMemcpyAsync(base, cells, cells_bytes, hipMemcpyHostToDevice, s));
+        if (int rc = launch_boot(reinterpret_cast<const scv_cell*>(base), reinterpret_cast<unsigned long long*>(base + o_out))) return rc;
+        SCV_HIP(hipMemcpyAsync(counts_out, base + o_out, out_bytes, hipMemcpyDeviceToHost, s));
+        SCV_HIP(hipStreamSynchronize(s));
+        uint32_t w = 0;
+        if (int rc = fetch_err(ctx, &w)) return rc;
+        return check_err_word(ctx, w);
+    });
 }
 
 int scv_aggregate_bootstrap_i32(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
@@ -1229,117 +1384,138 @@ int scv_aggregate_bootstrap_i32(scv_ctx* ctx, const int32_t* answers, const int3
                                 int64_t* cell_tokens_out, int64_t* tie_class_hits_out, int64_t* token_sum_out,
                                 int64_t* truth_count_sum_out, int32_t r_begin, int32_t r_end, uint64_t seed, int32_t M,
                                 int64_t* counts_out) {
-    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
-    if (!cells_out || !counts_out) return fail(SCV_ERR_ARG, "aggregate_bootstrap: cells_out and counts_out are required");
-    if (P <= 0 || P > 0xFFFFFFFFll || B <= 0 || M <= 0 || r_end < r_begin || r_begin < 0)
-        return fail(SCV_ERR_ARG, "aggregate_bootstrap: bad shape P=%lld B=%d M=%d r=[%d,%d)", (long long)P, B, M, r_begin, r_end);
-    if ((size_t)B * M * sizeof(uint32_t) > 64 * 1024) return fail(SCV_ERR_ARG, "bootstrap: B*M=%lld counters exceed 64 KiB of LDS", (long long)B * M);
-    scv_ctx::BootReq rq{r_begin, r_end, M, seed, counts_out, false};
-    if (r_end > r_begin) ctx->boot_req = &rq;
-    const int rc = scv_aggregate_i32(ctx, answers, tokens, n_valid, truth, P, B, N, SCV_MEM_DEVICE, cells_out, cell_tokens_out,
-                                     tie_class_hits_out, token_sum_out, truth_count_sum_out);
-    ctx->boot_req = nullptr;
-    if (rc != SCV_OK || rq.fused || r_end == r_begin) return rc;
-    // shape or occupancy did not allow the fused form: the bootstrap is queued behind the vote on the same stream
-    ctx->stat_boot_separate += 1;
-    return scv_bootstrap(ctx, cells_out, P, B, r_begin, r_end, seed, M, SCV_MEM_DEVICE, counts_out);
+    return guarded([&]() -> int {
+        if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+        if (!cells_out || !counts_out) return fail(SCV_ERR_ARG, "aggregate_bootstrap: cells_out and counts_out are required");
+        if (P <= 0 || P > 0xFFFFFFFFll || B <= 0 || M <= 0 || r_end < r_begin || r_begin < 0)
+            return fail(SCV_ERR_ARG, "aggregate_bootstrap: bad shape P=%lld B=%d M=%d r=[%d,%d)", (long long)P, B, M, r_begin, r_end);
+        if ((size_t)B * M * sizeof(uint32_t) > 64 * 1024) return fail(SCV_ERR_ARG, "bootstrap: B*M=%lld counters exceed 64 KiB of LDS", (long long)B * M);
+        scv_ctx::BootReq rq{r_begin, r_end, M, seed, counts_out, false};
+        if (r_end > r_begin) ctx->boot_req = &rq;
+        const int rc = scv_aggregate_i32(ctx, answers, tokens, n_valid, truth, P, B, N, SCV_MEM_DEVICE, cells_out, cell_tokens_out,
+                                         tie_class_hits_out, token_sum_out, truth_count_sum_out);
+        ctx->boot_req = nullptr;
+        if (rc != SCV_OK || rq.fused || r_end == r_begin) return rc;
+        // shape or occupancy did not allow the fused form: the bootstrap is queued behind the vote on the same stream
+        ctx->stat_boot_separate += 1;
+        return scv_bootstrap(ctx, cells_out, P, B, r_begin, r_end, seed, M, SCV_MEM_DEVICE, counts_out);
+    });
 }
 
 int scv_synth_fill_i32(scv_ctx* ctx, int32_t* answers, int32_t* tokens, int32_t* truth, int64_t P, int32_t B,
                        int64_t N, int64_t p_offset, uint64_t seed, int dist) {
-    if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
-    if (P < 0 || B < 0 || N < 0 || p_offset < 0) return fail(SCV_ERR_ARG, "synth_fill: negative shape");
-    if (dist < SCV_DIST_UNIFORM || dist > SCV_DIST_DEGENERATE_WRONG) return fail(SCV_ERR_ARG, "synth_fill: unknown dist %d", dist);
-    SCV_ENTER(ctx);
-    if (P == 0) return SCV_OK;
-    int64_t grid = P * (int64_t)B;
-    if (B == 0) grid = (P + 255) / 256;
-    const int64_t cap = (int64_t)ctx->num_cus * 16;
-    if (grid > cap) grid = cap;
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(scv::scv_synth_fill_k, dim3((unsigned)grid), dim3(256), 0, ctx->stream, answers, tokens, truth, P,
-                       B, N, p_offset, seed, dist);
-    SCV_HIP(hipGetLastError());
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
+        if (P < 0 || B < 0 || N < 0 || p_offset < 0) return fail(SCV_ERR_ARG, "synth_fill: negative shape");
+        if (dist < SCV_DIST_UNIFORM || dist > SCV_DIST_DEGENERATE_WRONG) return fail(SCV_ERR_ARG, "synth_fill: unknown dist %d", dist);
+        SCV_ENTER(ctx);
+        if (P == 0) return SCV_OK;
+        int64_t grid = P * (int64_t)B;
+        if (B == 0) grid = (P + 255) / 256;
+        const int64_t cap = (int64_t)ctx->num_cus * 16;
+        if (grid > cap) grid = cap;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(scv::scv_synth_fill_k, dim3((unsigned)grid), dim3(256), 0, ctx->stream, answers, tokens, truth, P,
+                           B, N, p_offset, seed, dist);
+        SCV_HIP(hipGetLastError());
+        return SCV_OK;
+    });
 }
 
 int scv_export_error_word(scv_ctx* ctx, int64_t* dst_device) {
-    if (!ctx || !dst_device) return fail(SCV_ERR_ARG, "NULL argument");
-    SCV_ENTER(ctx);
-    // the word as scv_sync would JUDGE it: under SCV_FLAG_CLAMP_TO_INVALID_BIN an out-of-domain vote is not an error (bit 0 dropped)
-    const uint32_t mask = (ctx->flags & SCV_FLAG_CLAMP_TO_INVALID_BIN) ? ~1u : ~0u;
-    hipLaunchKernelGGL(scv::scv_export_err_k, dim3(1), dim3(1), 0, ctx->stream, ctx->d_err, mask, reinterpret_cast<long long*>(dst_device));
-    SCV_HIP(hipGetLastError());
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!ctx || !dst_device) return fail(SCV_ERR_ARG, "NULL argument");
+        SCV_ENTER(ctx);
+        // the word as scv_sync would JUDGE it: under SCV_FLAG_CLAMP_TO_INVALID_BIN an out-of-domain vote is not an error (bit 0 dropped)
+        const uint32_t mask = (ctx->flags & SCV_FLAG_CLAMP_TO_INVALID_BIN) ? ~1u : ~0u;
+        hipLaunchKernelGGL(scv::scv_export_err_k, dim3(1), dim3(1), 0, ctx->stream, ctx->d_err, mask, reinterpret_cast<long long*>(dst_device));
+        SCV_HIP(hipGetLastError());
+        return SCV_OK;
+    });
 }
 
 int scv_last_kernel_ns(scv_ctx* ctx, uint64_t* ns_out) {
-    if (!ctx || !ns_out) return fail(SCV_ERR_ARG, "NULL argument");
-    if (!(ctx->flags & SCV_FLAG_TIMING) || ctx->events_used == 0)
-        return fail(SCV_ERR_NOT_TIMED, "no timed launch (create the ctx with SCV_FLAG_TIMING)");
-    SCV_ENTER(ctx);
-    EventPair& ev = ctx->events[ctx->events_used - 1];
-    SCV_HIP(hipEventSynchronize(ev.b));
-    float ms = 0.f;
-    SCV_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
-    *ns_out = (uint64_t)((double)ms * 1e6);
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!ctx || !ns_out) return fail(SCV_ERR_ARG, "NULL argument");
+        if (!(ctx->flags & SCV_FLAG_TIMING) || ctx->events_used == 0)
+            return fail(SCV_ERR_NOT_TIMED, "no timed launch (create the ctx with SCV_FLAG_TIMING)");
+        SCV_ENTER(ctx);
+        EventPair& ev = ctx->events[ctx->events_used - 1];
+        SCV_HIP(hipEventSynchronize(ev.b));
+        float ms = 0.f;
+        SCV_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
+        *ns_out = (uint64_t)((double)ms * 1e6);
+        return SCV_OK;
+    });
 }
 
 int scv_drain_kernel_ns(scv_ctx* ctx, uint64_t* total_ns_out, uint64_t* launches_out) {
-    if (!ctx || !total_ns_out || !launches_out) return fail(SCV_ERR_ARG, "NULL argument");
-    if (!(ctx->flags & SCV_FLAG_TIMING)) return fail(SCV_ERR_NOT_TIMED, "ctx was created without SCV_FLAG_TIMING");
-    SCV_ENTER(ctx);
-    double total = 0;
-    for (size_t i = 0; i < ctx->events_used; ++i) {
-        SCV_HIP(hipEventSynchronize(ctx->events[i].b));
-        float ms = 0.f;
-        SCV_HIP(hipEventElapsedTime(&ms, ctx->events[i].a, ctx->events[i].b));
-        total += (double)ms * 1e6;
-    }
-    *total_ns_out = (uint64_t)total;
-    *launches_out = ctx->events_used;
-    ctx->events_used = 0;
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!ctx || !total_ns_out || !launches_out) return fail(SCV_ERR_ARG, "NULL argument");
+        if (!(ctx->flags & SCV_FLAG_TIMING)) return fail(SCV_ERR_NOT_TIMED, "ctx was created without SCV_FLAG_TIMING");
+        SCV_ENTER(ctx);
+        double total = 0;
+        for (size_t i = 0; i < ctx->events_used; ++i) {
+            SCV_HIP(hipEventSynchronize(ctx->events[i].b));
+            float ms = 0.f;
+            SCV_HIP(hipEventElapsedTime(&ms, ctx->events[i].a, ctx->events[i].b));
+            total += (double)ms * 1e6;
+        }
+        *total_ns_out = (uint64_t)total;
+        *launches_out = ctx->events_used;
+        ctx->events_used = 0;
+        return SCV_OK;
+    });
 }
 
 int scv_host_alloc(void** out, size_t bytes) {
-    if (!out) return fail(SCV_ERR_ARG, "scv_host_alloc: out is NULL");
-    *out = nullptr;
-    if (bytes == 0) return SCV_OK;
-    SCV_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!out) return fail(SCV_ERR_ARG, "scv_host_alloc: out is NULL");
+        *out = nullptr;
+        if (bytes == 0) return SCV_OK;
+        SCV_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+        return SCV_OK;
+    });
 }
 
 int scv_host_free(void* p) {
-    if (!p) return SCV_OK;
-    SCV_HIP(hipHostFree(p));
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!p) return SCV_OK;
+        SCV_HIP(hipHostFree(p));
+        return SCV_OK;
+    });
 }
 
 int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
-    if (!ctx || !key || !out) return fail(SCV_ERR_ARG, "NULL argument");
-    if (!strcmp(key, "boot_fused")) *out = ctx->stat_boot_fused;
-    else if (!strcmp(key, "boot_separate")) *out = ctx->stat_boot_separate;
-    else if (!strcmp(key, "boot_recovered")) *out = ctx->stat_boot_recovered;
-    else if (!strcmp(key, "boot_cooperative")) *out = ctx->stat_boot_cooperative;
-    else if (!strcmp(key, "overwrite_fused")) *out = ctx->stat_overwrite_fused;
-    else if (!strcmp(key, "lds_counters")) *out = ctx->stat_lds_counters;
-    else if (!strcmp(key, "prefix_cells")) *out = ctx->stat_prefix_cells;
-    else if (!strcmp(key, "prefix_lane")) *out = ctx->stat_prefix_lane;
-    else if (!strcmp(key, "sort_cells")) *out = ctx->stat_sort_cells;
-    else if (!strcmp(key, "few_votes")) *out = ctx->stat_few_votes;
-    else return fail(SCV_ERR_ARG, "unknown stat '%s'", key);
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!ctx || !key || !out) return fail(SCV_ERR_ARG, "NULL argument");
+        if (!strcmp(key, "boot_fused")) *out = ctx->stat_boot_fused;
+        else if (!strcmp(key, "boot_separate")) *out = ctx->stat_boot_separate;
+        else if (!strcmp(key, "boot_recovered")) *out = ctx->stat_boot_recovered;
+        else if (!strcmp(key, "boot_cooperative")) *out = ctx->stat_boot_cooperative;
+        else if (!strcmp(key, "overwrite_fused")) *out = ctx->stat_overwrite_fused;
+        else if (!strcmp(key, "lds_counters")) *out = ctx->stat_lds_counters;
+        else if (!strcmp(key, "prefix_cells")) *out = ctx->stat_prefix_cells;
+        else if (!strcmp(key, "prefix_lane")) *out = ctx->stat_prefix_lane;
+        else if (!strcmp(key, "sort_cells")) *out = ctx->stat_sort_cells;
+        else if (!strcmp(key, "few_votes")) *out = ctx->stat_few_votes;
+        else if (!strcmp(key, "host_small_calls")) *out = ctx->stat_small_calls;
+        else if (!strcmp(key, "host_pipelined_calls")) *out = ctx->stat_pipelined_calls;
+        else if (!strcmp(key, "host_thread_start_failures")) *out = ctx->pipe ? ctx->pipe->start_failures : 0;
+        else return fail(SCV_ERR_ARG, "unknown stat '%s'", key);
+        return SCV_OK;
+    });
 }
 
 int scv_device_info(scv_ctx* ctx, int64_t info_out[4]) {
-    if (!ctx || !info_out) return fail(SCV_ERR_ARG, "NULL argument");
-    info_out[0] = ctx->num_cus;
-    info_out[1] = ctx->lds_max;
-    info_out[2] = ctx->clock_khz;
-    info_out[3] = ctx->hbm_bytes;
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!ctx || !info_out) return fail(SCV_ERR_ARG, "NULL argument");
+        info_out[0] = ctx->num_cus;
+        info_out[1] = ctx->lds_max;
+        info_out[2] = ctx->clock_khz;
+        info_out[3] = ctx->hbm_bytes;
+        return SCV_OK;
+    });
 }
 
 }  // extern "C"

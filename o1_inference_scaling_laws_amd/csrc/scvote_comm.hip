@@ -19,7 +19,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <vector>
 
@@ -34,11 +36,22 @@ int comm_fail(int code, const char* fmt, ...);   // sets scv_last_error's thread
 constexpr int kMaxRanks = 16;
 struct PeerPtrs { const long long* p[kMaxRanks]; };
 
+// How a kernel reads another device's (coarse-grained hipMalloc) buffer.  NT = __builtin_nontemporal_load (global_load ... nt: no
+// allocation in this device's caches, so no stale line can be kept between two exchanges); the ordinary load is the alternative the
+// create-time self-test also tries on distinct devices.  Which of the two the communicator uses is decided by that test
+// (scv_comm_get_stat "peer_loads"), not assumed.
+template <bool NT>
+__device__ __forceinline__ long long peer_load(const long long* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *reinterpret_cast<const volatile long long*>(p);
+}
+
 // out[i] = sum over the ranks of in_r[i]; the other ranks' buffers are read through peer access (xGMI)
+template <bool NT>
 __global__ __launch_bounds__(256) void scv_sum_peers_k(PeerPtrs in, int n, long long* out, int64_t count) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         long long s = 0;
-        for (int r = 0; r < n; ++r) s += __builtin_nontemporal_load(in.p[r] + i);
+        for (int r = 0; r < n; ++r) s += peer_load<NT>(in.p[r] + i);
         out[i] = s;
     }
 }
@@ -51,12 +64,14 @@ __device__ __host__ inline long long comm_pattern(int r, int k, int64_t i) {
 __global__ __launch_bounds__(256) void scv_comm_fill_k(long long* buf, int r, int k, int64_t count) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) buf[i] = comm_pattern(r, k, i);
 }
-// res[0] += words of `buf` that differ from `rank_lo..rank_hi`'s summed patterns; res[1] = min(first differing word)
-__global__ __launch_bounds__(256) void scv_comm_verify_k(const long long* buf, int rank_lo, int rank_hi, int k, int64_t count, unsigned long long* res) {
+// res[0] += words of `buf` that differ from `rank_lo..rank_hi`'s summed patterns; res[1] = min(first differing word).
+// `skew` is 0 except under the test hook SCV_TEST_FAULT=peer, which makes every expectation wrong (a self-test that must fail).
+template <bool NT>
+__global__ __launch_bounds__(256) void scv_comm_verify_k(const long long* buf, int rank_lo, int rank_hi, int k, int64_t count, unsigned long long* res, long long skew) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-        long long want = 0;
+        long long want = skew;
         for (int r = rank_lo; r < rank_hi; ++r) want += comm_pattern(r, k, i);
-        if (__builtin_nontemporal_load(buf + i) != want) { atomicAdd(&res[0], 1ull); atomicMin(&res[1], (unsigned long long)i); }
+        if (peer_load<NT>(buf + i) != want) { atomicAdd(&res[0], 1ull); atomicMin(&res[1], (unsigned long long)i); }
     }
 }
 }  // namespace scv
@@ -109,12 +124,37 @@ struct scv_comm {
     size_t tmp_bytes = 0;
     std::vector<ncclComm_t> nccl;
     int64_t stat_selftest_words = 0;     // words verified per rank by the create-time self-test (0: one rank, nothing to test)
+    // SCV_COMM_PEER: how scv_sum_peers_k reads the peers' buffers -- 0 nontemporal loads (the design), 1 ordinary loads (used only when
+    // the self-test saw nontemporal reads fail and ordinary ones pass), -1 no peer reads in this communicator (RCCL / one rank)
+    int peer_loads = -1;
+    int selftest_nt_ok = -1, selftest_plain_ok = -1;     // pairwise peer reads of the self-test: 1 all correct, 0 some wrong, -1 not run
 };
 
 namespace {
 constexpr size_t kTmpBytesAtCreate = 1 << 20;   // staging buffer of the one-shot all-reduce: 131072 int64 (B <= 127 budgets' counters) without
                                                 // ever allocating on the launch path (legal under hipGraph capture)
 int comm_selftest(scv_comm* c);
+}
+
+// No C++ exception crosses the C ABI (std::vector growth in here can throw std::bad_alloc): every extern "C" body runs inside guarded().
+template <class F>
+int guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return scv::comm_fail(SCV_ERR_ALLOC, "out of host memory (std::bad_alloc inside the library)");
+    } catch (const std::exception& e) {
+        return scv::comm_fail(SCV_ERR_ARG, "internal error: %s", e.what());
+    } catch (...) {
+        return scv::comm_fail(SCV_ERR_ARG, "internal error: unknown C++ exception");
+    }
+}
+
+// TEST HOOK: SCV_TEST_FAULT=peer makes the self-test of a SCV_COMM_PEER communicator fail (every expectation skewed), and makes it run
+// for one rank too -- so that a 1-GPU box can exercise "self-test failed -> RCCL" (MultiDeviceEngine, tests/test_gpu_parity.py).
+static bool peer_fault_for_test() {
+    const char* f = getenv("SCV_TEST_FAULT");
+    return f && !strcmp(f, "peer");
 }
 
 #define COMM_HIP(expr)                                                                                     \
@@ -126,92 +166,96 @@ int comm_selftest(scv_comm* c);
 extern "C" {
 
 int scv_comm_destroy(scv_comm* c) {
-    if (!c) return SCV_OK;
-    DeviceScope scope;
-    for (int r = 0; r < (int)c->ctx.size(); ++r) {
-        (void)hipSetDevice(c->devices[r]);
-        if (r < (int)c->nccl.size() && c->nccl[r] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl[r]);
-        if (r < (int)c->ready.size() && c->ready[r]) (void)hipEventDestroy(c->ready[r]);
-        if (r < (int)c->done.size() && c->done[r]) (void)hipEventDestroy(c->done[r]);
-        if (r < (int)c->tmp.size() && c->tmp[r]) (void)hipFree(c->tmp[r]);
-        (void)scv_destroy(c->ctx[r]);
-    }
-    delete c;
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!c) return SCV_OK;
+        DeviceScope scope;
+        for (int r = 0; r < (int)c->ctx.size(); ++r) {
+            (void)hipSetDevice(c->devices[r]);
+            if (r < (int)c->nccl.size() && c->nccl[r] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl[r]);
+            if (r < (int)c->ready.size() && c->ready[r]) (void)hipEventDestroy(c->ready[r]);
+            if (r < (int)c->done.size() && c->done[r]) (void)hipEventDestroy(c->done[r]);
+            if (r < (int)c->tmp.size() && c->tmp[r]) (void)hipFree(c->tmp[r]);
+            (void)scv_destroy(c->ctx[r]);
+        }
+        delete c;
+        return SCV_OK;
+    });
 }
 
 int scv_comm_create(scv_comm** out, const int* devices, int n, uint32_t ctx_flags, uint32_t comm_flags) {
-    if (!out) return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create: out is NULL");
-    *out = nullptr;
-    int visible = 0;
-    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return scv::comm_fail(SCV_ERR_NO_DEVICE, "no HIP device visible");
-    if (n == 0 || !devices) n = visible;                       // all visible devices
-    if (n < 1 || n > scv::kMaxRanks) return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create: %d ranks (1..%d supported)", n, scv::kMaxRanks);
-    scv_comm* c = new (std::nothrow) scv_comm();
-    if (!c) return scv::comm_fail(SCV_ERR_ALLOC, "out of host memory");
-    c->n = n;
-    c->flags = comm_flags;
-    DeviceScope scope;
-    for (int r = 0; r < n; ++r) {
-        const int d = devices ? devices[r] : r;
-        if (d < 0 || d >= visible) { scv_comm_destroy(c); return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create: device %d out of range (%d visible)", d, visible); }
-        c->devices.push_back(d);
-        scv_ctx* x = nullptr;
-        if (int rc = scv_create(&x, d, ctx_flags)) { scv_comm_destroy(c); return rc; }
-        c->ctx.push_back(x);
-    }
-    c->ready.assign(n, nullptr); c->done.assign(n, nullptr); c->tmp.assign(n, nullptr);
-    for (int r = 0; r < n; ++r) {
-        if (hipSetDevice(c->devices[r]) != hipSuccess || hipEventCreateWithFlags(&c->ready[r], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->done[r], hipEventDisableTiming) != hipSuccess) {
-            scv_comm_destroy(c);
-            return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create: event creation failed on device %d", c->devices[r]);
-        }
-        for (int j = 0; j < n; ++j) {                           // every rank reads every other rank's buffer: peer access both ways
-            if (c->devices[j] == c->devices[r]) continue;
-            int can = 0;
-            (void)hipDeviceCanAccessPeer(&can, c->devices[r], c->devices[j]);
-            if (!can && !(comm_flags & SCV_COMM_RCCL)) {
-                scv_comm_destroy(c);
-                return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create: device %d cannot access device %d (no xGMI / PCIe peer path): use SCV_COMM_RCCL", c->devices[r], c->devices[j]);
-            }
-            const hipError_t e = hipDeviceEnablePeerAccess(c->devices[j], 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled && !(comm_flags & SCV_COMM_RCCL)) {
-                scv_comm_destroy(c);
-                return scv::comm_fail(-(int)e, "hipDeviceEnablePeerAccess(%d -> %d): %s", c->devices[r], c->devices[j], hipGetErrorString(e));
-            }
-            (void)hipGetLastError();
-        }
-    }
-    if (comm_flags & SCV_COMM_RCCL) {
-        if (!g_rccl.load()) {
-            const char* why = dlerror();
-            scv_comm_destroy(c);
-            return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create: librccl could not be loaded (%s)", why ? why : "symbols missing");
-        }
-        c->nccl.assign(n, nullptr);
-        const int rc = g_rccl.CommInitAll(c->nccl.data(), n, c->devices.data());
-        if (rc != 0) {
-            const char* msg = g_rccl.GetErrorString(rc);
-            c->nccl.clear();
-            scv_comm_destroy(c);
-            return scv::comm_fail(-1000 - rc, "ncclCommInitAll: %s", msg);
-        }
-    }
-    if (n > 1 || (comm_flags & SCV_COMM_RCCL)) {
+    return guarded([&]() -> int {
+        if (!out) return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create: out is NULL");
+        *out = nullptr;
+        int visible = 0;
+        if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return scv::comm_fail(SCV_ERR_NO_DEVICE, "no HIP device visible");
+        if (n == 0 || !devices) n = visible;                       // all visible devices
+        if (n < 1 || n > scv::kMaxRanks) return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create: %d ranks (1..%d supported)", n, scv::kMaxRanks);
+        scv_comm* c = new (std::nothrow) scv_comm();
+        if (!c) return scv::comm_fail(SCV_ERR_ALLOC, "out of host memory");
+        c->n = n;
+        c->flags = comm_flags;
+        DeviceScope scope;
         for (int r = 0; r < n; ++r) {
-            if (hipSetDevice(c->devices[r]) != hipSuccess || hipMalloc(&c->tmp[r], kTmpBytesAtCreate) != hipSuccess) {
+            const int d = devices ? devices[r] : r;
+            if (d < 0 || d >= visible) { scv_comm_destroy(c); return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create: device %d out of range (%d visible)", d, visible); }
+            c->devices.push_back(d);
+            scv_ctx* x = nullptr;
+            if (int rc = scv_create(&x, d, ctx_flags)) { scv_comm_destroy(c); return rc; }
+            c->ctx.push_back(x);
+        }
+        c->ready.assign(n, nullptr); c->done.assign(n, nullptr); c->tmp.assign(n, nullptr);
+        for (int r = 0; r < n; ++r) {
+            if (hipSetDevice(c->devices[r]) != hipSuccess || hipEventCreateWithFlags(&c->ready[r], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->done[r], hipEventDisableTiming) != hipSuccess) {
                 scv_comm_destroy(c);
-                return scv::comm_fail(SCV_ERR_ALLOC, "scv_comm_create: staging buffer on device %d", c->devices[r]);
+                return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create: event creation failed on device %d", c->devices[r]);
+            }
+            for (int j = 0; j < n; ++j) {                           // every rank reads every other rank's buffer: peer access both ways
+                if (c->devices[j] == c->devices[r]) continue;
+                int can = 0;
+                (void)hipDeviceCanAccessPeer(&can, c->devices[r], c->devices[j]);
+                if (!can && !(comm_flags & SCV_COMM_RCCL)) {
+                    scv_comm_destroy(c);
+                    return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create: device %d cannot access device %d (no xGMI / PCIe peer path): use SCV_COMM_RCCL", c->devices[r], c->devices[j]);
+                }
+                const hipError_t e = hipDeviceEnablePeerAccess(c->devices[j], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled && !(comm_flags & SCV_COMM_RCCL)) {
+                    scv_comm_destroy(c);
+                    return scv::comm_fail(-(int)e, "hipDeviceEnablePeerAccess(%d -> %d): %s", c->devices[r], c->devices[j], hipGetErrorString(e));
+                }
+                (void)hipGetLastError();
             }
         }
-        c->tmp_bytes = kTmpBytesAtCreate;
-        // First contact with the devices happens HERE, loudly: known patterns through every peer path and through one whole
-        // all-reduce, verified on every device -- wrong xGMI visibility is an error at create, not a wrong accuracy later.
-        if (int rc = comm_selftest(c)) { scv_comm_destroy(c); return rc; }
-    }
-    *out = c;
-    return SCV_OK;
+        if (comm_flags & SCV_COMM_RCCL) {
+            if (!g_rccl.load()) {
+                const char* why = dlerror();
+                scv_comm_destroy(c);
+                return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create: librccl could not be loaded (%s)", why ? why : "symbols missing");
+            }
+            c->nccl.assign(n, nullptr);
+            const int rc = g_rccl.CommInitAll(c->nccl.data(), n, c->devices.data());
+            if (rc != 0) {
+                const char* msg = g_rccl.GetErrorString(rc);
+                c->nccl.clear();
+                scv_comm_destroy(c);
+                return scv::comm_fail(-1000 - rc, "ncclCommInitAll: %s", msg);
+            }
+        }
+        if (n > 1 || (comm_flags & SCV_COMM_RCCL) || peer_fault_for_test()) {
+            for (int r = 0; r < n; ++r) {
+                if (hipSetDevice(c->devices[r]) != hipSuccess || hipMalloc(&c->tmp[r], kTmpBytesAtCreate) != hipSuccess) {
+                    scv_comm_destroy(c);
+                    return scv::comm_fail(SCV_ERR_ALLOC, "scv_comm_create: staging buffer on device %d", c->devices[r]);
+                }
+            }
+            c->tmp_bytes = kTmpBytesAtCreate;
+            // First contact with the devices happens HERE, loudly: known patterns through every peer path and through one whole
+            // all-reduce, verified on every device -- wrong xGMI visibility is an error at create, not a wrong accuracy later.
+            if (int rc = comm_selftest(c)) { scv_comm_destroy(c); return rc; }
+        }
+        *out = c;
+        return SCV_OK;
+    });
 }
 
 int scv_comm_size(const scv_comm* c) { return c ? c->n : 0; }
@@ -219,62 +263,65 @@ int scv_comm_size(const scv_comm* c) { return c ? c->n : 0; }
 scv_ctx* scv_comm_ctx(scv_comm* c, int rank) { return (c && rank >= 0 && rank < c->n) ? c->ctx[rank] : nullptr; }
 
 int scv_allreduce_counters(scv_comm* c, int64_t* const* buffers, int64_t count) {
-    if (!c || !buffers) return scv::comm_fail(SCV_ERR_ARG, "scv_allreduce_counters: NULL argument");
-    if (count < 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allreduce_counters: negative count");
-    for (int r = 0; r < c->n; ++r)
-        if (!buffers[r] && count > 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allreduce_counters: buffer of rank %d is NULL", r);
-    if (count == 0 || (c->n == 1 && !(c->flags & SCV_COMM_RCCL))) return SCV_OK;    // one rank: the buffer already holds the sum
-    DeviceScope scope;
-    if (c->flags & SCV_COMM_RCCL) {                            // (one rank included: a 1-GPU box then executes the RCCL call path itself)
-        int rc = g_rccl.GroupStart();
-        for (int r = 0; r < c->n && rc == 0; ++r)
-            rc = g_rccl.AllReduce(buffers[r], buffers[r], (size_t)count, kNcclInt64, kNcclSum, c->nccl[r], scv::ctx_stream(c->ctx[r]));
-        const int rc2 = g_rccl.GroupEnd();
-        if (rc == 0) rc = rc2;
-        if (rc != 0) return scv::comm_fail(-1000 - rc, "ncclAllReduce: %s", g_rccl.GetErrorString(rc));
-        return SCV_OK;
-    }
-    // ---- one-shot over peer access --------------------------------------------------------------------------------
-    const size_t bytes = (size_t)count * sizeof(int64_t);
-    if (bytes > c->tmp_bytes) {
-        for (int r = 0; r < c->n; ++r) {                       // growing synchronises, frees and allocates: not while a stream is being captured
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(scv::ctx_stream(c->ctx[r]), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-            if (cap != hipStreamCaptureStatusNone)
-                return scv::comm_fail(SCV_ERR_ARG, "scv_allreduce_counters: %lld words need a larger staging buffer while rank %d's stream is being captured: "
-                                      "run this size once outside the capture first", (long long)count, r);
+    return guarded([&]() -> int {
+        if (!c || !buffers) return scv::comm_fail(SCV_ERR_ARG, "scv_allreduce_counters: NULL argument");
+        if (count < 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allreduce_counters: negative count");
+        for (int r = 0; r < c->n; ++r)
+            if (!buffers[r] && count > 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allreduce_counters: buffer of rank %d is NULL", r);
+        if (count == 0 || (c->n == 1 && !(c->flags & SCV_COMM_RCCL))) return SCV_OK;    // one rank: the buffer already holds the sum
+        DeviceScope scope;
+        if (c->flags & SCV_COMM_RCCL) {                            // (one rank included: a 1-GPU box then executes the RCCL call path itself)
+            int rc = g_rccl.GroupStart();
+            for (int r = 0; r < c->n && rc == 0; ++r)
+                rc = g_rccl.AllReduce(buffers[r], buffers[r], (size_t)count, kNcclInt64, kNcclSum, c->nccl[r], scv::ctx_stream(c->ctx[r]));
+            const int rc2 = g_rccl.GroupEnd();
+            if (rc == 0) rc = rc2;
+            if (rc != 0) return scv::comm_fail(-1000 - rc, "ncclAllReduce: %s", g_rccl.GetErrorString(rc));
+            return SCV_OK;
         }
-        for (int r = 0; r < c->n; ++r) {
+        // ---- one-shot over peer access --------------------------------------------------------------------------------
+        const size_t bytes = (size_t)count * sizeof(int64_t);
+        if (bytes > c->tmp_bytes) {
+            for (int r = 0; r < c->n; ++r) {                       // growing synchronises, frees and allocates: not while a stream is being captured
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(scv::ctx_stream(c->ctx[r]), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+                if (cap != hipStreamCaptureStatusNone)
+                    return scv::comm_fail(SCV_ERR_ARG, "scv_allreduce_counters: %lld words need a larger staging buffer while rank %d's stream is being captured: "
+                                          "run this size once outside the capture first", (long long)count, r);
+            }
+            for (int r = 0; r < c->n; ++r) {
+                COMM_HIP(hipSetDevice(c->devices[r]));
+                COMM_HIP(hipStreamSynchronize(scv::ctx_stream(c->ctx[r])));
+                if (c->tmp[r]) { COMM_HIP(hipFree(c->tmp[r])); c->tmp[r] = nullptr; }
+                COMM_HIP(hipMalloc(&c->tmp[r], bytes));
+            }
+            c->tmp_bytes = bytes;
+        }
+        scv::PeerPtrs in;
+        for (int r = 0; r < scv::kMaxRanks; ++r) in.p[r] = r < c->n ? reinterpret_cast<const long long*>(buffers[r]) : nullptr;
+        for (int r = 0; r < c->n; ++r) {                           // 1. every rank's counters are complete at `ready`
             COMM_HIP(hipSetDevice(c->devices[r]));
-            COMM_HIP(hipStreamSynchronize(scv::ctx_stream(c->ctx[r])));
-            if (c->tmp[r]) { COMM_HIP(hipFree(c->tmp[r])); c->tmp[r] = nullptr; }
-            COMM_HIP(hipMalloc(&c->tmp[r], bytes));
+            COMM_HIP(hipEventRecord(c->ready[r], scv::ctx_stream(c->ctx[r])));
         }
-        c->tmp_bytes = bytes;
-    }
-    scv::PeerPtrs in;
-    for (int r = 0; r < scv::kMaxRanks; ++r) in.p[r] = r < c->n ? reinterpret_cast<const long long*>(buffers[r]) : nullptr;
-    for (int r = 0; r < c->n; ++r) {                           // 1. every rank's counters are complete at `ready`
-        COMM_HIP(hipSetDevice(c->devices[r]));
-        COMM_HIP(hipEventRecord(c->ready[r], scv::ctx_stream(c->ctx[r])));
-    }
-    for (int r = 0; r < c->n; ++r) {                           // 2. sum all ranks' buffers into this rank's staging buffer
-        COMM_HIP(hipSetDevice(c->devices[r]));
-        hipStream_t s = scv::ctx_stream(c->ctx[r]);
-        for (int j = 0; j < c->n; ++j) if (j != r) COMM_HIP(hipStreamWaitEvent(s, c->ready[j], 0));
-        int64_t grid = (count + 255) / 256;
-        if (grid > 64) grid = 64;
-        hipLaunchKernelGGL(scv::scv_sum_peers_k, dim3((unsigned)grid), dim3(256), 0, s, in, c->n, static_cast<long long*>(c->tmp[r]), count);
-        COMM_HIP(hipGetLastError());
-        COMM_HIP(hipEventRecord(c->done[r], s));
-    }
-    for (int r = 0; r < c->n; ++r) {                           // 3. nobody reads the buffers any more: the sum replaces them
-        COMM_HIP(hipSetDevice(c->devices[r]));
-        hipStream_t s = scv::ctx_stream(c->ctx[r]);
-        for (int j = 0; j < c->n; ++j) if (j != r) COMM_HIP(hipStreamWaitEvent(s, c->done[j], 0));
-        COMM_HIP(hipMemcpyAsync(buffers[r], c->tmp[r], bytes, hipMemcpyDeviceToDevice, s));
-    }
-    return SCV_OK;
+        for (int r = 0; r < c->n; ++r) {                           // 2. sum all ranks' buffers into this rank's staging buffer
+            COMM_HIP(hipSetDevice(c->devices[r]));
+            hipStream_t s = scv::ctx_stream(c->ctx[r]);
+            for (int j = 0; j < c->n; ++j) if (j != r) COMM_HIP(hipStreamWaitEvent(s, c->ready[j], 0));
+            int64_t grid = (count + 255) / 256;
+            if (grid > 64) grid = 64;
+            if (c->peer_loads == 1) hipLaunchKernelGGL(scv::scv_sum_peers_k<false>, dim3((unsigned)grid), dim3(256), 0, s, in, c->n, static_cast<long long*>(c->tmp[r]), count);
+            else hipLaunchKernelGGL(scv::scv_sum_peers_k<true>, dim3((unsigned)grid), dim3(256), 0, s, in, c->n, static_cast<long long*>(c->tmp[r]), count);
+            COMM_HIP(hipGetLastError());
+            COMM_HIP(hipEventRecord(c->done[r], s));
+        }
+        for (int r = 0; r < c->n; ++r) {                           // 3. nobody reads the buffers any more: the sum replaces them
+            COMM_HIP(hipSetDevice(c->devices[r]));
+            hipStream_t s = scv::ctx_stream(c->ctx[r]);
+            for (int j = 0; j < c->n; ++j) if (j != r) COMM_HIP(hipStreamWaitEvent(s, c->done[j], 0));
+            COMM_HIP(hipMemcpyAsync(buffers[r], c->tmp[r], bytes, hipMemcpyDeviceToDevice, s));
+        }
+        return SCV_OK;
+    });
 }
 
 // In-place all-gather of byte blocks: bufs[r] (on rank r's device) is the WHOLE gathered buffer, in which rank r has written its
@@ -329,55 +376,71 @@ static int allgather_blocks(scv_comm* c, void* const* bufs, const int64_t* bytes
 }
 
 int scv_allgather_cells(scv_comm* c, scv_cell* const* tables, const int64_t* rows, int32_t B) {
-    if (!c || !rows || B < 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allgather_cells: bad argument");
-    std::vector<int64_t> bytes(c->n);
-    for (int r = 0; r < c->n; ++r) {
-        if (rows[r] < 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allgather_cells: negative row count of rank %d", r);
-        bytes[r] = rows[r] * (int64_t)B * (int64_t)sizeof(scv_cell);
-    }
-    return allgather_blocks(c, reinterpret_cast<void* const*>(tables), bytes.data(), "scv_allgather_cells");
+    return guarded([&]() -> int {
+        if (!c || !rows || B < 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allgather_cells: bad argument");
+        std::vector<int64_t> bytes(c->n);
+        for (int r = 0; r < c->n; ++r) {
+            if (rows[r] < 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allgather_cells: negative row count of rank %d", r);
+            bytes[r] = rows[r] * (int64_t)B * (int64_t)sizeof(scv_cell);
+        }
+        return allgather_blocks(c, reinterpret_cast<void* const*>(tables), bytes.data(), "scv_allgather_cells");
+    });
 }
 
 int scv_allgather_i64(scv_comm* c, int64_t* const* buffers, const int64_t* counts) {
-    if (!c || !counts) return scv::comm_fail(SCV_ERR_ARG, "scv_allgather_i64: bad argument");
-    std::vector<int64_t> bytes(c->n);
-    for (int r = 0; r < c->n; ++r) {
-        if (counts[r] < 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allgather_i64: negative count of rank %d", r);
-        bytes[r] = counts[r] * (int64_t)sizeof(int64_t);
-    }
-    return allgather_blocks(c, reinterpret_cast<void* const*>(buffers), bytes.data(), "scv_allgather_i64");
+    return guarded([&]() -> int {
+        if (!c || !counts) return scv::comm_fail(SCV_ERR_ARG, "scv_allgather_i64: bad argument");
+        std::vector<int64_t> bytes(c->n);
+        for (int r = 0; r < c->n; ++r) {
+            if (counts[r] < 0) return scv::comm_fail(SCV_ERR_ARG, "scv_allgather_i64: negative count of rank %d", r);
+            bytes[r] = counts[r] * (int64_t)sizeof(int64_t);
+        }
+        return allgather_blocks(c, reinterpret_cast<void* const*>(buffers), bytes.data(), "scv_allgather_i64");
+    });
 }
 
 int scv_comm_get_stat(scv_comm* c, const char* key, int64_t* out) {
-    if (!c || !key || !out) return scv::comm_fail(SCV_ERR_ARG, "scv_comm_get_stat: NULL argument");
-    if (!strcmp(key, "selftest_words")) *out = c->stat_selftest_words;
-    else if (!strcmp(key, "staging_bytes")) *out = (int64_t)c->tmp_bytes;
-    else return scv::comm_fail(SCV_ERR_ARG, "scv_comm_get_stat: unknown key '%s'", key);
-    return SCV_OK;
+    return guarded([&]() -> int {
+        if (!c || !key || !out) return scv::comm_fail(SCV_ERR_ARG, "scv_comm_get_stat: NULL argument");
+        if (!strcmp(key, "selftest_words")) *out = c->stat_selftest_words;
+        else if (!strcmp(key, "staging_bytes")) *out = (int64_t)c->tmp_bytes;
+        else if (!strcmp(key, "peer_loads")) *out = c->peer_loads;
+        else if (!strcmp(key, "selftest_nt_ok")) *out = c->selftest_nt_ok;
+        else if (!strcmp(key, "selftest_plain_ok")) *out = c->selftest_plain_ok;
+        else return scv::comm_fail(SCV_ERR_ARG, "scv_comm_get_stat: unknown key '%s'", key);
+        return SCV_OK;
+    });
 }
 
 int scv_comm_sync(scv_comm* c) {
-    if (!c) return scv::comm_fail(SCV_ERR_ARG, "comm is NULL");
-    int first = SCV_OK;
-    for (int r = 0; r < c->n; ++r) {
-        const int rc = scv_sync(c->ctx[r]);
-        if (rc != SCV_OK && first == SCV_OK) first = rc;
-    }
-    return first;
+    return guarded([&]() -> int {
+        if (!c) return scv::comm_fail(SCV_ERR_ARG, "comm is NULL");
+        int first = SCV_OK;
+        for (int r = 0; r < c->n; ++r) {
+            const int rc = scv_sync(c->ctx[r]);
+            if (rc != SCV_OK && first == SCV_OK) first = rc;
+        }
+        return first;
+    });
 }
 
 }  // extern "C"
 
 namespace {
-// Create-time self-test (ranks > 1).  Two rounds with different patterns -- the second round catches a reader that kept stale
-// lines of a peer's buffer from the first:
-//   (a) SCV_COMM_PEER: every rank reads every OTHER rank's pattern buffer directly (the access path of scv_sum_peers_k, ordered by
-//       the same cross-device events) and compares it with that rank's closed-form pattern -> an error names the device PAIR;
+// Create-time self-test (ranks > 1, or RCCL).  Two rounds with different patterns -- the second round catches a reader that kept
+// stale lines of a peer's buffer from the first:
+//   (a) SCV_COMM_PEER: every rank reads every OTHER rank's pattern buffer directly, ordered by the same cross-device events as the
+//       all-reduce, once with nontemporal loads (the access path of scv_sum_peers_k) and once with ordinary loads, and compares it
+//       with that rank's closed-form pattern.  The result decides how this communicator reads its peers ("peer_loads": nontemporal
+//       when that was right in every round, else ordinary loads when THOSE were right in every round, else the create fails and
+//       names the device pair -- the caller then uses SCV_COMM_RCCL; MultiDeviceEngine does so by itself);
 //   (b) one scv_allreduce_counters of the pattern buffers, verified on every device against the closed-form sum -> names the device;
 //   (c) one scv_allgather_i64 of per-rank blocks, verified on every device.
 int comm_selftest(scv_comm* c) {
     constexpr int64_t K = 8216 + 1;                            // the production payload: packed counters at B = 8 + the error word
     const int n = c->n;
+    const bool peer = !(c->flags & SCV_COMM_RCCL);
+    const long long skew = (peer && peer_fault_for_test()) ? 1 : 0;
     std::vector<long long*> buf(n, nullptr), gat(n, nullptr);
     std::vector<unsigned long long*> res(n, nullptr);
     auto cleanup = [&]() {
@@ -391,16 +454,21 @@ int comm_selftest(scv_comm* c) {
     struct Cleanup { decltype(cleanup)& f; ~Cleanup() { f(); } } guard{cleanup};
     DeviceScope scope;
     const int64_t blk = 1031;                                  // all-gather block of every rank (words)
-    const size_t res_bytes = (size_t)(2 * (n + 2)) * sizeof(unsigned long long);
+    // result slots of a rank (2 words each: wrong words, first wrong word): [0, n) pair reads, nontemporal | [n, 2n) pair reads,
+    // ordinary loads | 2n the all-reduce | 2n + 1 the all-gather
+    const int slots = 2 * n + 2;
+    const size_t res_bytes = (size_t)(2 * slots) * sizeof(unsigned long long);
     for (int r = 0; r < n; ++r) {
         COMM_HIP(hipSetDevice(c->devices[r]));
         COMM_HIP(hipMalloc((void**)&buf[r], K * sizeof(long long)));
         COMM_HIP(hipMalloc((void**)&gat[r], (size_t)n * blk * sizeof(long long)));
         COMM_HIP(hipMalloc((void**)&res[r], res_bytes));
     }
-    std::vector<unsigned long long> init(2 * (n + 2));
+    std::vector<unsigned long long> init(2 * slots);
     for (size_t i = 0; i < init.size(); i += 2) { init[i] = 0; init[i + 1] = ~0ull; }
-    std::vector<unsigned long long> host(2 * (n + 2));
+    std::vector<unsigned long long> host(2 * slots);
+    bool nt_ok = true, plain_ok = true;
+    char nt_msg[384] = "";
     for (int round = 0; round < 2; ++round) {
         for (int r = 0; r < n; ++r) {
             COMM_HIP(hipSetDevice(c->devices[r]));
@@ -411,14 +479,15 @@ int comm_selftest(scv_comm* c) {
             COMM_HIP(hipGetLastError());
             COMM_HIP(hipEventRecord(c->ready[r], s));
         }
-        if (!(c->flags & SCV_COMM_RCCL)) {                     // (a) pairwise peer reads
+        if (peer && n > 1) {                                   // (a) pairwise peer reads, both load kinds
             for (int r = 0; r < n; ++r) {
                 COMM_HIP(hipSetDevice(c->devices[r]));
                 hipStream_t s = scv::ctx_stream(c->ctx[r]);
                 for (int j = 0; j < n; ++j) {
                     if (j == r) continue;
                     COMM_HIP(hipStreamWaitEvent(s, c->ready[j], 0));
-                    hipLaunchKernelGGL(scv::scv_comm_verify_k, dim3(8), dim3(256), 0, s, buf[j], j, j + 1, round, K, res[r] + 2 * j);
+                    hipLaunchKernelGGL(scv::scv_comm_verify_k<true>, dim3(8), dim3(256), 0, s, buf[j], j, j + 1, round, K, res[r] + 2 * j, skew);
+                    hipLaunchKernelGGL(scv::scv_comm_verify_k<false>, dim3(8), dim3(256), 0, s, buf[j], j, j + 1, round, K, res[r] + 2 * (n + j), skew);
                     COMM_HIP(hipGetLastError());
                 }
                 COMM_HIP(hipEventRecord(c->done[r], s));
@@ -427,6 +496,26 @@ int comm_selftest(scv_comm* c) {
                 COMM_HIP(hipSetDevice(c->devices[r]));
                 for (int j = 0; j < n; ++j) if (j != r) COMM_HIP(hipStreamWaitEvent(scv::ctx_stream(c->ctx[r]), c->done[j], 0));
             }
+            // the verdict on the two load kinds is needed before the all-reduce below picks one (a host sync at create costs nothing)
+            for (int r = 0; r < n; ++r) {
+                COMM_HIP(hipSetDevice(c->devices[r]));
+                COMM_HIP(hipMemcpyAsync(host.data(), res[r], res_bytes, hipMemcpyDeviceToHost, scv::ctx_stream(c->ctx[r])));
+                COMM_HIP(hipStreamSynchronize(scv::ctx_stream(c->ctx[r])));
+                for (int j = 0; j < n; ++j) {
+                    if (host[2 * j] && nt_ok) {
+                        nt_ok = false;
+                        snprintf(nt_msg, sizeof nt_msg, "round %d: device %d (rank %d) reads %llu of %lld words of device %d's (rank %d) buffer wrong over peer access "
+                                 "(nontemporal loads), first at word %llu", round, c->devices[r], r, host[2 * j], (long long)K, c->devices[j], j, host[2 * j + 1]);
+                    }
+                    if (host[2 * (n + j)]) plain_ok = false;
+                }
+            }
+            c->selftest_nt_ok = nt_ok ? 1 : 0;
+            c->selftest_plain_ok = plain_ok ? 1 : 0;
+            if (!nt_ok && !plain_ok)
+                return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create self-test (%s; ordinary loads wrong too): peer visibility between this device pair is broken -- "
+                                      "use SCV_COMM_RCCL", nt_msg);
+            c->peer_loads = nt_ok ? 0 : 1;
         }
         std::vector<int64_t*> bp(n), gp(n);
         std::vector<int64_t> cnt(n, blk);
@@ -436,29 +525,25 @@ int comm_selftest(scv_comm* c) {
         for (int r = 0; r < n; ++r) {
             COMM_HIP(hipSetDevice(c->devices[r]));
             hipStream_t s = scv::ctx_stream(c->ctx[r]);
-            hipLaunchKernelGGL(scv::scv_comm_verify_k, dim3(8), dim3(256), 0, s, buf[r], 0, n, round, K, res[r] + 2 * n);
+            hipLaunchKernelGGL(scv::scv_comm_verify_k<true>, dim3(8), dim3(256), 0, s, buf[r], 0, n, round, K, res[r] + 2 * (2 * n), skew);
             for (int j = 0; j < n; ++j)                        // block j of the gathered buffer = rank j's pattern (round + 2); one slot for all blocks
-                hipLaunchKernelGGL(scv::scv_comm_verify_k, dim3(8), dim3(256), 0, s, gat[r] + (int64_t)j * blk, j, j + 1, round + 2, blk, res[r] + 2 * (n + 1));
+                hipLaunchKernelGGL(scv::scv_comm_verify_k<true>, dim3(8), dim3(256), 0, s, gat[r] + (int64_t)j * blk, j, j + 1, round + 2, blk, res[r] + 2 * (2 * n + 1), skew);
             COMM_HIP(hipGetLastError());
         }
         for (int r = 0; r < n; ++r) {
             COMM_HIP(hipSetDevice(c->devices[r]));
             COMM_HIP(hipMemcpyAsync(host.data(), res[r], res_bytes, hipMemcpyDeviceToHost, scv::ctx_stream(c->ctx[r])));
             COMM_HIP(hipStreamSynchronize(scv::ctx_stream(c->ctx[r])));
-            for (int j = 0; j < n; ++j)
-                if (host[2 * j])
-                    return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create self-test (round %d): device %d (rank %d) reads %llu of %lld words of device %d's (rank %d) buffer wrong "
-                                          "over peer access, first at word %llu: peer visibility between this device pair is broken -- use SCV_COMM_RCCL",
-                                          round, c->devices[r], r, host[2 * j], (long long)K, c->devices[j], j, host[2 * j + 1]);
-            if (host[2 * n])
+            const char* how = peer ? (c->peer_loads == 1 ? "one-shot over peer access, ordinary loads" : "one-shot over peer access") : "RCCL";
+            if (host[2 * (2 * n)])
                 return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create self-test (round %d): after one all-reduce of known patterns device %d (rank %d) holds %llu of %lld wrong sums "
-                                      "(first at word %llu; %s)", round, c->devices[r], r, host[2 * n], (long long)K, host[2 * n + 1], (c->flags & SCV_COMM_RCCL) ? "RCCL" : "one-shot over peer access");
-            if (host[2 * (n + 1)])
+                                      "(first at word %llu; %s)", round, c->devices[r], r, host[2 * (2 * n)], (long long)K, host[2 * (2 * n) + 1], how);
+            if (host[2 * (2 * n + 1)])
                 return scv::comm_fail(SCV_ERR_ARG, "scv_comm_create self-test (round %d): after one all-gather of known blocks device %d (rank %d) holds %llu wrong words "
-                                      "(first at word %llu of a block; %s)", round, c->devices[r], r, host[2 * (n + 1)], host[2 * (n + 1) + 1], (c->flags & SCV_COMM_RCCL) ? "RCCL" : "peer copies");
+                                      "(first at word %llu of a block; %s)", round, c->devices[r], r, host[2 * (2 * n + 1)], host[2 * (2 * n + 1) + 1], peer ? "peer copies" : "RCCL");
         }
     }
-    c->stat_selftest_words = 2 * (K * (int64_t)((c->flags & SCV_COMM_RCCL) ? 1 : n) + (int64_t)n * blk);
+    c->stat_selftest_words = 2 * (K * (int64_t)(peer ? n : 1) + (int64_t)n * blk);
     return SCV_OK;
 }
 }  // namespace

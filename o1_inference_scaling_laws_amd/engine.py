@@ -482,6 +482,9 @@ class MultiDeviceEngine:
                     e.bootstrap_device(table, r0, r1, seed, M, out=full[r0:r1])
             boots.append(full)
         self.all_gather_i64(boots, [(r1 - r0) * B * M for r0, r1 in bounds])
+        # every engine's copy of the three exchanged buffers (each must be complete): what a caller that wants to verify the
+        # exchange step on EVERY rank reads back (bench.py does, after its timed region)
+        self.last_c5 = {"counters": counters, "tables": tables, "boots": boots}
         return counters[0], tables[0], boots[0], M
 
     def _run(self, fn_name, rows, truth, per_shard_kwargs, shared_kwargs):

@@ -70,7 +70,7 @@ def test_two_ranks_equal_one_rank_word_for_word(tmp_path):
     common = ["--samples", str(1 << 15), "--steps", "3", "--warmup", "1", "--resident", "4"]
     two = _bench(["--problems-per-step", "48", *common, "--dump", str(tmp_path / "two.npz")], ranks=2)
     one = _bench(["--problems-per-step", "96", *common, "--dump", str(tmp_path / "one.npz"), "--no-cpu-baseline"])
-    assert two["n_gpus"] == 2 and two["cpu_baseline"] is None and two["parity"].startswith("bit-exact: rank 0")
+    assert two["n_gpus"] == 2 and two["cpu_baseline"] is None and two["parity"].startswith("bit-exact: EVERY rank's first 32 problems") and two["allreduce_verified"] is True and two["parity_ranks_checked"] == 2
     assert two["config"]["backend"] == "gloo" and two["config"]["devices_shared_by_ranks"] is True
     a, b = np.load(tmp_path / "two.npz")["counters"], np.load(tmp_path / "one.npz")["counters"]
     assert a.shape == b.shape == (8 * 1027,) and np.array_equal(a, b) and a.sum() > 0
@@ -197,7 +197,7 @@ def test_single_process_communicator_runs_equal_the_torch_run_word_for_word(tmp_
     c5 = ["--workload", "c5", "--problems", "300", "--samples", str(1 << 14), "--resamples", "101", "--steps", "2", "--warmup", "1", "--dist", "3"]
     p5 = _bench(["--comm", "peer", "--gpus", "3", "--share-device", *c5, "--dump", str(tmp_path / "p5.npz")])
     t5 = _bench([*c5, "--dump", str(tmp_path / "t5.npz"), "--no-cpu-baseline"])
-    assert p5["parity"].startswith("bit-exact: rank 0") and "bootstrap_parity" in p5["c5"] and p5["c5"]["device_error_word"] == 0
+    assert p5["parity"].startswith("bit-exact: EVERY rank's first 32 problems") and p5["allreduce_verified"] is True and p5["parity_ranks_checked"] == 3 and "bootstrap_parity" in p5["c5"] and p5["c5"]["device_error_word"] == 0
     x, y = np.load(tmp_path / "p5.npz"), np.load(tmp_path / "t5.npz")
     for k in ("counters", "cells", "boot"):
         assert x[k].shape == y[k].shape and np.array_equal(x[k], y[k]), k
@@ -211,3 +211,88 @@ def test_single_process_communicator_with_too_few_gpus_is_one_json_error_line():
     assert out.returncode != 0
     d = _last_json(out.stdout)
     assert "error" in d and f"--gpus {n}" in d["error"] and d["value"] is None
+
+
+# ---- rehearsal at the target rank count: 8 ranks, P = 10 000 in shards of 1250, every stack, C3/C4 and C5 ----
+
+EIGHT = ["--samples", "256", "--steps", "2", "--warmup", "1", "--resident", "2"]
+
+
+def _assert_self_verified(d, ranks, oracle=True):
+    x = d["exchange_check"]
+    assert d["allreduce_verified"] is True and x["allreduce_verified"] is True and x["ranks_verified"] == ranks
+    assert x["allreduce_words"] == (8 * 1027 if "C5" not in d["config"]["workload"] else 1027)
+    if oracle:
+        assert d["parity_ranks_checked"] == ranks and x["parity_problems_per_rank"] == 32
+        assert d["parity"].startswith("bit-exact: EVERY rank's first 32 problems")
+    else:
+        assert d["parity_ranks_checked"] == 0
+
+
+def test_eight_ranks_c4_shape_every_stack_equals_one_rank(tmp_path):
+    """C4's shape at the target rank count on the 1-GPU box: 8 ranks x 1250 problems per step (a 10 000-problem step), torch/gloo
+    processes and ONE process over the library's peer communicator (8 contexts on cuda:0), and single-process RCCL on one device,
+    all equal to one rank x 10 000 problems word for word -- and each multi-rank line has verified its own exchange step on EVERY
+    rank (pre-reduce counters gathered independently, numpy sum == every rank's all-reduced buffer) and sent 32 problems of EVERY
+    rank's last chunk through the oracle."""
+    one = _bench(["--problems-per-step", "10000", *EIGHT, "--no-cpu-baseline", "--dump", str(tmp_path / "one.npz")])
+    want = np.load(tmp_path / "one.npz")["counters"]
+    assert want.shape == (8 * 1027,) and want.sum() > 0
+    tor = _bench(["--problems-per-step", "1250", *EIGHT, "--dump", str(tmp_path / "torch8.npz")], ranks=8)
+    assert tor["n_gpus"] == 8 and tor["config"]["backend"] == "gloo" and np.array_equal(np.load(tmp_path / "torch8.npz")["counters"], want)
+    _assert_self_verified(tor, 8)
+    peer = _bench(["--comm", "peer", "--gpus", "8", "--share-device", "--problems-per-step", "1250", *EIGHT, "--dump", str(tmp_path / "peer8.npz")])
+    assert peer["n_gpus"] == 8 and peer["config"]["devices"] == [0] * 8 and np.array_equal(np.load(tmp_path / "peer8.npz")["counters"], want)
+    _assert_self_verified(peer, 8)
+    rccl = _bench(["--comm", "rccl", "--gpus", "1", "--problems-per-step", "10000", *EIGHT, "--dump", str(tmp_path / "rccl1.npz")])
+    assert np.array_equal(np.load(tmp_path / "rccl1.npz")["counters"], want) and rccl["config"]["rccl_ranks"] == 1
+    _assert_self_verified(rccl, 1)
+    assert tor["accuracy_last_step"] == peer["accuracy_last_step"] == rccl["accuracy_last_step"] == one["accuracy_last_step"]
+
+
+def test_eight_ranks_c5_every_stack_equals_one_rank(tmp_path):
+    """C5 at the target rank count: P = 10 000 in shards of 1250, R = 1000 resamples = 125 per rank; counters, the gathered
+    cell table and the whole resample table of the 8-rank runs (torch/gloo processes; one process, peer communicator) equal
+    the 1-rank run's, which bench.py compares with the oracle; every rank verified its gathered tables."""
+    c5 = ["--workload", "c5", "--problems", "10000", "--samples", "256", "--resamples", "1000", "--steps", "2", "--warmup", "1", "--dist", "3"]
+    one = _bench([*c5, "--dump", str(tmp_path / "one.npz"), "--cpu-baseline-seconds", "0.3"])
+    assert "bootstrap_parity" in one["c5"]
+    tor = _bench([*c5, "--dump", str(tmp_path / "t8.npz")], ranks=8)
+    peer = _bench(["--comm", "peer", "--gpus", "8", "--share-device", *c5, "--dump", str(tmp_path / "p8.npz")])
+    a = np.load(tmp_path / "one.npz")
+    for name in ("t8", "p8"):
+        b = np.load(tmp_path / f"{name}.npz")
+        for k in ("counters", "cells", "boot"):
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), (name, k)
+    assert a["boot"].shape[0] == 1000 and a["cells"].shape[:2] == (10000, 1)
+    _assert_self_verified(tor, 8)
+    _assert_self_verified(peer, 8)
+    assert tor["exchange_check"]["c5_resample_table_equal_on_every_rank"] is True
+    assert "bootstrap_parity" in tor["c5"] and "bootstrap_parity" in peer["c5"]
+    assert one["c5"]["pass_at_k"] == tor["c5"]["pass_at_k"]
+
+
+def test_multi_rank_line_checks_the_closed_form_of_the_degenerate_distribution():
+    """--dist 2: every cell is a strict win, so tie_class_hits[b][1] == ranks x problems and truth_count_sum[b] == that x N whatever
+    the sharding; the multi-rank lines check it on the independently gathered sum."""
+    d = _bench(["--problems-per-step", "100", "--samples", "512", "--steps", "2", "--warmup", "1", "--resident", "2", "--dist", "2"], ranks=4)
+    assert d["exchange_check"]["closed_form"].startswith("D2: tie_class_hits[b][1] == 400") and d["allreduce_verified"] is True
+    p = _bench(["--comm", "peer", "--gpus", "4", "--share-device", "--problems-per-step", "100", "--samples", "512", "--steps", "2", "--warmup", "1",
+                "--resident", "2", "--dist", "5"])
+    assert p["exchange_check"]["closed_form"].startswith("D5: tie_class_hits[b][1] == 0") and p["allreduce_verified"] is True
+
+
+@pytest.mark.parametrize("stack", ["torch", "peer"])
+def test_a_wrong_sum_on_one_rank_stops_the_line(stack):
+    """The check has teeth: one word of ONE rank's all-reduced buffer off by one (what a stale peer read would look like) => no
+    bench line, exit status != 0, and the error names the rank and the word."""
+    env = dict(os.environ, SCV_BENCH_FAULT="2:1030")
+    base = ["--problems-per-step", "64", "--samples", "256", "--steps", "2", "--warmup", "1", "--resident", "2", "--no-cpu-baseline"]
+    if stack == "torch":
+        cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "3", *base, "--backend", "gloo", "--share-device"]
+    else:
+        cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--comm", "peer", "--gpus", "3", "--share-device", *base]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert out.returncode != 0
+    text = out.stdout + out.stderr
+    assert "rank 2: all-reduced counters != independently gathered sum: word 1030" in text and '"value"' not in text.split("EXCHANGE")[0][-400:]

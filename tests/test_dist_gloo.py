@@ -323,3 +323,66 @@ def test_c5_pipeline_errors_are_collective():
     assert _run_c5("domain") == {0: ("domain-remote", None), 1: ("domain-local", None)}
     got = _run_c5("overflow")
     assert {v[0] for v in got.values()} <= {"scv", "domain-remote"} and len(got) == 2 and "ok" not in {v[0] for v in got.values()}
+
+
+# ---- rehearsal at the target rank count (north_star: "shard across the 8 GPUs of one node"): world = 8, P = 10 000 ----------
+
+P8, B8, N8, R8 = 10_000, 2, 24, 1000
+
+
+def _worker_eight(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from o1_inference_scaling_laws_amd import passk
+        lo, hi = scv_dist.shard_bounds(P8, rank, world)
+        assert hi - lo == 1250
+        a, t, tr = coracle.synth_fill(hi - lo, B8, N8, SEED, 3, p_offset=lo, want_tokens=True)
+        eng = _CpuDeviceEngine()
+        # C4's shape: block of 1250 problems -> packed counters -> ONE all-reduce
+        res = scv_dist.aggregate_sharded(eng, torch.from_numpy(a), torch.from_numpy(tr), P8, tokens_local=torch.from_numpy(t))
+        # C5's shape on budget 0: vote -> all-reduce (+ error word) -> cell all-gather -> 125 resamples per rank -> gather
+        a0 = np.ascontiguousarray(a[:, :1, :])
+        d = passk.evaluate_device(eng, torch.from_numpy(a0), torch.from_numpy(tr), P8, R8, 77)
+        assert (d.r1 - d.r0) == R8 // world and tuple(d.cells.shape) == (P8, 1, 16)
+        passk.check(d, eng)
+        boot = passk.gather_bootstrap(d, R8, engine=eng)
+        q.put((rank, res.tie_class_hits.copy(), res.token_sum.copy(), res.truth_count_sum.copy(), [res.accuracy(b) for b in range(B8)],
+               d.counters.numpy().copy(), d.cells.numpy().copy(), boot.numpy().copy(), d.M))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_of_1250_problems_equal_the_unsharded_evaluation():
+    """VERDICT r4 next #1b: world = 8 with P = 10 000 (1250-problem shards; C5: 1000 resamples = 125 per rank) on gloo.
+    EVERY rank's all-reduced counters, gathered cell table and gathered resample table equal the unsharded oracle run."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_eight, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=600)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a, t, tr = coracle.synth_fill(P8, B8, N8, SEED, 3, want_tokens=True)
+    whole = coracle.aggregate(a, tr, tokens=t)
+    whole0 = coracle.aggregate(np.ascontiguousarray(a[:, :1, :]), tr)
+    M = got[0][7]
+    rc, want_boot = coracle.bootstrap(whole0["cells"], 0, R8, 77, M)
+    assert rc == 0 and M >= 3                      # D3: two- and three-way ties are present
+    ref_acc = [AggregateResult.from_counters(_pack(whole), P8, B8).accuracy(b) for b in range(B8)]
+    for r in range(world):
+        tie, tok, tcs, acc, c5_counters, c5_cells, boot, m = got[r]
+        assert np.array_equal(tie, whole["tie_class_hits"]) and np.array_equal(tok, whole["token_sum"]), r
+        assert np.array_equal(tcs, whole["truth_count_sum"]) and acc == ref_acc, r
+        assert m == M and np.array_equal(c5_counters, _pack(whole0)), r
+        assert np.array_equal(c5_cells, whole0["cells"].view(np.uint8).reshape(P8, 1, 16)), r
+        assert boot.shape == (R8, 1, M) and np.array_equal(boot, want_boot), r

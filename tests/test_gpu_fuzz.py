@@ -11,7 +11,7 @@ from tests._adapters import OracleEngine, assert_results_equal
 
 pytestmark = pytest.mark.gpu
 
-DEFAULTS = (("path", 0), ("segs", 0), ("grid", 0), ("auto_geometry", 1), ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0),
+DEFAULTS = (("path", 0), ("segs", 0), ("grid", 0), ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0),
             ("prefix_path", 0), ("sort_n_min", 8), ("sort_n_max", 64))
 GEOMETRIES = ((4, 256, 2), (8, 256, 4), (8, 512, 4), (16, 256, 4), (16, 512, 4), (16, 1024, 4))       # (copies, threads, unroll) instantiated
 
@@ -103,5 +103,4 @@ def test_random_configuration_is_bit_exact(hip_engine, seed):
     finally:
         for k, v in DEFAULTS:
             hip_engine.set_option(k, v)
-        hip_engine.set_tuning(copies=16, threads=1024, wg_per_cu=1, unroll=4)
-        hip_engine.set_option("auto_geometry", 1)
+        hip_engine.set_tuning(-1, -1, -1, -1)                    # back to the library's own geometry

@@ -178,8 +178,7 @@ def test_every_kernel_variant_is_bit_exact(hip_engine, copies, threads, unroll):
         assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
         assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), want, check_tokens=False)
     finally:
-        hip_engine.set_tuning(copies=16, threads=1024, wg_per_cu=1, unroll=4)
-        hip_engine.set_option("auto_geometry", 1)
+        hip_engine.set_tuning(-1, -1, -1, -1)                    # back to the library's own geometry
         hip_engine.set_option("path", 0)
 
 
@@ -203,9 +202,10 @@ def _with_options(eng, opts):
             for k, v in opts.items():
                 eng.set_option(k, v)
         def __exit__(self_, *exc):
-            for k, v in (("path", 0), ("segs", 0), ("grid", 0), ("auto_geometry", 1), ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0),
+            for k, v in (("path", 0), ("segs", 0), ("grid", 0), ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0),
                          ("prefix_path", 0), ("boot_path", 0), ("sort_n_min", 8), ("sort_n_max", 64)):
                 eng.set_option(k, v)
+            eng.set_tuning(-1, -1, -1, -1)
     return _Ctx()
 
 

@@ -48,7 +48,7 @@ def main():
                     if tune:
                         eng.set_tuning(*tune)
                     else:
-                        eng.set_option("auto_geometry", 1)
+                        eng.set_tuning(-1, -1, -1, -1)
                     def step(i):
                         a, tr = bufs[i % 5]
                         if not overwrite:
@@ -81,7 +81,7 @@ def main():
                     r = {"config": label, "overwrite": overwrite, "hip_event_timing": timing, "error": str(e)}
                 rows.append(r)
                 print(json.dumps(r), flush=True)
-        eng.set_option("path", 0); eng.set_option("segs", 0); eng.set_option("auto_geometry", 1)
+        eng.set_option("path", 0); eng.set_option("segs", 0); eng.set_tuning(-1, -1, -1, -1)
         eng.close()
         del bufs
         torch.cuda.empty_cache()
