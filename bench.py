@@ -277,6 +277,12 @@ def cpu_baseline(args, B, N, gpu_first_cells, first_off, gpu_last_cells, last_of
                 "results": [dict(P=r["P"], N=r["N"], reference_seconds=r["seconds"], **r["dropin"]) for r in ref["results"] if "dropin" in r],
             }
             dropin_loop["speedup_vs_reference_at_largest_N"] = dropin_loop["results"][-1]["speedup_vs_reference"]
+            # both driver families of the reference end to end (o1.py:314-315: 19 budgets at P = 30), reference vs drop-in
+            dropin_loop["family"] = ref.get("family")
+            fam = ref.get("family") or {}
+            for k in ("dropin_unbatched", "dropin_batched"):
+                if k in fam and not fam[k]["records_equal_to_reference"]:
+                    sys.exit(f"PARITY FAILURE: {k} records of the reference's driver families differ from the live reference's")
             dropin_loop["all_equal_to_reference"] = all(r["equal_to_reference"] for r in dropin_loop["results"])
             if not dropin_loop["all_equal_to_reference"]:
                 sys.exit("PARITY FAILURE: the drop-in's (accuracy, avg_tokens_used) differ from the live reference's on the same cache")

@@ -261,11 +261,15 @@ int scv_export_error_word(scv_ctx* ctx, int64_t* dst_device);
  *                SCV_COMM_RCCL: ncclCommInitAll + grouped ncclAllReduce(ncclInt64, ncclSum); librccl is resolved at run time
  *                (the copy the process already holds, else /opt/rocm's); distinct devices only.
  *
- * scv_comm_create with more than one rank ends with a SELF-TEST (first contact with the devices is loud, not a wrong accuracy
- * later): two rounds of known int64 patterns -- (PEER) every rank reads every other rank's buffer directly through the access
- * path of the all-reduce, then one whole scv_allreduce_counters of the production payload (8217 words) and one scv_allgather_i64,
- * each verified on every device.  A failure returns SCV_ERR_ARG with a message that names the device pair (peer read) or the
- * device (collective); the second round catches a reader that kept stale lines of a peer's first-round buffer.
+ * scv_comm_create with more than one rank -- or with SCV_COMM_RCCL and any rank count -- ends with a SELF-TEST (first contact with
+ * the devices is loud, not a wrong accuracy later): two rounds of known int64 patterns -- (PEER) every rank reads every other rank's
+ * buffer directly, ordered by the all-reduce's own cross-device events, once with nontemporal loads and once with ordinary loads,
+ * then one whole scv_allreduce_counters of the production payload (8217 words) and one scv_allgather_i64, each verified on every
+ * device.  The peer reads decide how this communicator reads its peers (nontemporal loads when they were right in both rounds,
+ * else ordinary loads when those were; "peer_loads" says which); when neither kind was right, or a collective's result is wrong,
+ * the create fails with SCV_ERR_ARG and a message ("... self-test ...") that names the device pair (peer read) or the device
+ * (collective) -- the caller then creates the communicator with SCV_COMM_RCCL (the Python MultiDeviceEngine does that by
+ * itself, with a warning).  The second round catches a reader that kept stale lines of a peer's first-round buffer.
  *
  * scv_allreduce_counters: buffers[r] is a DEVICE pointer on rank r's device (count int64 each, e.g. the packed counters
  * tie_class_hits | token_sum | truth_count_sum, optionally one more word from scv_export_error_word); in place, SUM, ordered
@@ -284,7 +288,10 @@ int scv_export_error_word(scv_ctx* ctx, int64_t* dst_device);
  *   counts[0] + ... + counts[r - 1] of buffers[r]) -- the gather of the resample slices counts_out [r_end - r_begin, B, M].
  * Both are asynchronous and ordered behind everything queued on the ranks' ctx streams.
  * scv_comm_sync = scv_sync on every rank (first error wins).  scv_comm_get_stat: "selftest_words" (words verified per rank at
- * create; 0 with one rank), "staging_bytes" (current size of the all-reduce's staging buffer).
+ * create; 0 with one SCV_COMM_PEER rank), "staging_bytes" (current size of the all-reduce's staging buffer), "peer_loads" (0: the
+ * one-shot all-reduce reads its peers with nontemporal loads, 1: with ordinary loads, -1: no peer reads -- RCCL or one rank),
+ * "selftest_nt_ok" / "selftest_plain_ok" (pairwise peer reads of the self-test with either load kind: 1 all right, 0 some wrong,
+ * -1 not run).
  */
 typedef struct scv_comm scv_comm;
 #define SCV_COMM_PEER 0x0u

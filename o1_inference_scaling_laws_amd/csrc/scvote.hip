@@ -873,7 +873,7 @@ int recover_fused_bootstrap(scv_ctx* ctx, uint32_t* w) {
     if (!ctx->boot_last.valid)
         return fail(SCV_ERR_ARG, "fused bootstrap: grid barrier timed out and the request is not known any more (graph replay of an older capture?); use option boot_path = 2");
     const scv_ctx::BootLast q = ctx->boot_last;
-    *w &= ~(4u | 2u);                            // bit 2 (class overflow) is re-derived by the re-run over the complete table
+    *w &= ~(4u | 2u);                            // bit 1 (value 2: class overflow) is re-derived by the re-run over the complete table
     if (int rc = scv_bootstrap(ctx, q.cells, q.P, q.B, q.r0, q.r1, q.seed, q.M, SCV_MEM_DEVICE, q.out)) return rc;
     uint32_t again = 0;
     if (int rc = fetch_err(ctx, &again, true)) return rc;        // synchronises the stream

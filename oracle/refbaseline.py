@@ -67,6 +67,64 @@ def _time_dropin(o1, engine, ds, cache, N, ref_acc, ref_avg, repeats):
             setattr(o1, k, v)
 
 
+def _family_records(o1, ds, cache):
+    """The reference's two drivers as its import runs them (o1.py:314-315): 11 majority-vote budgets + 8 ask-nicely budgets = 19
+    calls of run_experiments (or, with the batched drop-in, 3 engine calls).  The plot functions -- matplotlib, not the path -- are
+    replaced by collectors; what they would have dumped (plot_helpers.py:59-60, 85-86: json.dump(results, f, indent=2)) is returned
+    as the log text."""
+    import contextlib
+    import io
+    got = {}
+    saved = (o1.plot_majority_vote_graph, o1.plot_just_ask_nicely_graph)
+    o1.plot_majority_vote_graph = lambda results, shade=False: got.__setitem__("majority_vote", list(results))
+    o1.plot_just_ask_nicely_graph = lambda results, full=False: got.__setitem__("just_ask_nicely", list(results))
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            c0 = time.perf_counter()
+            o1.run_majority_vote_inference_experiments(ds, cache)
+            o1.run_just_ask_nicely_experiments(ds, cache)
+            dt = time.perf_counter() - c0
+    finally:
+        o1.plot_majority_vote_graph, o1.plot_just_ask_nicely_graph = saved
+    logs = {k: json.dumps([dict(r, avg_tokens_used=float(r["avg_tokens_used"])) for r in v], indent=2) for k, v in got.items()}
+    return dt, got, logs
+
+
+def _time_family(o1, engine, ds, cache, repeats):
+    """The whole pipeline family end to end: the unmodified reference, then the same two driver calls with the drop-in installed
+    (unbatched: the reference's own driver loops, 19 engine calls; batched: 3 engine calls)."""
+    from o1_inference_scaling_laws_amd import o1_dropin
+    ref_s, ref_rec, ref_logs = min((_family_records(o1, ds, cache) for _ in range(max(1, repeats))), key=lambda x: x[0])
+    out = {"budgets": sum(len(v) for v in ref_rec.values()), "reference_seconds": ref_s}
+    saved = {k: getattr(o1, k) for k in _REBOUND}
+    for batched in (False, True):
+        try:
+            cfg = o1_dropin.install(o1, engine=engine, batched=batched)
+            cfg.plot_majority_vote_graph = lambda results, shade=False: o1.plot_majority_vote_graph(results, shade)     # (the collectors installed
+            cfg.plot_just_ask_nicely_graph = lambda results, full=False: o1.plot_just_ask_nicely_graph(results, full)   # by _family_records)
+            _family_records(o1, ds, cache)                                   # warm
+            best = None
+            for _ in range(max(2, repeats)):
+                for k in cfg.timings:
+                    cfg.timings[k] = 0
+                dt, rec, logs = _family_records(o1, ds, cache)
+                if best is None or dt < best[0]:
+                    best = (dt, rec, logs, dict(cfg.timings))
+            dt, rec, logs, split = best
+            close = all(abs(g["accuracy"] - w["accuracy"]) < 1e-12 and float(g["avg_tokens_used"]) == float(w["avg_tokens_used"])
+                        and g["token_limit"] == w["token_limit"] for k in ref_rec for g, w in zip(rec[k], ref_rec[k]))
+            out["dropin_batched" if batched else "dropin_unbatched"] = {
+                "seconds": dt, "speedup_vs_reference": ref_s / dt, "engine_calls": split["calls"],
+                "split_s": {"extract": split["extract"], "engine_call": split["engine"], "kernel": split["kernel"], "floats": split["floats"]},
+                "engine_call_us_mean": split["engine"] / max(split["calls"], 1) * 1e6,
+                "records_equal_to_reference": bool(close and all(len(rec[k]) == len(ref_rec[k]) for k in ref_rec)),
+                "log_bytes_equal_to_reference": bool(logs == ref_logs)}
+        finally:
+            for k, v in saved.items():
+                setattr(o1, k, v)
+    return out
+
+
 def run(ns, seed: int, dist: int, repeats: int = 1, dropin: bool = False, engine_kind: str = "hip"):
     from oracle import coracle, pyoracle
     from oracle import ref_harness as rh
@@ -81,6 +139,7 @@ def run(ns, seed: int, dist: int, repeats: int = 1, dropin: bool = False, engine
     boot = [(p, T, 0, int(a0[p, 0, 0]), int(t0[p, 0, 0])) for p in range(P) for T in [2 ** i for i in range(4, 11)]]
     boot += [(p, 2048, i, int(a0[p, 0, i]), int(t0[p, 0, i])) for p in range(P) for i in range(8)]
     results = []
+    family = None
     engine, engine_what, dropin_error = None, None, None
     if dropin:
         try:
@@ -92,6 +151,11 @@ def run(ns, seed: int, dist: int, repeats: int = 1, dropin: bool = False, engine
         if engine is not None:                                 # first call of a process: context, staging pipeline, pinned slots
             cache8 = rh.build_cache(consts, ds, [(p, 2048, i, int(a0[p, 0, i]), int(t0[p, 0, i])) for p in range(P) for i in range(8)])
             _time_dropin(o1, engine, ds, cache8, 8, *o1.run_experiments(ds, cache8, 2048, 8), 1)
+            # the reference's own shape: both driver families on the cache its import ran on (P = 30; N = 1 ... 8; 19 budgets)
+            try:
+                family = _time_family(o1, engine, ds, rh.build_cache(consts, ds, boot), repeats)
+            except Exception as e:                             # reported, never fatal for the timing of the reference itself
+                family = {"error": f"{type(e).__name__}: {e}"}
         for N in ns:
             a, t, tr = coracle.synth_fill(P, 1, N, seed, dist, want_tokens=True)
             assert [int(x) for x in tr] == [int(x) for x in tr0]
@@ -116,7 +180,7 @@ def run(ns, seed: int, dist: int, repeats: int = 1, dropin: bool = False, engine
     if engine is not None and hasattr(engine, "close"):
         engine.close()
     return {"available": True, "reference": kind, "host_cores": os.cpu_count(), "results": results,
-            "dropin_engine": engine_what, "dropin_error": dropin_error,
+            "dropin_engine": engine_what, "dropin_error": dropin_error, "family": family,
             "what": "unmodified o1.run_experiments (o1.py:216-247) on a warm in-memory synthetic cache, save_cache no-op'd"}
 
 

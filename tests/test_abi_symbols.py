@@ -115,3 +115,23 @@ def test_communicator_refuses_without_a_device():
     for flags in (_lib.COMM_PEER, _lib.COMM_RCCL):
         assert L.scv_comm_create(ctypes.byref(comm), None, 0, 0, flags) == _lib.ERR_NO_DEVICE and not comm.value
     assert b"no HIP device" in L.scv_last_error()
+
+
+def test_every_extern_c_entry_runs_inside_the_exception_guard():
+    """SURVEY 8b / INTEGRATION.md: no C++ exception crosses the ABI.  Every int-returning extern "C" function of the two host
+    translation units has a body that is one `return guarded([&]() -> int { ... });` (csrc/scvote.hip, csrc/scvote_comm.hip),
+    except the one-line accessors that cannot throw; the GPU suite injects the faults (test_no_cpp_exception_crosses_the_abi)."""
+    trivial = {"scv_comm_size"}
+    for unit in ("scvote.hip", "scvote_comm.hip"):
+        src = open(os.path.join(REPO, "o1_inference_scaling_laws_amd", "csrc", unit)).read()
+        blocks = re.findall(r'extern "C" \{(.*?)\n\}  // extern "C"', src, flags=re.S)
+        assert blocks, unit
+        seen = 0
+        for blk in blocks:
+            for m in re.finditer(r"^int (scv_\w+)\([^)]*\) \{\n(.*?)\n\}$", blk, flags=re.S | re.M):
+                name, body = m.group(1), m.group(2)
+                if name in trivial:
+                    continue
+                seen += 1
+                assert body.lstrip().startswith("return guarded([&]() -> int {") and body.rstrip().endswith("});"), (unit, name)
+        assert seen >= (19 if unit == "scvote.hip" else 7), (unit, seen)

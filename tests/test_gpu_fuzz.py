@@ -12,7 +12,7 @@ from tests._adapters import OracleEngine, assert_results_equal
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = (("path", 0), ("segs", 0), ("grid", 0), ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0),
-            ("prefix_path", 0), ("sort_n_min", 8), ("sort_n_max", 64))
+            ("prefix_path", 0), ("sort_n_min", 8), ("sort_n_max", 64), ("host_small_kb", 1024))
 GEOMETRIES = ((4, 256, 2), (8, 256, 4), (8, 512, 4), (16, 256, 4), (16, 512, 4), (16, 1024, 4))       # (copies, threads, unroll) instantiated
 
 
@@ -76,6 +76,8 @@ def _draw(rng):
 def test_random_configuration_is_bit_exact(hip_engine, seed):
     rng = np.random.default_rng(10_000 + seed)
     P, B, N, dist, narrow, tokens, nv, opts, tuning, prefix = _draw(rng)
+    if np.random.default_rng(777_000 + seed).random() < 0.4:       # (its own stream: the seeds' shapes stay what they were in rounds 3-4)
+        opts["host_small_kb"] = 0                                  # small inputs through the staging pipeline instead of the one-block path
     if N == 0:
         a = np.zeros((P, B, 0), np.int32); t = np.zeros((P, B, 0), np.int32); tr = np.zeros(P, np.int32)
     else:

@@ -30,15 +30,23 @@ SHAPES = [  # (P, B, N): aligned, unaligned rows (N % 4 != 0), tiny, one vote, m
 ]
 
 
+@pytest.mark.parametrize("small_kb", [1024, 0])   # HOST mode's two forms: the one-block small path (default below 1 MiB) / always the pipeline
 @pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_host_mode_bit_exact_vs_oracle(hip_engine, dist, shape):
+def test_host_mode_bit_exact_vs_oracle(hip_engine, dist, shape, small_kb):
     P, B, N = shape
     a, t, tr = coracle.synth_fill(P, B, N, 1000 + dist, dist, want_tokens=True)
-    got = hip_engine.aggregate(a, tr, tokens=t)
-    assert_results_equal(got, oracle(a, tr, tokens=t))
-    got = hip_engine.aggregate(a, tr)            # votes-only kernel variant
-    assert_results_equal(got, oracle(a, tr), check_tokens=False)
+    hip_engine.set_option("host_small_kb", small_kb)
+    try:
+        n0 = hip_engine.stat("host_small_calls")
+        got = hip_engine.aggregate(a, tr, tokens=t)
+        assert_results_equal(got, oracle(a, tr, tokens=t))
+        got = hip_engine.aggregate(a, tr)            # votes-only kernel variant
+        assert_results_equal(got, oracle(a, tr), check_tokens=False)
+        fits = 2 * a.nbytes + 24 * P * B + 8216 * B + 4096 <= 1 << 20
+        assert hip_engine.stat("host_small_calls") - n0 == (2 if (small_kb and fits) else (1 if small_kb and a.nbytes + 24 * P * B + 8216 * B + 4096 <= 1 << 20 else 0))
+    finally:
+        hip_engine.set_option("host_small_kb", 1024)
 
 
 @pytest.mark.parametrize("n_valid", [[4096, 2048, 1024, 1, 0, 3, 4095, 17], [1, 1, 1, 1, 2, 4, 8, 16]])
@@ -80,22 +88,34 @@ def test_negative_tokens_and_int64_sums(hip_engine):
     assert got.token_sum[0] == got.cell_tokens.sum()
 
 
-def test_host_mode_streams_problem_chunks(hip_engine, monkeypatch):
+def test_host_mode_streams_problem_chunks(hip_engine):
     """SCV_MEM_HOST stages problem-chunks through one HBM block (C3 is 335 GB: it never fits at once).
-    Force many small chunks and check cells, per-cell tokens and the accumulated counters."""
+    Force many small chunks and check cells, per-cell tokens and the accumulated counters -- the dense call and the prefix call
+    (the chunk size is the "stage_mb" option, and only THIS test's launches are counted)."""
     import ctypes
-    monkeypatch.setenv("SCV_STAGE_MB", "1")                    # 1 MiB of votes(+tokens) per chunk
-    a, t, tr = coracle.synth_fill(97, 3, 4099, 31, 3, want_tokens=True)     # 4.8 MB of votes -> ~10 chunks
-    nv = np.array([4099, 2048, 1], dtype=np.int32)
-    want = oracle(a, tr, tokens=t, n_valid=nv)
-    assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
-    pool, tpool = a[:, 0, :], t[:, 0, :]
-    assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool),
-                         OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool))
-    ns = ctypes.c_uint64()
-    assert hip_engine._L.scv_last_kernel_ns(hip_engine._ctx, ctypes.byref(ns)) == 0 and ns.value > 0
-    total, n = hip_engine.drain_kernel_ns()
-    assert n >= 10 and total > 0
+    hip_engine.set_option("stage_mb", 1)                       # 1 MiB of votes(+tokens) per chunk
+    hip_engine.set_option("host_small_kb", 0)                  # the prefix call's pool (1.6 MB with tokens ... ) must take the pipeline too
+    try:
+        a, t, tr = coracle.synth_fill(97, 3, 4099, 31, 3, want_tokens=True)     # 4.8 MB of votes (+ 4.8 MB of tokens) -> 10 chunks
+        nv = np.array([4099, 2048, 1], dtype=np.int32)
+        want = oracle(a, tr, tokens=t, n_valid=nv)
+        hip_engine.sync()
+        hip_engine.drain_kernel_ns()
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want)
+        total, n_dense = hip_engine.drain_kernel_ns()
+        assert n_dense >= 9 and total > 0
+        pool, tpool = np.ascontiguousarray(a[:, 0, :]), np.ascontiguousarray(t[:, 0, :])
+        big_pool, big_tpool = np.tile(pool, (4, 1)), np.tile(tpool, (4, 1))                  # 388 problems x 4099: 12.7 MB -> many chunks
+        big_tr = np.tile(tr, 4)
+        assert_results_equal(hip_engine.aggregate_prefix(big_pool, big_tr, nv, tokens=big_tpool),
+                             OracleEngine().aggregate_prefix(big_pool, big_tr, nv, tokens=big_tpool))
+        ns = ctypes.c_uint64()
+        assert hip_engine._L.scv_last_kernel_ns(hip_engine._ctx, ctypes.byref(ns)) == 0 and ns.value > 0
+        total, n_prefix = hip_engine.drain_kernel_ns()
+        assert n_prefix >= 8 and total > 0
+    finally:
+        hip_engine.set_option("stage_mb", 128)
+        hip_engine.set_option("host_small_kb", 1024)
 
 
 @pytest.mark.parametrize("threads", [1, 5])
@@ -129,6 +149,98 @@ def test_host_mode_pipeline_and_pinned_sources(hip_engine, threads):
     finally:
         hip_engine.set_option("stage_mb", 128)
         hip_engine.set_option("copy_threads", 6)
+
+
+def test_host_small_calls_take_one_block_and_no_threads(hip_engine):
+    """every call the reference itself makes (P = 30, N <= 128; o1.py:277,302) is far below 1 MiB and goes
+    through ONE pinned block / one H2D / the kernel / one D2H / one sync -- dense and prefix, with tokens, ragged budgets,
+    counters only, a domain error reported by the same call (and the next call clean again), the error word not leaking into
+    DEVICE-mode calls of the same ctx."""
+    import torch
+    for (P, B, N, dist) in ((30, 1, 16, 1), (30, 8, 128, 3), (30, 11, 8, 1), (30, 19, 64, 4), (30, 1, 1, 1), (7, 3, 1001, 0), (100, 4, 257, 1)):
+        a, t, tr = coracle.synth_fill(P, B, N, 50 + N, dist, want_tokens=True)
+        nv = np.array([max(0, N >> (B - 1 - b)) for b in range(B)], dtype=np.int32)
+        n0, p0 = hip_engine.stat("host_small_calls"), hip_engine.stat("host_pipelined_calls")
+        assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+        assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)
+        got = hip_engine.aggregate(a, tr, tokens=t, want_cells=False)
+        want = oracle(a, tr, tokens=t)
+        assert got.cells is None and np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum)
+        pool, tpool = np.ascontiguousarray(a[:, 0, :]), np.ascontiguousarray(t[:, 0, :])
+        assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool))
+        assert hip_engine.stat("host_small_calls") - n0 == 4 and hip_engine.stat("host_pipelined_calls") == p0
+    a, _, tr = coracle.synth_fill(30, 2, 64, 9, 1)
+    bad = a.copy()
+    bad[17, 1, 33] = 5000
+    with pytest.raises(_lib.DomainError):
+        hip_engine.aggregate(bad, tr)
+    assert_results_equal(hip_engine.aggregate(a, tr), oracle(a, tr), check_tokens=False)       # the next call is clean
+    dev = torch.device("cuda", hip_engine.device)
+    hip_engine.aggregate_device(torch.from_numpy(a).to(dev), torch.from_numpy(tr).to(dev))
+    hip_engine.sync()                                                                           # no stale error in the ctx's own word
+
+
+FAULT_SCRIPT = """
+import sys, warnings
+import numpy as np
+sys.path.insert(0, {repo!r})
+from o1_inference_scaling_laws_amd import _lib
+from o1_inference_scaling_laws_amd.engine import Engine, MultiDeviceEngine
+from oracle import coracle
+a, t, tr = coracle.synth_fill(300, 2, 4096, 3, 1, want_tokens=True)          # 19.7 MB of votes + tokens: the staging pipeline
+want = coracle.aggregate(a, tr, tokens=t)
+mode = {mode!r}
+if mode == "peer":
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        mde = MultiDeviceEngine([0])
+    assert mde.rccl and mde.fell_back_to_rccl and any("self-test" in str(x.message) for x in w), [str(x.message) for x in w]
+    got = mde.aggregate(a, tr, tokens=t)
+    assert np.array_equal(got.tie_class_hits, want["tie_class_hits"]) and np.array_equal(got.token_sum, want["token_sum"])
+    import torch
+    shards = mde.scatter(a[:40], tr[:40])
+    cnt, _, _ = mde.aggregate_device(shards)
+    mde.sync()
+    w40 = coracle.aggregate(a[:40], tr[:40])
+    assert np.array_equal(cnt.cpu().numpy()[: 2 * 1025].reshape(2, 1025), w40["tie_class_hits"])
+    assert mde.stat("peer_loads") == -1 and mde.stat("selftest_words") > 0
+    print("FALLBACK-OK")
+else:
+    eng = Engine()
+    try:
+        got = eng.aggregate(a, tr, tokens=t)
+        assert np.array_equal(got.tie_class_hits, want["tie_class_hits"]) and np.array_equal(got.cell_tokens, want["cell_tokens"])
+        print("RESULT-OK", eng.stat("host_thread_start_failures"))
+    except _lib.ScvError as e:
+        print("ERROR-CODE", e.code, str(e))
+    # the ctx is still usable for a call that does not hit the fault (the small path has no threads and builds no pieces)
+    small = eng.aggregate(a[:5, :, :64], tr[:5])
+    assert np.array_equal(small.tie_class_hits, coracle.aggregate(a[:5, :, :64], tr[:5])["tie_class_hits"])
+    print("STILL-ALIVE")
+"""
+
+
+@pytest.mark.parametrize("mode", ["thread", "alloc", "throw", "peer"])
+def test_no_cpp_exception_crosses_the_abi(mode):
+    """what the standard library can throw inside the host side of the library (std::system_error from
+    std::thread in a container at its thread limit, std::bad_alloc, anything else) comes back as a result or an error code, never
+    std::terminate (a subprocess, so an abort would be seen as a signal).  SCV_TEST_FAULT injects each: `thread` -> the pipeline
+    runs on the calling thread alone and the result is right; `alloc` -> SCV_ERR_ALLOC; `throw` -> SCV_ERR_ARG 'internal error';
+    `peer` -> the SCV_COMM_PEER self-test fails and MultiDeviceEngine falls back to RCCL with a warning."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", FAULT_SCRIPT.format(repo=repo, mode=mode)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, SCV_TEST_FAULT=mode), cwd=repo)
+    assert out.returncode == 0, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+    if mode == "thread":
+        assert "RESULT-OK" in out.stdout and int(out.stdout.split("RESULT-OK")[1].split()[0]) >= 1 and "STILL-ALIVE" in out.stdout
+    elif mode == "alloc":
+        assert f"ERROR-CODE {_lib.ERR_ALLOC}" in out.stdout and "std::bad_alloc" in out.stdout and "STILL-ALIVE" in out.stdout
+    elif mode == "throw":
+        assert f"ERROR-CODE {_lib.ERR_ARG}" in out.stdout and "internal error" in out.stdout and "STILL-ALIVE" in out.stdout
+    else:
+        assert "FALLBACK-OK" in out.stdout
 
 
 def test_empty_shapes(hip_engine):
