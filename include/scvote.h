@@ -122,7 +122,9 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  *   "grid"                > 0: exact persistent grid (0: from the CU count, balanced so that all workgroups stream the same number of items)
  *   "segs"                split-N segments per cell (0 auto)
  *   "prefix_path"         scv_aggregate_prefix_i32: 0 auto | 1 one lane per problem, every budget out of one pass (pools <= 64) |
- *                         2 the cell kernels on pool rows (pools <= 4096) | 3 one streaming pass, a histogram snapshot per boundary
+ *                         2 the cell kernels on pool rows (pools <= 4096) | 3 one streaming pass, a histogram snapshot per boundary |
+ *                         4 one pass per problem over its pool row, 16 / 32 / 64 lanes per problem, every budget a snapshot of the running
+ *                         mode statistics (pools <= 4096: auto above 64 votes; "reg_shape" = 16 / 32 / 64 forces the lanes per problem)
  *   "boot_path"           scv_aggregate_bootstrap_i32: 0 auto (ONE cooperative launch when the shape allows it) | 1 one ORDINARY launch |
  *                         2 two launches, LDS-resident code table | 3 two launches, global gathers (also scv_bootstrap's kernel)
  *   "boot_spin_limit"     default 2^20: polls at the grid barrier before a workgroup of an ordinary one-launch form gives up and leaves
@@ -326,8 +328,8 @@ int scv_host_free(void* p);
  * (scv_aggregate_bootstrap_i32: one launch / two), "boot_cooperative" (one-launch forms started as cooperative launches),
  * "boot_recovered" (grid-barrier timeouts repaired by scv_sync with a separate bootstrap launch), "overwrite_fused" (counters
  * overwritten by the vote kernel's last workgroup), "lds_counters" (register-resident launches that produced their counters
- * themselves), "sort_cells" (sorted-cells launches), "few_votes" (launches of the kernel for cells of exactly 1, 2 or 4 votes), "prefix_cells" / "prefix_lane" (prefix calls served by the cell kernels / by
- * the one-lane-per-problem kernel), "host_small_calls" / "host_pipelined_calls" (HOST-mode calls served by the one-block small path / by
+ * themselves), "sort_cells" (sorted-cells launches), "few_votes" (launches of the kernel for cells of exactly 1, 2 or 4 votes), "prefix_cells" / "prefix_lane" / "prefix_pool" (prefix calls served by the cell kernels / by
+ * the one-lane-per-problem kernel / by the one-pass-per-problem kernel), "host_small_calls" / "host_pipelined_calls" (HOST-mode calls served by the one-block small path / by
  * the staging pipeline), "host_thread_start_failures" (worker threads of the staging pipeline the system refused to start: the
  * pipeline runs with the threads it has, the calling thread at least). */
 int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out);

@@ -185,7 +185,8 @@ struct scv_ctx {
     int reg_shape = 0;       // force a register-resident shape (parity tests, A/B runs), see launch_aggregate
     int fused_counters_max = 4096;  // cells: at or below, counters inside the hot kernel; above, scv_reduce_cells; 0: always the reduction
     int grid_override = 0;   // > 0: exact persistent grid size
-    int prefix_path = 0;     // prefix budgets: 0 auto | 1 one lane per problem | 2 cell kernels on pool rows | 3 one-pass streaming snapshots
+    int prefix_path = 0;     // prefix budgets: 0 auto | 1 one lane per problem | 2 cell kernels on pool rows | 3 one-pass streaming snapshots |
+                             // 4 one pass per problem, G lanes per problem (scv_prefix_pool; "reg_shape" 16 / 32 / 64 forces G)
     int boot_path = 0;       // vote + bootstrap: 0 auto (one cooperative launch when the shape allows) | 1 one ORDINARY launch | 2 two launches,
                              // LDS-resident code table | 3 two launches, global gathers
     int boot_spin_limit = 1 << 20;   // polls (x s_sleep 8) a workgroup waits at the grid barrier before giving up (tests force 1)
@@ -199,7 +200,7 @@ struct scv_ctx {
     struct BootReq { int32_t r0, r1, M; uint64_t seed; int64_t* out; bool fused; }* boot_req = nullptr;   // set for the duration of one call
     // the last fused request, kept so that a grid-barrier timeout can be repaired at scv_sync by a separate bootstrap launch
     struct BootLast { const scv_cell* cells = nullptr; int64_t P = 0; int32_t B = 0, r0 = 0, r1 = 0, M = 0; uint64_t seed = 0; int64_t* out = nullptr; bool valid = false; } boot_last;
-    int64_t stat_boot_recovered = 0, stat_boot_cooperative = 0, stat_sort_cells = 0, stat_few_votes = 0;
+    int64_t stat_boot_recovered = 0, stat_boot_cooperative = 0, stat_sort_cells = 0, stat_few_votes = 0, stat_prefix_pool = 0;
     // split-N scratch (grown on demand)
     void* d_partial = nullptr;
     size_t d_partial_bytes = 0;
@@ -252,6 +253,7 @@ using scv::pick_kernel;
 using scv::pick_reg_kernel;
 using scv::pick_dense_kernel;
 using scv::pick_sort_kernel;
+using scv::pick_prefix_pool_kernel;
 
 // Every entry point runs on the ctx device and leaves the caller's current HIP device as it found it
 // (a process driving several GPUs from one thread -- MultiDeviceEngine -- must not have torch's
@@ -727,6 +729,92 @@ bool prefix_lane_eligible(const scv_ctx* ctx, int32_t B, int64_t N, int* nv, siz
     return *lds <= (size_t)24 * 1024;   // + up to 128 KiB for the staged cell records (B <= 8)
 }
 
+// One pass per problem over its pool row, every budget a snapshot of the running mode statistics (scvote_prefix.hip.h).
+int launch_prefix_pool(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, const int32_t* n_valid, const int32_t* truth,
+                       int64_t P, int32_t B, int64_t N, scv_cell* cells, int64_t* cell_tokens, int64_t* tie, int64_t* tok_sum,
+                       int64_t* truth_sum, bool rows_aligned) {
+    scv::AggArgs a;
+    a.pool_rows = 1;
+    a.answers = pool; a.tokens = tokens; a.n_valid = n_valid; a.truth = truth;
+    a.ncells = P * (int64_t)B; a.N = N; a.B = B; a.P = P;
+    a.cells = cells; a.cell_tokens = cell_tokens;
+    a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
+    a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
+    a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
+    a.err_flag = ctx->d_err;
+    a.prefetch = 0; a.sorted = 1;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0;
+    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr;
+    const bool tok = tokens != nullptr;
+    const bool want_counters = tie || truth_sum || (tok && tok_sum);
+    // lanes per problem: 16 up to 512 votes (4 problems per wave: the fixed work per boundary is shared by 4), a whole wave beyond
+    int g = N <= 512 ? 16 : 64;
+    if (ctx->reg_shape == 16 || ctx->reg_shape == 32 || ctx->reg_shape == 64) g = ctx->reg_shape;
+    const RegKernel rk = pick_prefix_pool_kernel(g, tok, rows_aligned);
+    a.wave_lds_words = (int32_t)((64 / g) * scv::kBins + scv::kPrefixPoolLaneWords);
+    int W = rk.waves;
+    const size_t fixed_words = 2 * (size_t)B + 64;
+    while (W > 1 && ((size_t)W * a.wave_lds_words + fixed_words) * 4 > (size_t)ctx->lds_max) --W;
+    size_t lds = ((size_t)W * a.wave_lds_words + 2 * (size_t)B) * sizeof(uint32_t);
+    const bool use_reduce = want_counters && ctx->fused_counters_max == 0;          // forced (tests): counters from the cell table
+    if (use_reduce) {
+        a.tie_hits = nullptr; a.token_sum = nullptr; a.truth_sum = nullptr;
+        if (!a.cells || (tok && tok_sum && !a.cell_tokens)) {
+            const size_t cb = (size_t)a.ncells * sizeof(scv_cell);
+            if (int rc = ensure_cells(ctx, cb + (size_t)a.ncells * sizeof(int64_t) + 256)) return rc;
+            if (!a.cells) a.cells = static_cast<scv_cell*>(ctx->d_cells);
+            if (tok && !a.cell_tokens) a.cell_tokens = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->d_cells) + ((cb + 255) / 256) * 256);
+        }
+    }
+    if (ctx->overwrite_counters && want_counters) {      // overwrite semantics: a memset node in front
+        if (tie) SCV_HIP(hipMemsetAsync(tie, 0, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), ctx->stream));
+        if (tok_sum) SCV_HIP(hipMemsetAsync(tok_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
+        if (truth_sum) SCV_HIP(hipMemsetAsync(truth_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
+    }
+    // per-budget counters in the LDS the histograms leave free: [B][TCL] tie classes + 2 B sums per workgroup, flushed by the same launch
+    if (want_counters && !use_reduce) {
+        const int64_t spare_words = ((int64_t)ctx->lds_max - (int64_t)lds) / 4 - 64;
+        const int64_t full = (N < 1024 ? N : 1024) + 1;
+        int64_t tcl = spare_words > 4 * (int64_t)B + 2 ? (spare_words - 4 * (int64_t)B - 2) / B : 0;
+        if (tcl > full) tcl = full;
+        if (tcl >= 8 || tcl == full) {
+            a.acc_classes = (int32_t)tcl;
+            lds += ((((size_t)B * tcl + 1) & ~(size_t)1) + 4 * (size_t)B) * sizeof(uint32_t);
+            ctx->stat_lds_counters += 1;
+        }
+    }
+    SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rk.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    SCV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rk.fn), W * 64, lds));
+    if (per_cu < 1) per_cu = 1;
+    const int64_t nbatches = (P + (64 / g) - 1) / (64 / g);
+    int64_t grid = (int64_t)ctx->num_cus * per_cu;
+    if (ctx->grid_override > 0) grid = ctx->grid_override;
+    const int64_t wgs_needed = (nbatches + W - 1) / W;
+    if (grid > wgs_needed) grid = wgs_needed;
+    EventPair* ev = nullptr;
+    if (int rc = next_event_pair(ctx, &ev)) return rc;
+    if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+    hipLaunchKernelGGL(rk.fn, dim3((unsigned)grid), dim3((unsigned)(W * 64)), lds, ctx->stream, a);
+    SCV_HIP(hipGetLastError());
+    ctx->stat_prefix_pool += 1;
+    if (use_reduce) {
+        int64_t chunks = (P + 2047) / 2048;
+        const int64_t cap = ((int64_t)ctx->num_cus * 8 + B - 1) / B;
+        if (chunks > cap) chunks = cap;
+        if (chunks < 1) chunks = 1;
+        auto* th = reinterpret_cast<unsigned long long*>(tie);
+        auto* ts = reinterpret_cast<unsigned long long*>(tok_sum);
+        auto* tc = reinterpret_cast<unsigned long long*>(truth_sum);
+        if (tok && tok_sum) hipLaunchKernelGGL((scv::scv_reduce_cells<true>), dim3((unsigned)chunks, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
+        else hipLaunchKernelGGL((scv::scv_reduce_cells<false>), dim3((unsigned)chunks, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, ctx->stream, a.cells, a.cell_tokens, P, B, th, ts, tc);
+        SCV_HIP(hipGetLastError());
+    }
+    if (ev) SCV_HIP(hipEventRecord(ev->b, ctx->stream));
+    ctx->err_dirty = true;
+    return SCV_OK;
+}
+
 // Prefix budgets over one pool [P, N] (scv_aggregate_prefix_i32).  Same outputs as launch_aggregate on the dense [P, B, N]
 // expansion.  Option "prefix_path" forces one of the three forms (parity tests).
 int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, const int32_t* n_valid,
@@ -738,6 +826,9 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     size_t lane_lds = 0;
     const bool lane_ok = prefix_lane_eligible(ctx, B, N, &lane_nv, &lane_lds) && (ctx->prefix_path == 0 || ctx->prefix_path == 1);
     const bool rows_aligned = (N % 4 == 0) && (((uintptr_t)pool & 15u) == 0) && (!tokens || ((uintptr_t)tokens & 15u) == 0);
+    // pools of 65 .. 4096 votes (and shorter ones when forced): ONE pass per problem, every budget a snapshot (scv_prefix_pool)
+    const bool pool_ok = ctx->path == 0 && N >= 1 && N <= 4096 && B <= scv::kMaxSortedB && ((ctx->prefix_path == 0 && !lane_ok) || ctx->prefix_path == 4);
+    if (pool_ok) return launch_prefix_pool(ctx, pool, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, rows_aligned);
     if (!lane_ok && pool_rows_eligible(ctx, B, N, rows_aligned) && (ctx->prefix_path == 0 || ctx->prefix_path == 2)) {
         ctx->stat_prefix_cells += 1;
         return launch_aggregate(ctx, pool, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, true);
@@ -1029,7 +1120,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
         else if (!strcmp(key, "fused_counters_max")) { if (value < 0) return fail(SCV_ERR_ARG, "fused_counters_max < 0"); ctx->fused_counters_max = (int)(value > (1 << 30) ? (1 << 30) : value); }
         else if (!strcmp(key, "grid")) { if (value < 0 || value > (1 << 20)) return fail(SCV_ERR_ARG, "grid out of range"); ctx->grid_override = (int)value; }
         else if (!strcmp(key, "segs")) { if (value < 0 || value > 4096) return fail(SCV_ERR_ARG, "segs out of range"); ctx->segs_override = (int)value; }
-        else if (!strcmp(key, "prefix_path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "prefix_path must be 0..3"); ctx->prefix_path = (int)value; }
+        else if (!strcmp(key, "prefix_path")) { if (value < 0 || value > 4) return fail(SCV_ERR_ARG, "prefix_path must be 0..4"); ctx->prefix_path = (int)value; }
         else if (!strcmp(key, "boot_path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "boot_path must be 0..3"); ctx->boot_path = (int)value; }
         else if (!strcmp(key, "boot_spin_limit")) { if (value < 1 || value > (1 << 30)) return fail(SCV_ERR_ARG, "boot_spin_limit out of range"); ctx->boot_spin_limit = (int)value; }
         else if (!strcmp(key, "stage_mb")) { if (value < 1 || value > 65536) return fail(SCV_ERR_ARG, "stage_mb out of range"); ctx->stage_mb = (int)value; }
@@ -1497,6 +1588,7 @@ int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
         else if (!strcmp(key, "lds_counters")) *out = ctx->stat_lds_counters;
         else if (!strcmp(key, "prefix_cells")) *out = ctx->stat_prefix_cells;
         else if (!strcmp(key, "prefix_lane")) *out = ctx->stat_prefix_lane;
+    else if (!strcmp(key, "prefix_pool")) *out = ctx->stat_prefix_pool;
         else if (!strcmp(key, "sort_cells")) *out = ctx->stat_sort_cells;
         else if (!strcmp(key, "few_votes")) *out = ctx->stat_few_votes;
         else if (!strcmp(key, "host_small_calls")) *out = ctx->stat_small_calls;

@@ -36,6 +36,11 @@ RegKernel pick_dense_kernel(int v, int h, bool tok, bool vec);
 // .waves = the launch bound in waves
 RegKernel pick_sort_kernel(int nv, bool tok, bool lin);
 
+// scv_prefix_pool<g lanes per problem>: prefix budgets over one pool row per problem, every budget out of one pass (scvote_prefix.hip.h);
+// .waves = the launch bound in waves; words of LDS per wave = 64 / g x 1024 (histograms) + kPrefixPoolLaneWords
+constexpr int kPrefixPoolLaneWords = 64;          // behind a wave's histograms: one trash word per lane
+RegKernel pick_prefix_pool_kernel(int g, bool tok, bool vec);
+
 // ---- shared by the table translation units ------------------------------------------------------------------------
 template <int RL2, int T, int U>
 inline KernelFn stream_tok(bool tok, bool xtra) {

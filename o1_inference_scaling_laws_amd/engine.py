@@ -66,7 +66,13 @@ class AggregateResult:
 
 
 def _np_ptr(a):
-    return None if a is None else a.ctypes.data_as(C.c_void_p)
+    # (the address as a plain int: ndarray.ctypes.data_as(c_void_p) costs 2.2 us per argument, a fifth of a reference-sized call)
+    return None if a is None else a.ctypes.data
+
+
+def _out(shape, dtype, written: bool):
+    """Output array of a HOST-mode call: the library overwrites every element when the call has work (P, B > 0)."""
+    return np.empty(shape, dtype=dtype) if written else np.zeros(shape, dtype=dtype)
 
 
 def pinned_empty(shape, dtype=np.int32) -> np.ndarray:
@@ -186,11 +192,12 @@ class Engine:
             n_valid = np.ascontiguousarray(n_valid, dtype=np.int32)
             if n_valid.shape != (B,):
                 raise ValueError("n_valid must be [B]")
-        cells = np.zeros((P, B), dtype=CELL_DTYPE) if want_cells else None
-        cell_tokens = np.zeros((P, B), dtype=np.int64) if (want_cells and tokens is not None) else None
-        tie = np.zeros((B, TIE_CLASSES), dtype=np.int64)
-        tok = np.zeros((B,), dtype=np.int64)
-        tcs = np.zeros((B,), dtype=np.int64)
+        w = P > 0 and B > 0
+        cells = _out((P, B), CELL_DTYPE, w) if want_cells else None
+        cell_tokens = _out((P, B), np.int64, w) if (want_cells and tokens is not None) else None
+        tie = _out((B, TIE_CLASSES), np.int64, w)
+        tok = _out((B,), np.int64, w and tokens is not None)
+        tcs = _out((B,), np.int64, w)
         check(self._L.scv_aggregate_i32(self._ctx, _np_ptr(answers), _np_ptr(tokens), _np_ptr(n_valid),
                                         _np_ptr(truth), P, B, N, _lib.MEM_HOST, _np_ptr(cells),
                                         _np_ptr(cell_tokens), _np_ptr(tie), _np_ptr(tok), _np_ptr(tcs)))
@@ -213,11 +220,12 @@ class Engine:
             tokens = np.ascontiguousarray(tokens, dtype=np.int32)
             if tokens.shape != pool.shape:
                 raise ValueError("tokens must match pool")
-        cells = np.zeros((P, B), dtype=CELL_DTYPE) if want_cells else None
-        cell_tokens = np.zeros((P, B), dtype=np.int64) if (want_cells and tokens is not None) else None
-        tie = np.zeros((B, TIE_CLASSES), dtype=np.int64)
-        tok = np.zeros((B,), dtype=np.int64)
-        tcs = np.zeros((B,), dtype=np.int64)
+        w = P > 0 and B > 0
+        cells = _out((P, B), CELL_DTYPE, w) if want_cells else None
+        cell_tokens = _out((P, B), np.int64, w) if (want_cells and tokens is not None) else None
+        tie = _out((B, TIE_CLASSES), np.int64, w)
+        tok = _out((B,), np.int64, w and tokens is not None)
+        tcs = _out((B,), np.int64, w)
         check(self._L.scv_aggregate_prefix_i32(self._ctx, _np_ptr(pool), _np_ptr(tokens), _np_ptr(n_valid),
                                                _np_ptr(truth), P, B, N, _lib.MEM_HOST, _np_ptr(cells),
                                                _np_ptr(cell_tokens), _np_ptr(tie), _np_ptr(tok), _np_ptr(tcs)))

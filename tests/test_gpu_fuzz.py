@@ -76,6 +76,10 @@ def _draw(rng):
 def test_random_configuration_is_bit_exact(hip_engine, seed):
     rng = np.random.default_rng(10_000 + seed)
     P, B, N, dist, narrow, tokens, nv, opts, tuning, prefix = _draw(rng)
+    if prefix and "prefix_path" in opts and np.random.default_rng(555_000 + seed).random() < 0.4:
+        opts["prefix_path"] = 4                                    # one pass per problem (pools <= 4096; longer ones fall through to the streaming pass)
+        if "reg_shape" not in opts or opts["reg_shape"] > 64:
+            opts["reg_shape"] = int(np.random.default_rng(556_000 + seed).choice([0, 16, 32, 64]))
     if np.random.default_rng(777_000 + seed).random() < 0.4:       # (its own stream: the seeds' shapes stay what they were in rounds 3-4)
         opts["host_small_kb"] = 0                                  # small inputs through the staging pipeline instead of the one-block path
     if N == 0:

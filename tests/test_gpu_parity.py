@@ -809,6 +809,12 @@ def test_prefix_mode_equals_dense_oracle(hip_engine, case):
             assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
         with _with_options(hip_engine, {"prefix_path": 3}):       # one streaming pass, a snapshot per boundary
             assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+        for g in (16, 32, 64):                                    # one pass per problem, g lanes per problem (scv_prefix_pool)
+            with _with_options(hip_engine, {"prefix_path": 4, "reg_shape": g}):
+                before = hip_engine.stat("prefix_pool")
+                assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+                assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
+                assert hip_engine.stat("prefix_pool") == before + 2
 
 
 @pytest.mark.parametrize("dist", [0, 1, 3, 4, 5])
@@ -826,11 +832,22 @@ def test_prefix_budgets_over_short_pools_run_on_the_cell_kernels(hip_engine, dis
     for nv in ([1 << k for k in range(N.bit_length()) if (1 << k) <= N] + [N], [N, 0, 1, max(1, N // 3), N, max(0, N - 1)]):
         nv = np.array(nv, dtype=np.int32)
         want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
-        stat = "prefix_lane" if N <= 64 else "prefix_cells"          # one lane per problem / cell kernels on pool rows
+        stat = "prefix_lane" if N <= 64 else "prefix_pool"           # one lane per problem / one pass per problem over G lanes
         before = hip_engine.stat(stat)
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
         assert hip_engine.stat(stat) == before + 1
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
+        if N > 64:
+            with _with_options(hip_engine, {"prefix_path": 2}):          # the cell kernels on pool rows (a cell per problem and budget)
+                before = hip_engine.stat("prefix_cells")
+                assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+                assert hip_engine.stat("prefix_cells") == before + 1
+            got = hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool, want_cells=False)     # no cell table
+            assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum) and np.array_equal(got.truth_count_sum, want.truth_count_sum)
+        for g in (16, 32, 64):                                           # every pool length on every lanes-per-problem shape
+            with _with_options(hip_engine, {"prefix_path": 4, "reg_shape": g, "grid": 0 if g == 32 else 2}):
+                assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+                assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
         if N <= 64:
             with _with_options(hip_engine, {"prefix_path": 2}):
                 before = hip_engine.stat("prefix_cells")
@@ -865,6 +882,32 @@ def test_prefix_lane_kernel_with_many_budgets(hip_engine, P, N, B):
     want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
     assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
     assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
+
+
+@pytest.mark.parametrize("P,N,B,dist", [(300, 100, 200, 1), (90, 700, 512, 3), (40, 4096, 37, 1), (1000, 256, 17, 2), (500, 129, 16, 5), (777, 68, 33, 4),
+                                         (5000, 128, 8, 1)])
+def test_prefix_pool_kernel_with_many_budgets(hip_engine, P, N, B, dist):
+    """scv_prefix_pool latches one record per lane and writes them every G boundaries: more budgets than lanes per problem, budgets that
+    repeat, are unsorted, include 0 and values beyond N (clamped), counter tables that do not fit the LDS whole (classes above the part
+    that fits go to memory directly), degenerate distributions (every lane of a problem on one bin), more batches than waves."""
+    rng = np.random.default_rng(B + N)
+    a, t, tr = coracle.synth_fill(P, 1, N, 31 + B, dist, want_tokens=True)
+    pool, tpool = a[:, 0, :], t[:, 0, :]
+    nv = rng.integers(0, N + 3, size=B).astype(np.int32)
+    want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
+    for opts in ({}, {"prefix_path": 4, "reg_shape": 16}, {"prefix_path": 4, "reg_shape": 32, "grid": 1}, {"prefix_path": 4, "reg_shape": 64},
+                 {"prefix_path": 4, "fused_counters_max": 0}):
+        with _with_options(hip_engine, opts):
+            assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+            assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
+    bad = pool.copy()
+    bad[P // 2, N - 1] = 1 << 20                                   # out-of-domain vote in the last slot: seen only by budgets that reach it
+    short = np.minimum(nv, N - 1).astype(np.int32)
+    with _with_options(hip_engine, {"prefix_path": 4}):
+        assert_results_equal(hip_engine.aggregate_prefix(bad, tr, short), OracleEngine().aggregate_prefix(pool, tr, short), check_tokens=False)
+        if (nv >= N).any():
+            with pytest.raises(_lib.DomainError):
+                hip_engine.aggregate_prefix(bad, tr, nv)
 
 
 def test_prefix_mode_device_and_errors(hip_engine):
