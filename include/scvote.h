@@ -124,7 +124,7 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  *   "prefix_path"         scv_aggregate_prefix_i32: 0 auto | 1 one lane per problem, every budget out of one pass (pools <= 64) |
  *                         2 the cell kernels on pool rows (pools <= 4096) | 3 one streaming pass, a histogram snapshot per boundary |
  *                         4 one pass per problem over its pool row, 16 / 32 / 64 lanes per problem, every budget a snapshot of the running
- *                         mode statistics (pools <= 4096: auto above 64 votes; "reg_shape" = 16 / 32 / 64 forces the lanes per problem)
+ *                         mode statistics (pools <= 4096: auto above 64 votes and for budget lists too long for path 1; "reg_shape" = 16 / 32 forces the lanes per problem)
  *   "boot_path"           scv_aggregate_bootstrap_i32: 0 auto (ONE cooperative launch when the shape allows it) | 1 one ORDINARY launch |
  *                         2 two launches, LDS-resident code table | 3 two launches, global gathers (also scv_bootstrap's kernel)
  *   "boot_spin_limit"     default 2^20: polls at the grid barrier before a workgroup of an ordinary one-launch form gives up and leaves

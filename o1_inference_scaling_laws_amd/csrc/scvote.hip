@@ -335,7 +335,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.err_flag = ctx->d_err;
     a.prefetch = 1;
     a.sorted = 1;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
@@ -354,6 +354,9 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         else if (N <= ctx->reg_n_max && Nreg <= 8192) kind = REG;
         else kind = STREAM;
         if (kind == LANE && lane_kernel_lds(B, N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : 32))) > (size_t)60 * 1024) kind = REG;   // (thousands of budgets)
+        // 17 .. 32 votes with tokens on one lane per cell need 256 VGPRs + scratch at 512 threads (pool rows / sorted cells switched off
+        // only -- dense cells of this length are sorted): the register-resident shape of 64 votes takes them
+        if (kind == LANE && tok && N > 16) kind = REG;
     }
 
     // ---- per-budget counters: inside the launch (LDS tables of the cell kernels; per-cell atomics of the streaming kernel for few
@@ -563,7 +566,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         if (nv == 4) { if (tok) SCV_LANE(4, 1024, true); else SCV_LANE(4, 1024, false); }
         else if (nv == 8) { if (tok) SCV_LANE(8, 1024, true); else SCV_LANE(8, 1024, false); }
         else if (nv == 16) { if (tok) SCV_LANE(16, 512, true); else SCV_LANE(16, 1024, false); }
-        else { if (tok) SCV_LANE(32, 512, true); else SCV_LANE(32, 512, false); }
+        else SCV_LANE(32, 512, false);                              // (with tokens: REG, see the decision above)
 #undef SCV_LANE
         SCV_HIP(hipGetLastError());
         return finish(ev);
@@ -721,12 +724,20 @@ bool pool_rows_eligible(const scv_ctx* ctx, int32_t B, int64_t N, bool rows_alig
     return lane_kernel_lds(B, nv) <= (size_t)60 * 1024;
 }
 
-// pools of up to 64 samples: scv_lane_prefix (tie classes 0..nv, two sums, order + sorted n_valid per budget in LDS)
-bool prefix_lane_eligible(const scv_ctx* ctx, int32_t B, int64_t N, int* nv, size_t* lds) {
+// pools of up to 64 samples: scv_lane_prefix (tie classes 0..nv, two sums, order + sorted n_valid per budget in LDS; the snapshots of a
+// wave's 64 x B cells staged in LDS: 16 bytes each, 24 with tokens -- budget lists whose snapshots do not fit even a 256-thread workgroup
+// run on scv_prefix_pool, which holds one record per lane whatever the number of budgets)
+bool prefix_lane_eligible(const scv_ctx* ctx, int32_t B, int64_t N, bool tok, int* nv, size_t* lds, int* threads) {
     if (ctx->path != 0 || N < 1 || N > 64 || B > scv::kMaxSortedB) return false;
     *nv = N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : 64)));
     *lds = ((((size_t)B * (*nv + 1) + 1) & ~(size_t)1) + 6 * (size_t)B) * sizeof(uint32_t);
-    return *lds <= (size_t)24 * 1024;   // + up to 128 KiB for the staged cell records (B <= 8)
+    if (*lds > (size_t)24 * 1024) return false;
+    const size_t counters_bytes = (*lds + 15) & ~(size_t)15;
+    const size_t per_wave = (size_t)64 * B * (sizeof(scv_cell) + (tok ? sizeof(int64_t) : 0));
+    for (int t = *nv == 64 ? 256 : 1024; t >= 256; t >>= 1) {
+        if (counters_bytes + (size_t)(t / 64) * per_wave + 1024 <= (size_t)ctx->lds_max) { *threads = t; return true; }
+    }
+    return false;
 }
 
 // One pass per problem over its pool row, every budget a snapshot of the running mode statistics (scvote_prefix.hip.h).
@@ -743,19 +754,20 @@ int launch_prefix_pool(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
     a.prefetch = 0; a.sorted = 1;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
-    // lanes per problem: 16 up to 512 votes (4 problems per wave: the fixed work per boundary is shared by 4), a whole wave beyond
-    int g = N <= 512 ? 16 : 64;
-    if (ctx->reg_shape == 16 || ctx->reg_shape == 32 || ctx->reg_shape == 64) g = ctx->reg_shape;
+    // lanes per problem: 16 up to 1024 votes (4 problems per wave share the fixed work per boundary; 16-bit bins: 16 waves per CU), 32 beyond
+    // (measured: 1024 votes 68 us at 16 lanes against 82 at 32, 4096 votes 100 against 87)
+    int g = N <= 1024 ? 16 : 32;
+    if (ctx->reg_shape == 16 || ctx->reg_shape == 32) g = ctx->reg_shape;
     const RegKernel rk = pick_prefix_pool_kernel(g, tok, rows_aligned);
-    a.wave_lds_words = (int32_t)((64 / g) * scv::kBins + scv::kPrefixPoolLaneWords);
+    a.wave_lds_words = (int32_t)(scv::prefix_pool_hist_words(g) + scv::kPrefixPoolLaneWords);
     int W = rk.waves;
-    const size_t fixed_words = 2 * (size_t)B + 64;
-    while (W > 1 && ((size_t)W * a.wave_lds_words + fixed_words) * 4 > (size_t)ctx->lds_max) --W;
-    size_t lds = ((size_t)W * a.wave_lds_words + 2 * (size_t)B) * sizeof(uint32_t);
+    const size_t fixed_words = 2 * (size_t)B + scv::kPrefixPoolFixedWords;
+    while (W > 1 && ((size_t)W * a.wave_lds_words + fixed_words + 64) * 4 > (size_t)ctx->lds_max) --W;
+    size_t lds = ((size_t)W * a.wave_lds_words + fixed_words) * sizeof(uint32_t);
     const bool use_reduce = want_counters && ctx->fused_counters_max == 0;          // forced (tests): counters from the cell table
     if (use_reduce) {
         a.tie_hits = nullptr; a.token_sum = nullptr; a.truth_sum = nullptr;
@@ -822,9 +834,9 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
                   int64_t* tie, int64_t* tok_sum, int64_t* truth_sum) {
     const int64_t ncells = P * (int64_t)B;
     if (ncells == 0) return SCV_OK;
-    int lane_nv = 0;
+    int lane_nv = 0, lane_threads = 0;
     size_t lane_lds = 0;
-    const bool lane_ok = prefix_lane_eligible(ctx, B, N, &lane_nv, &lane_lds) && (ctx->prefix_path == 0 || ctx->prefix_path == 1);
+    const bool lane_ok = prefix_lane_eligible(ctx, B, N, tokens != nullptr, &lane_nv, &lane_lds, &lane_threads) && (ctx->prefix_path == 0 || ctx->prefix_path == 1);
     const bool rows_aligned = (N % 4 == 0) && (((uintptr_t)pool & 15u) == 0) && (!tokens || ((uintptr_t)tokens & 15u) == 0);
     // pools of 65 .. 4096 votes (and shorter ones when forced): ONE pass per problem, every budget a snapshot (scv_prefix_pool)
     const bool pool_ok = ctx->path == 0 && N >= 1 && N <= 4096 && B <= scv::kMaxSortedB && ((ctx->prefix_path == 0 && !lane_ok) || ctx->prefix_path == 4);
@@ -843,7 +855,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
     a.prefetch = 0; a.sorted = 1;
-    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0; a.lane_stage = 0;
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr;
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
@@ -872,20 +884,14 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
         // Workgroup size.  N <= 32: 1024 threads, one workgroup per CU (the end-of-launch flush is one device atomic per
         // workgroup and counter, ~12 ns each on one address).  N = 64 needs 95-151 VGPRs: 256 threads, as many workgroups
         // as are resident (measured 61-64 us against 84-86 us with 768 / 1024 threads, which spill or leave a second, nearly
-        // empty round).  Snapshots are staged in LDS (24 bytes x 64 x B per wave with tokens) when that fits, in
-        // smaller workgroups if need be; with many budgets the reductions run at every boundary instead.
+        // empty round).  Snapshots are staged in LDS (24 bytes x 64 x B per wave with tokens), in smaller workgroups if need be
+        // (prefix_lane_eligible picked the size).
         const size_t counters_bytes = (lane_lds + 15) & ~(size_t)15;
         const size_t per_wave = (size_t)64 * B * (sizeof(scv_cell) + (tok ? sizeof(int64_t) : 0));
-        int T = lane_nv == 64 ? 256 : 1024;
-        bool staged = false;
-        for (int t = T; t >= 256; t >>= 1) {
-            if (counters_bytes + (size_t)(t / 64) * per_wave + 1024 <= (size_t)ctx->lds_max) { T = t; staged = true; break; }
-        }
-        const size_t lds_total = staged ? counters_bytes + (size_t)(T / 64) * per_wave : lane_lds;
-        a.lane_stage = staged ? 1 : 0;
+        const int T = lane_threads;
+        const size_t lds_total = counters_bytes + (size_t)(T / 64) * per_wave;
         KernelFn fn;
-#define SCV_LP2(NVV, TBB) (tok ? (staged ? (KernelFn)scv::scv_lane_prefix<NVV, TBB, true, true> : (KernelFn)scv::scv_lane_prefix<NVV, TBB, true, false>) \
-                              : (staged ? (KernelFn)scv::scv_lane_prefix<NVV, TBB, false, true> : (KernelFn)scv::scv_lane_prefix<NVV, TBB, false, false>))
+#define SCV_LP2(NVV, TBB) (tok ? (KernelFn)scv::scv_lane_prefix<NVV, TBB, true> : (KernelFn)scv::scv_lane_prefix<NVV, TBB, false>)
         fn = lane_nv == 4 ? SCV_LP2(4, 1024) : (lane_nv == 8 ? SCV_LP2(8, 1024) : (lane_nv == 16 ? SCV_LP2(16, 1024) : (lane_nv == 32 ? SCV_LP2(32, 1024) : SCV_LP2(64, 256))));
 #undef SCV_LP2
         SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));

@@ -36,9 +36,16 @@ RegKernel pick_dense_kernel(int v, int h, bool tok, bool vec);
 // .waves = the launch bound in waves
 RegKernel pick_sort_kernel(int nv, bool tok, bool lin);
 
-// scv_prefix_pool<g lanes per problem>: prefix budgets over one pool row per problem, every budget out of one pass (scvote_prefix.hip.h);
-// .waves = the launch bound in waves; words of LDS per wave = 64 / g x 1024 (histograms) + kPrefixPoolLaneWords
+// scv_prefix_pool<g lanes per problem, v vectors per lane>: prefix budgets over one pool row per problem, every budget out of one pass
+// (scvote_prefix.hip.h); shapes (16, 4) and (32, 4); .waves = the launch bound in waves; words of LDS per wave = prefix_pool_hist_words(g) +
+// kPrefixPoolLaneWords; behind the waves ord[B] | nvs[B] | kPrefixPoolFixedWords (the head map) | the counter tables
 constexpr int kPrefixPoolLaneWords = 64;          // behind a wave's histograms: one trash word per lane
+constexpr int kPrefixPoolFixedWords = 32;
+#ifndef SCV_PREFIX_H16
+#define SCV_PREFIX_H16 1
+#endif
+constexpr bool prefix_pool_h16(int g) { return SCV_PREFIX_H16 != 0 && g == 16; }           // 16-bit bins, two per word
+constexpr int prefix_pool_hist_words(int g) { return (64 / g) * (prefix_pool_h16(g) ? kBins / 2 : kBins); }
 RegKernel pick_prefix_pool_kernel(int g, bool tok, bool vec);
 
 // ---- shared by the table translation units ------------------------------------------------------------------------

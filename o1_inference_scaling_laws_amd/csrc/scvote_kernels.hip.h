@@ -5,9 +5,12 @@
 //                     votes, sum tokens), o1.py:202 (statistics.multimode) and o1.py:204-213 (tie-aware
 //                     score), and accumulates the integer part of the per-budget reduction o1.py:229-245.
 // scv_merge_partials  finishes cells that were split over several workgroups.
-// scv_small_cells[_reg], scv_tiny_cells   the same arithmetic for short cells (one wave per cell /
-//                     several cells per wave) -- the reference's own N = 1..128.
-// scv_prefix_hist, scv_small_prefix       budgets that are prefixes of one sample pool, one pass.
+// scv_few_votes       cells of exactly 1 / 2 / 4 votes in whole blocks (the reference's most common sizes, o1.py:276, 302).
+// scv_lane_cells      one lane per cell, registers only: N = 3, 5 .. 7, partial blocks, pool rows of up to 32 votes.
+// scv_reg_cells, scv_reg_dense      a cell in the registers of 16 / 32 / 64 lanes, 16-bit bins in LDS (64 < N <= 8192).
+// (scv_sort_cells -- one lane per cell, rows by LDS-DMA, packed sorting network: csrc/scvote_sort.hip.h -- 5 / 8 <= N <= 64.)
+// scv_lane_prefix, scv_prefix_hist  budgets that are prefixes of one sample pool, one pass: pools of up to 64 votes / beyond 4096
+// (scv_prefix_pool -- G lanes per problem, ranks from returning LDS atomics: csrc/scvote_prefix.hip.h -- 65 .. 4096 votes).
 // scv_reduce_cells    per-budget integer counters from the cell table when cells are short and many.
 // scv_bootstrap_k     problem-level bootstrap over the per-cell table.
 // scv_synth_fill_k    closed-form synthetic generator (spec: include/scvote.h).
@@ -67,8 +70,6 @@ struct AggArgs {
     int32_t wave_lds_words; // register-resident kernels: LDS words per wave (histograms + n_valid cache)
     int32_t pool_rows;      // cell kernels (register-resident, one-lane-per-cell): != 0 = prefix budgets over one pool: cell (p, b) reads
                             // row p of answers / tokens [P, N] (its first n_valid[b] votes) instead of row p * B + b of [P, B, N]
-    int32_t lane_stage;     // scv_lane_prefix: != 0 = a wave's 64 x B cell records are transposed through LDS and written as one
-                            // contiguous block (a lane's own records are B * 16 bytes apart)
     int32_t acc_classes;    // register-resident kernels: > 0 = per-budget counters accumulate in LDS (this many tie classes per
                             // budget; larger classes go to memory directly) and are flushed once per workgroup
     // single-launch modes of the streaming kernel (agent-scope hand-offs inside the launch, no second kernel):
@@ -1349,12 +1350,13 @@ __device__ __forceinline__ void wg_counters_flush(const AggArgs& a, const WgCoun
 // state at its boundary: every budget of a problem comes out of ONE pass over its N votes (N (N - 1) / 2 compares: 2016
 // at N = 64) instead of one count per budget.  Boundaries are visited in ascending order (rank sort of n_valid in
 // LDS; unsorted / duplicate / empty budgets allowed); the per-budget counters accumulate in LDS as in scv_lane_cells.
-// TB: launch bound (the block may be smaller); STAGE: a boundary only stores the lane's snapshot (16-byte cell record,
-// token sum) in LDS, and the counters of all B budgets are taken from the snapshots after the last vote, then the wave's
-// 64 x B records leave as one contiguous block -- the unrolled vote loop then carries 64 tiny snapshot sites instead of 64
-// copies of the reductions (with tokens the latter did not fully unroll and put the token registers in scratch: 230 us).
-// !STAGE (many budgets: 24 B x 64 x B per wave do not fit): reductions at the boundary, records written directly.
-template <int NV, int TB, bool TOK, bool STAGE>
+// TB: launch bound (the block may be smaller).  A boundary only stores the lane's snapshot (16-byte cell record, token sum) in
+// LDS, and the counters of all B budgets are taken from the snapshots after the last vote, then the wave's 64 x B records
+// leave as one contiguous block -- the unrolled vote loop then carries 64 tiny snapshot sites instead of 64 copies of the
+// reductions (with tokens the latter did not fully unroll and put the token registers in scratch: 230 us).  Budget lists
+// whose snapshots do not fit the LDS (24 B x 64 x B per wave with tokens) run on scv_prefix_pool (round 5; rounds 2-4 kept
+// a second form of this kernel with the reductions at every boundary for them).
+template <int NV, int TB, bool TOK>
 __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
     constexpr int TC = NV + 1;                                       // tie classes 0..NV
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1410,7 +1412,7 @@ __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
         const int32_t* trow = TOK ? a.tokens + off : nullptr;
         // next boundary in a scalar register: the per-vote test is then one s_cmp (an LDS read per vote otherwise)
         auto boundary = [&](int kk) -> int32_t { return kk < B ? __builtin_amdgcn_readfirstlane(nvs[kk]) : -1; };
-        if (TOK && STAGE) {
+        if (TOK) {
             // Token sums of the budgets in a pass of their own, BEFORE the votes are loaded: 64 token registers next to
             // 64 votes + 32 packed pairs meant 226 VGPRs (2 waves per SIMD); the running sum is snapshot into the staged
             // slots at the same boundaries the vote pass will visit.
@@ -1460,7 +1462,6 @@ __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
         const int32_t truth = a.truth[live ? p : 0];
         const uint32_t tcmp = (truth >= 0 && truth < kBins) ? (uint32_t)truth : 0xffffffffu;
         uint32_t maxc = 0, n_modes = 0, min_mode = 0xffffu, tc = 0;
-        long long tok = 0;
         int k = 0;                                                   // next boundary (wave-uniform)
         auto emit = [&](int32_t b) {
             const bool any = maxc > 0;
@@ -1470,16 +1471,8 @@ __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
             rec.y = tc;
             rec.z = (n_modes & 0xffffu) | ((any ? (min_mode & 0xffffu) : 0xffffu) << 16);
             rec.w = hit;
-            if (STAGE) {
-                stage_rec[lane * B + b] = rec;                       // (an inactive lane's slot is never copied out or counted;
+            stage_rec[lane * B + b] = rec;                           // (an inactive lane's slot is never copied out or counted;
                                                                      //  its token sum was staged by the token pass)
-            } else {
-                if (live) {
-                    if (a.cells) reinterpret_cast<uint4*>(a.cells)[p * B + b] = rec;
-                    if (TOK && a.cell_tokens) a.cell_tokens[p * B + b] = tok;
-                }
-                count_budget(b, hit, n_modes, live ? tc : 0u, live ? tok : 0ll);
-            }
         };
         int32_t next_n = boundary(0);
         while (next_n == 0) { emit(__builtin_amdgcn_readfirstlane(ord[k])); next_n = boundary(++k); }
@@ -1493,24 +1486,6 @@ __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
             if (2 * m + 1 < N) bad |= x[2 * m + 1];
             const uint32_t lo = x[2 * m] < 1023u ? x[2 * m] : 1023u, hi = x[2 * m + 1] < 1023u ? x[2 * m + 1] : 1023u;
             xp[m] = lo | (hi << 16);
-        }
-        // tokens are loaded after the votes are packed (64 + 64 live registers would spill at NV = 64)
-        int32_t tk[(TOK && !STAGE) ? NV : 1];
-        if (TOK && !STAGE) {
-            if (vec) {
-#pragma unroll
-                for (int kq = 0; kq < NV / 4; ++kq) {
-                    int4 y = make_int4(0, 0, 0, 0);
-                    if (4 * kq < N) y = stream_load(reinterpret_cast<const int4*>(trow) + kq);
-                    tk[4 * kq] = y.x; tk[4 * kq + 1] = y.y; tk[4 * kq + 2] = y.z; tk[4 * kq + 3] = y.w;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    tk[i] = 0;
-                    if (i < N) tk[i] = __builtin_nontemporal_load(trow + i);
-                }
-            }
         }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -1529,31 +1504,28 @@ __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
                 min_mode = gt ? xi : ((eq && xi < min_mode) ? xi : min_mode);
                 maxc = gt ? c : maxc;
                 tc += xi == tcmp ? 1u : 0u;
-                if (TOK && !STAGE) tok += (long long)tk[i];
                 while (next_n == i + 1) { emit(__builtin_amdgcn_readfirstlane(ord[k])); next_n = boundary(++k); }
             }
         }
-        if (STAGE) {
-            // LDS operations of a wave are in order: the snapshots are complete here
-            __builtin_amdgcn_wave_barrier();
-            for (int32_t b = 0; b < B; ++b) {
-                const uint4 rec = stage_rec[lane * B + b];
-                long long tv = 0;
-                if (TOK) tv = stage_tok[lane * B + b];
-                count_budget(b, live ? rec.w : 0u, rec.z & 0xffffu, live ? rec.y : 0u, live ? tv : 0ll);
-            }
-            // the wave's block: cells[p0 * B .. (p0 + 64) * B), contiguous
-            const int64_t nrec = (a.P - p0 < 64 ? a.P - p0 : 64) * B;
-            if (a.cells) {
-                uint4* out = reinterpret_cast<uint4*>(a.cells) + p0 * B;
-                for (int64_t r = lane; r < nrec; r += 64) out[r] = stage_rec[r];
-            }
-            if (TOK && a.cell_tokens) {
-                long long* out = reinterpret_cast<long long*>(a.cell_tokens) + p0 * B;
-                for (int64_t r = lane; r < nrec; r += 64) out[r] = stage_tok[r];
-            }
-            __builtin_amdgcn_wave_barrier();
+        // LDS operations of a wave are in order: the snapshots are complete here
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t b = 0; b < B; ++b) {
+            const uint4 rec = stage_rec[lane * B + b];
+            long long tv = 0;
+            if (TOK) tv = stage_tok[lane * B + b];
+            count_budget(b, live ? rec.w : 0u, rec.z & 0xffffu, live ? rec.y : 0u, live ? tv : 0ll);
         }
+        // the wave's block: cells[p0 * B .. (p0 + 64) * B), contiguous
+        const int64_t nrec = (a.P - p0 < 64 ? a.P - p0 : 64) * B;
+        if (a.cells) {
+            uint4* out = reinterpret_cast<uint4*>(a.cells) + p0 * B;
+            for (int64_t r = lane; r < nrec; r += 64) out[r] = stage_rec[r];
+        }
+        if (TOK && a.cell_tokens) {
+            long long* out = reinterpret_cast<long long*>(a.cell_tokens) + p0 * B;
+            for (int64_t r = lane; r < nrec; r += 64) out[r] = stage_tok[r];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
     __syncthreads();

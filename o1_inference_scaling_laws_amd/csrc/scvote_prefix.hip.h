@@ -5,8 +5,9 @@
 // completions.  Dense [P, B, N] (or the cell kernels on pool rows, one cell per (problem, budget)) re-read and re-count the
 // prefix B times; here a problem's pool row is read ONCE and every vote is counted ONCE, whatever the number of budgets.
 //
-// How (pools of up to 4096 votes; a problem occupies G = 16 / 32 / 64 adjacent lanes, 64 / G problems per wave):
-//  * the problem has a private 1024-bin histogram in LDS (32-bit bins).  Vote i goes in with ONE returning LDS atomic
+// How (pools of up to 4096 votes; a problem occupies G = 16 / 32 adjacent lanes, 64 / G problems per wave):
+//  * the problem has a private 1024-bin histogram in LDS (32-bit bins at G = 32; 16-bit bins, two per word, at G = 16: 8 KiB of
+//    histograms per wave instead of 16, so 16 waves per CU are resident instead of 8).  Vote i goes in with ONE returning LDS atomic
 //    (ds_add_rtn_u32): the returned old count + 1 is the vote's RANK r_i = #{ j <= i in serialisation order : x_j == x_i }.
 //    Among the votes of a prefix every bin with final count c contributes the ranks 1 .. c exactly once, so with
 //    M = max rank over the prefix:
@@ -14,21 +15,37 @@
 //        min(modes) = min{ x_i : r_i == M }
 //    -- order-free facts about the multiset of (value, rank) pairs: the lanes of a problem add their votes concurrently, the
 //    only ordering that matters is that the votes below a budget's boundary are all in before its snapshot and none above.
-//  * every lane keeps two running registers over ITS votes: K = max (r << 10 | 1023 - x) (the group maximum is M and the
-//    smallest modal value) and S = (its largest rank << 16 | how many of its votes have that rank).  A boundary costs one
+//  * every lane keeps two running registers over ITS votes: K = max (r << 18 | A), A = the LDS byte address of the vote's bin in a
+//    histogram stored by DESCENDING value (the group maximum is M and the smallest modal value: the address doubles as the value,
+//    12 VALU per vote at G = 32, 15 with the half-word arithmetic of G = 16), and S = (its largest rank << 18 | how many of its
+//    votes have that rank).  A boundary costs one
 //    group all-reduce of K, one of S's count where the lane's rank equals M (packed with the lane's truth votes), and for
-//    the tokens stream one 64-bit sum: ~16 wave instructions per budget, not a re-read and a re-count.
+//    the tokens stream one 64-bit sum -- not a re-read and a re-count.  The reduced pair is LATCHED by one lane of the
+//    problem; after G boundaries (or the last) the lanes turn their pairs into records side by side, write them --
+//    cells[p, b] for consecutive b are 16 bytes apart -- and add to the per-workgroup LDS counter tables (o1.py:238-240 as
+//    integers), flushed once per workgroup.
+//  * THE HEAD: budgets of up to 16 votes (the reference's 1, 2, 4, 8, 16) come out of ONE inclusive scan, not one reduction
+//    each.  Lane l < 16 of the problem loads vote l; its rank IN INDEX ORDER is 1 + #{ j < l : x_j == x_l } (15 row_shr
+//    compares inside the 16-lane DPP row), and the prefix statistics are a scan of (rank, 1) under
+//        (M1, n1) + (M2, n2) = M1 > M2 ? (M1, n1) : M2 > M1 ? (M2, n2) : (M1, n1 + n2)
+//    (associative, commutative; 4 row_shr steps) next to a running maximum of the keys and a running sum of the truth votes:
+//    afterwards lane l holds the complete record of the prefix of l + 1 votes and the lane n_valid[b] - 1 writes budget b's.
+//    The head's votes enter the histogram with one plain ds_add; the vectors below skip them.
 //  * votes equal to the problem's TRUTH do not enter the histogram: the lane counts them (truth_count is needed anyway --
 //    pass@k's c and the hit test of o1.py:206) and the boundary merges the two: max_count = max(M, truth votes), the truth
 //    joins the modes on a tie.  The truth is the one value known before looking at the data that is usually the hot one;
 //    up to G lanes adding to one bin would be serialised.  Inactive vote slots and truth votes add to a word of the lane's own.
+//  * a row is held V 16-byte vectors per lane at a time (a CHUNK of 16 G V votes: the whole row up to 256 votes at G = 16, 512 at
+//    G = 32), vector k of lane l = votes (k G + l) 4 .. + 3.  The NEXT chunk -- of this row, or the first of the next problem's
+//    row with its truth and head -- is requested at the top of the current one into a second register set, so every load has a
+//    whole chunk's work to land.  The record stores of a problem's LAST boundaries are issued at the top of the next problem, right
+//    behind those requests: hipcc cannot count the vector-memory operations of the dynamic boundary loops and waits for the
+//    next chunk with s_waitcnt vmcnt(0), which then finds nothing younger than a chunk's work (a store issued at the END of a
+//    problem would be waited for whole at the top of the next).  Loads are unconditional (a vector beyond the longest budget
+//    re-reads vector 0: a cache hit).
 //  * boundaries are visited in ascending order (rank sort of n_valid in LDS: unsorted / duplicate / empty budgets are fine) and are
-//    wave-uniform (n_valid is per budget, not per problem), so all control flow below is scalar.  The first 4 G votes of a
-//    row are held TRANSPOSED (slot q of lane l = vote q G + l, four dword loads): the reference's budgets 1, 2, 4 ... 2^k
-//    then fall on whole slots from G upwards (and below G need only slot 0); later blocks are one dwordx4 per lane.
-//  * the record of boundary k is latched by lane k % G of the problem; after G boundaries (or the last) the lanes write
-//    their records side by side -- cells[p, b] for consecutive b are 16 bytes apart: one contiguous store per problem -- and
-//    add to the per-workgroup LDS counter tables (o1.py:238-240 as integers), flushed once per workgroup.
+//    wave-uniform (n_valid is per budget, not per problem), so all control flow below is scalar: a vector is counted whole (no
+//    masks) unless a boundary cuts it.
 //
 // Algorithmic bytes: 4 per vote of the pool (8 with tokens), 16 written per (problem, budget) -- DESIGN.md 3.8.
 #pragma once
@@ -38,19 +55,76 @@
 
 namespace scv {
 
-template <int G>
-constexpr int prefix_pool_waves() { return G == 16 ? 8 : 16; }       // histograms: 64 / G x 4 KiB per wave
+#ifndef SCV_PREFIX_H16
+#define SCV_PREFIX_H16 1                            // 0: 32-bit bins at G = 16 too (A/B builds)
+#endif
+// waves per workgroup = what the LDS of a CU (64 / G histograms per wave) and the registers (the token variants hold two more register sets) allow
+template <int G, bool TOK>
+constexpr int prefix_pool_waves() { return TOK ? 8 : (G == 16 ? (prefix_pool_h16(16) ? 16 : 8) : 12); }
+constexpr int kRankShift = 18;                      // keys: rank << 18 | LDS byte address (< 160 KiB); ranks are <= 4096
+
+constexpr int kPrefixHead = 16;                     // votes served by the head scan (one DPP row)
 
 __device__ __forceinline__ uint32_t lds_add_rtn(uint32_t addr) {
     return __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>((uintptr_t)addr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+template <int SH>
+__device__ __forceinline__ uint32_t row_shr_or(uint32_t v, uint32_t fill) {     // lane l <- lane l - SH of its 16-lane row; `fill` where there is none
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 + SH, 0xf, 0xf, false);
+}
+// 1 + number of lower lanes of the row holding the same value (values that must match nothing are made unique by the caller)
+__device__ __forceinline__ uint32_t row_rank_in_order(uint32_t xs) {
+    uint32_t r = 1u;
+#define SCV_RANK_STEP(k) r += (row_shr_or<k>(xs, 0xfffffffeu) == xs) ? 1u : 0u;
+    SCV_RANK_STEP(1) SCV_RANK_STEP(2) SCV_RANK_STEP(3) SCV_RANK_STEP(4) SCV_RANK_STEP(5) SCV_RANK_STEP(6) SCV_RANK_STEP(7) SCV_RANK_STEP(8)
+    SCV_RANK_STEP(9) SCV_RANK_STEP(10) SCV_RANK_STEP(11) SCV_RANK_STEP(12) SCV_RANK_STEP(13) SCV_RANK_STEP(14) SCV_RANK_STEP(15)
+#undef SCV_RANK_STEP
+    return r;
+}
+// (max rank << 18 | votes at that rank) of two disjoint sets of votes
+__device__ __forceinline__ uint32_t rank_count_merge(uint32_t a, uint32_t b) {
+    const uint32_t hi = a > b ? a : b;
+    return ((a ^ b) < (1u << 18)) ? a + (b & ((1u << 18) - 1u)) : hi;
+}
+template <int SH>
+__device__ __forceinline__ void head_scan_step(uint32_t& KS, uint32_t& WS, uint32_t& TS) {
+    const uint32_t k = row_shr_or<SH>(KS, 0u);
+    KS = k > KS ? k : KS;
+    WS = rank_count_merge(WS, row_shr_or<SH>(WS, 0u));
+    TS += row_shr_or<SH>(TS, 0u);
+}
+// inclusive prefix sum over the row of a 64-bit value, as three limbs of 22 / 21 / 21 bits (16 x 2^22 < 2^32: no carries across lanes)
+__device__ __forceinline__ long long row_prefix_sum_i64(long long v) {
+    const unsigned long long u = (unsigned long long)v;
+    uint32_t s0 = (uint32_t)(u & 0x3fffffu), s1 = (uint32_t)((u >> 22) & 0x1fffffu), s2 = (uint32_t)((u >> 43) & 0x1fffffu);
+#define SCV_SUM_STEP(k) s0 += row_shr_or<k>(s0, 0u); s1 += row_shr_or<k>(s1, 0u); s2 += row_shr_or<k>(s2, 0u);
+    SCV_SUM_STEP(1) SCV_SUM_STEP(2) SCV_SUM_STEP(4) SCV_SUM_STEP(8)
+#undef SCV_SUM_STEP
+    return (long long)((unsigned long long)s0 + ((unsigned long long)s1 << 22) + ((unsigned long long)s2 << 43));
+}
 
-// G lanes per problem; TOK: tokens stream; VEC: every pool row is 16-byte aligned (N % 4 == 0 and aligned bases).
-template <int G, bool TOK, bool VEC>
-__global__ __launch_bounds__((64 * prefix_pool_waves<G>())) void scv_prefix_pool(const AggArgs a) {
+// compiler barrier that also pins the registers of `r` (their values exist before the statement, memory operations stay behind it)
+template <typename T, int NREG>
+__device__ __forceinline__ void pin_before_loads(T (&r)[NREG]) {
+    if constexpr (NREG >= 8) {
+#pragma unroll
+        for (int i = 0; i + 8 <= NREG; i += 8)
+            asm volatile("" : "+v"(r[i]), "+v"(r[i + 1]), "+v"(r[i + 2]), "+v"(r[i + 3]), "+v"(r[i + 4]), "+v"(r[i + 5]), "+v"(r[i + 6]), "+v"(r[i + 7]) : : "memory");
+    } else asm volatile("" : : : "memory");
+}
+
+// G lanes per problem, V vectors per lane per chunk; TOK: tokens stream; VEC: every pool row is 16-byte aligned (N % 4 == 0, aligned bases).
+// LDS: per wave 64 / G x 1024 bins + kPrefixPoolLaneWords; behind the waves: ord[B] | nvs[B] | head map (32 words) | counter tables.
+template <int G, int V, bool TOK, bool VEC>
+__global__ __launch_bounds__((64 * prefix_pool_waves<G, TOK>())) void scv_prefix_pool(const AggArgs a) {
     constexpr int C = 64 / G;                  // problems per wave
-    constexpr int BLK = 4 * G;                 // votes of a problem per block (4 per lane)
-    constexpr int HW = C * kBins;              // histogram words per wave
+    constexpr int VB = 4 * G;                  // votes of a problem per vector
+    constexpr int CH = VB * V;                 // votes of a problem per chunk
+    constexpr bool H16 = prefix_pool_h16(G);   // 16-bit bins, two per word
+    constexpr int BS = H16 ? 1 : 2;            // log2(bytes per bin)
+    constexpr int HW = prefix_pool_hist_words(G);                    // histogram words per wave
+    constexpr uint32_t RK1 = 1u << kRankShift;
+    constexpr int HEAD = kPrefixHead;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_wg[];
     const int tid = (int)threadIdx.x, T = (int)blockDim.x;
     const int lane = tid & 63, nw = T >> 6;
@@ -58,10 +132,13 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G>())) void scv_prefix_pool
     uint32_t* smem = smem_wg + (tid >> 6) * a.wave_lds_words;
     int32_t* ord = reinterpret_cast<int32_t*>(smem_wg + (int64_t)nw * a.wave_lds_words);   // budgets by ascending n_valid
     int32_t* nvs = ord + a.B;                                                             // their n_valid, ascending
+    int32_t* hmap = nvs + a.B;                 // [0, 16): the budget whose n_valid is i + 1 (-1: none); [16, 32): how many budgets have it
     {
         uint4* h4 = reinterpret_cast<uint4*>(smem);
         for (int i = lane; i < (HW + kPrefixPoolLaneWords) / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
     }
+    if (tid < 32) hmap[tid] = tid < HEAD ? -1 : 0;
+    __syncthreads();
     for (int b = tid; b < a.B; b += T) {
         const int64_t nb = valid_len(a, b);
         int rank = 0;
@@ -71,48 +148,62 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G>())) void scv_prefix_pool
         }
         ord[rank] = b;
         nvs[rank] = (int32_t)nb;
+        if (nb >= 1 && nb <= HEAD) {
+            hmap[nb - 1] = b;
+            atomicAdd(reinterpret_cast<uint32_t*>(hmap) + HEAD + (nb - 1), 1u);
+        }
     }
-    const WgCounters wgc = wg_counters_begin(a, reinterpret_cast<uint32_t*>(nvs + a.B), tid, T);
+    const WgCounters wgc = wg_counters_begin(a, reinterpret_cast<uint32_t*>(hmap + kPrefixPoolFixedWords), tid, T);
     __syncthreads();
 
     const uint32_t base = (uint32_t)(uintptr_t)(lds_u32*)smem;       // LDS byte offset of this wave's region
-    const uint32_t hbase = base + (uint32_t)sub * (kBins * 4u);      // this problem's histogram
+    const uint32_t hbase = base + (uint32_t)sub * ((uint32_t)kBins << BS);              // this problem's histogram
+    const uint32_t htop = hbase + (1023u << BS);                     // the bin of value 0: value x lives at htop - (x << BS)
     const uint32_t trash = base + (uint32_t)HW * 4u + (uint32_t)lane * 4u;
-    const int32_t N = (int32_t)a.N, B = a.B;
+    const int32_t B = a.B;
     const int32_t nmax = __builtin_amdgcn_readfirstlane(B > 0 ? nvs[B - 1] : 0);          // votes of the longest budget
+    // budgets without votes (kz of them, first in the order), budgets the head serves (up to kh); is some head length asked for twice?
+    int32_t kz = 0, kh = 0;
+    bool head_dup = false;
+    {
+        uint32_t z = 0, h = 0;
+        for (int k = lane; k < B; k += 64) { const int32_t nv = nvs[k]; z += nv == 0; h += nv <= HEAD; }
+        kz = (int32_t)wave_sum_u32(z);
+        kh = (int32_t)wave_sum_u32(h);
+        head_dup = __any(lane < HEAD && hmap[HEAD + (lane & (HEAD - 1))] > 1);
+    }
+    const int32_t my_head_budget = (l < HEAD) ? hmap[l] : -1;        // the budget this lane's head prefix answers (no duplicates)
+    const int32_t nchunks = (nmax + CH - 1) / CH;
     const int64_t nwaves = (int64_t)gridDim.x * nw;
     const int64_t wave = (int64_t)blockIdx.x * nw + (tid >> 6);
     const int64_t nbatches = (a.P + C - 1) / C;
     uint32_t bad = 0;
 
-    uint32_t cur[4] = {0, 0, 0, 0}, nxt[4] = {0, 0, 0, 0};     // votes of the current / the next block
-    int32_t tcur[4] = {0, 0, 0, 0}, tnxt[4] = {0, 0, 0, 0};     // their tokens
-    // block j of problem row `row`: loads only (unconditional: a slot past the row re-reads element 0 and is never active)
-    auto load_block = [&](const int32_t* row, const int32_t* trow, int32_t j, uint32_t (&v)[4], int32_t (&t)[4]) {
-        if (j == 0) {
+    uint32_t cur[4 * V], nxt[4 * V];           // the chunk being counted / the chunk in flight: vector k in [4 k, 4 k + 3]
+    int32_t tcur[TOK ? 4 * V : 1], tnxt[TOK ? 4 * V : 1];            // their tokens
+    uint32_t hv_n = 0;                         // in flight: the next problem's head (vote l of the row, lanes l < 16), its token, its truth
+    int32_t ht_n = 0, truth_n = 0;
+    // chunk c of a row -> nxt: loads only
+    auto load_chunk = [&](const int32_t* row, const int32_t* trow, int32_t c) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int32_t idx = q * G + l;
-                const int32_t ii = idx < N ? idx : 0;
-                v[q] = (uint32_t)__builtin_nontemporal_load(row + ii);
-                if (TOK) t[q] = __builtin_nontemporal_load(trow + ii);
-            }
-        } else if (VEC) {
-            int32_t vi = j * G + l;
-            vi = vi * 4 < N ? vi : 0;
-            const int4 x = stream_load(reinterpret_cast<const int4*>(row) + vi);
-            v[0] = (uint32_t)x.x; v[1] = (uint32_t)x.y; v[2] = (uint32_t)x.z; v[3] = (uint32_t)x.w;
-            if (TOK) {
-                const int4 y = stream_load(reinterpret_cast<const int4*>(trow) + vi);
-                t[0] = y.x; t[1] = y.y; t[2] = y.z; t[3] = y.w;
-            }
-        } else {
+        for (int k = 0; k < V; ++k) {
+            const int32_t vi = (c * V + k) * G + l;                  // in 16-byte units
+            if (VEC) {
+                const int32_t vj = vi * 4 < nmax ? vi : 0;
+                const int4 x = stream_load(reinterpret_cast<const int4*>(row) + vj);
+                nxt[4 * k] = (uint32_t)x.x; nxt[4 * k + 1] = (uint32_t)x.y; nxt[4 * k + 2] = (uint32_t)x.z; nxt[4 * k + 3] = (uint32_t)x.w;
+                if constexpr (TOK) {
+                    const int4 y = stream_load(reinterpret_cast<const int4*>(trow) + vj);
+                    tnxt[4 * k] = y.x; tnxt[4 * k + 1] = y.y; tnxt[4 * k + 2] = y.z; tnxt[4 * k + 3] = y.w;
+                }
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int32_t idx = j * BLK + 4 * l + q;
-                const int32_t ii = idx < N ? idx : 0;
-                v[q] = (uint32_t)__builtin_nontemporal_load(row + ii);
-                if (TOK) t[q] = __builtin_nontemporal_load(trow + ii);
+                for (int q = 0; q < 4; ++q) {
+                    const int32_t idx = vi * 4 + q;
+                    const int32_t ii = idx < nmax ? idx : 0;
+                    nxt[4 * k + q] = (uint32_t)__builtin_nontemporal_load(row + ii);
+                    if constexpr (TOK) tnxt[4 * k + q] = __builtin_nontemporal_load(trow + ii);
+                }
             }
         }
     };
@@ -120,11 +211,42 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G>())) void scv_prefix_pool
         const int64_t p = bt * C + sub;
         return p < a.P ? p : 0;
     };
+    auto load_head = [&](int64_t r) {
+        const int32_t ii = (l < HEAD && l < nmax) ? l : 0;
+        hv_n = (uint32_t)__builtin_nontemporal_load(a.answers + r * a.N + ii);
+        if constexpr (TOK) ht_n = __builtin_nontemporal_load(a.tokens + r * a.N + ii);
+        truth_n = a.truth[r];
+    };
+
+    // o1.py:204-213 + statistics.py:599-601 from a reduced pair; the record and the counters of (problem pp, budget b) by ONE lane
+    auto emit = [&](int64_t pp, uint32_t tcmp, int32_t b, uint32_t gK, uint32_t packed, long long tok) {
+        const uint32_t Mh = gK >> kRankShift;                         // largest count among the values that are not the truth
+        const uint32_t tc = packed & 0xffffu;                         // votes for the truth (<= 4096)
+        const uint32_t nmh = Mh ? packed >> 16 : 0u;                  // values (not the truth) whose count is Mh (<= 1023)
+        const uint32_t M = Mh > tc ? Mh : tc;
+        const uint32_t hit = (tc == M && M > 0u) ? 1u : 0u;           // o1.py:206 (multimode([]) == []: no hit)
+        const uint32_t nm = (Mh == M ? nmh : 0u) + hit;
+        uint32_t mm = Mh == M ? (htop - (gK & (RK1 - 1u))) >> BS : 1024u;
+        if (hit && tcmp < mm) mm = tcmp;
+        const int64_t cell = pp * B + b;
+        if (a.cells) reinterpret_cast<uint4*>(a.cells)[cell] = make_uint4(M, tc, (nm & 0xffffu) | ((M ? (mm & 0xffffu) : 0xffffu) << 16), hit);
+        if (TOK && a.cell_tokens) a.cell_tokens[cell] = tok;
+        if (wgc.tcl > 0) wg_counters_add<TOK>(a, wgc, b, hit, nm, tc, tok);
+        else {
+            if (a.tie_hits && hit) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + nm], 1ull);
+            if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)tok);
+            if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)tc);
+        }
+    };
+    // the pairs of the previous problem's last boundaries, latched and not yet written (lane j < Dn holds one)
+    uint32_t DK = 0, DP = 0, Dtcmp = 0;
+    int32_t Db = 0, Dn = 0;
+    long long Dtok = 0;
 
     if (wave < nbatches && nmax > 0) {
         const int64_t r0 = row_of(wave);
-        load_block(a.answers + r0 * a.N, TOK ? a.tokens + r0 * a.N : nullptr, 0, cur, tcur);
-        if (BLK < nmax) load_block(a.answers + r0 * a.N, TOK ? a.tokens + r0 * a.N : nullptr, 1, nxt, tnxt);
+        load_head(r0);
+        load_chunk(a.answers + r0 * a.N, TOK ? a.tokens + r0 * a.N : nullptr, 0);
     }
     for (int64_t bt = wave; bt < nbatches; bt += nwaves) {
         const int64_t p = bt * C + sub;
@@ -132,133 +254,178 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G>())) void scv_prefix_pool
         const int64_t prow = live ? p : 0;
         const int32_t* row = a.answers + prow * a.N;
         const int32_t* trow = TOK ? a.tokens + prow * a.N : nullptr;
-        const int32_t truth = a.truth[prow];
-        const uint32_t tcmp = (truth >= 0 && truth < kBins) ? (uint32_t)truth : 0xffffffffu;
+        const int64_t rnext = row_of(bt + nwaves < nbatches ? bt + nwaves : bt);          // (the last batch re-reads its own row)
+        uint32_t tcmp = 0xffffffffu;
 
         // running state of this lane over its votes of the prefix so far
         uint32_t S = 0;                        // largest rank of a vote of this lane << 16 | number of its votes with that rank
         uint32_t K = 0;                        // max over its votes of rank << 10 | 1023 - value
         uint32_t tcl = 0;                      // its votes equal to the truth
         long long tsum = 0;                    // its tokens
-        // one vote: `use` = counts for the histogram (active and not the truth)
-        auto post = [&](uint32_t vc, uint32_t old, bool use) {
-            const uint32_t r = use ? old + 1u : 0u;
-            const uint32_t Tr = r << 16;
+        // one vote after its atomic has returned: Tr = its rank << 18 (0: not counted), A = its bin's address
+        auto post = [&](uint32_t A, uint32_t Tr) {
             const uint32_t S1 = S > Tr ? S : Tr;
-            S = S1 + (((S1 ^ Tr) < 0x10000u) ? 1u : 0u);             // (r == 0 while the lane's rank is 0: a count nobody reads)
-            const uint32_t key = (r << 10) | (1023u - vc);           // r == 0: below every real key
+            S = S1 + (((S1 ^ Tr) < RK1) ? 1u : 0u);                  // (Tr == 0 while the lane's rank is 0: a count nobody reads)
+            const uint32_t key = Tr | A;                             // Tr == 0: below every real key
             K = key > K ? key : K;
         };
-        // the four slots of block j, votes with lo <= index < hi (FULL: the whole block is inside, no masks)
-        auto pass = [&](const uint32_t (&v)[4], const int32_t (&t)[4], int32_t j, int32_t lo, int32_t hi, auto full_tag) {
+        // the returning atomic of one vote (`use`: active and not the truth) -> its rank << 18, 0 when it does not count
+        auto count_vote = [&](uint32_t A, bool use) -> uint32_t {
+            uint32_t x;
+            if (H16) {
+                const uint32_t inc = __builtin_amdgcn_alignbyte(1u, 1u, A);                 // 1 or 1 << 16 by the half of the word
+                const uint32_t old = __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>((uintptr_t)(use ? (A & ~3u) : trash)), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                x = __builtin_amdgcn_alignbyte(0u, old, A);          // the bin's half in the low 16 bits (the shift below drops the rest: counts are < 2^14)
+            } else x = lds_add_rtn(use ? A : trash);
+            const uint32_t Tr = (x << kRankShift) + RK1;
+            return use ? Tr : 0u;
+        };
+        // vector k (its first vote is vote `vb` of the row): the votes with lo <= index < hi (FULL: all of them, no masks)
+        auto pass = [&](int k, int32_t vb, int32_t lo, int32_t hi, auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
-            uint32_t vc[4], old[4];
-            bool use[4];
+            // domain check of the whole vector up front (o1.py:140 int(extracted_answer) is unbounded; the extractor maps it into bins 0..1023):
+            // the clamp runs only in the -- wave-uniform, rare -- case that some slot, counted or not, holds a larger value
+            uint32_t vq[4] = {cur[4 * k], cur[4 * k + 1], cur[4 * k + 2], cur[4 * k + 3]};
+            if (__any((vq[0] | vq[1] | vq[2] | vq[3]) > 1023u)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                        // (cur[] keeps the value: a later pass over this vector may be the one that counts it)
+                    const bool act = FULL || (uint32_t)(vb + 4 * l + q - lo) < (uint32_t)(hi - lo);
+                    bad |= act ? vq[q] : 0u;
+                    vq[q] = vq[q] < 1023u ? vq[q] : 1023u;
+                }
+            }
+            uint32_t A[4], Tr[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int32_t idx = j == 0 ? q * G + l : j * BLK + 4 * l + q;
-                const bool act = FULL || (uint32_t)(idx - lo) < (uint32_t)(hi - lo);
-                bad |= act ? v[q] : 0u;
-                vc[q] = v[q] < 1023u ? v[q] : 1023u;
-                const bool is_t = vc[q] == tcmp;
-                use[q] = act && !is_t;
+                const uint32_t v = vq[q];
+                const bool act = FULL || (uint32_t)(vb + 4 * l + q - lo) < (uint32_t)(hi - lo);
+                const bool is_t = v == tcmp;
+                A[q] = htop - (v << BS);
                 tcl += (act && is_t) ? 1u : 0u;
-                if (TOK) tsum += act ? (long long)t[q] : 0ll;
-                old[q] = lds_add_rtn(use[q] ? hbase + (vc[q] << 2) : trash);
+                if constexpr (TOK) tsum += act ? (long long)tcur[4 * k + q] : 0ll;
+                Tr[q] = count_vote(A[q], act && !is_t);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) post(vc[q], old[q], use[q]);
+            for (int q = 0; q < 4; ++q) post(A[q], Tr[q]);
         };
-        // one slot of a block (budgets below 4 G votes touch one slot at a time)
-        auto pass_slot = [&](uint32_t v, int32_t t, int32_t idx, int32_t lo, int32_t hi) {
-            const bool act = (uint32_t)(idx - lo) < (uint32_t)(hi - lo);
-            bad |= act ? v : 0u;
-            const uint32_t vc = v < 1023u ? v : 1023u;
-            const bool is_t = vc == tcmp;
-            const bool use = act && !is_t;
-            tcl += (act && is_t) ? 1u : 0u;
-            if (TOK) tsum += act ? (long long)t : 0ll;
-            const uint32_t old = lds_add_rtn(use ? hbase + (vc << 2) : trash);
-            post(vc, old, use);
+        // the pair this lane has latched (the nl-th boundary since the last flush sits in lane nl)
+        uint32_t LK = 0, LP = 0;
+        int32_t Lb = 0, nl = 0;
+        long long Ltok = 0;
+        // boundary k: every vote below it is in, none above
+        auto boundary = [&](int32_t k) {
+            const uint32_t gK = cellgroup_max<G>(K);
+            const uint32_t cnt = ((S ^ gK) < RK1) ? (S & (RK1 - 1u)) : 0u;        // this lane's votes at the group's maximum rank
+            const uint32_t packed = cellgroup_sum<G>((cnt << 16) | tcl);
+            long long gtok = 0;
+            if constexpr (TOK) gtok = cellgroup_sum_i64<G>(tsum);
+            const int32_t b = __builtin_amdgcn_readfirstlane(ord[k]);
+            if (l == nl) { LK = gK; LP = packed; Lb = b; Ltok = gtok; }
+            nl += 1;
+            if (nl == G) {
+                if (live) emit(p, tcmp, Lb, LK, LP, Ltok);
+                nl = 0;
+            }
+        };
+        // the previous problem's last records (their stores land while this problem is counted)
+        auto flush_deferred = [&]() {
+            if (l < Dn) emit(p - nwaves * C, Dtcmp, Db, DK, DP, Dtok);
+            Dn = 0;
         };
 
-        // the record this lane has latched (boundary k of the current group of G boundaries sits in lane k % G)
-        uint32_t rx = 0, ry = 0, rz = 0xffff0000u, rw = 0;
-        long long rtok = 0;
+        int32_t kb = 0;
+        if (nchunks == 0) {
+            flush_deferred();
+            for (; kb < kz; ++kb) boundary(kb);                        // every budget is empty
+        }
         int32_t pos = 0;                       // votes [0, pos) are in
-        int32_t cj = 0;                        // block held by `cur` (`nxt` holds cj + 1 when that block is needed)
-        for (int32_t k = 0; k < B; ++k) {
-            const int32_t hi = __builtin_amdgcn_readfirstlane(nvs[k]);
-            while (pos < hi) {
-                const int32_t blo = cj * BLK, bhi = blo + BLK;
-                const int32_t seg = hi < bhi ? hi : bhi;
-                if (pos == blo && seg == bhi) pass(cur, tcur, cj, blo, bhi, std::true_type{});
-                else if (seg - pos >= 2 * G || cj > 0) pass(cur, tcur, cj, pos, seg, std::false_type{});
-                else {
-                    // block 0, a short range: only the slots it touches (slot q holds votes [q G, (q + 1) G))
+        int32_t nvk = 0x7fffffff;              // n_valid of boundary kb
+        for (int32_t c = 0; c < nchunks; ++c) {
+            // ---- top of a chunk: it has landed; request the one after it ---------------------------------------------------------
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (q * G < seg && (q + 1) * G > pos) pass_slot(cur[q], TOK ? tcur[q] : 0, q * G + l, pos, seg);
-                }
-                pos = seg;
-                if (pos == bhi) {              // block consumed: the next one becomes current, the one after it is requested
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { cur[q] = nxt[q]; if (TOK) tcur[q] = tnxt[q]; }
-                    cj += 1;
-                    if ((cj + 1) * BLK < nmax) load_block(row, trow, cj + 1, nxt, tnxt);
-                }
+            for (int i = 0; i < 4 * V; ++i) { cur[i] = nxt[i]; if constexpr (TOK) tcur[i] = tnxt[i]; }
+            uint32_t hv = 0;
+            int32_t ht = 0;
+            if (c == 0) {
+                hv = hv_n; ht = ht_n;
+                tcmp = (truth_n >= 0 && truth_n < kBins) ? (uint32_t)truth_n : 0xffffffffu;
             }
-            if (k == B - 1 && bt + nwaves < nbatches) {
-                // every vote of this batch is in: the next batch's first blocks fly while the last boundary is reduced and the
-                // histograms are cleared
-                const int64_t rn = row_of(bt + nwaves);
-                load_block(a.answers + rn * a.N, TOK ? a.tokens + rn * a.N : nullptr, 0, cur, tcur);
-                if (BLK < nmax) load_block(a.answers + rn * a.N, TOK ? a.tokens + rn * a.N : nullptr, 1, nxt, tnxt);
+            // everything that was in flight is consumed HERE, before the next requests: a use behind them would make hipcc wait for them too
+            pin_before_loads(cur); pin_before_loads(tcur);
+            asm volatile("" : "+v"(hv), "+v"(ht), "+v"(tcmp) : : "memory");
+            if (c + 1 < nchunks) load_chunk(row, trow, c + 1);
+            else {
+                load_head(rnext);
+                load_chunk(a.answers + rnext * a.N, TOK ? a.tokens + rnext * a.N : nullptr, 0);
             }
-            // ---- boundary k: statistics.multimode of the prefix (statistics.py:599-601) + o1.py:204-213 ------------
-            const uint32_t gK = cellgroup_max<G>(K);
-            const uint32_t Mh = gK >> 10;                             // largest count among the values that are not the truth
-            const uint32_t cnt = ((S >> 16) == Mh) ? (S & 0xffffu) : 0u;
-            const uint32_t packed = cellgroup_sum<G>((cnt << 16) | tcl);
-            const uint32_t tc = packed & 0xffffu;                     // votes for the truth (<= 4096)
-            const uint32_t nmh = Mh ? packed >> 16 : 0u;              // values (not the truth) whose count is Mh (<= 1023)
-            const uint32_t M = Mh > tc ? Mh : tc;
-            const uint32_t hit = (tc == M && M > 0u) ? 1u : 0u;       // o1.py:206 (multimode([]) == []: no hit)
-            const uint32_t nm = (Mh == M ? nmh : 0u) + hit;
-            uint32_t mm = Mh == M ? 1023u - (gK & 1023u) : 1024u;
-            if (hit && tcmp < mm) mm = tcmp;
-            long long gtok = 0;
-            if (TOK) gtok = cellgroup_sum_i64<G>(tsum);
-            if (l == (k % G)) {
-                rx = M; ry = tc; rw = hit;
-                rz = (nm & 0xffffu) | ((M ? (mm & 0xffffu) : 0xffffu) << 16);
-                rtok = gtok;
-            }
-            // ---- G boundaries latched (or the last one): the lanes write their records and count them ----------------
-            if ((k % G) == G - 1 || k == B - 1) {
-                const int32_t k0 = k - (k % G);
-                if (live && k0 + l <= k) {
-                    const int32_t b = ord[k0 + l];
-                    const int64_t cell = p * B + b;
-                    if (a.cells) reinterpret_cast<uint4*>(a.cells)[cell] = make_uint4(rx, ry, rz, rw);
-                    if (TOK && a.cell_tokens) a.cell_tokens[cell] = rtok;
-                    const uint32_t n_modes = rz & 0xffffu;
-                    if (wgc.tcl > 0) wg_counters_add<TOK>(a, wgc, b, rw, n_modes, ry, rtok);
-                    else {
-                        if (a.tie_hits && rw) atomicAdd(&a.tie_hits[(int64_t)b * SCV_TIE_CLASSES + n_modes], 1ull);
-                        if (TOK && a.token_sum) atomicAdd(&a.token_sum[b], (unsigned long long)rtok);
-                        if (a.truth_sum) atomicAdd(&a.truth_sum[b], (unsigned long long)ry);
+            if (c == 0) {
+                flush_deferred();
+                for (; kb < kz; ++kb) boundary(kb);                    // budgets without votes
+                // ---- the head: budgets of up to 16 votes out of one scan ----------------------------------------------------
+                const bool act = l < HEAD && l < nmax;
+                bad |= act ? hv : 0u;
+                const uint32_t hc = hv < 1023u ? hv : 1023u;
+                const bool is_t = hc == tcmp;
+                const bool use = act && !is_t;
+                const uint32_t r = row_rank_in_order(use ? hc : (0xffff0000u | (uint32_t)lane));
+                const uint32_t A = htop - (hc << BS);
+                if (H16) lds_add(use ? (A & ~3u) : trash, __builtin_amdgcn_alignbyte(1u, 1u, A));
+                else lds_add(use ? A : trash, 1u);
+                K = use ? (r << kRankShift) | A : 0u;
+                S = use ? (r << kRankShift) | 1u : 0u;
+                tcl = (act && is_t) ? 1u : 0u;
+                if constexpr (TOK) tsum = act ? (long long)ht : 0ll;
+                if (kh > kz) {
+                    uint32_t KS = K, WS = S, TS = tcl;
+                    head_scan_step<1>(KS, WS, TS); head_scan_step<2>(KS, WS, TS); head_scan_step<4>(KS, WS, TS); head_scan_step<8>(KS, WS, TS);
+                    long long tks = 0;
+                    if constexpr (TOK) tks = row_prefix_sum_i64(tsum);
+                    const uint32_t packed = ((WS & (RK1 - 1u)) << 16) | TS;
+                    if (!head_dup) {
+                        if (live && my_head_budget >= 0) emit(p, tcmp, my_head_budget, KS, packed, tks);
+                    } else {
+                        for (int32_t k = kz; k < kh; ++k) {
+                            const int32_t hi = __builtin_amdgcn_readfirstlane(nvs[k]);
+                            const int32_t b = __builtin_amdgcn_readfirstlane(ord[k]);
+                            if (live && l == hi - 1) emit(p, tcmp, b, KS, packed, tks);
+                        }
                     }
+                }
+                kb = kh;
+                pos = HEAD < nmax ? HEAD : nmax;
+                nvk = kb < B ? __builtin_amdgcn_readfirstlane(nvs[kb]) : 0x7fffffff;
+            }
+            // ---- the chunk's vectors ----------------------------------------------------------------------------------------
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const int32_t vb = c * CH + k * VB, ve = vb + VB;
+                while (nvk <= ve) {                                  // boundaries inside (or at the end of) this vector
+                    if (nvk > pos) { pass(k, vb, pos, nvk, std::false_type{}); pos = nvk; }
+                    boundary(kb);
+                    kb += 1;
+                    nvk = kb < B ? __builtin_amdgcn_readfirstlane(nvs[kb]) : 0x7fffffff;
+                }
+                if (kb < B && pos < ve) {                            // a later boundary needs the rest of the vector
+                    if (pos <= vb) pass(k, vb, vb, ve, std::true_type{});
+                    else pass(k, vb, pos, ve, std::false_type{});
+                    pos = ve;
                 }
             }
         }
+        // the boundaries latched since the last flush are written at the top of the next problem
+        DK = LK; DP = LP; Db = Lb; Dtok = Ltok; Dtcmp = tcmp;
+        Dn = live ? nl : 0;
         // the problem's histogram is zero again before the next batch's first vote (LDS operations of a wave execute in order)
         if (nmax > 0) {
             lds_v4u* h4 = reinterpret_cast<lds_v4u*>((uintptr_t)hbase);
 #pragma unroll
-            for (int i = 0; i < kBins / 4 / G; ++i) h4[i * G + l] = scv_v4u{0u, 0u, 0u, 0u};
+            for (int i = 0; i < (kBins << BS) / 16 / G; ++i) h4[i * G + l] = scv_v4u{0u, 0u, 0u, 0u};
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (l < Dn) {                              // the last problem of this wave: batch wave + (its batches - 1) * nwaves
+        const int64_t last_bt = wave + ((nbatches - 1 - wave) / nwaves) * nwaves;
+        emit(last_bt * C + sub, Dtcmp, Db, DK, DP, Dtok);
     }
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
     wg_counters_flush<TOK>(a, wgc, tid, T);

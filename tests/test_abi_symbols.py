@@ -98,8 +98,7 @@ def test_no_kernel_spills_to_scratch():
     spec.loader.exec_module(mod)
     rows = mod.collect()
     assert 100 <= len(rows) <= 130, len(rows)                        # round 4: pruned from 231 (at most 130)
-    allowed = {"scv_lane_cells<32, 512, true>"}                      # 12 B, N = 17..32 with tokens: known, measured
-    spilled = {r[0]: r[4] for r in rows if r[4] and r[0] not in allowed}
+    spilled = {r[0]: r[4] for r in rows if r[4]}                     # (round 5: no exception left -- 17..32 votes with tokens on one lane per cell went to scv_reg_cells)
     assert not spilled, spilled
     head = [r for r in rows if r[0] == "scv_hist_argmax<4, 1024, 4, false, false>"]
     assert head and head[0][1] <= 128 and head[0][4] == 0            # the headline kernel: 16 waves per CU need <= 128 VGPRs
