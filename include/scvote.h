@@ -125,6 +125,12 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  *                         2 the cell kernels on pool rows (pools <= 4096) | 3 one streaming pass, a histogram snapshot per boundary |
  *                         4 one pass per problem over its pool row, 16 / 32 / 64 lanes per problem, every budget a snapshot of the running
  *                         mode statistics (pools <= 4096: auto above 64 votes and for budget lists too long for path 1; "reg_shape" = 16 / 32 forces the lanes per problem)
+ *                         auto includes: pools of 17 .. 64 votes (N % 4 == 0) whose budgets are all 0, a power of two <= 16 (pools <= 32) / <= 32, or
+ *                         >= N come out of ONE sort per problem (scv_sort_prefix).  A HOST-mode call reads the budgets; a DEVICE-mode call queues that
+ *                         kernel in front of the general one and the two decide from n_valid which of them does the work (~4 us for the one that
+ *                         leaves).  | 5 = auto, and the caller PROMISES budgets of that form for such pools: a DEVICE-mode call queues scv_sort_prefix
+ *                         alone; a list that breaks the promise computes nothing and is SCV_ERR_ARG (at the call in HOST mode, at the next
+ *                         synchronisation in DEVICE mode).  1 .. 4 switch the kernel off
  *   "boot_path"           scv_aggregate_bootstrap_i32: 0 auto (ONE cooperative launch when the shape allows it) | 1 one ORDINARY launch |
  *                         2 two launches, LDS-resident code table | 3 two launches, global gathers (also scv_bootstrap's kernel)
  *   "boot_spin_limit"     default 2^20: polls at the grid barrier before a workgroup of an ordinary one-launch form gives up and leaves
@@ -329,7 +335,8 @@ int scv_host_free(void* p);
  * "boot_recovered" (grid-barrier timeouts repaired by scv_sync with a separate bootstrap launch), "overwrite_fused" (counters
  * overwritten by the vote kernel's last workgroup), "lds_counters" (register-resident launches that produced their counters
  * themselves), "sort_cells" (sorted-cells launches), "few_votes" (launches of the kernel for cells of exactly 1, 2 or 4 votes), "prefix_cells" / "prefix_lane" / "prefix_pool" (prefix calls served by the cell kernels / by
- * the one-lane-per-problem kernel / by the one-pass-per-problem kernel), "host_small_calls" / "host_pipelined_calls" (HOST-mode calls served by the one-block small path / by
+ * the one-lane-per-problem kernel / by the one-pass-per-problem kernel), "prefix_sort" (launches of scv_sort_prefix: every power-of-two budget out of one
+ * sort per problem -- queued, that is: a DEVICE-mode launch may find budgets it does not serve and leave them to the kernel behind it), "host_small_calls" / "host_pipelined_calls" (HOST-mode calls served by the one-block small path / by
  * the staging pipeline), "host_thread_start_failures" (worker threads of the staging pipeline the system refused to start: the
  * pipeline runs with the threads it has, the calling thread at least). */
 int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out);

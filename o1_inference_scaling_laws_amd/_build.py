@@ -14,12 +14,13 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(CSRC, "libscvote.so")
 UNITS = ["scvote.hip", "scvote_stream_c4.hip", "scvote_stream_c8.hip", "scvote_stream_c16.hip",
-         "scvote_reg_g16.hip", "scvote_reg_g32.hip", "scvote_reg_g64.hip", "scvote_dense.hip", "scvote_comm.hip", "scvote_sort.hip", "scvote_prefix.hip"]
+         "scvote_reg_g16.hip", "scvote_reg_g32.hip", "scvote_reg_g64.hip", "scvote_dense.hip", "scvote_comm.hip", "scvote_sort.hip", "scvote_prefix.hip", "scvote_sort_prefix.hip"]
 HEADERS = [os.path.join(CSRC, "scvote_kernels.hip.h"), os.path.join(CSRC, "scvote_dispatch.h"),
            os.path.join(os.path.dirname(HERE), "include", "scvote.h")]
 UNIT_HEADERS = {"scvote_sort.hip": [os.path.join(CSRC, "scvote_sort.hip.h"), os.path.join(CSRC, "scvote_sortnet.h")],
-                "scvote_prefix.hip": [os.path.join(CSRC, "scvote_prefix.hip.h")]}      # headers only one unit includes
-SOURCES = UNITS + ["scvote_kernels.hip.h", "scvote_sort.hip.h", "scvote_sortnet.h", "scvote_prefix.hip.h", "scvote_dispatch.h"]          # (tools/kernel_resources.py lists them)
+                "scvote_prefix.hip": [os.path.join(CSRC, "scvote_prefix.hip.h")],
+                "scvote_sort_prefix.hip": [os.path.join(CSRC, "scvote_sort_prefix.hip.h"), os.path.join(CSRC, "scvote_sort.hip.h"), os.path.join(CSRC, "scvote_sortnet.h")]}      # headers only one unit includes
+SOURCES = UNITS + ["scvote_kernels.hip.h", "scvote_sort.hip.h", "scvote_sortnet.h", "scvote_prefix.hip.h", "scvote_sort_prefix.hip.h", "scvote_dispatch.h"]          # (tools/kernel_resources.py lists them)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 

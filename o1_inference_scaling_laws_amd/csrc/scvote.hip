@@ -201,6 +201,8 @@ struct scv_ctx {
     // the last fused request, kept so that a grid-barrier timeout can be repaired at scv_sync by a separate bootstrap launch
     struct BootLast { const scv_cell* cells = nullptr; int64_t P = 0; int32_t B = 0, r0 = 0, r1 = 0, M = 0; uint64_t seed = 0; int64_t* out = nullptr; bool valid = false; } boot_last;
     int64_t stat_boot_recovered = 0, stat_boot_cooperative = 0, stat_sort_cells = 0, stat_few_votes = 0, stat_prefix_pool = 0;
+    int64_t stat_prefix_sort = 0;
+    const int32_t* nv_host = nullptr;   // HOST-mode calls: the caller's n_valid (host memory) for the duration of the call -- launch_prefix reads the budgets
     // split-N scratch (grown on demand)
     void* d_partial = nullptr;
     size_t d_partial_bytes = 0;
@@ -254,6 +256,7 @@ using scv::pick_reg_kernel;
 using scv::pick_dense_kernel;
 using scv::pick_sort_kernel;
 using scv::pick_prefix_pool_kernel;
+using scv::pick_sort_prefix_kernel;
 
 // Every entry point runs on the ctx device and leaves the caller's current HIP device as it found it
 // (a process driving several GPUs from one thread -- MultiDeviceEngine -- must not have torch's
@@ -743,8 +746,9 @@ bool prefix_lane_eligible(const scv_ctx* ctx, int32_t B, int64_t N, bool tok, in
 // One pass per problem over its pool row, every budget a snapshot of the running mode statistics (scvote_prefix.hip.h).
 int launch_prefix_pool(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, const int32_t* n_valid, const int32_t* truth,
                        int64_t P, int32_t B, int64_t N, scv_cell* cells, int64_t* cell_tokens, int64_t* tie, int64_t* tok_sum,
-                       int64_t* truth_sum, bool rows_aligned) {
+                       int64_t* truth_sum, bool rows_aligned, int skip_sortable = 0, EventPair* ev_open = nullptr, bool counters_cleared = false) {
     scv::AggArgs a;
+    a.skip_sortable = skip_sortable;
     a.pool_rows = 1;
     a.answers = pool; a.tokens = tokens; a.n_valid = n_valid; a.truth = truth;
     a.ncells = P * (int64_t)B; a.N = N; a.B = B; a.P = P;
@@ -778,7 +782,7 @@ int launch_prefix_pool(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
             if (tok && !a.cell_tokens) a.cell_tokens = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->d_cells) + ((cb + 255) / 256) * 256);
         }
     }
-    if (ctx->overwrite_counters && want_counters) {      // overwrite semantics: a memset node in front
+    if (ctx->overwrite_counters && want_counters && !counters_cleared) {      // overwrite semantics: a memset node in front
         if (tie) SCV_HIP(hipMemsetAsync(tie, 0, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), ctx->stream));
         if (tok_sum) SCV_HIP(hipMemsetAsync(tok_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
         if (truth_sum) SCV_HIP(hipMemsetAsync(truth_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
@@ -804,9 +808,11 @@ int launch_prefix_pool(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
     if (ctx->grid_override > 0) grid = ctx->grid_override;
     const int64_t wgs_needed = (nbatches + W - 1) / W;
     if (grid > wgs_needed) grid = wgs_needed;
-    EventPair* ev = nullptr;
-    if (int rc = next_event_pair(ctx, &ev)) return rc;
-    if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+    EventPair* ev = ev_open;                             // (open: scv_sort_prefix was queued in front, inside the same pair)
+    if (!ev_open) {
+        if (int rc = next_event_pair(ctx, &ev)) return rc;
+        if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+    }
     hipLaunchKernelGGL(rk.fn, dim3((unsigned)grid), dim3((unsigned)(W * 64)), lds, ctx->stream, a);
     SCV_HIP(hipGetLastError());
     ctx->stat_prefix_pool += 1;
@@ -827,6 +833,53 @@ int launch_prefix_pool(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
     return SCV_OK;
 }
 
+// Budgets that are powers of two (and the whole row) over pools of 17 .. 64 votes: every budget out of ONE sort per problem
+// (scv_sort_prefix, scvote_sort_prefix.hip.h).  Returns through *queued whether the kernel was launched; the kernel itself leaves without
+// side effects when some budget is not of that form (the caller then queues the general kernel behind it, a.skip_sortable = *nv_out).
+int launch_sort_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, const int32_t* n_valid, const int32_t* truth,
+                       int64_t P, int32_t B, int64_t N, scv_cell* cells, int64_t* cell_tokens, int64_t* tie, int64_t* tok_sum,
+                       int64_t* truth_sum, bool promised, bool* queued, int* nv_out) {
+    *queued = false;
+    const bool tok = tokens != nullptr;
+    const int nv = N <= 32 ? 32 : 64;
+    const RegKernel rk = pick_sort_prefix_kernel(nv, tok);
+    const int64_t ps = (N / 4) | 1;
+    const int64_t region_words = 64 * ps * 4 * (tok ? 2 : 1) + 64;
+    const int64_t tail_words = scv::sort_prefix_tail_words(nv, B);
+    int W = rk.waves;
+    while (W > 2 && (W * region_words + tail_words) * 4 + 1024 > ctx->lds_max) --W;
+    if ((W * region_words + tail_words) * 4 + 1024 > ctx->lds_max) return SCV_OK;
+    scv::AggArgs a;
+    a.pool_rows = 1;
+    a.answers = pool; a.tokens = tokens; a.n_valid = n_valid; a.truth = truth;
+    a.ncells = P * (int64_t)B; a.N = N; a.B = B; a.P = P;
+    a.cells = cells; a.cell_tokens = cell_tokens;
+    a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
+    a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
+    a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
+    a.err_flag = ctx->d_err;
+    a.prefetch = promised ? 1 : 0; a.sorted = 1;                    // (prefetch: here "the caller promised budgets of this kernel's form")
+    a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.acc_classes = 0;
+    a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr;
+    a.wave_lds_words = (int32_t)region_words;
+    const size_t lds = (size_t)(W * region_words + tail_words) * sizeof(uint32_t);
+    SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rk.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    SCV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rk.fn), W * 64, lds));
+    if (per_cu < 1) per_cu = 1;
+    const int64_t nsteps = (P + 63) / 64;
+    int64_t grid = (nsteps + W - 1) / W;
+    if (grid > (int64_t)ctx->num_cus * per_cu) grid = (int64_t)ctx->num_cus * per_cu;
+    if (ctx->grid_override > 0) grid = ctx->grid_override;
+    hipLaunchKernelGGL(rk.fn, dim3((unsigned)grid), dim3((unsigned)(W * 64)), lds, ctx->stream, a);
+    SCV_HIP(hipGetLastError());
+    ctx->stat_prefix_sort += 1;
+    ctx->err_dirty = true;
+    *queued = true;
+    *nv_out = nv;
+    return SCV_OK;
+}
+
 // Prefix budgets over one pool [P, N] (scv_aggregate_prefix_i32).  Same outputs as launch_aggregate on the dense [P, B, N]
 // expansion.  Option "prefix_path" forces one of the three forms (parity tests).
 int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, const int32_t* n_valid,
@@ -836,16 +889,57 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     if (ncells == 0) return SCV_OK;
     int lane_nv = 0, lane_threads = 0;
     size_t lane_lds = 0;
-    const bool lane_ok = prefix_lane_eligible(ctx, B, N, tokens != nullptr, &lane_nv, &lane_lds, &lane_threads) && (ctx->prefix_path == 0 || ctx->prefix_path == 1);
+    const bool lane_ok = prefix_lane_eligible(ctx, B, N, tokens != nullptr, &lane_nv, &lane_lds, &lane_threads) && (ctx->prefix_path == 0 || ctx->prefix_path == 1 || ctx->prefix_path == 5);
     const bool rows_aligned = (N % 4 == 0) && (((uintptr_t)pool & 15u) == 0) && (!tokens || ((uintptr_t)tokens & 15u) == 0);
+    // pools of 17 .. 64 votes, budgets that are powers of two (the reference's own, o1.py:274-277): every budget out of one sort per problem.
+    // The budgets live in n_valid: a HOST-mode call reads them; a DEVICE-mode call queues scv_sort_prefix AND the general kernel -- each
+    // decides from n_valid, in its first microsecond, whether the launch is its own.
+    int skip_sortable = 0;
+    EventPair* ev_open = nullptr;
+    bool counters_cleared = false;
+    const bool want_any_counters = tie || truth_sum || (tokens && tok_sum);
+    if (ctx->path == 0 && (ctx->prefix_path == 0 || ctx->prefix_path == 5) && ctx->sort_n_max >= 64 && ctx->fused_counters_max != 0 && rows_aligned &&
+        N > 16 && N <= 64 && B <= scv::kMaxSortedB) {
+        // prefix_path = 5: the caller PROMISES budgets of that form (a DEVICE-mode call then queues scv_sort_prefix alone; a list that breaks
+        // the promise is an error, reported like a domain error at the next synchronisation)
+        const bool promised = ctx->prefix_path == 5;
+        bool known = promised, served = true;
+        if (ctx->nv_host) {
+            known = true;
+            const int64_t np = N <= 32 ? 16 : 32;
+            for (int32_t b = 0; b < B; ++b) {
+                const int64_t n = ctx->nv_host[b];
+                if (!(n <= 0 || n >= N || ((n & (n - 1)) == 0 && n <= np))) { served = false; break; }
+            }
+        }
+        if (!served && promised) return fail(SCV_ERR_ARG, "prefix_path = 5 promises budgets that are 0, a power of two <= %d, or >= N", N <= 32 ? 16 : 32);
+        if (served) {
+            if (int rc = next_event_pair(ctx, &ev_open)) return rc;
+            if (ctx->overwrite_counters && want_any_counters) {
+                if (tie) SCV_HIP(hipMemsetAsync(tie, 0, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), ctx->stream));
+                if (tok_sum) SCV_HIP(hipMemsetAsync(tok_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
+                if (truth_sum) SCV_HIP(hipMemsetAsync(truth_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
+                counters_cleared = true;
+            }
+            if (ev_open) SCV_HIP(hipEventRecord(ev_open->a, ctx->stream));
+            bool queued = false;
+            if (int rc = launch_sort_prefix(ctx, pool, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, promised, &queued, &skip_sortable)) return rc;
+            if (queued && known) {
+                if (ev_open) SCV_HIP(hipEventRecord(ev_open->b, ctx->stream));
+                return SCV_OK;
+            }
+            if (!queued) skip_sortable = 0;
+        }
+    }
     // pools of 65 .. 4096 votes (and shorter ones when forced): ONE pass per problem, every budget a snapshot (scv_prefix_pool)
-    const bool pool_ok = ctx->path == 0 && N >= 1 && N <= 4096 && B <= scv::kMaxSortedB && ((ctx->prefix_path == 0 && !lane_ok) || ctx->prefix_path == 4);
-    if (pool_ok) return launch_prefix_pool(ctx, pool, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, rows_aligned);
-    if (!lane_ok && pool_rows_eligible(ctx, B, N, rows_aligned) && (ctx->prefix_path == 0 || ctx->prefix_path == 2)) {
+    const bool pool_ok = ctx->path == 0 && N >= 1 && N <= 4096 && B <= scv::kMaxSortedB && (((ctx->prefix_path == 0 || ctx->prefix_path == 5) && !lane_ok) || ctx->prefix_path == 4);
+    if (pool_ok) return launch_prefix_pool(ctx, pool, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, rows_aligned, skip_sortable, ev_open, counters_cleared);
+    if (!lane_ok && !skip_sortable && pool_rows_eligible(ctx, B, N, rows_aligned) && (ctx->prefix_path == 0 || ctx->prefix_path == 2)) {
         ctx->stat_prefix_cells += 1;
         return launch_aggregate(ctx, pool, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, true);
     }
     scv::AggArgs a;
+    a.skip_sortable = skip_sortable;
     a.pool_rows = 0;
     a.answers = pool; a.tokens = tokens; a.n_valid = n_valid; a.truth = truth;
     a.ncells = ncells; a.N = N; a.B = B; a.P = P;
@@ -871,14 +965,16 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
             if (tok && !a.cell_tokens) a.cell_tokens = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->d_cells) + ((cb + 255) / 256) * 256);
         }
     }
-    if (ctx->overwrite_counters && want_counters) {      // overwrite semantics: a memset node in front (no fused variant here)
+    if (ctx->overwrite_counters && want_counters && !counters_cleared) {      // overwrite semantics: a memset node in front (no fused variant here)
         if (tie) SCV_HIP(hipMemsetAsync(tie, 0, (size_t)B * SCV_TIE_CLASSES * sizeof(int64_t), ctx->stream));
         if (tok_sum) SCV_HIP(hipMemsetAsync(tok_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
         if (truth_sum) SCV_HIP(hipMemsetAsync(truth_sum, 0, (size_t)B * sizeof(int64_t), ctx->stream));
     }
-    EventPair* ev = nullptr;
-    if (int rc = next_event_pair(ctx, &ev)) return rc;
-    if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+    EventPair* ev = ev_open;
+    if (!ev_open) {
+        if (int rc = next_event_pair(ctx, &ev)) return rc;
+        if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+    }
     if (lane_ok) {
         a.wave_lds_words = rows_aligned ? 1 : 0;   // "vec" flag
         // Workgroup size.  N <= 32: 1024 threads, one workgroup per CU (the end-of-launch flush is one device atomic per
@@ -909,7 +1005,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
         if (N < 32768) { copies = 8; threads = 256; wg_per_cu = 4; }
         else if (N < 262144) { copies = 16; threads = 512; wg_per_cu = 2; }
         else { copies = 16; threads = 1024; wg_per_cu = 1; }
-        const size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords + scv::kMaxSortedB) * sizeof(uint32_t);
+        const size_t lds = ((size_t)scv::kBins * copies + scv::kRedWords + 2 * (size_t)scv::kMaxSortedB) * sizeof(uint32_t);
         int64_t grid = (int64_t)ctx->num_cus * wg_per_cu;
         if (grid > P) grid = P;
         { const int64_t rounds = (P + grid - 1) / grid; grid = (P + rounds - 1) / rounds; }
@@ -962,6 +1058,7 @@ int check_err_word(scv_ctx* ctx, uint32_t w) {
     if ((w & 1u) && !(ctx->flags & SCV_FLAG_CLAMP_TO_INVALID_BIN))
         return fail(SCV_ERR_DOMAIN, "a vote outside bins 0..1023 was seen; results are invalid");
     if (w & 2u) return fail(SCV_ERR_ARG, "bootstrap: a drawn hit had n_modes >= M");
+    if (w & 8u) return fail(SCV_ERR_ARG, "prefix_path = 5 promised budgets that are 0, a power of two or >= N: the list in n_valid is not; nothing was computed");
     return SCV_OK;
 }
 
@@ -1126,7 +1223,7 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
         else if (!strcmp(key, "fused_counters_max")) { if (value < 0) return fail(SCV_ERR_ARG, "fused_counters_max < 0"); ctx->fused_counters_max = (int)(value > (1 << 30) ? (1 << 30) : value); }
         else if (!strcmp(key, "grid")) { if (value < 0 || value > (1 << 20)) return fail(SCV_ERR_ARG, "grid out of range"); ctx->grid_override = (int)value; }
         else if (!strcmp(key, "segs")) { if (value < 0 || value > 4096) return fail(SCV_ERR_ARG, "segs out of range"); ctx->segs_override = (int)value; }
-        else if (!strcmp(key, "prefix_path")) { if (value < 0 || value > 4) return fail(SCV_ERR_ARG, "prefix_path must be 0..4"); ctx->prefix_path = (int)value; }
+        else if (!strcmp(key, "prefix_path")) { if (value < 0 || value > 5) return fail(SCV_ERR_ARG, "prefix_path must be 0..5"); ctx->prefix_path = (int)value; }
         else if (!strcmp(key, "boot_path")) { if (value < 0 || value > 3) return fail(SCV_ERR_ARG, "boot_path must be 0..3"); ctx->boot_path = (int)value; }
         else if (!strcmp(key, "boot_spin_limit")) { if (value < 1 || value > (1 << 30)) return fail(SCV_ERR_ARG, "boot_spin_limit out of range"); ctx->boot_spin_limit = (int)value; }
         else if (!strcmp(key, "stage_mb")) { if (value < 1 || value > 65536) return fail(SCV_ERR_ARG, "stage_mb out of range"); ctx->stage_mb = (int)value; }
@@ -1394,8 +1491,9 @@ int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const in
                       tie_class_hits_out, token_sum_out, truth_count_sum_out);
 
     // HOST mode accumulates its own zeroed counters over the chunks: the DEVICE-mode overwrite option must not apply
-    struct Restore { scv_ctx* c; int v; ~Restore() { c->overwrite_counters = v; } } restore{ctx, ctx->overwrite_counters};
+    struct Restore { scv_ctx* c; int v; ~Restore() { c->overwrite_counters = v; c->nv_host = nullptr; } } restore{ctx, ctx->overwrite_counters};
     ctx->overwrite_counters = 0;
+    ctx->nv_host = prefix ? n_valid : nullptr;
     bool small = false;
     if (int rc = host_small(ctx, prefix, answers, tokens, n_valid, truth, P, B, N, cells_out, cell_tokens_out,
                             tie_class_hits_out, token_sum_out, truth_count_sum_out, &small)) return rc;
@@ -1595,6 +1693,7 @@ int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
         else if (!strcmp(key, "prefix_cells")) *out = ctx->stat_prefix_cells;
         else if (!strcmp(key, "prefix_lane")) *out = ctx->stat_prefix_lane;
     else if (!strcmp(key, "prefix_pool")) *out = ctx->stat_prefix_pool;
+    else if (!strcmp(key, "prefix_sort")) *out = ctx->stat_prefix_sort;
         else if (!strcmp(key, "sort_cells")) *out = ctx->stat_sort_cells;
         else if (!strcmp(key, "few_votes")) *out = ctx->stat_few_votes;
         else if (!strcmp(key, "host_small_calls")) *out = ctx->stat_small_calls;

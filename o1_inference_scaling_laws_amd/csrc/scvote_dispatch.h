@@ -48,6 +48,13 @@ constexpr bool prefix_pool_h16(int g) { return SCV_PREFIX_H16 != 0 && g == 16; }
 constexpr int prefix_pool_hist_words(int g) { return (64 / g) * (prefix_pool_h16(g) ? kBins / 2 : kBins); }
 RegKernel pick_prefix_pool_kernel(int g, bool tok, bool vec);
 
+// scv_sort_prefix<nv votes per lane>: prefix budgets that are powers of two (and the whole row) over pools of nv / 2 < N <= nv votes, out of
+// one sort per problem (scvote_sort_prefix.hip.h); .waves = the launch bound in waves; LDS words behind the waves' regions:
+// sort_prefix_tail_words(nv, B)
+constexpr int sort_prefix_classes(int nv) { int l = 0; while ((1 << l) < nv / 2) ++l; return l + 3; }
+constexpr long long sort_prefix_tail_words(int nv, int B) { return 16 + ((B + 3) & ~3) + ((sort_prefix_classes(nv) * (nv + 1) + 1) & ~1) + 4 * sort_prefix_classes(nv); }
+RegKernel pick_sort_prefix_kernel(int nv, bool tok);
+
 // ---- shared by the table translation units ------------------------------------------------------------------------
 template <int RL2, int T, int U>
 inline KernelFn stream_tok(bool tok, bool xtra) {

@@ -87,6 +87,8 @@ struct AggArgs {
     unsigned long long* boot_out;   // [r1 - r0][B][M]
     uint32_t* partial;      // split-N: [ncells * segs][1024] partial histograms
     long long* partial_tok; // split-N: [ncells * segs] partial token sums
+    int32_t skip_sortable = 0;      // prefix kernels queued BEHIND scv_sort_prefix<NV> (DEVICE mode: the host cannot read n_valid): = NV; the
+                                    // launch leaves at once when every budget is of the form that kernel serves (it has done the work)
 };
 
 // 64-lane reductions on the VALU (DPP), not through the LDS crossbar: __shfl_xor lowers to
@@ -223,17 +225,66 @@ __device__ __forceinline__ int64_t valid_len(const AggArgs& a, int32_t b) {
     return nv < 0 ? 0 : (nv > a.N ? a.N : nv);
 }
 
+// Rank of budget b (nb votes) among the launch's budgets by valid length, ties by index: the number of budgets in front of it.  Every
+// lane of the wave calls it together (lanes without a budget pass any b): the lengths arrive 64 at a time with ONE coalesced load and
+// are handed round with v_readlane -- round 5: the obvious loop (a load of n_valid[c] per comparison, each waiting for the one before)
+// cost 0.65 us per comparison, B^2 of them: 32 us of a 57 us launch at 7 budgets, 53 us at 9.
+template <bool DESCENDING, typename F>
+__device__ __forceinline__ int budget_rank_of(const AggArgs& a, int32_t b, int64_t nb, F key_of) {
+    const int lane = (int)threadIdx.x & 63;
+    int rank = 0;
+    for (int c0 = 0; c0 < a.B; c0 += 64) {
+        const int cc = c0 + lane;
+        const int32_t mine = cc < a.B ? (int32_t)key_of(cc) : 0;
+        const int m = a.B - c0 < 64 ? a.B - c0 : 64;
+        for (int j = 0; j < m; ++j) {
+            const int64_t nc = (int64_t)__builtin_amdgcn_readlane(mine, j);
+            const int c = c0 + j;
+            rank += DESCENDING ? ((nc > nb) || (nc == nb && c < b)) : ((nc < nb) || (nc == nb && c < b));
+        }
+    }
+    return rank;
+}
+template <bool DESCENDING>
+__device__ __forceinline__ int budget_rank(const AggArgs& a, int32_t b, int64_t nb) {
+    return budget_rank_of<DESCENDING>(a, b, nb, [&](int c) { return valid_len(a, c); });
+}
+
+// ---- scv_sort_prefix (scvote_sort_prefix.hip.h): which budget lists it serves ---------------------------------------------------
+constexpr int sv_log2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+// class of a budget of n votes over pool rows of N votes on the shape of NV votes per lane (NV / 2 < N <= NV): 0 = no votes |
+// 1 + j = the first 2^j votes, 2^j <= NV / 2 | log2(NV / 2) + 2 = all N votes | -1 = not served
+template <int NV>
+__device__ __forceinline__ int sort_prefix_class(int64_t n, int64_t N) {
+    constexpr int NP = NV / 2;
+    if (n <= 0) return 0;
+    if (n >= N) return sv_log2(NP) + 2;
+    if ((n & (n - 1)) == 0 && n <= NP) return 1 + (31 - __builtin_clz((uint32_t)n));
+    return -1;
+}
+// true when every budget of the launch has a class (every thread of the workgroup calls it: one __syncthreads inside)
+template <int NV>
+__device__ __forceinline__ bool sort_prefix_serves(const AggArgs& a, int tid, int nthreads) {
+    int bad = 0;
+    for (int b = tid; b < a.B; b += nthreads) bad |= sort_prefix_class<NV>(valid_len(a, b), a.N) < 0 ? 1 : 0;
+    return __syncthreads_or(bad) == 0;
+}
+// ... asked by the kernels the host queues behind scv_sort_prefix (a.skip_sortable = its NV; 0: never)
+__device__ __forceinline__ bool sort_prefix_took_it(const AggArgs& a, int tid, int nthreads) {
+    if (a.skip_sortable == 64) return sort_prefix_serves<64>(a, tid, nthreads);
+    if (a.skip_sortable == 32) return sort_prefix_serves<32>(a, tid, nthreads);
+    return false;
+}
+
 // returns true when `ord` is in use (caller must __syncthreads() before reading it)
 __device__ __forceinline__ bool build_budget_order(const AggArgs& a, int32_t* ord, int tid, int nthreads) {
     if (!a.sorted || !a.n_valid || a.B > kMaxSortedB) return false;
-    for (int b = tid; b < a.B; b += nthreads) {
-        const int64_t nb = valid_len(a, b);
-        int rank = 0;
-        for (int c = 0; c < a.B; ++c) {
-            const int64_t nc = valid_len(a, c);
-            rank += (nc > nb) || (nc == nb && c < b);
-        }
-        ord[rank] = b;
+    for (int b0 = 0; b0 < a.B; b0 += nthreads) {                     // (whole waves: budget_rank hands the lengths round the lanes)
+        const int b = b0 + tid;
+        const bool have = b < a.B;
+        const int64_t nb = have ? valid_len(a, b) : 0;
+        const int rank = budget_rank<true>(a, b, nb);
+        if (have) ord[rank] = b;
     }
     return true;
 }
@@ -1372,16 +1423,14 @@ __global__ __launch_bounds__(TB) void scv_lane_prefix(const AggArgs a) {
     long long* stage_tok = reinterpret_cast<long long*>(stage_base + (int64_t)(T >> 6) * 64 * a.B) + (int64_t)(threadIdx.x >> 6) * 64 * a.B;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    if (sort_prefix_took_it(a, tid, T)) return;
     for (int64_t i = tid; i < tie_words + 4 * (int64_t)a.B; i += T) lds[i] = 0;
-    for (int b = tid; b < a.B; b += T) {
-        const int64_t nb = valid_len(a, b);
-        int rank = 0;
-        for (int c = 0; c < a.B; ++c) {
-            const int64_t nc = valid_len(a, c);
-            rank += (nc < nb) || (nc == nb && c < b);
-        }
-        ord[rank] = b;
-        nvs[rank] = (int32_t)nb;
+    for (int b0 = 0; b0 < a.B; b0 += T) {
+        const int b = b0 + tid;
+        const bool have = b < a.B;
+        const int64_t nb = have ? valid_len(a, b) : 0;
+        const int rank = budget_rank<false>(a, b, nb);
+        if (have) { ord[rank] = b; nvs[rank] = (int32_t)nb; }
     }
     __syncthreads();
     const bool vec = a.wave_lds_words != 0;                          // host: N % 4 == 0 and 16-byte aligned bases
@@ -2396,6 +2445,8 @@ __global__ __launch_bounds__(T) void scv_prefix_hist(const AggArgs a) {
         for (int i = tid; i < kBins * R / 4; i += T) h4[i] = make_uint4(0, 0, 0, 0);
     }
     build_budget_order(a, ord, tid, T);   // host guarantees n_valid != NULL, B <= kMaxSortedB, sorted = 1
+    int32_t* nvb = ord + kMaxSortedB;     // valid length per budget (a load of n_valid per boundary and problem would stall the workgroup each time)
+    for (int b = tid; b < a.B; b += T) nvb[b] = (int32_t)valid_len(a, b);
     __syncthreads();
 
     uint32_t bad = 0;
@@ -2407,7 +2458,7 @@ __global__ __launch_bounds__(T) void scv_prefix_hist(const AggArgs a) {
         int64_t done = 0;
         for (int32_t k = a.B - 1; k >= 0; --k) {               // ascending n_valid
             const int32_t b = ord[k];
-            const int64_t n = valid_len(a, b);
+            const int64_t n = nvb[b];
             if (n > done) {
                 stream_row<RL2, T, U, TOK>(a, hist, copy, row + done, TOK ? trow + done : nullptr, n - done, tid, bad, tsum);
                 done = n;

@@ -133,24 +133,25 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G, TOK>())) void scv_prefix
     int32_t* ord = reinterpret_cast<int32_t*>(smem_wg + (int64_t)nw * a.wave_lds_words);   // budgets by ascending n_valid
     int32_t* nvs = ord + a.B;                                                             // their n_valid, ascending
     int32_t* hmap = nvs + a.B;                 // [0, 16): the budget whose n_valid is i + 1 (-1: none); [16, 32): how many budgets have it
+    if (sort_prefix_took_it(a, tid, T)) return;
     {
         uint4* h4 = reinterpret_cast<uint4*>(smem);
         for (int i = lane; i < (HW + kPrefixPoolLaneWords) / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
     }
     if (tid < 32) hmap[tid] = tid < HEAD ? -1 : 0;
     __syncthreads();
-    for (int b = tid; b < a.B; b += T) {
-        const int64_t nb = valid_len(a, b);
-        int rank = 0;
-        for (int c = 0; c < a.B; ++c) {
-            const int64_t nc = valid_len(a, c);
-            rank += (nc < nb) || (nc == nb && c < b);
-        }
-        ord[rank] = b;
-        nvs[rank] = (int32_t)nb;
-        if (nb >= 1 && nb <= HEAD) {
-            hmap[nb - 1] = b;
-            atomicAdd(reinterpret_cast<uint32_t*>(hmap) + HEAD + (nb - 1), 1u);
+    for (int b0 = 0; b0 < a.B; b0 += T) {
+        const int b = b0 + tid;
+        const bool have = b < a.B;
+        const int64_t nb = have ? valid_len(a, b) : 0;
+        const int rank = budget_rank<false>(a, b, nb);
+        if (have) {
+            ord[rank] = b;
+            nvs[rank] = (int32_t)nb;
+            if (nb >= 1 && nb <= HEAD) {
+                hmap[nb - 1] = b;
+                atomicAdd(reinterpret_cast<uint32_t*>(hmap) + HEAD + (nb - 1), 1u);
+            }
         }
     }
     const WgCounters wgc = wg_counters_begin(a, reinterpret_cast<uint32_t*>(hmap + kPrefixPoolFixedWords), tid, T);

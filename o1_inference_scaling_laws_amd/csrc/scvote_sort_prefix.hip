@@ -1,0 +1,21 @@
+// Prefix budgets that are powers of two over short pools, out of ONE sort per problem (scv_sort_prefix<NV, TOK>).
+#include "scvote_sort_prefix.hip.h"
+#include "scvote_dispatch.h"
+namespace scv {
+// nv: votes per lane (32 / 64); .waves = the launch bound in waves
+RegKernel pick_sort_prefix_kernel(int nv, bool tok) {
+    if (nv == 32) return tok ? RegKernel{(KernelFn)scv_sort_prefix<32, true>, sort_prefix_threads(32) / 64} : RegKernel{(KernelFn)scv_sort_prefix<32, false>, sort_prefix_threads(32) / 64};
+    return tok ? RegKernel{(KernelFn)scv_sort_prefix<64, true>, sort_prefix_threads(64) / 64} : RegKernel{(KernelFn)scv_sort_prefix<64, false>, sort_prefix_threads(64) / 64};
+}
+}  // namespace scv
+#ifdef SCV_SP_TIMELINE
+// measurement build only: read (and clear) the phase sums of scv_sort_prefix
+extern "C" int scv_debug_sort_prefix_timeline(unsigned long long* out8, int clear) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(scv::scv_sp_timeline), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (clear) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(scv::scv_sp_timeline), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

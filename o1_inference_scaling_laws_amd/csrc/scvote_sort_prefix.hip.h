@@ -1,0 +1,465 @@
+// scvote_sort_prefix.hip.h -- prefix budgets over SHORT pools (17 .. 64 votes), the budgets of the reference itself: powers of two.
+//
+// The reference's sweep (/root/reference/o1.py:274-277): the budgets of a problem are majority votes over the first 1, 2, 4 ... N samples
+// of ONE list of completions.  scv_sort_cells sorts a cell's votes in registers with Batcher's odd-even mergesort: after the merge phase
+// p of that network every aligned block of 2 p wires is sorted -- in particular wires 0 .. 2 p - 1, the FIRST 2 p votes of the row.  A
+// run scan over that block IS the majority vote of the budget 2 p: maj@2, 4, 8 ... NV / 2 fall out of the one sort that maj@N needs
+// anyway.  One lane per problem, rows by LDS-DMA exactly as in scv_sort_cells (scvote_sort.hip.h): the pool row is
+// read ONCE, sorted ONCE, and every budget costs a scan of its own block (~8 plain VALU per vote of the block) and one 16-byte record.
+//
+// Budget CLASSES of a launch (wave-uniform: n_valid is per budget, not per problem): 0 = no votes | 1 + j = the first 2^j votes,
+// 2^j <= NV / 2 | the last = all N votes (NV / 2 < N <= NV: the host picks the shape).  A launch whose budgets are not all of this form
+// leaves WITHOUT side effects (every workgroup finds the same verdict from n_valid): in DEVICE mode the host cannot read n_valid, so it
+// queues this kernel AND the general one (scv_lane_prefix / scv_prefix_pool with a.skip_sortable = NV), which leaves when this one
+// runs; in HOST mode it knows and queues one.  Budgets of a class share the record; their counters (o1.py:238-240 as integers) are kept
+// per CLASS (registers + a [classes][NV + 1] table in LDS, whatever the number of budgets) and handed to the budgets at the end.
+//
+// Records of a step are packed (7 + 7 + 7 + 10 + 1 bits) and written at the top of the NEXT step, behind the wait for its image: a store
+// issued at the end of a step would be waited for whole by that s_waitcnt vmcnt(0).
+//
+// Algorithmic bytes: 4 per vote of the pool (8 with tokens), 16 written per (problem, budget) (24 with tokens) -- DESIGN.md 3.8.
+#pragma once
+
+#include "scvote_sort.hip.h"
+
+namespace scv {
+
+// exchanges of the merge phases p' <= pmax of sv_make_network<N>() (the generator's own loops)
+template <int N>
+constexpr int sv_phase_end(int pmax) {
+    int n = 0;
+    for (int p = 1; p < N && p <= pmax; p *= 2)
+        for (int k = p; k >= 1; k /= 2)
+            for (int j = k % p; j <= N - 1 - k; j += 2 * k)
+                for (int i = 0; i <= (k - 1 < N - j - k - 1 ? k - 1 : N - j - k - 1); ++i)
+                    if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) ++n;
+    return n;
+}
+template <int NP, int FROM, typename Tick, int... I>
+__device__ __forceinline__ void sv_sort_halves_range(uint32_t (&R)[NP], Tick& tick, std::integer_sequence<int, I...>) {
+    ((sv_ce(R[SvNet<NP>::net.a[FROM + I]], R[SvNet<NP>::net.b[FROM + I]]), tick(R[SvNet<NP>::net.a[FROM + I]])), ...);
+}
+// the lockstep network phase by phase; hook(integral_constant<2 p>) after phase p: wires 0 .. 2 p - 1 are sorted in both halves
+template <int NP, int P, typename Tick, typename Hook>
+__device__ __forceinline__ void sv_sort_phases(uint32_t (&R)[NP], Tick& tick, Hook& hook) {
+    if constexpr (P < NP) {
+        constexpr int from = sv_phase_end<NP>(P / 2), to = sv_phase_end<NP>(P);
+        sv_sort_halves_range<NP, from>(R, tick, std::make_integer_sequence<int, to - from>{});
+        hook(std::integral_constant<int, 2 * P>{});
+        sv_sort_phases<NP, 2 * P>(R, tick, hook);
+    }
+}
+// the halves of a lockstep-sorted register file into one ascending sequence (the tail of sv_sort for NP a power of two)
+template <int NP, typename Tick>
+__device__ __forceinline__ void sv_merge_halves(uint32_t (&R)[NP], Tick& tick) {
+    static_assert(sv_pow2(NP), "power-of-two shapes");
+#pragma unroll
+    for (int r = 0; r < NP / 2; ++r) { sv_ce_cross(R[r], R[NP - 1 - r]); tick(R[r]); }
+#pragma unroll
+    for (int j = NP >> 1; j > 0; j >>= 1) {
+#pragma unroll
+        for (int r = 0; r < NP; ++r) {
+            const int l = r ^ j;
+            if (l > r) { sv_ce(R[r], R[l]); tick(R[r]); }
+        }
+    }
+}
+
+struct BlockStats { uint32_t max_run, at_max, min_at_max; };
+// statistics.multimode of the M sorted values in the LOW halves of R[0 .. M - 1]: key = (M - length of the run ending here) << 10 | value,
+// the smallest key is the last element of the longest run with the smallest value; a maximal run reaches its length once
+template <int M, int NP>
+__device__ __forceinline__ BlockStats sv_scan_block(const uint32_t (&R)[NP]) {
+    static_assert(M <= NP, "a block of the low halves");
+    uint32_t key[M];
+    uint32_t prev = 0xffffffffu, s = 0, km = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const uint32_t x = R[i] & 0xffffu;
+        s = (x != prev) ? (uint32_t)i : s;
+        key[i] = (((uint32_t)(M - 1 - i) + s) << 10) | x;
+        km = key[i] < km ? key[i] : km;
+        prev = x;
+    }
+    const uint32_t thr = km | 0x3ffu;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) cnt += key[i] <= thr ? 1u : 0u;
+    return BlockStats{(uint32_t)M - (km >> 10), cnt, km & 0x3ffu};
+}
+
+#ifdef SCV_SP_TIMELINE
+// Measurement build only (tools/sort_prefix_timeline.py; never defined for the product library): shader cycles every wave spent in the
+// phases of a step, summed over all waves: 0 wait for the copy | 1 rows -> registers, packed, truth prefix | 2 the previous records |
+// 3 sort (+ the next copy's pieces) | 4 the block scans between the phases | 5 final scan | 6 loop control, prologue; [7] = steps
+__device__ unsigned long long scv_sp_timeline[8];
+#define SP_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_now = __builtin_readcyclecounter(); \
+                         __builtin_amdgcn_sched_barrier(0); tl[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define SP_STAMP(i) do { } while (0)
+#endif
+
+// NV: capacity of the shape (32 / 64); host contract: NV / 2 < N <= NV, N % 4 == 0, 16-byte aligned bases, B <= kMaxSortedB,
+// a.wave_lds_words = 64 * PS * 4 (twice with tokens) + 64, PS = (N / 4) | 1.  LDS behind the waves' regions: class offsets [16] |
+// budgets by class [B rounded to 4] | tie classes [classes][NV + 1] | truth sums [classes] | token sums [classes] (64-bit).
+constexpr int sort_prefix_threads(int nv) { return 512; }
+template <int NV, bool TOK>
+__global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const AggArgs a) {
+    constexpr int NP = NV / 2, RSM = NV / 4;
+    constexpr int QMAX = RSM + 1;
+    constexpr int TC = NV + 1;
+    constexpr int LG = sv_log2(NP);
+    constexpr int NC = LG + 3, CF = LG + 2;                          // classes; the class of all N votes
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, T = (int)blockDim.x, NW = T >> 6;
+    const int32_t N = (int32_t)a.N, B = a.B;
+    const uint32_t RS = (uint32_t)N >> 2, PS = RS | 1u;
+    const uint32_t rowbytes = (uint32_t)N * 4u;
+    int32_t* cbeg = reinterpret_cast<int32_t*>(lds + (int64_t)NW * a.wave_lds_words);   // [c]: first position of class c in ordl; [NC] = B
+    int32_t* ordl = cbeg + 16;                                                           // budgets by class
+    uint32_t* tie = reinterpret_cast<uint32_t*>(ordl + ((B + 3) & ~3));                  // [NC][TC]
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(tie + ((NC * TC + 1) & ~1));   // [NC] truth sums | [NC] token sums
+
+    if (tid < 16) cbeg[tid] = 0;
+    for (int i = tid; i < NC * TC; i += T) tie[i] = 0;
+    for (int i = tid; i < 2 * NC; i += T) acc[i] = 0;
+    __syncthreads();
+    {
+        int bad = 0;
+        for (int b0 = 0; b0 < B; b0 += T) {
+            const int b = b0 + tid;
+            const bool have = b < B;
+            const int c = have ? sort_prefix_class<NV>(valid_len(a, b), N) : 0;
+            bad |= c < 0 ? 1 : 0;
+            // (a list this kernel does not serve: the ranks are not used)
+            const int rank = budget_rank_of<false>(a, b, (int64_t)c, [&](int o) { return sort_prefix_class<NV>(valid_len(a, o), N); });
+            if (have && c >= 0 && rank >= 0 && rank < B) {
+                ordl[rank] = b;
+                atomicAdd(reinterpret_cast<uint32_t*>(cbeg) + c + 1, 1u);
+            }
+        }
+        if (__syncthreads_or(bad)) {                                 // (the general kernel queued behind this one takes the launch ...
+            if (a.prefetch && tid == 0) atomicOr(a.err_flag, 8u);    //  ... unless the caller promised such budgets: option prefix_path = 5)
+            return;
+        }
+    }
+    if (tid == 0) {
+        for (int c = 1; c <= NC; ++c) cbeg[c] += cbeg[c - 1];
+    }
+    __syncthreads();
+    int32_t cb[NC + 1];
+#pragma unroll
+    for (int c = 0; c <= NC; ++c) cb[c] = __builtin_amdgcn_readfirstlane(cbeg[c]);
+    // votes the longest budget sees (the domain check looks no further)
+    int32_t nmax = 0;
+#pragma unroll
+    for (int c = 1; c < CF; ++c) if (cb[c + 1] > cb[c]) nmax = 1 << (c - 1);
+    if (cb[CF + 1] > cb[CF]) nmax = N;
+
+    const uint32_t rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32*)(lds + (int64_t)wid * a.wave_lds_words));
+    const uint32_t img_bytes = 64u * PS * 16u;
+    const uint32_t tru_off = img_bytes * (TOK ? 2u : 1u);
+    uint32_t off[QMAX];
+    {
+        uint32_t c = (uint32_t)lane / PS, k = (uint32_t)lane - c * PS;
+        const uint32_t dc = 64u / PS, dk = 64u - dc * PS;
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            off[q] = c * rowbytes + (k < RS ? k : RS - 1u) * 16u;
+            c += dc; k += dk;
+            if (k >= PS) { k -= PS; c += 1; }
+        }
+    }
+    const int64_t nwaves = (int64_t)gridDim.x * NW;
+    const int64_t wave = sv_uniform64((int64_t)blockIdx.x * NW + wid);
+    const int64_t nsteps = (a.P + 63) / 64;
+    const int64_t total_bytes = a.P * (int64_t)rowbytes;
+    auto issue = [&](int64_t st) {                                   // the copy of step st's 64 rows into this wave's image(s), and its truths
+        const int64_t byte0 = st * 64 * (int64_t)rowbytes;
+        const int64_t rem = total_bytes - byte0 - 16;
+        const uint32_t lim = rem > 0x7fffffffll ? 0x7fffffffu : (uint32_t)rem;
+        const char* g = reinterpret_cast<const char*>(a.answers) + byte0;
+        const char* gt = TOK ? reinterpret_cast<const char*>(a.tokens) + byte0 : nullptr;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            if ((uint32_t)q < PS) {
+                const uint32_t o = off[q] < lim ? off[q] : lim;
+                sv_dma16(g, o, rbase + (uint32_t)q * 1024u);
+                if (TOK) sv_dma16(gt, o, rbase + img_bytes + (uint32_t)q * 1024u);
+            }
+        }
+    };
+    auto issue_truth = [&](int64_t st) {
+        const int64_t left = a.P - st * 64;
+        const uint32_t live_rows = left > 64 ? 64u : (uint32_t)left;
+        const int32_t* tp = reinterpret_cast<const int32_t*>(sv_uniform64((int64_t)(uintptr_t)(a.truth + st * 64)));
+        sv_dma4(tp, ((uint32_t)lane < live_rows ? (uint32_t)lane : 0u) * 4u, rbase + tru_off);
+    };
+
+    // per class, per lane: truth votes (and tokens) of its problems; uniform: hits with one mode
+    uint32_t tcs[NC];
+    uint32_t h1[NC];
+    long long toks[TOK ? NC : 1];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { tcs[c] = 0; h1[c] = 0; if (TOK) toks[c] = 0; }
+    uint32_t bad = 0;
+    // the previous step's records, packed: max_count | truth_count << 7 | n_modes << 14 | min_mode << 21 | hit << 31
+    uint32_t D[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) D[c] = 0;
+    int64_t Dp0 = 0;
+    uint32_t Dlive = 0;
+    // The [64][B] records of the previous step leave through this wave's image, between the step's rows having been read and the next copy
+    // being started: every lane writes its B records where they lie in memory (cells[p][b], 16 B apart), then the table goes out in pieces of
+    // 1 KiB of consecutive addresses.  (Written straight from the lanes -- 16 B every 16 B bytes apart -- a step spent 12-20 000 cycles
+    // ISSUING its B stores: profiles/r05_sort_prefix_timeline.log.)  Budget lists longer than the image (PS KiB) are written directly.
+    auto flush_records = [&]() {
+        if (!a.cells || Dlive == 0) return;
+        const bool staged = (uint32_t)B <= PS;
+        uint4* const rowp = reinterpret_cast<uint4*>(a.cells) + (Dp0 + lane) * (int64_t)B;
+        const uint32_t lrow = rbase + (uint32_t)lane * (uint32_t)B * 16u;
+        const bool wr = (uint32_t)lane < Dlive;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (cb[c + 1] > cb[c]) {
+                const uint32_t d = D[c];
+                const scv_v4u rec = c == 0 ? scv_v4u{0u, 0u, 0xffff0000u, 0u}
+                                           : scv_v4u{d & 0x7fu, (d >> 7) & 0x7fu, ((d >> 14) & 0x7fu) | (((d >> 21) & 0x3ffu) << 16), d >> 31};
+                for (int32_t j = cb[c]; j < cb[c + 1]; ++j) {
+                    const int32_t b = __builtin_amdgcn_readfirstlane(ordl[j]);
+                    if (staged) *reinterpret_cast<lds_v4u*>((uintptr_t)(lrow + (uint32_t)b * 16u)) = rec;
+                    else if (wr) __builtin_nontemporal_store(rec, reinterpret_cast<scv_v4u*>(rowp) + b);
+                }
+            }
+        }
+        if (staged) {
+            scv_v4u* const out = reinterpret_cast<scv_v4u*>(a.cells) + Dp0 * (int64_t)B;
+            const uint32_t nrec = Dlive * (uint32_t)B;
+            for (int32_t i = 0; i < B; ++i) {
+                const uint32_t k = (uint32_t)i * 64u + (uint32_t)lane;
+                const scv_v4u rec = *reinterpret_cast<lds_v4u*>((uintptr_t)(rbase + k * 16u));
+                if (k < nrec) __builtin_nontemporal_store(rec, out + k);
+            }
+        }
+        Dlive = 0;
+    };
+
+    int64_t st = wave;
+    if (st < nsteps) { issue(st); issue_truth(st); }
+#ifdef SCV_SP_TIMELINE
+    unsigned long long tl[7] = {0, 0, 0, 0, 0, 0, 0}, tl_steps = 0;
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
+    for (; st < nsteps; st += nwaves) {
+        SP_STAMP(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this step's images and truths have landed (and every older store)
+        SP_STAMP(0);
+        const int64_t left = a.P - st * 64;
+        const uint32_t live_rows = left >= 64 ? 64u : (uint32_t)left;
+        const bool live = (uint32_t)lane < live_rows;
+        const int32_t trj = (int32_t)*reinterpret_cast<lds_u32*>((uintptr_t)(rbase + tru_off + (uint32_t)lane * 4u));
+        const uint32_t tcmp = (trj >= 0 && trj < kBins) ? (uint32_t)trj : 0x7fffu;
+        const uint32_t ra = rbase + (uint32_t)lane * (PS * 16u);
+        uint32_t w[NV];
+#pragma unroll
+        for (int k = 0; k < RSM / 2; ++k) {
+            const uint32_t k0 = (uint32_t)k < RS ? (uint32_t)k : RS - 1u, k1 = (uint32_t)(k + RSM / 2) < RS ? (uint32_t)(k + RSM / 2) : RS - 1u;
+            const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k0));
+            const scv_v4u h = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k1));
+            w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+            w[NP + 4 * k] = h.x; w[NP + 4 * k + 1] = h.y; w[NP + 4 * k + 2] = h.z; w[NP + 4 * k + 3] = h.w;
+        }
+        int64_t* const ctok_row = (TOK && a.cell_tokens) ? a.cell_tokens + (st * 64 + lane) * (int64_t)B : nullptr;
+        if constexpr (TOK) {
+            // running token sum in index order; the classes take their snapshots (no sort involved: written and counted right here)
+            // (the [64][B] token sums leave like the records: through the votes image -- its rows are in registers --, in memory order)
+            const bool tstaged = (uint32_t)B <= PS;
+            const uint32_t ltok = rbase + (uint32_t)lane * (uint32_t)B * 8u;
+            auto tok_class = [&](int c, long long v) {
+                if (cb[c + 1] > cb[c]) {
+                    toks[c] += live ? v : 0ll;
+                    if (a.cell_tokens) {
+                        for (int32_t j = cb[c]; j < cb[c + 1]; ++j) {
+                            const int32_t b = __builtin_amdgcn_readfirstlane(ordl[j]);
+                            if (tstaged) *reinterpret_cast<lds_v2u*>((uintptr_t)(ltok + (uint32_t)b * 8u)) = scv_v2u{(uint32_t)(unsigned long long)v, (uint32_t)((unsigned long long)v >> 32)};
+                            else if (live) ctok_row[b] = v;
+                        }
+                    }
+                }
+            };
+            tok_class(0, 0ll);
+            long long run = 0;
+#pragma unroll
+            for (int k = 0; k < RSM; ++k) {
+                if ((uint32_t)k < RS) {
+                    const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + img_bytes + 16u * k));
+                    const int32_t y[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        run += (long long)y[e];
+                        const int idx1 = 4 * k + e + 1;                   // votes summed so far (a constant after unrolling)
+                        if ((idx1 & (idx1 - 1)) == 0 && idx1 <= NP) tok_class(1 + __builtin_ctz((unsigned)idx1), run);
+                    }
+                }
+            }
+            tok_class(CF, run);
+            if (a.cell_tokens && tstaged) {
+                char* const out = reinterpret_cast<char*>(a.cell_tokens + st * 64 * (int64_t)B);
+                const uint32_t ntok = live_rows * (uint32_t)B;
+                for (int32_t i = 0; 2 * 64 * i < 64 * B; ++i) {           // 16 bytes = two sums per lane and piece
+                    const uint32_t k = (uint32_t)i * 64u + (uint32_t)lane;
+                    const scv_v4u two = *reinterpret_cast<lds_v4u*>((uintptr_t)(rbase + k * 16u));
+                    if (2u * k + 1u < ntok) __builtin_nontemporal_store(two, reinterpret_cast<scv_v4u*>(out) + k);
+                    else if (2u * k < ntok) *reinterpret_cast<scv_v2u*>(out + (size_t)k * 16u) = scv_v2u{two.x, two.y};
+                }
+            }
+        }
+        uint32_t R[NP];
+#pragma unroll
+        for (int r = 0; r < NP; ++r) R[r] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(w[r], w[r + NP]));
+        uint32_t orv = 0;
+#pragma unroll
+        for (int r = 0; r < NP; ++r) orv |= R[r];
+        if (__any((orv & 0xfc00fc00u) != 0u)) {                      // (rare: o1.py:140 int(extracted_answer) is unbounded; the extractor maps it into the bins)
+            const int32_t seen = live ? nmax : 0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                bad |= i < seen ? w[i] : 0u;
+                w[i] = w[i] < 1023u ? w[i] : 1023u;
+            }
+#pragma unroll
+            for (int r = 0; r < NP; ++r) R[r] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(w[r], w[r + NP]));
+        }
+        if (N != NV) {                                               // slots behind the row: distinct sentinels behind every vote
+            const uint32_t n2 = (uint32_t)N | ((uint32_t)N << 16);
+#pragma unroll
+            for (int r = 0; r < NP; ++r)
+                R[r] = sv_sentinel(R[r], n2, (uint32_t)(r + 1) | ((uint32_t)(r + NP + 1) << 16),
+                                   (0x8000u | (uint32_t)r) | ((0x8000u | (uint32_t)(r + NP)) << 16));
+        }
+        // truth votes among the first 2^j votes (index order, before the sort), j = 0 .. LG: one byte each
+        uint32_t tcp[2] = {0u, 0u};
+        {
+            uint32_t run = 0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                run += w[i] == tcmp ? 1u : 0u;
+                const int idx1 = i + 1;
+                if ((idx1 & (idx1 - 1)) == 0) {
+                    const int j = __builtin_ctz((unsigned)idx1);
+                    tcp[j / 4] |= run << (8 * (j % 4));
+                    tcs[1 + j] += live ? run : 0u;                   // (a class without budgets: never read)
+                }
+            }
+        }
+        SP_STAMP(1);
+        // the previous step's records leave now: a whole sort lies between these stores and the next wait
+        flush_records();
+        SP_STAMP(2);
+        const bool have_next = st + nwaves < nsteps;
+        constexpr bool CAN_SPREAD = !TOK;
+        const bool spread = CAN_SPREAD && have_next;
+        const int64_t nbyte0 = (st + nwaves) * 64 * (int64_t)rowbytes;
+        const int64_t nrem = total_bytes - nbyte0 - 16;
+        const uint32_t nlim = nrem > 0x7fffffffll ? 0x7fffffffu : (nrem < 0 ? 0u : (uint32_t)nrem);
+        const char* const ng = reinterpret_cast<const char*>(a.answers) + nbyte0;
+        if (have_next) {
+            if (spread) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_truth(st + nwaves); }
+            else { issue(st + nwaves); issue_truth(st + nwaves); }
+        }
+        constexpr int STEP = sv_sort_ticks<NP>() / QMAX > 0 ? sv_sort_ticks<NP>() / QMAX : 1;
+        int ticks = 0;
+        auto piece = [&](int q, uint32_t& dep) __attribute__((always_inline)) {
+            if constexpr (CAN_SPREAD) {
+                if ((uint32_t)q < PS) sv_dma16_pinned(ng, off[q] < nlim ? off[q] : nlim, (uint32_t)__builtin_amdgcn_readfirstlane((int)(rbase + (uint32_t)q * 1024u)), dep);
+            }
+        };
+        auto tick = [&](uint32_t& reg) __attribute__((always_inline)) {
+            if constexpr (CAN_SPREAD) {
+                if (spread && ticks % STEP == 0 && ticks / STEP < QMAX) piece(ticks / STEP, reg);
+            }
+            ++ticks;
+        };
+        // record + counters of one class from its statistics (tc = truth votes of the class's prefix)
+        auto close_class = [&](int c, uint32_t maxc, uint32_t n_modes, uint32_t mm, uint32_t tc) {
+            const uint32_t hit = tc == maxc ? 1u : 0u;                // o1.py:206 (every class here has votes)
+            D[c] = maxc | (tc << 7) | (n_modes << 14) | (mm << 21) | (hit << 31);
+            h1[c] += (uint32_t)__builtin_popcountll(__ballot(live && hit && n_modes == 1u));
+            if (live && hit && n_modes != 1u) atomicAdd(&tie[c * TC + (int32_t)n_modes], 1u);
+        };
+        if (cb[2] > cb[1]) close_class(1, 1u, 1u, R[0] & 0x3ffu, tcp[0] & 0xffu);      // the first vote alone
+        auto hook = [&](auto m_tag) __attribute__((always_inline)) {
+            constexpr int M = decltype(m_tag)::value;
+            constexpr int c = 1 + sv_log2(M);
+            SP_STAMP(3);
+            if (cb[c + 1] > cb[c]) {
+                const BlockStats s = sv_scan_block<M, NP>(R);
+                close_class(c, s.max_run, s.at_max, s.min_at_max, (tcp[(c - 1) / 4] >> (8 * ((c - 1) % 4))) & 0xffu);
+            }
+            SP_STAMP(4);
+        };
+        sv_sort_phases<NP, 1>(R, tick, hook);
+        sv_merge_halves<NP>(R, tick);
+        if constexpr (CAN_SPREAD) {
+            if (spread) {
+#pragma unroll
+                for (int q = (sv_sort_ticks<NP>() + STEP - 1) / STEP; q < QMAX; ++q) piece(q, R[0]);
+            }
+        }
+        SP_STAMP(3);
+        if (cb[CF + 1] > cb[CF]) {
+            const SortedStats s = sv_scan<NP>(R, tcmp | (tcmp << 16));
+            const uint32_t n_modes = s.at_max - ((NV == 64 && s.max_run == 1u) ? (uint32_t)(NV - N) : 0u);
+            tcs[CF] += live ? s.truth_votes : 0u;
+            close_class(CF, s.max_run, n_modes, s.min_at_max, s.truth_votes);
+        }
+        Dp0 = st * 64;
+        Dlive = live_rows;
+        SP_STAMP(5);
+#ifdef SCV_SP_TIMELINE
+        ++tl_steps;
+#endif
+    }
+#ifdef SCV_SP_TIMELINE
+    if (lane == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&scv_sp_timeline[i], tl[i]);
+        atomicAdd(&scv_sp_timeline[7], tl_steps);
+    }
+#endif
+    flush_records();
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+    const bool counters = a.tie_hits || a.truth_sum || (TOK && a.token_sum);
+    if (counters) {
+#pragma unroll
+        for (int c = 1; c < NC; ++c) {
+            if (cb[c + 1] > cb[c]) {
+                const long long ts = wave_sum_i64((long long)tcs[c]);
+                long long tk = 0;
+                if (TOK) tk = wave_sum_i64(toks[c]);
+                if (lane == 0) {
+                    if (h1[c]) atomicAdd(&tie[c * TC + 1], h1[c]);
+                    if (ts) atomicAdd(&acc[c], (unsigned long long)ts);
+                    if (TOK && tk) atomicAdd(&acc[NC + c], (unsigned long long)tk);
+                }
+            }
+        }
+        __syncthreads();
+        // the classes' counters to their budgets
+        for (int64_t i = tid; i < (int64_t)B * TC; i += T) {
+            const int32_t j = (int32_t)(i / TC), k = (int32_t)(i - (int64_t)j * TC);
+            int c = 0;
+            while (c < NC - 1 && j >= cbeg[c + 1]) ++c;
+            const uint32_t v = tie[c * TC + k];
+            if (v && a.tie_hits) atomicAdd(&a.tie_hits[(int64_t)ordl[j] * SCV_TIE_CLASSES + k], (unsigned long long)v);
+        }
+        for (int j = tid; j < B; j += T) {
+            int c = 0;
+            while (c < NC - 1 && j >= cbeg[c + 1]) ++c;
+            if (a.truth_sum && acc[c]) atomicAdd(&a.truth_sum[ordl[j]], acc[c]);
+            if (TOK && a.token_sum && acc[NC + c]) atomicAdd(&a.token_sum[ordl[j]], acc[NC + c]);
+        }
+    }
+}
+
+}  // namespace scv

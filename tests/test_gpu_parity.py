@@ -833,6 +833,8 @@ def test_prefix_budgets_over_short_pools_run_on_the_cell_kernels(hip_engine, dis
         nv = np.array(nv, dtype=np.int32)
         want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
         stat = "prefix_lane" if N <= 64 else "prefix_pool"           # one lane per problem / one pass per problem over G lanes
+        if 16 < N <= 64 and N % 4 == 0 and all(n == 0 or n >= N or (n & (n - 1) == 0 and n <= (16 if N <= 32 else 32)) for n in nv.tolist()):
+            stat = "prefix_sort"                                     # powers of two (and the whole row): one sort per problem
         before = hip_engine.stat(stat)
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
         assert hip_engine.stat(stat) == before + 1
@@ -908,6 +910,82 @@ def test_prefix_pool_kernel_with_many_budgets(hip_engine, P, N, B, dist):
         if (nv >= N).any():
             with pytest.raises(_lib.DomainError):
                 hip_engine.aggregate_prefix(bad, tr, nv)
+
+
+SORT_PREFIX_BUDGETS = [
+    lambda N: [1 << k for k in range(7) if (1 << k) <= (16 if N <= 32 else 32)] + [N],        # the reference's sweep (o1.py:274-277)
+    lambda N: [N, 0, 4, 4, 1, N + 5, 16, 2, 0],                                                # unsorted, duplicates, empty, beyond the row
+    lambda N: [8],
+    lambda N: [0, 0],
+    lambda N: [N],
+    lambda N: [2, (16 if N <= 32 else 32)],
+]
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("shape", [(1, 64), (63, 64), (64, 64), (65, 64), (1000, 64), (5000, 64), (333, 60), (700, 52), (129, 48), (900, 40), (77, 36),
+                                   (2000, 32), (300, 28), (450, 24), (999, 20)], ids=lambda s: f"P{s[0]}_N{s[1]}")
+def test_prefix_budgets_that_are_powers_of_two_come_out_of_one_sort(hip_engine, dist, shape):
+    """scv_sort_prefix (o1.py:274-277: maj@1, 2, 4 ... over one list of completions): after merge phase p of the sorting network the first 2 p
+    votes of the row are sorted, so every power-of-two budget is a run scan of its block.  HOST mode reads the budgets and queues the one
+    kernel that serves them; DEVICE mode queues scv_sort_prefix and the general kernel, which decide from n_valid -- exactly one of them
+    does the work, whatever the list.  Bit-exact against the oracle on the dense expansion, cells, counters and token sums."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import CELL_DTYPE, AggregateResult
+    P, N = shape
+    a, t, tr = coracle.synth_fill(P, 1, N, 400 + N + P, dist, want_tokens=True)
+    pool, tpool = a[:, 0, :], t[:, 0, :]
+    dev = torch.device("cuda:0")
+    dpool, dtok, dtr = torch.from_numpy(pool.copy()).to(dev), torch.from_numpy(tpool.copy()).to(dev), torch.from_numpy(tr).to(dev)
+    for mk in SORT_PREFIX_BUDGETS:
+        nv = np.array(mk(N), dtype=np.int32)
+        want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
+        before, lane0 = hip_engine.stat("prefix_sort"), hip_engine.stat("prefix_lane")
+        assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+        assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
+        assert hip_engine.stat("prefix_sort") == before + 2 and hip_engine.stat("prefix_lane") == lane0      # HOST mode: this kernel alone
+        got = hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool, want_cells=False)                       # no cell table
+        assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum) and np.array_equal(got.truth_count_sum, want.truth_count_sum)
+        with _with_options(hip_engine, {"grid": 1}):                                                           # one workgroup walks every step
+            assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+        for tk in (None, dtok):                                                                                 # DEVICE mode: both kernels queued
+            c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, torch.from_numpy(nv).to(dev), tokens=tk)
+            hip_engine.sync()
+            got = AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells), None if tk is None else ctok.cpu().numpy())
+            assert_results_equal(got, want, check_tokens=tk is not None)
+    # a list with a budget that is neither: HOST mode does not queue the kernel, DEVICE mode queues it and it leaves the launch alone
+    nv = np.array([1, 2, 3, N], dtype=np.int32)
+    want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
+    before = hip_engine.stat("prefix_sort")
+    assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+    assert hip_engine.stat("prefix_sort") == before
+    c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, torch.from_numpy(nv).to(dev), tokens=dtok)
+    hip_engine.sync()
+    assert hip_engine.stat("prefix_sort") == before + 1
+    assert_results_equal(AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells), ctok.cpu().numpy()), want)
+    # prefix_path = 5: the caller promises such budgets -- a DEVICE-mode call queues scv_sort_prefix alone; a broken promise is an error
+    nv = np.array(SORT_PREFIX_BUDGETS[1](N), dtype=np.int32)
+    want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
+    with _with_options(hip_engine, {"prefix_path": 5}):
+        lane0, pool0 = hip_engine.stat("prefix_lane"), hip_engine.stat("prefix_pool")
+        c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, torch.from_numpy(nv).to(dev), tokens=dtok)
+        hip_engine.sync()
+        assert hip_engine.stat("prefix_lane") == lane0 and hip_engine.stat("prefix_pool") == pool0
+        assert_results_equal(AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells), ctok.cpu().numpy()), want)
+        with pytest.raises(_lib.ScvError):
+            hip_engine.aggregate_prefix(pool, tr, np.array([1, 3, N], dtype=np.int32))
+        hip_engine.aggregate_prefix_device(dpool, dtr, torch.tensor([1, 3, N], dtype=torch.int32, device=dev))
+        with pytest.raises(_lib.ScvError):
+            hip_engine.sync()
+        assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)       # (the error is gone with the call that raised it)
+    # an out-of-domain vote is an error only for budgets that reach it; negative votes are out of domain too
+    if P >= 3 and N >= 36:
+        bad = pool.copy()
+        bad[P // 2, 33] = 5000
+        bad[P - 1, N - 1] = -7
+        assert_results_equal(hip_engine.aggregate_prefix(bad, tr, np.array([1, 32], dtype=np.int32)), OracleEngine().aggregate_prefix(pool, tr, np.array([1, 32], dtype=np.int32)), check_tokens=False)
+        with pytest.raises(_lib.DomainError):
+            hip_engine.aggregate_prefix(bad, tr, np.array([1, 32, N], dtype=np.int32))
 
 
 def test_prefix_mode_device_and_errors(hip_engine):

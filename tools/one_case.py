@@ -11,11 +11,11 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run_prefix(eng, torch, P, N, tokens, dist, rounds):
+def run_prefix(eng, torch, P, N, tokens, dist, rounds, nv_list=None, no_cells=False):
     import statistics
     from o1_inference_scaling_laws_amd.engine import counters_size
     dev = torch.device("cuda:0")
-    nv = [1 << k for k in range(N.bit_length()) if (1 << k) <= N]
+    nv = nv_list or [1 << k for k in range(N.bit_length()) if (1 << k) <= N]
     B = len(nv)
     pool = torch.empty((P, 1, N), dtype=torch.int32, device=dev)
     tk = torch.empty((P, 1, N), dtype=torch.int32, device=dev) if tokens else None
@@ -23,7 +23,7 @@ def run_prefix(eng, torch, P, N, tokens, dist, rounds):
     eng.synth_fill_device(pool, tk, tr, P=P, B=1, N=N, seed=4, dist=dist)
     nvt = torch.tensor(nv, dtype=torch.int32, device=dev)
     counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
-    cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
+    cells = None if no_cells else torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
     eng.sync(); eng.drain_kernel_ns()
     ts = []
     for r in range(rounds + 1):
@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (scv_set_option)")
     ap.add_argument("--no-cells", action="store_true", help="counters only: no cell table is written")
+    ap.add_argument("--nv", default="", help="prefix mode: the budgets, comma separated (default 1, 2, 4 ... N)")
     ap.add_argument("--prefix", action="store_true", help="prefix budgets 1, 2, 4 ... N over one pool [P, N] (B is ignored)")
     args = ap.parse_args()
     import torch
@@ -58,7 +59,7 @@ def main():
         k, v = kv.split("=")
         eng.set_option(k, int(v))
     if args.prefix:
-        r = run_prefix(eng, torch, args.P, args.N, args.tokens, args.dist, args.rounds)
+        r = run_prefix(eng, torch, args.P, args.N, args.tokens, args.dist, args.rounds, [int(x) for x in args.nv.split(',')] if args.nv else None, args.no_cells)
     else:
         r = run(eng, torch, args.P, args.B, args.N, args.tokens, dist=args.dist, rounds=args.rounds, want_cells=not args.no_cells)
     r["opts"] = args.opt
