@@ -178,7 +178,6 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G, TOK>())) void scv_prefix
     const int64_t nwaves = (int64_t)gridDim.x * nw;
     const int64_t wave = (int64_t)blockIdx.x * nw + (tid >> 6);
     const int64_t nbatches = (a.P + C - 1) / C;
-    uint32_t bad = 0;
 
     uint32_t cur[4 * V], nxt[4 * V];           // the chunk being counted / the chunk in flight: vector k in [4 k, 4 k + 3]
     int32_t tcur[TOK ? 4 * V : 1], tnxt[TOK ? 4 * V : 1];            // their tokens
@@ -220,15 +219,18 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G, TOK>())) void scv_prefix
     };
 
     // o1.py:204-213 + statistics.py:599-601 from a reduced pair; the record and the counters of (problem pp, budget b) by ONE lane
-    auto emit = [&](int64_t pp, uint32_t tcmp, int32_t b, uint32_t gK, uint32_t packed, long long tok) {
-        const uint32_t Mh = gK >> kRankShift;                         // largest count among the values that are not the truth
+    auto emit = [&](int64_t pp, uint32_t tcmp, int32_t b, uint32_t gK, uint32_t packed, uint32_t pc, uint32_t pval, long long tok) {
+        const uint32_t Mh = gK >> kRankShift;                         // largest count among the values that are neither the truth nor the pivot
         const uint32_t tc = packed & 0xffffu;                         // votes for the truth (<= 4096)
-        const uint32_t nmh = Mh ? packed >> 16 : 0u;                  // values (not the truth) whose count is Mh (<= 1023)
-        const uint32_t M = Mh > tc ? Mh : tc;
+        const uint32_t nmh = Mh ? packed >> 16 : 0u;                  // values (of the histogram) whose count is Mh (<= 1023)
+        uint32_t M = Mh > tc ? Mh : tc;
+        M = pc > M ? pc : M;                                          // pc: votes for the problem's pivot value pval
         const uint32_t hit = (tc == M && M > 0u) ? 1u : 0u;           // o1.py:206 (multimode([]) == []: no hit)
-        const uint32_t nm = (Mh == M ? nmh : 0u) + hit;
+        const uint32_t pin = (pc == M && pc > 0u) ? 1u : 0u;
+        const uint32_t nm = (Mh == M ? nmh : 0u) + hit + pin;
         uint32_t mm = Mh == M ? (htop - (gK & (RK1 - 1u))) >> BS : 1024u;
         if (hit && tcmp < mm) mm = tcmp;
+        if (pin && pval < mm) mm = pval;
         const int64_t cell = pp * B + b;
         if (a.cells) reinterpret_cast<uint4*>(a.cells)[cell] = make_uint4(M, tc, (nm & 0xffffu) | ((M ? (mm & 0xffffu) : 0xffffu) << 16), hit);
         if (TOK && a.cell_tokens) a.cell_tokens[cell] = tok;
@@ -240,8 +242,9 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G, TOK>())) void scv_prefix
         }
     };
     // the pairs of the previous problem's last boundaries, latched and not yet written (lane j < Dn holds one)
-    uint32_t DK = 0, DP = 0, Dtcmp = 0;
-    int32_t Db = 0, Dn = 0;
+    uint32_t DK = 0, DP = 0;
+    uint32_t Dbp = 0;                          // budget | pivot votes << 16
+    uint32_t Dtp = 0;                          // the problem's truth (0xffff: none) | its pivot value << 16 | pairs held << 26
     long long Dtok = 0;
 
     if (wave < nbatches && nmax > 0) {
@@ -262,6 +265,8 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G, TOK>())) void scv_prefix
         uint32_t S = 0;                        // largest rank of a vote of this lane << 16 | number of its votes with that rank
         uint32_t K = 0;                        // max over its votes of rank << 10 | 1023 - value
         uint32_t tcl = 0;                      // its votes equal to the truth
+        uint32_t pcl = 0;                      // its votes equal to the problem's pivot
+        uint32_t pv = 0xffffffffu;             // the pivot: the most frequent value among the first 16 votes that are not the truth
         long long tsum = 0;                    // its tokens
         // one vote after its atomic has returned: Tr = its rank << 18 (0: not counted), A = its bin's address
         auto post = [&](uint32_t A, uint32_t Tr) {
@@ -288,12 +293,14 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G, TOK>())) void scv_prefix
             // the clamp runs only in the -- wave-uniform, rare -- case that some slot, counted or not, holds a larger value
             uint32_t vq[4] = {cur[4 * k], cur[4 * k + 1], cur[4 * k + 2], cur[4 * k + 3]};
             if (__any((vq[0] | vq[1] | vq[2] | vq[3]) > 1023u)) {
+                uint32_t bad = 0;                                    // (reported right here: an accumulator across the kernel is a register the vote path needs)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                        // (cur[] keeps the value: a later pass over this vector may be the one that counts it)
                     const bool act = FULL || (uint32_t)(vb + 4 * l + q - lo) < (uint32_t)(hi - lo);
                     bad |= act ? vq[q] : 0u;
                     vq[q] = vq[q] < 1023u ? vq[q] : 1023u;
                 }
+                if (bad > 1023u) atomicOr(a.err_flag, 1u);
             }
             uint32_t A[4], Tr[4];
 #pragma unroll
@@ -302,36 +309,40 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G, TOK>())) void scv_prefix
                 const bool act = FULL || (uint32_t)(vb + 4 * l + q - lo) < (uint32_t)(hi - lo);
                 const bool is_t = v == tcmp;
                 A[q] = htop - (v << BS);
+                const bool is_p = v == pv;
                 tcl += (act && is_t) ? 1u : 0u;
+                pcl += (act && is_p) ? 1u : 0u;                      // (2 VALU per vote for the pivot; a second vote path for waves without one
+                                                                     //  did not fit the registers of 16 waves per CU)
                 if constexpr (TOK) tsum += act ? (long long)tcur[4 * k + q] : 0ll;
-                Tr[q] = count_vote(A[q], act && !is_t);
+                Tr[q] = count_vote(A[q], act && !is_t && !is_p);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) post(A[q], Tr[q]);
         };
         // the pair this lane has latched (the nl-th boundary since the last flush sits in lane nl)
-        uint32_t LK = 0, LP = 0;
-        int32_t Lb = 0, nl = 0;
+        uint32_t LK = 0, LP = 0, Lbp = 0;      // Lbp: budget | pivot votes << 16 (budgets < 512, votes <= 4096)
+        int32_t nl = 0;
         long long Ltok = 0;
         // boundary k: every vote below it is in, none above
         auto boundary = [&](int32_t k) {
             const uint32_t gK = cellgroup_max<G>(K);
             const uint32_t cnt = ((S ^ gK) < RK1) ? (S & (RK1 - 1u)) : 0u;        // this lane's votes at the group's maximum rank
             const uint32_t packed = cellgroup_sum<G>((cnt << 16) | tcl);
+            const uint32_t gpc = cellgroup_sum<G>(pcl);
             long long gtok = 0;
             if constexpr (TOK) gtok = cellgroup_sum_i64<G>(tsum);
             const int32_t b = __builtin_amdgcn_readfirstlane(ord[k]);
-            if (l == nl) { LK = gK; LP = packed; Lb = b; Ltok = gtok; }
+            if (l == nl) { LK = gK; LP = packed; Lbp = (uint32_t)b | (gpc << 16); Ltok = gtok; }
             nl += 1;
             if (nl == G) {
-                if (live) emit(p, tcmp, Lb, LK, LP, Ltok);
+                if (live) emit(p, tcmp, (int32_t)(Lbp & 0xffffu), LK, LP, Lbp >> 16, pv, Ltok);
                 nl = 0;
             }
         };
         // the previous problem's last records (their stores land while this problem is counted)
         auto flush_deferred = [&]() {
-            if (l < Dn) emit(p - nwaves * C, Dtcmp, Db, DK, DP, Dtok);
-            Dn = 0;
+            if ((uint32_t)l < (Dtp >> 26)) emit(p - nwaves * C, (Dtp & 0xffffu) == 0xffffu ? 0xffffffffu : (Dtp & 0xffffu), (int32_t)(Dbp & 0xffffu), DK, DP, Dbp >> 16, (Dtp >> 16) & 0x3ffu, Dtok);
+            Dtp = 0;
         };
 
         int32_t kb = 0;
@@ -364,31 +375,42 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G, TOK>())) void scv_prefix
                 for (; kb < kz; ++kb) boundary(kb);                    // budgets without votes
                 // ---- the head: budgets of up to 16 votes out of one scan ----------------------------------------------------
                 const bool act = l < HEAD && l < nmax;
-                bad |= act ? hv : 0u;
+                if (act && hv > 1023u) atomicOr(a.err_flag, 1u);
                 const uint32_t hc = hv < 1023u ? hv : 1023u;
                 const bool is_t = hc == tcmp;
-                const bool use = act && !is_t;
-                const uint32_t r = row_rank_in_order(use ? hc : (0xffff0000u | (uint32_t)lane));
+                const bool cand = act && !is_t;
+                const uint32_t r = row_rank_in_order(cand ? hc : (0xffff0000u | (uint32_t)lane));
                 const uint32_t A = htop - (hc << BS);
+                // THE PIVOT: the most frequent value among these votes that is not the truth.  Its votes -- here and in the vectors below --
+                // are counted by the lanes like the truth's and never enter the histogram: a wrong majority, an exact tie with the truth or
+                // one wrong answer throughout would otherwise send up to G returning atomics per instruction to ONE bin (measured before:
+                // 4096-vote pools 50 us on D0 .. D2, 106 / 91 / 177 us on D3 / D4 / D5; with the pivot 53-56 and 69 / 54 / 53).  Ranks of the
+                // other values do not depend on it.
+                const uint32_t pk = cellgroup_max<G>(cand ? ((r << kRankShift) | A) : 0u);
+                // (a value with fewer than 3 of the 16 votes is not hot: no pivot, and a wave without pivots runs the plain vote path)
+                pv = (pk >> kRankShift) >= 3u ? (htop - (pk & (RK1 - 1u))) >> BS : 0xffffffffu;
+                const bool is_p = cand && hc == pv;
+                const bool use = cand && !is_p;
                 if (H16) lds_add(use ? (A & ~3u) : trash, __builtin_amdgcn_alignbyte(1u, 1u, A));
                 else lds_add(use ? A : trash, 1u);
                 K = use ? (r << kRankShift) | A : 0u;
                 S = use ? (r << kRankShift) | 1u : 0u;
                 tcl = (act && is_t) ? 1u : 0u;
+                pcl = is_p ? 1u : 0u;
                 if constexpr (TOK) tsum = act ? (long long)ht : 0ll;
                 if (kh > kz) {
-                    uint32_t KS = K, WS = S, TS = tcl;
+                    uint32_t KS = K, WS = S, TS = tcl | (pcl << 16);                 // (truth and pivot votes: two sums of at most 16 in one register)
                     head_scan_step<1>(KS, WS, TS); head_scan_step<2>(KS, WS, TS); head_scan_step<4>(KS, WS, TS); head_scan_step<8>(KS, WS, TS);
                     long long tks = 0;
                     if constexpr (TOK) tks = row_prefix_sum_i64(tsum);
-                    const uint32_t packed = ((WS & (RK1 - 1u)) << 16) | TS;
+                    const uint32_t packed = ((WS & (RK1 - 1u)) << 16) | (TS & 0xffffu);
                     if (!head_dup) {
-                        if (live && my_head_budget >= 0) emit(p, tcmp, my_head_budget, KS, packed, tks);
+                        if (live && my_head_budget >= 0) emit(p, tcmp, my_head_budget, KS, packed, TS >> 16, pv, tks);
                     } else {
                         for (int32_t k = kz; k < kh; ++k) {
                             const int32_t hi = __builtin_amdgcn_readfirstlane(nvs[k]);
                             const int32_t b = __builtin_amdgcn_readfirstlane(ord[k]);
-                            if (live && l == hi - 1) emit(p, tcmp, b, KS, packed, tks);
+                            if (live && l == hi - 1) emit(p, tcmp, b, KS, packed, TS >> 16, pv, tks);
                         }
                     }
                 }
@@ -414,8 +436,8 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G, TOK>())) void scv_prefix
             }
         }
         // the boundaries latched since the last flush are written at the top of the next problem
-        DK = LK; DP = LP; Db = Lb; Dtok = Ltok; Dtcmp = tcmp;
-        Dn = live ? nl : 0;
+        DK = LK; DP = LP; Dbp = Lbp; Dtok = Ltok;
+        Dtp = (tcmp & 0xffffu) | ((pv & 0x3ffu) << 16) | ((live ? (uint32_t)nl : 0u) << 26);
         // the problem's histogram is zero again before the next batch's first vote (LDS operations of a wave execute in order)
         if (nmax > 0) {
             lds_v4u* h4 = reinterpret_cast<lds_v4u*>((uintptr_t)hbase);
@@ -424,11 +446,10 @@ __global__ __launch_bounds__((64 * prefix_pool_waves<G, TOK>())) void scv_prefix
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (l < Dn) {                              // the last problem of this wave: batch wave + (its batches - 1) * nwaves
+    if ((uint32_t)l < (Dtp >> 26)) {           // the last problem of this wave: batch wave + (its batches - 1) * nwaves
         const int64_t last_bt = wave + ((nbatches - 1 - wave) / nwaves) * nwaves;
-        emit(last_bt * C + sub, Dtcmp, Db, DK, DP, Dtok);
+        emit(last_bt * C + sub, (Dtp & 0xffffu) == 0xffffu ? 0xffffffffu : (Dtp & 0xffffu), (int32_t)(Dbp & 0xffffu), DK, DP, Dbp >> 16, (Dtp >> 16) & 0x3ffu, Dtok);
     }
-    if (bad > 1023u) atomicOr(a.err_flag, 1u);
     wg_counters_flush<TOK>(a, wgc, tid, T);
 }
 
