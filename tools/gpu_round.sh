@@ -1,7 +1,8 @@
 #!/bin/bash
 # ONE GPU-box session = ONE consistent evidence set: the bench line FIRST, then rocprofv3 --kernel-trace --stats and the
 # PMC passes of the SAME command, the read-ceiling probes, the parity suite, the other bench forms, the regimes table and the per-regime
-# PMC passes -- all of the same library on the same box.  Outputs -> gpurun_out/ ; tools/summarize_profiles.py rNN copies the judged files.
+# PMC passes -- all of the same library on the same box.  (Round 4's probes of the memory pipe and of the VALU issue rates -- hbm_probe --dma / --dmawork /
+# --vmemq, valu_probe, sort_timeline -- are not repeated: profiles/r04_*.)  Outputs -> gpurun_out/ ; tools/summarize_profiles.py rNN copies the judged files.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
@@ -42,14 +43,15 @@ for f in ('bench_comm_peer_2ctx', 'bench_comm_rccl_1gpu'):
     d = json.load(open('gpurun_out/%s.json' % f)); r = d['roofline']
     print(f, 'kernel ms per rank min/max', round(r['kernel_avg_ms_per_rank_min'], 3), round(r['kernel_avg_ms_per_rank_max'], 3), 'exposed all-reduce us', r['exposed_allreduce_us'], 'selftest words', d['config']['comm_selftest_words_per_rank'], 'create s', round(d['config']['comm_create_s'], 3))"
 echo "== regimes"; timeout 1200 python tools/regimes.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/regimes.log | tail -8
-echo "== PMC per regime (sorted cells 48 / 64, register-resident 128 / 256 / 1024, dense 2048 / 8192, lane 3, few votes 1 / 4)"
-SHAPES="6400000:4:1 1600000:4:4 1000000:4:3 400000:4:48 400000:4:64 200000:4:128 100000:4:256 50000:4:1024 40000:4:2048 10000:4:8192" timeout 1500 bash tools/prof_regimes.sh r04 > gpurun_out/prof_regimes_r04.log 2>&1; tail -3 gpurun_out/prof_regimes_r04.log
-echo "== sorted cells: parity sweep"; timeout 900 python tools/sort_check.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/sort_check.log | grep -v "tok=1" | head -8
-echo "== LDS-DMA path ceiling"; timeout 300 ./tools/hbm_probe.bin 1000 --dma 2>&1 | tee gpurun_out/hbm_probe_dma.log | tail -4
-echo "== VALU issue rates"; timeout 300 ./tools/valu_probe.bin 2>&1 | tee gpurun_out/valu_probe.log | grep -E "pk_min|xor|alignbit" | head -6
-echo "== the copy + a sorted-cells step's VALU work: self-issued against a producer wave"; timeout 300 ./tools/hbm_probe.bin 1000 --dmawork > gpurun_out/hbm_probe_dmawork.log 2>&1; grep -E "16 KiB.*(1280|   0) pk_min" gpurun_out/hbm_probe_dmawork.log | head -8
-echo "== cycles to issue an LDS-DMA piece"; timeout 120 ./tools/hbm_probe.bin 1000 --vmemq > gpurun_out/hbm_probe_vmemq.log 2>&1; grep -E "lds +256 workgroup\(s\) x  8|stamps alone\) +1 workgroup\(s\) x  1" gpurun_out/hbm_probe_vmemq.log | cut -c1-200
-echo "== phase timeline of scv_sort_cells (measurement builds)"; timeout 600 python tools/sort_timeline.py 2>&1 | grep -v amdgpu.ids > gpurun_out/sort_timeline.log; timeout 600 python tools/sort_timeline.py --nospread 16 32 48 64 2>&1 | grep -v amdgpu.ids > gpurun_out/sort_timeline_nospread.log; tail -2 gpurun_out/sort_timeline.log | cut -c1-300
-echo "== prefix budgets over short pools"; timeout 600 python tools/prefix_small.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/prefix_small.log | tail -14
+echo "== PMC per regime (sorted cells 48 / 64, register-resident 96 / 128 / 256 / 1024, dense 2048 / 8192, lane 3, few votes 1 / 4)"
+SHAPES="6400000:4:1 1600000:4:4 1000000:4:3 400000:4:48 400000:4:64 270000:4:96 200000:4:128 100000:4:256 50000:4:1024 40000:4:2048 10000:4:8192" timeout 1500 bash tools/prof_regimes.sh r05 > gpurun_out/prof_regimes_r05.log 2>&1; tail -3 gpurun_out/prof_regimes_r05.log
+echo "== PMC of the prefix-budget kernels (budgets 1, 2, 4 ... N over one pool: scv_sort_prefix 32 / 64, scv_prefix_pool 256 / 1024 / 4096)"
+MODE=prefix SHAPES="200000:1:32 200000:1:64 100000:1:256 50000:1:1024 20000:1:4096" timeout 900 bash tools/prof_regimes.sh r05_prefix > gpurun_out/prof_regimes_r05_prefix.log 2>&1; tail -3 gpurun_out/prof_regimes_r05_prefix.log
+echo "== prefix budgets over short pools (auto: DEVICE mode queues scv_sort_prefix and the general kernel for pools of 17 .. 64 votes)"; timeout 600 python tools/prefix_small.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/prefix_small.log | cut -c1-140 | tail -14
+echo "== ... with the budgets promised to be powers of two (prefix_path = 5: one launch)"; timeout 600 python tools/prefix_small.py prefix_path=5 2>&1 | grep -v amdgpu.ids | tee gpurun_out/prefix_small_promised.log | cut -c1-140 | sed -n 3,4p
+echo "== ... the general kernels alone (prefix_path = 1: one lane per problem up to 64 votes)"; timeout 600 python tools/prefix_small.py prefix_path=1 2>&1 | grep -v amdgpu.ids | tee gpurun_out/prefix_small_lane.log | cut -c1-140 | sed -n 3,4p
+echo "== prefix pools over the distributions D0 .. D5"; timeout 600 bash tools/prefix_dists.sh 2>&1 | tee gpurun_out/prefix_dists.log | tail -18
+echo "== ranks from returning atomics against the register-resident cell kernels (dense cells of 96 .. 1024 votes, D0 .. D5)"; timeout 900 python tools/rtn_ab.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/rtn_ab.log | cut -c1-200 | tail -6
+echo "== phase timeline of scv_sort_prefix (measurement build)"; timeout 300 python tools/sort_prefix_timeline.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/sort_prefix_timeline.log | cut -c1-260 | tail -8
 echo "== host mode"; timeout 600 python tools/host_mode_bench.py 2>&1 | grep -v amdgpu | tee gpurun_out/host_mode.log | tail -12
 cd $R; du -sh gpurun_out

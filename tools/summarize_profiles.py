@@ -34,7 +34,23 @@ if kt:
     for r in csv.DictReader(open(kt)):
         if "scv_hist_argmax" in r["Kernel_Name"]:
             lines += [f"Dispatch geometry of `scv_hist_argmax`: grid {r['Grid_Size_X']} threads / workgroup {r['Workgroup_Size_X']}"
-                      f" = {int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])} workgroups, LDS {r['LDS_Block_Size']} B, VGPR {r['VGPR_Count']}, SGPR {r['SGPR_Count']}, scratch {r['Scratch_Size']}.", ""]
+                      f" = {int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])} workgroups; rocprofv3's trace fields: LDS_Block_Size {r['LDS_Block_Size']} B "
+                      f"(STATIC LDS only: this kernel's LDS is dynamic, sized by the host), VGPR_Count {r['VGPR_Count']} (the trace's own unit), SGPR_Count {r['SGPR_Count']}, scratch {r['Scratch_Size']}."]
+            # what the kernel really occupies: the compiler's metadata (tools/kernel_resources.py) and the host's LDS request
+            try:
+                import re
+                sys.path.insert(0, os.path.join(R, "tools"))
+                import kernel_resources
+                m = re.search(r"scv_hist_argmax<(\d+), (\d+), (\d+), (\w+), (\w+)>", r["Kernel_Name"])
+                want = f"scv_hist_argmax<{m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>" if m else None
+                row = next((x for x in kernel_resources.collect() if x[0] == want), None)
+                if row:
+                    copies = 1 << int(m.group(1))
+                    lines += [f"Compiler metadata of `{want}`: {row[1]} VGPRs, {row[3]} SGPRs, {row[4]} B scratch; dynamic LDS requested by the host = "
+                              f"(1024 bins x {copies} copies + 96 words) x 4 B = {(1024 * copies + 96) * 4} B per workgroup."]
+            except Exception as e:      # (the summary must not fail on a box without hipcc)
+                lines += [f"(compiler metadata not available here: {e})"]
+            lines += [""]
             break
 pmc = collections.defaultdict(list)
 for sub in ("prof_fetch", "prof_write", "prof_lds"):
