@@ -19,7 +19,7 @@ def main():
     dev = torch.device("cuda:0")
     out = []
     for (P, N, with_tokens) in [(400000, 8, False), (400000, 16, False), (200000, 32, False), (200000, 64, False), (200000, 8, True), (200000, 16, True),
-                                (200000, 32, True), (200000, 64, True), (100000, 256, False), (50000, 1024, False), (20000, 4096, False), (4000, 16384, False)]:
+                                (200000, 32, True), (200000, 64, True), (200000, 128, False), (200000, 128, True), (100000, 256, False), (50000, 1024, False), (20000, 4096, False), (4000, 16384, False)]:
         nv = [1 << k for k in range(N.bit_length()) if (1 << k) <= N]
         B = len(nv)
         pool = torch.empty((P, 1, N), dtype=torch.int32, device=dev)

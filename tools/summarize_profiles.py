@@ -16,20 +16,24 @@ G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
 os.makedirs(P, exist_ok=True)
 
 
-def newest(pattern):
+def newest(pattern, containing=None):
+    """newest file matching the pattern; `containing`: only files whose text has that string (the profiled command spawns the read-ceiling
+    probe, a process with trace files of its own)"""
     files = glob.glob(os.path.join(G, pattern))
+    if containing:
+        files = [f for f in files if containing in open(f).read()]
     return max(files, key=os.path.getmtime) if files else None
 
 
 lines = [f"# rocprofv3 summary {tag} (MI355X, `python bench.py --steps 8 --warmup 2 --no-cpu-baseline`; same box and session as {tag}_bench.json: tools/gpu_round.sh)", ""]
-ks = newest("prof_trace/*/*_kernel_stats.csv")
+ks = newest("prof_trace/*/*_kernel_stats.csv", "scv_hist_argmax")
 if ks:
     shutil.copy(ks, os.path.join(P, f"{tag}_kernel_stats.csv"))
     lines += ["## kernel-trace --stats (8 timed + 2 warmup + 1 parity step)", "", "| kernel | calls | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(ks)):
         lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {float(r['MinNs'])/1e6:.3f} | {float(r['MaxNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |")
     lines.append("")
-kt = newest("prof_trace/*/*_kernel_trace.csv")
+kt = newest("prof_trace/*/*_kernel_trace.csv", "scv_hist_argmax")
 if kt:
     for r in csv.DictReader(open(kt)):
         if "scv_hist_argmax" in r["Kernel_Name"]:
@@ -88,12 +92,14 @@ if pmc:
 for name in ("bench.json", "hbm_probe.log", "hbm_probe_percu.log", "hbm_probe_dma.log", "bench_c5.json", "bench_c2.json", "bench_c2_one_launch.json", "bench_c2_graph.json",
              "bench_c2_graph10.json", "bench_dists.jsonl", "bench_tokens.jsonl", "bench_comm_peer_2ctx.json", "bench_comm_rccl_1gpu.json", "bench_2ranks_shared_gpu.json",
              "regimes.log", "regimes.json", "sort_check.log", "prefix_small.log", "host_mode.log", "pytest_gpu.log", "smoke.log",
-             "valu_probe.log", "sort_timeline.log", "sort_timeline_nospread.log", "hbm_probe_dmawork.log", "hbm_probe_vmemq.log"):
+             "valu_probe.log", "sort_timeline.log", "sort_timeline_nospread.log", "hbm_probe_dmawork.log", "hbm_probe_vmemq.log",
+             "prefix_small_promised.log", "prefix_small_lane.log", "prefix_dists.log", "rtn_ab.log", "sort_prefix_timeline.log", "gpu_round_" + tag + ".log"):
     src = os.path.join(G, name)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name.replace('bench_c5.json', 'bench_c5_1gpu.json')}"))
-summ = os.path.join(G, f"prof_regimes_{tag}", "summary.md")
-if os.path.exists(summ):
-    shutil.copy(summ, os.path.join(P, f"{tag}_regimes_pmc.md"))
+for sub, out in ((f"prof_regimes_{tag}", f"{tag}_regimes_pmc.md"), (f"prof_regimes_{tag}_prefix", f"{tag}_prefix_pmc.md")):
+    summ = os.path.join(G, sub, "summary.md")
+    if os.path.exists(summ):
+        shutil.copy(summ, os.path.join(P, out))
 open(os.path.join(P, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
