@@ -105,9 +105,9 @@ int scv_sync(scv_ctx* ctx);
  */
 int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unroll);
 /*
- * Launch options.  None is needed for correct results: the defaults are the measured choices.  The keys exist
+ * Launch options.  None is needed for correct results: the defaults are the measured choices (DESIGN_HISTORY.md 4).  The keys exist
  * so that every kernel of the family can be forced (parity tests) and the dispatch bounds re-measured; every choice that was
- * measured slower in rounds 1-3 is gone from the library (DESIGN.md 4 lists them with their numbers).
+ * measured slower in rounds 1-3 is gone from the library (DESIGN_HISTORY.md 4 lists them with their numbers).
  *   "overwrite_counters"  default 0; 1: DEVICE-mode per-budget counters are OVERWRITTEN, not accumulated into (with few long cells the
  *                         streaming kernel's last workgroup does it and the call is one launch, otherwise a memset precedes the launch)
  *   "path"                0 auto | 1 streaming, whole cells | 2 streaming, split-N + merge | 4 register-resident cells | 5 sorted cells

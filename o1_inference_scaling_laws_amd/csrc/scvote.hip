@@ -192,7 +192,7 @@ struct scv_ctx {
     int boot_spin_limit = 1 << 20;   // polls (x s_sleep 8) a workgroup waits at the grid barrier before giving up (tests force 1)
     int stage_mb = 128;      // HOST mode: chunk size (votes + tokens) of the staging pipeline
     int copy_threads = 6;    // HOST mode (4-8 reach the link rate; 16+ were unstable: 30-55 GB/s run to run): threads copying pageable caller memory
-    // fixed choices that used to be options (measured: DESIGN.md 4 "dead ends")
+    // fixed choices that used to be options (measured: DESIGN_HISTORY.md 4 "dead ends")
     static constexpr int tiny_n_max = 32;   // N <= this (and below sort_n_min): one lane per cell, registers only (scv_lane_cells)
     void* d_tickets = nullptr;   // arrival counters of the single-launch modes (all zero between launches)
     size_t d_tickets_words = 0;

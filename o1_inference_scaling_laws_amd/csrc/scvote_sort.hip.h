@@ -313,7 +313,7 @@ constexpr int sort_cells_threads(int nv) { return nv >= 64 ? 512 : 1024; }
 // words (conflict-free for odd N, 2-way for N = 2 mod 4).  Host contract: 1 <= N <= NV, a.wave_lds_words covers
 // 64 * N * 4 + 16 bytes rounded up to whole KiB (twice with tokens: the token base has its own misalignment).
 //
-// Measured and not kept (profiles/r03_sort_cells_ab.log, r03_ab_n128.log): two blocks of 64 cells per step, two image
+// Measured and not kept (profiles/r03_sort_cells_ab.log, r03_ab_n128.log; DESIGN_HISTORY.md 4): two blocks of 64 cells per step, two image
 // buffers per wave with the copy two steps ahead, 32 resident waves per CU for the 8-vote shape, a 128-vote shape staged in two
 // half-rows, the copy's pieces issued back to back instead of between the compare-exchanges.
 #ifdef SCV_SORT_TIMELINE
