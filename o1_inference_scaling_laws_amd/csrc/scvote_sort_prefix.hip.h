@@ -120,42 +120,6 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
     uint32_t* tie = reinterpret_cast<uint32_t*>(ordl + ((B + 3) & ~3));                  // [NC][TC]
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(tie + ((NC * TC + 1) & ~1));   // [NC] truth sums | [NC] token sums
 
-    if (tid < 16) cbeg[tid] = 0;
-    for (int i = tid; i < NC * TC; i += T) tie[i] = 0;
-    for (int i = tid; i < 2 * NC; i += T) acc[i] = 0;
-    __syncthreads();
-    {
-        int bad = 0;
-        for (int b0 = 0; b0 < B; b0 += T) {
-            const int b = b0 + tid;
-            const bool have = b < B;
-            const int c = have ? sort_prefix_class<NV>(valid_len(a, b), N) : 0;
-            bad |= c < 0 ? 1 : 0;
-            // (a list this kernel does not serve: the ranks are not used)
-            const int rank = budget_rank_of<false>(a, b, (int64_t)c, [&](int o) { return sort_prefix_class<NV>(valid_len(a, o), N); });
-            if (have && c >= 0 && rank >= 0 && rank < B) {
-                ordl[rank] = b;
-                atomicAdd(reinterpret_cast<uint32_t*>(cbeg) + c + 1, 1u);
-            }
-        }
-        if (__syncthreads_or(bad)) {                                 // (the general kernel queued behind this one takes the launch ...
-            if (a.prefetch && tid == 0) atomicOr(a.err_flag, 8u);    //  ... unless the caller promised such budgets: option prefix_path = 5)
-            return;
-        }
-    }
-    if (tid == 0) {
-        for (int c = 1; c <= NC; ++c) cbeg[c] += cbeg[c - 1];
-    }
-    __syncthreads();
-    int32_t cb[NC + 1];
-#pragma unroll
-    for (int c = 0; c <= NC; ++c) cb[c] = __builtin_amdgcn_readfirstlane(cbeg[c]);
-    // votes the longest budget sees (the domain check looks no further)
-    int32_t nmax = 0;
-#pragma unroll
-    for (int c = 1; c < CF; ++c) if (cb[c + 1] > cb[c]) nmax = 1 << (c - 1);
-    if (cb[CF + 1] > cb[CF]) nmax = N;
-
     const uint32_t rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32*)(lds + (int64_t)wid * a.wave_lds_words));
     const uint32_t img_bytes = 64u * PS * 16u;
     const uint32_t tru_off = img_bytes * (TOK ? 2u : 1u);
@@ -196,6 +160,70 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
         const int32_t* tp = reinterpret_cast<const int32_t*>(sv_uniform64((int64_t)(uintptr_t)(a.truth + st * 64)));
         sv_dma4(tp, ((uint32_t)lane < live_rows ? (uint32_t)lane : 0u) * 4u, rbase + tru_off);
     };
+
+    int64_t st = wave;
+    int32_t cb[NC + 1];
+    if (tid < 16) cbeg[tid] = 0;
+    for (int i = tid; i < NC * TC; i += T) tie[i] = 0;
+    for (int i = tid; i < 2 * NC; i += T) acc[i] = 0;
+    bool issued = false;
+    if (B <= 64) {
+        // Up to 64 budgets (every list of the reference): ONE coalesced load of n_valid per wave, then everything about the classes in
+        // registers -- counts by ballot, positions by mbcnt -- with the first copy already in flight (no further load, one barrier).
+        const bool have = lane < B;
+        int cls = have ? sort_prefix_class<NV>(valid_len(a, lane), N) : NC;
+        if (__any(have && cls < 0)) {                                 // (the general kernel queued behind this one takes the launch ...
+            if (a.prefetch && tid == 0) atomicOr(a.err_flag, 8u);    //  ... unless the caller promised such budgets: option prefix_path = 5)
+            return;
+        }
+        // (the load has returned -- the verdict needed it --: nothing the compiler would wait for with vmcnt(0) follows the copy)
+        if (st < nsteps) { issue(st); issue_truth(st); issued = true; }
+        uint32_t pos = 0;
+        cb[0] = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            pos = cls == c ? (uint32_t)cb[c] + before : pos;
+            cb[c + 1] = cb[c] + (int32_t)__builtin_popcountll(m);
+        }
+        if (wid == 0 && have) ordl[pos] = lane;
+        if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c <= NC; ++c) cbeg[c] = cb[c];
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();
+        int bad = 0;
+        for (int b0 = 0; b0 < B; b0 += T) {
+            const int b = b0 + tid;
+            const bool have = b < B;
+            const int c = have ? sort_prefix_class<NV>(valid_len(a, b), N) : 0;
+            bad |= c < 0 ? 1 : 0;
+            // (a list this kernel does not serve: the ranks are not used)
+            const int rank = budget_rank_of<false>(a, b, (int64_t)c, [&](int o) { return sort_prefix_class<NV>(valid_len(a, o), N); });
+            if (have && c >= 0 && rank >= 0 && rank < B) {
+                ordl[rank] = b;
+                atomicAdd(reinterpret_cast<uint32_t*>(cbeg) + c + 1, 1u);
+            }
+        }
+        if (__syncthreads_or(bad)) {
+            if (a.prefetch && tid == 0) atomicOr(a.err_flag, 8u);
+            return;
+        }
+        if (tid == 0) {
+            for (int c = 1; c <= NC; ++c) cbeg[c] += cbeg[c - 1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c <= NC; ++c) cb[c] = __builtin_amdgcn_readfirstlane(cbeg[c]);
+    }
+    // votes the longest budget sees (the domain check looks no further)
+    int32_t nmax = 0;
+#pragma unroll
+    for (int c = 1; c < CF; ++c) if (cb[c + 1] > cb[c]) nmax = 1 << (c - 1);
+    if (cb[CF + 1] > cb[CF]) nmax = N;
 
     // per class, per lane: truth votes (and tokens) of its problems; uniform: hits with one mode
     uint32_t tcs[NC];
@@ -245,8 +273,7 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
         Dlive = 0;
     };
 
-    int64_t st = wave;
-    if (st < nsteps) { issue(st); issue_truth(st); }
+    if (!issued && st < nsteps) { issue(st); issue_truth(st); }
 #ifdef SCV_SP_TIMELINE
     unsigned long long tl[7] = {0, 0, 0, 0, 0, 0, 0}, tl_steps = 0;
     unsigned long long t_last = __builtin_readcyclecounter();
