@@ -766,6 +766,7 @@ int launch_prefix_pool(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
     // (measured: 1024 votes 68 us at 16 lanes against 82 at 32, 4096 votes 100 against 87)
     int g = N <= 1024 ? 16 : 32;
     if (ctx->reg_shape == 16 || ctx->reg_shape == 32) g = ctx->reg_shape;
+    if (!rows_aligned) g = 16;                                       // (the only unaligned shape: scvote_prefix.hip)
     const RegKernel rk = pick_prefix_pool_kernel(g, tok, rows_aligned);
     a.wave_lds_words = (int32_t)(scv::prefix_pool_hist_words(g) + scv::kPrefixPoolLaneWords);
     int W = rk.waves;
@@ -841,9 +842,9 @@ int launch_sort_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
                        int64_t* truth_sum, bool promised, bool* queued, int* nv_out) {
     *queued = false;
     const bool tok = tokens != nullptr;
-    const int nv = N <= 32 ? 32 : 64;
+    const int nv = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
     const RegKernel rk = pick_sort_prefix_kernel(nv, tok);
-    const int64_t ps = (N / 4) | 1;
+    const int64_t ps = nv == 128 ? 17 : ((N / 4) | 1);                 // (128: the row goes through the image in two halves of up to 64 votes)
     const int64_t region_words = 64 * ps * 4 * (tok ? 2 : 1) + 64;
     const int64_t tail_words = scv::sort_prefix_tail_words(nv, B);
     int W = rk.waves;
@@ -899,20 +900,20 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     bool counters_cleared = false;
     const bool want_any_counters = tie || truth_sum || (tokens && tok_sum);
     if (ctx->path == 0 && (ctx->prefix_path == 0 || ctx->prefix_path == 5) && ctx->sort_n_max >= 64 && ctx->fused_counters_max != 0 && rows_aligned &&
-        N > 16 && N <= 64 && B <= scv::kMaxSortedB) {
+        N > 16 && N <= 128 && B <= scv::kMaxSortedB) {
         // prefix_path = 5: the caller PROMISES budgets of that form (a DEVICE-mode call then queues scv_sort_prefix alone; a list that breaks
         // the promise is an error, reported like a domain error at the next synchronisation)
         const bool promised = ctx->prefix_path == 5;
         bool known = promised, served = true;
         if (ctx->nv_host) {
             known = true;
-            const int64_t np = N <= 32 ? 16 : 32;
+            const int64_t np = N <= 32 ? 16 : (N <= 64 ? 32 : 64);
             for (int32_t b = 0; b < B; ++b) {
                 const int64_t n = ctx->nv_host[b];
                 if (!(n <= 0 || n >= N || ((n & (n - 1)) == 0 && n <= np))) { served = false; break; }
             }
         }
-        if (!served && promised) return fail(SCV_ERR_ARG, "prefix_path = 5 promises budgets that are 0, a power of two <= %d, or >= N", N <= 32 ? 16 : 32);
+        if (!served && promised) return fail(SCV_ERR_ARG, "prefix_path = 5 promises budgets that are 0, a power of two <= %d, or >= N", N <= 32 ? 16 : (N <= 64 ? 32 : 64));
         if (served) {
             if (int rc = next_event_pair(ctx, &ev_open)) return rc;
             if (ctx->overwrite_counters && want_any_counters) {

@@ -272,6 +272,7 @@ __device__ __forceinline__ bool sort_prefix_serves(const AggArgs& a, int tid, in
 }
 // ... asked by the kernels the host queues behind scv_sort_prefix (a.skip_sortable = its NV; 0: never)
 __device__ __forceinline__ bool sort_prefix_took_it(const AggArgs& a, int tid, int nthreads) {
+    if (a.skip_sortable == 128) return sort_prefix_serves<128>(a, tid, nthreads);
     if (a.skip_sortable == 64) return sort_prefix_serves<64>(a, tid, nthreads);
     if (a.skip_sortable == 32) return sort_prefix_serves<32>(a, tid, nthreads);
     return false;

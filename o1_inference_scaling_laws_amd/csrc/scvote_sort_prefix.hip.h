@@ -489,4 +489,475 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
     }
 }
 
+
+// ---- pools of 68 .. 128 votes: the reference's largest (o1.py:266-276: T = 2^18 -> N = 128) ------------------------------------------------
+//
+// scv_sort_prefix2: one lane per problem, the row in TWO halves through the same 17 KiB image (a whole 128-vote row per lane would be a 33 KiB
+// image: four waves per CU).  Half A = votes 0 .. 63: the 64-vote machinery above, unchanged -- its merge phases give maj@2 .. 32, its finished
+// sort maj@64 (packed scan); half B = votes 64 .. N - 1 is copied while A is sorted, sorted by the same network, and the two sorted halves are
+// joined by a bitonic merge ACROSS the two register files (flip stage: lo(A[r]) against hi(B[31 - r]), hi(A[r]) against lo(B[31 - r]); then
+// each file is a bitonic sequence of 64: the stage between the halves of a register, five lockstep stages).  maj@N is a run scan of the 128
+// sorted values in plain 32-bit arithmetic (run lengths up to 128 do not fit the packed scan's 6-bit field): running (length, best, count, value),
+// 10 VALU per vote, no keys kept.  Per step: phase A = wait, rows A -> registers, the previous step's records leave through the image, copy B,
+// sort A with the block scans, scan 64; phase B = wait, rows B -> registers, the token sums leave through the image, copy the next A, sort B,
+// merge, scan 128.  Classes: 0 | 1 + j for 2^j votes, j = 0 .. 6 | 8 = all N votes.
+template <int NP>
+__device__ __forceinline__ void sv_flip_files(uint32_t (&A)[NP], uint32_t (&Bv)[NP]) {
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+        const uint32_t t = __builtin_amdgcn_alignbit(Bv[NP - 1 - r], Bv[NP - 1 - r], 16);
+        const uint32_t mn = pk_min_c(A[r], t), mx = pk_max_c(A[r], t);
+        A[r] = mn;
+        Bv[NP - 1 - r] = __builtin_amdgcn_alignbit(mx, mx, 16);
+    }
+}
+// a register file whose 2 NP elements (element i = half i / NP of X[i % NP]) form a bitonic sequence -> ascending
+template <int NP>
+__device__ __forceinline__ void sv_merge_bitonic_file(uint32_t (&X)[NP]) {
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+        const uint32_t t = __builtin_amdgcn_alignbit(X[r], X[r], 16);
+        const uint32_t mn = pk_min_c(X[r], t), mx = pk_max_c(X[r], t);
+        X[r] = (mn & 0xffffu) | (mx & 0xffff0000u);
+    }
+#pragma unroll
+    for (int j = NP >> 1; j > 0; j >>= 1) {
+#pragma unroll
+        for (int r = 0; r < NP; ++r) {
+            const int l = r ^ j;
+            if (l > r) sv_ce(X[r], X[l]);
+        }
+    }
+}
+// statistics.multimode of the 4 NP sorted values lo(A[0..]), hi(A[0..]), lo(B[0..]), hi(B[0..]) in one pass: a run's length grows until the value
+// changes; the first run to reach a new maximum is the smallest such value (ascending order), later runs that reach it are counted
+template <int NP>
+__device__ __forceinline__ BlockStats sv_scan_files(const uint32_t (&A)[NP], const uint32_t (&Bv)[NP]) {
+    uint32_t prev = 0xffffffffu, len = 0, best = 0, cnt = 0, minv = 0;
+    auto feed = [&](uint32_t x) {
+        len = x == prev ? len + 1u : 1u;
+        prev = x;
+        const bool gt = len > best;
+        cnt = gt ? 1u : cnt + (len == best ? 1u : 0u);
+        minv = gt ? x : minv;
+        best = gt ? len : best;
+    };
+#pragma unroll
+    for (int r = 0; r < NP; ++r) feed(A[r] & 0xffffu);
+#pragma unroll
+    for (int r = 0; r < NP; ++r) feed(A[r] >> 16);
+#pragma unroll
+    for (int r = 0; r < NP; ++r) feed(Bv[r] & 0xffffu);
+#pragma unroll
+    for (int r = 0; r < NP; ++r) feed(Bv[r] >> 16);
+    return BlockStats{best, cnt, minv};
+}
+
+// ... of the M sorted values in the LOW halves of R[0 .. M - 1], the same way (no key per element held: the 128-vote kernel has no registers for them)
+template <int M, int NP>
+__device__ __forceinline__ BlockStats sv_scan_block_running(const uint32_t (&R)[NP]) {
+    uint32_t prev = 0xffffffffu, len = 0, best = 0, cnt = 0, minv = 0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const uint32_t x = R[i] & 0xffffu;
+        len = x == prev ? len + 1u : 1u;
+        prev = x;
+        const bool gt = len > best;
+        cnt = gt ? 1u : cnt + (len == best ? 1u : 0u);
+        minv = gt ? x : minv;
+        best = gt ? len : best;
+    }
+    return BlockStats{best, cnt, minv};
+}
+
+constexpr int sort_prefix2_threads(bool tok) { return tok ? 256 : 512; }
+
+// Host contract: 64 < N <= 128, N % 4 == 0, 16-byte aligned bases, B <= kMaxSortedB, every budget 0, a power of two <= 64 or >= N (checked
+// here: a list that is not leaves the launch to the kernel queued behind it); a.wave_lds_words = 64 * 17 * 4 (twice with tokens) + 64.
+template <bool TOK>
+__global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(const AggArgs a) {
+    constexpr int NV = 128, NH = 64, NP = 32, RSH = 16;             // votes per lane; per half; packed registers per half; 16-byte slots per half row
+    constexpr uint32_t PS = 17u;                                     // slots of a padded half row in the image
+    constexpr int TC = NV + 1;
+    constexpr int NC = 9, CF = 8;                                    // classes 0 | 1 .. 7 (1 .. 64 votes) | 8 (all N)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, T = (int)blockDim.x, NW = T >> 6;
+    const int32_t N = (int32_t)a.N, B = a.B;
+    const uint32_t nB = (uint32_t)N - (uint32_t)NH;                  // votes of half B (4 .. 64)
+    const uint32_t RSB = nB >> 2;                                    // its slots
+    const uint32_t rowbytes = (uint32_t)N * 4u;
+    int32_t* cbeg = reinterpret_cast<int32_t*>(lds + (int64_t)NW * a.wave_lds_words);
+    int32_t* ordl = cbeg + 16;
+    uint32_t* tie = reinterpret_cast<uint32_t*>(ordl + ((B + 3) & ~3));                  // [NC][TC]
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(tie + ((NC * TC + 1) & ~1));   // [NC] truth sums | [NC] token sums
+
+    const uint32_t rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32*)(lds + (int64_t)wid * a.wave_lds_words));
+    constexpr uint32_t img_bytes = 64u * PS * 16u;
+    const uint32_t tru_off = img_bytes * (TOK ? 2u : 1u);
+    // slot s = 64 q + lane of the image is chunk k = s % 17 of row c = s / 17; s += 64 is (c, k) += (3, 13) with a carry: walked again by every
+    // copy (17 registers of offsets held across the loop were the registers the kernel did not have)
+    const uint32_t c0 = (uint32_t)lane / PS, k0 = (uint32_t)lane - c0 * PS;
+    const int64_t nwaves = (int64_t)gridDim.x * NW;
+    const int64_t wave = sv_uniform64((int64_t)blockIdx.x * NW + wid);
+    const int64_t nsteps = (a.P + 63) / 64;
+    const int64_t total_bytes = a.P * (int64_t)rowbytes;
+    // the copy of half h (0: votes 0 .. 63, 1: votes 64 .. N - 1) of step st's 64 rows into this wave's image(s)
+    auto issue_half = [&](int64_t st, int h) {
+        const int64_t byte0 = st * 64 * (int64_t)rowbytes;
+        const int64_t rem = total_bytes - byte0 - 16;
+        const uint32_t lim = rem > 0x7fffffffll ? 0x7fffffffu : (uint32_t)rem;
+        const char* g = reinterpret_cast<const char*>(a.answers) + byte0;
+        const char* gt = TOK ? reinterpret_cast<const char*>(a.tokens) + byte0 : nullptr;
+        const uint32_t kmax = h ? RSB - 1u : (uint32_t)RSH - 1u, add = h ? 256u : 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the rows of the image's previous content are in registers, staged tables have left)
+        uint32_t cr = c0 * rowbytes + add, kq = k0;
+#pragma unroll
+        for (int q = 0; q < (int)PS; ++q) {
+            uint32_t o = cr + (kq < kmax ? kq : kmax) * 16u;
+            o = o < lim ? o : lim;
+            sv_dma16(g, o, rbase + (uint32_t)q * 1024u);
+            if (TOK) sv_dma16(gt, o, rbase + img_bytes + (uint32_t)q * 1024u);
+            kq += 64u - 3u * PS; cr += 3u * rowbytes;
+            if (kq >= PS) { kq -= PS; cr += rowbytes; }
+        }
+    };
+    auto issue_truth = [&](int64_t st) {
+        const int64_t left = a.P - st * 64;
+        const uint32_t live_rows = left > 64 ? 64u : (uint32_t)left;
+        const int32_t* tp = reinterpret_cast<const int32_t*>(sv_uniform64((int64_t)(uintptr_t)(a.truth + st * 64)));
+        sv_dma4(tp, ((uint32_t)lane < live_rows ? (uint32_t)lane : 0u) * 4u, rbase + tru_off);
+    };
+
+    int64_t st = wave;
+    int32_t cb[NC + 1];
+    if (tid < 16) cbeg[tid] = 0;
+    for (int i = tid; i < NC * TC; i += T) tie[i] = 0;
+    for (int i = tid; i < 2 * NC; i += T) acc[i] = 0;
+    bool issued = false;
+    if (B <= 64) {                                                   // (as in scv_sort_prefix: one load of n_valid per wave, the classes in registers)
+        const bool have = lane < B;
+        int cls = have ? sort_prefix_class<NV>(valid_len(a, lane), N) : NC;
+        if (__any(have && cls < 0)) {
+            if (a.prefetch && tid == 0) atomicOr(a.err_flag, 8u);
+            return;
+        }
+        if (st < nsteps) { issue_half(st, 0); issue_truth(st); issued = true; }
+        uint32_t pos = 0;
+        cb[0] = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            pos = cls == c ? (uint32_t)cb[c] + before : pos;
+            cb[c + 1] = cb[c] + (int32_t)__builtin_popcountll(m);
+        }
+        if (wid == 0 && have) ordl[pos] = lane;
+        if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c <= NC; ++c) cbeg[c] = cb[c];
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();
+        int bad = 0;
+        for (int b0 = 0; b0 < B; b0 += T) {
+            const int b = b0 + tid;
+            const bool have = b < B;
+            const int c = have ? sort_prefix_class<NV>(valid_len(a, b), N) : 0;
+            bad |= c < 0 ? 1 : 0;
+            const int rank = budget_rank_of<false>(a, b, (int64_t)c, [&](int o) { return sort_prefix_class<NV>(valid_len(a, o), N); });
+            if (have && c >= 0 && rank >= 0 && rank < B) {
+                ordl[rank] = b;
+                atomicAdd(reinterpret_cast<uint32_t*>(cbeg) + c + 1, 1u);
+            }
+        }
+        if (__syncthreads_or(bad)) {
+            if (a.prefetch && tid == 0) atomicOr(a.err_flag, 8u);
+            return;
+        }
+        if (tid == 0) {
+            for (int c = 1; c <= NC; ++c) cbeg[c] += cbeg[c - 1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c <= NC; ++c) cb[c] = __builtin_amdgcn_readfirstlane(cbeg[c]);
+    }
+    int32_t nmax = 0;                                                // votes the longest budget sees (the domain check looks no further)
+#pragma unroll
+    for (int c = 1; c < CF; ++c) if (cb[c + 1] > cb[c]) nmax = 1 << (c - 1);
+    if (cb[CF + 1] > cb[CF]) nmax = N;
+    const bool want_full = cb[CF + 1] > cb[CF];
+
+    uint32_t tcs[NC];
+    uint32_t h1[NC];
+    long long toks[TOK ? NC : 1];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { tcs[c] = 0; h1[c] = 0; if (TOK) toks[c] = 0; }
+    uint32_t bad = 0;
+    // the previous step's records, packed: D[c] = max_count | truth_count << 8 | n_modes << 16 | hit << 31; min_mode (10 bits) of class c
+    // in Dm[c / 3] at bit 10 (c % 3)
+    uint32_t D[NC], Dm[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) D[c] = 0;
+    int64_t Dp0 = 0;
+    uint32_t Dlive = 0;
+    const bool staged = (uint32_t)B <= PS;
+    auto flush_records = [&]() {                                     // through the votes image, in memory order (see scv_sort_prefix)
+        if (!a.cells || Dlive == 0) return;
+        uint4* const rowp = reinterpret_cast<uint4*>(a.cells) + (Dp0 + lane) * (int64_t)B;
+        const uint32_t lrow = rbase + (uint32_t)lane * (uint32_t)B * 16u;
+        const bool wr = (uint32_t)lane < Dlive;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (cb[c + 1] > cb[c]) {
+                const uint32_t d = D[c], mm = (Dm[c / 3] >> (10 * (c % 3))) & 0x3ffu;
+                const scv_v4u rec = c == 0 ? scv_v4u{0u, 0u, 0xffff0000u, 0u}
+                                           : scv_v4u{d & 0xffu, (d >> 8) & 0xffu, ((d >> 16) & 0xffu) | (mm << 16), d >> 31};
+                for (int32_t j = cb[c]; j < cb[c + 1]; ++j) {
+                    const int32_t b = __builtin_amdgcn_readfirstlane(ordl[j]);
+                    if (staged) *reinterpret_cast<lds_v4u*>((uintptr_t)(lrow + (uint32_t)b * 16u)) = rec;
+                    else if (wr) __builtin_nontemporal_store(rec, reinterpret_cast<scv_v4u*>(rowp) + b);
+                }
+            }
+        }
+        if (staged) {
+            scv_v4u* const out = reinterpret_cast<scv_v4u*>(a.cells) + Dp0 * (int64_t)B;
+            const uint32_t nrec = Dlive * (uint32_t)B;
+            for (int32_t i = 0; i < B; ++i) {
+                const uint32_t k = (uint32_t)i * 64u + (uint32_t)lane;
+                const scv_v4u rec = *reinterpret_cast<lds_v4u*>((uintptr_t)(rbase + k * 16u));
+                if (k < nrec) __builtin_nontemporal_store(rec, out + k);
+            }
+        }
+        Dlive = 0;
+    };
+
+    if (!issued && st < nsteps) { issue_half(st, 0); issue_truth(st); }
+    for (; st < nsteps; st += nwaves) {
+        // ================================ phase A: votes 0 .. 63 ================================
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // half A and the truths have landed (and every older store)
+        const int64_t left = a.P - st * 64;
+        const uint32_t live_rows = left >= 64 ? 64u : (uint32_t)left;
+        const bool live = (uint32_t)lane < live_rows;
+        const int32_t trj = (int32_t)*reinterpret_cast<lds_u32*>((uintptr_t)(rbase + tru_off + (uint32_t)lane * 4u));
+        const uint32_t tcmp = (trj >= 0 && trj < kBins) ? (uint32_t)trj : 0x7fffu;
+        const uint32_t ra = rbase + (uint32_t)lane * (PS * 16u);
+        uint32_t w[NH];
+#pragma unroll
+        for (int k = 0; k < RSH; ++k) {
+            const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k));
+            w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+        }
+        long long tsnap[TOK ? 8 : 1];                                // token sums of the first 1, 2, 4 .. 64 votes; [7] grows into the whole row's
+        if constexpr (TOK) {
+            long long run = 0;
+#pragma unroll
+            for (int k = 0; k < RSH; ++k) {
+                const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + img_bytes + 16u * k));
+                const int32_t y[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    run += (long long)y[e];
+                    const int idx1 = 4 * k + e + 1;
+                    if ((idx1 & (idx1 - 1)) == 0) tsnap[__builtin_ctz((unsigned)idx1)] = run;
+                }
+            }
+        }
+        flush_records();                                             // the previous step's records leave through the image: its rows are in registers
+        issue_half(st, 1);                                           // half B flies while A is sorted
+        uint32_t RA[NP];
+#pragma unroll
+        for (int r = 0; r < NP; ++r) RA[r] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(w[r], w[r + NP]));
+        {
+            uint32_t orv = 0;
+#pragma unroll
+            for (int r = 0; r < NP; ++r) orv |= RA[r];
+            if (__any((orv & 0xfc00fc00u) != 0u)) {
+                const int32_t seen = live ? (nmax < NH ? nmax : NH) : 0;
+#pragma unroll
+                for (int i = 0; i < NH; ++i) {
+                    bad |= i < seen ? w[i] : 0u;
+                    w[i] = w[i] < 1023u ? w[i] : 1023u;
+                }
+#pragma unroll
+                for (int r = 0; r < NP; ++r) RA[r] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(w[r], w[r + NP]));
+            }
+        }
+        // truth votes among the first 2^j votes (index order), j = 0 .. 6: one byte each; tcA = among all 64
+        uint32_t tcp[2] = {0u, 0u};
+        uint32_t tcA = 0;
+        {
+            uint32_t run = 0;
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                run += w[i] == tcmp ? 1u : 0u;
+                const int idx1 = i + 1;
+                if ((idx1 & (idx1 - 1)) == 0) {
+                    const int j = __builtin_ctz((unsigned)idx1);
+                    tcp[j / 4] |= run << (8 * (j % 4));
+                    tcs[1 + j] += live ? run : 0u;
+                }
+            }
+            tcA = run;
+        }
+        Dm[0] = Dm[1] = Dm[2] = 0u;
+        auto close_class = [&](int c, uint32_t maxc, uint32_t n_modes, uint32_t mm, uint32_t tc) {
+            const uint32_t hit = tc == maxc ? 1u : 0u;                // o1.py:206 (every class here has votes)
+            D[c] = maxc | (tc << 8) | (n_modes << 16) | (hit << 31);
+            Dm[c / 3] |= mm << (10 * (c % 3));
+            h1[c] += (uint32_t)__builtin_popcountll(__ballot(live && hit && n_modes == 1u));
+            if (live && hit && n_modes != 1u) atomicAdd(&tie[c * TC + (int32_t)n_modes], 1u);
+        };
+        auto tc_of = [&](int c) -> uint32_t { return (tcp[(c - 1) / 4] >> (8 * ((c - 1) % 4))) & 0xffu; };
+        if (cb[2] > cb[1]) close_class(1, 1u, 1u, RA[0] & 0x3ffu, tc_of(1));
+        SvNoTick none;
+        auto hook = [&](auto m_tag) __attribute__((always_inline)) {
+            constexpr int M = decltype(m_tag)::value;
+            constexpr int c = 1 + sv_log2(M);
+            if (cb[c + 1] > cb[c]) {
+                const BlockStats s = sv_scan_block_running<M, NP>(RA);
+                close_class(c, s.max_run, s.at_max, s.min_at_max, tc_of(c));
+            }
+        };
+        sv_sort_phases<NP, 1>(RA, none, hook);
+        sv_merge_halves<NP>(RA, none);
+        if (cb[8] > cb[7]) {                                         // the first 64 votes: the packed scan of the sorted half
+            const SortedStats s = sv_scan<NP>(RA, 0x7fff7fffu);
+            close_class(7, s.max_run, s.at_max, s.min_at_max, tc_of(7));
+        }
+        // ================================ phase B: votes 64 .. N - 1 ================================
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // half B has landed
+        uint32_t RB[NP];
+        uint32_t tcB = 0;
+        {
+            uint32_t v[NH];
+#pragma unroll
+            for (int k = 0; k < RSH; ++k) {
+                const uint32_t kk = (uint32_t)k < RSB ? (uint32_t)k : RSB - 1u;
+                const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * kk));
+                v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+            }
+            if constexpr (TOK) {
+                long long run = tsnap[6];
+#pragma unroll
+                for (int k = 0; k < RSH; ++k) {
+                    if ((uint32_t)k < RSB) {
+                        const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + img_bytes + 16u * k));
+                        run += (long long)(int32_t)q.x + (long long)(int32_t)q.y + (long long)(int32_t)q.z + (long long)(int32_t)q.w;
+                    }
+                }
+                tsnap[7] = run;
+            }
+#pragma unroll
+            for (int r = 0; r < NP; ++r) RB[r] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(v[r], v[r + NP]));
+            uint32_t orv = 0;
+#pragma unroll
+            for (int r = 0; r < NP; ++r) orv |= RB[r];
+            if (__any((orv & 0xfc00fc00u) != 0u)) {
+                const int32_t seen = live ? (nmax - NH > 0 ? nmax - NH : 0) : 0;
+#pragma unroll
+                for (int i = 0; i < NH; ++i) {
+                    bad |= i < seen ? v[i] : 0u;
+                    v[i] = v[i] < 1023u ? v[i] : 1023u;
+                }
+#pragma unroll
+                for (int r = 0; r < NP; ++r) RB[r] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(v[r], v[r + NP]));
+            }
+            if (want_full) {                                         // (whole slots under a scalar branch: 64 uniform "i < nB" masks cost 128 SGPRs)
+#pragma unroll
+                for (int k = 0; k < RSH; ++k) {
+                    if ((uint32_t)k < RSB) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tcB += v[4 * k + e] == tcmp ? 1u : 0u;
+                    }
+                }
+            }
+        }
+        // the image is free: this step's token sums leave through it, then the next step's half A is copied
+        if constexpr (TOK) {
+            const uint32_t ltok = rbase + (uint32_t)lane * (uint32_t)B * 8u;
+            int64_t* const ctok_row = a.cell_tokens ? a.cell_tokens + (st * 64 + lane) * (int64_t)B : nullptr;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (cb[c + 1] > cb[c]) {
+                    const long long v = c == 0 ? 0ll : (c == CF ? tsnap[7] : tsnap[c - 1]);
+                    toks[c] += live ? v : 0ll;
+                    if (a.cell_tokens) {
+                        for (int32_t j = cb[c]; j < cb[c + 1]; ++j) {
+                            const int32_t b = __builtin_amdgcn_readfirstlane(ordl[j]);
+                            if (staged) *reinterpret_cast<lds_v2u*>((uintptr_t)(ltok + (uint32_t)b * 8u)) = scv_v2u{(uint32_t)(unsigned long long)v, (uint32_t)((unsigned long long)v >> 32)};
+                            else if (live) ctok_row[b] = v;
+                        }
+                    }
+                }
+            }
+            if (a.cell_tokens && staged) {
+                char* const out = reinterpret_cast<char*>(a.cell_tokens + st * 64 * (int64_t)B);
+                const uint32_t ntok = live_rows * (uint32_t)B;
+                for (int32_t i = 0; 2 * 64 * i < 64 * B; ++i) {
+                    const uint32_t k = (uint32_t)i * 64u + (uint32_t)lane;
+                    const scv_v4u two = *reinterpret_cast<lds_v4u*>((uintptr_t)(rbase + k * 16u));
+                    if (2u * k + 1u < ntok) __builtin_nontemporal_store(two, reinterpret_cast<scv_v4u*>(out) + k);
+                    else if (2u * k < ntok) *reinterpret_cast<scv_v2u*>(out + (size_t)k * 16u) = scv_v2u{two.x, two.y};
+                }
+            }
+        }
+        if (st + nwaves < nsteps) { issue_half(st + nwaves, 0); issue_truth(st + nwaves); }
+        if (want_full) {
+            if (nB != (uint32_t)NH) {                                // slots behind the row: distinct sentinels behind every vote
+                const uint32_t n2 = nB | (nB << 16);
+#pragma unroll
+                for (int r = 0; r < NP; ++r)
+                    RB[r] = sv_sentinel(RB[r], n2, (uint32_t)(r + 1) | ((uint32_t)(r + NP + 1) << 16),
+                                        (0x8000u | (uint32_t)r) | ((0x8000u | (uint32_t)(r + NP)) << 16));
+            }
+            sv_sort<NP>(RB, none);
+            sv_flip_files<NP>(RA, RB);
+            sv_merge_bitonic_file<NP>(RA);
+            sv_merge_bitonic_file<NP>(RB);
+            const BlockStats s = sv_scan_files<NP>(RA, RB);
+            // (sentinels are runs of length 1: they count as modes only when every vote is distinct, and come off again)
+            const uint32_t n_modes = s.at_max - (s.max_run == 1u ? (uint32_t)NV - (uint32_t)N : 0u);
+            const uint32_t tc = tcA + tcB;
+            tcs[CF] += live ? tc : 0u;
+            close_class(CF, s.max_run, n_modes, s.min_at_max, tc);
+        }
+        Dp0 = st * 64;
+        Dlive = live_rows;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    flush_records();
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+    const bool counters = a.tie_hits || a.truth_sum || (TOK && a.token_sum);
+    if (counters) {
+#pragma unroll
+        for (int c = 1; c < NC; ++c) {
+            if (cb[c + 1] > cb[c]) {
+                const long long ts = wave_sum_i64((long long)tcs[c]);
+                long long tk = 0;
+                if (TOK) tk = wave_sum_i64(toks[c]);
+                if (lane == 0) {
+                    if (h1[c]) atomicAdd(&tie[c * TC + 1], h1[c]);
+                    if (ts) atomicAdd(&acc[c], (unsigned long long)ts);
+                    if (TOK && tk) atomicAdd(&acc[NC + c], (unsigned long long)tk);
+                }
+            }
+        }
+        __syncthreads();
+        for (int64_t i = tid; i < (int64_t)B * TC; i += T) {
+            const int32_t j = (int32_t)(i / TC), k = (int32_t)(i - (int64_t)j * TC);
+            int c = 0;
+            while (c < NC - 1 && j >= cbeg[c + 1]) ++c;
+            const uint32_t v = tie[c * TC + k];
+            if (v && a.tie_hits) atomicAdd(&a.tie_hits[(int64_t)ordl[j] * SCV_TIE_CLASSES + k], (unsigned long long)v);
+        }
+        for (int j = tid; j < B; j += T) {
+            int c = 0;
+            while (c < NC - 1 && j >= cbeg[c + 1]) ++c;
+            if (a.truth_sum && acc[c]) atomicAdd(&a.truth_sum[ordl[j]], acc[c]);
+            if (TOK && a.token_sum && acc[NC + c]) atomicAdd(&a.token_sum[ordl[j]], acc[NC + c]);
+        }
+    }
+}
+
 }  // namespace scv

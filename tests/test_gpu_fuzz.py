@@ -115,8 +115,10 @@ def test_random_configuration_is_bit_exact(hip_engine, seed):
 def _draw_prefix(rng):
     """Prefix budgets over one pool per problem (o1.py:274-277): shapes that reach every prefix kernel of round 5 -- scv_sort_prefix (pools of
     17 .. 64 votes, power-of-two budgets), scv_lane_prefix, scv_prefix_pool (pivot, head, chunks), the cell kernels on pool rows, scv_prefix_hist."""
-    kind = rng.choice(["sort64", "sort32", "short", "pool", "long"], p=[0.3, 0.2, 0.15, 0.25, 0.10])
-    if kind == "sort64":
+    kind = rng.choice(["sort128", "sort64", "sort32", "short", "pool", "long"], p=[0.2, 0.2, 0.15, 0.12, 0.23, 0.10])
+    if kind == "sort128":
+        N = int(rng.choice([68, 72, 80, 96, 100, 112, 124, 128]))
+    elif kind == "sort64":
         N = int(rng.choice([36, 40, 44, 48, 52, 56, 60, 64]))
     elif kind == "sort32":
         N = int(rng.choice([20, 24, 28, 32]))
@@ -126,7 +128,7 @@ def _draw_prefix(rng):
         N = int(rng.integers(65, 1500))
     else:
         N = int(rng.integers(1500, 9000))
-    P = int(rng.integers(1, 2000 if N <= 64 else (300 if N <= 1500 else 40)))
+    P = int(rng.integers(1, 2000 if N <= 128 else (300 if N <= 1500 else 40)))
     pow2 = [1 << k for k in range(N.bit_length()) if (1 << k) <= N]
     lists = rng.choice(["pow2", "pow2_subset", "random", "mixed"], p=[0.35, 0.25, 0.25, 0.15])
     if lists == "pow2":

@@ -833,7 +833,7 @@ def test_prefix_budgets_over_short_pools_run_on_the_cell_kernels(hip_engine, dis
         nv = np.array(nv, dtype=np.int32)
         want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
         stat = "prefix_lane" if N <= 64 else "prefix_pool"           # one lane per problem / one pass per problem over G lanes
-        if 16 < N <= 64 and N % 4 == 0 and all(n == 0 or n >= N or (n & (n - 1) == 0 and n <= (16 if N <= 32 else 32)) for n in nv.tolist()):
+        if 16 < N <= 128 and N % 4 == 0 and all(n == 0 or n >= N or (n & (n - 1) == 0 and n <= (16 if N <= 32 else (32 if N <= 64 else 64))) for n in nv.tolist()):
             stat = "prefix_sort"                                     # powers of two (and the whole row): one sort per problem
         before = hip_engine.stat(stat)
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
@@ -912,22 +912,28 @@ def test_prefix_pool_kernel_with_many_budgets(hip_engine, P, N, B, dist):
                 hip_engine.aggregate_prefix(bad, tr, nv)
 
 
+def _sort_prefix_top(N):
+    return 16 if N <= 32 else (32 if N <= 64 else 64)                                          # the largest power-of-two budget scv_sort_prefix serves
+
+
 SORT_PREFIX_BUDGETS = [
-    lambda N: [1 << k for k in range(7) if (1 << k) <= (16 if N <= 32 else 32)] + [N],        # the reference's sweep (o1.py:274-277)
+    lambda N: [1 << k for k in range(8) if (1 << k) <= _sort_prefix_top(N)] + [N],            # the reference's sweep (o1.py:274-277)
     lambda N: [N, 0, 4, 4, 1, N + 5, 16, 2, 0],                                                # unsorted, duplicates, empty, beyond the row
     lambda N: [8],
     lambda N: [0, 0],
     lambda N: [N],
-    lambda N: [2, (16 if N <= 32 else 32)],
+    lambda N: [2, _sort_prefix_top(N)],
 ]
 
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("shape", [(1, 64), (63, 64), (64, 64), (65, 64), (1000, 64), (5000, 64), (333, 60), (700, 52), (129, 48), (900, 40), (77, 36),
-                                   (2000, 32), (300, 28), (450, 24), (999, 20)], ids=lambda s: f"P{s[0]}_N{s[1]}")
+                                   (2000, 32), (300, 28), (450, 24), (999, 20),
+                                   (1, 128), (64, 128), (65, 128), (3000, 128), (700, 124), (333, 100), (129, 96), (500, 72), (900, 68)], ids=lambda s: f"P{s[0]}_N{s[1]}")
 def test_prefix_budgets_that_are_powers_of_two_come_out_of_one_sort(hip_engine, dist, shape):
     """scv_sort_prefix (o1.py:274-277: maj@1, 2, 4 ... over one list of completions): after merge phase p of the sorting network the first 2 p
-    votes of the row are sorted, so every power-of-two budget is a run scan of its block.  HOST mode reads the budgets and queues the one
+    votes of the row are sorted, so every power-of-two budget is a run scan of its block (pools of 68 .. 128 votes: scv_sort_prefix2, the row in two
+    halves, the sorted halves merged across two register files).  HOST mode reads the budgets and queues the one
     kernel that serves them; DEVICE mode queues scv_sort_prefix and the general kernel, which decide from n_valid -- exactly one of them
     does the work, whatever the list.  Bit-exact against the oracle on the dense expansion, cells, counters and token sums."""
     import torch
