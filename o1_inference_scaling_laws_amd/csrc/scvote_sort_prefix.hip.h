@@ -687,6 +687,7 @@ __global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(co
     for (int c = 1; c < CF; ++c) if (cb[c + 1] > cb[c]) nmax = 1 << (c - 1);
     if (cb[CF + 1] > cb[CF]) nmax = N;
     const bool want_full = cb[CF + 1] > cb[CF];
+    const bool need_b = want_full || TOK;                            // (no budget beyond 64 votes and no token sums: half B is never read)
 
     uint32_t tcs[NC];
     uint32_t h1[NC];
@@ -764,7 +765,8 @@ __global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(co
             }
         }
         flush_records();                                             // the previous step's records leave through the image: its rows are in registers
-        issue_half(st, 1);                                           // half B flies while A is sorted
+        if (need_b) issue_half(st, 1);                               // half B flies while A is sorted
+        else if (st + nwaves < nsteps) { issue_half(st + nwaves, 0); issue_truth(st + nwaves); }
         uint32_t RA[NP];
 #pragma unroll
         for (int r = 0; r < NP; ++r) RA[r] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(w[r], w[r + NP]));
@@ -826,6 +828,7 @@ __global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(co
             close_class(7, s.max_run, s.at_max, s.min_at_max, tc_of(7));
         }
         // ================================ phase B: votes 64 .. N - 1 ================================
+        if (!need_b) { Dp0 = st * 64; Dlive = live_rows; continue; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // half B has landed
         uint32_t RB[NP];
         uint32_t tcB = 0;
