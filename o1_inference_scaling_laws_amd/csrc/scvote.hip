@@ -845,7 +845,8 @@ int launch_sort_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
     const int nv = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
     const RegKernel rk = pick_sort_prefix_kernel(nv, tok);
     const int64_t ps = nv == 128 ? 17 : ((N / 4) | 1);                 // (128: the row goes through the image in two halves of up to 64 votes)
-    const int64_t region_words = 64 * ps * 4 * (tok ? 2 : 1) + 64;
+    // one image per wave (scv_sort_prefix: a step's tokens follow its votes through it; scv_sort_prefix2 keeps a tokens image of its own)
+    const int64_t region_words = 64 * ps * 4 * ((tok && nv == 128) ? 2 : 1) + 64;
     const int64_t tail_words = scv::sort_prefix_tail_words(nv, B);
     int W = rk.waves;
     while (W > 2 && (W * region_words + tail_words) * 4 + 1024 > ctx->lds_max) --W;

@@ -100,7 +100,7 @@ __device__ unsigned long long scv_sp_timeline[8];
 #endif
 
 // NV: capacity of the shape (32 / 64); host contract: NV / 2 < N <= NV, N % 4 == 0, 16-byte aligned bases, B <= kMaxSortedB,
-// a.wave_lds_words = 64 * PS * 4 (twice with tokens) + 64, PS = (N / 4) | 1.  LDS behind the waves' regions: class offsets [16] |
+// a.wave_lds_words = 64 * PS * 4 + 64, PS = (N / 4) | 1 (one image: with tokens it holds a step's votes, then its tokens).  LDS behind the waves' regions: class offsets [16] |
 // budgets by class [B rounded to 4] | tie classes [classes][NV + 1] | truth sums [classes] | token sums [classes] (64-bit).
 constexpr int sort_prefix_threads(int nv) { return 512; }
 template <int NV, bool TOK>
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
 
     const uint32_t rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32*)(lds + (int64_t)wid * a.wave_lds_words));
     const uint32_t img_bytes = 64u * PS * 16u;
-    const uint32_t tru_off = img_bytes * (TOK ? 2u : 1u);
+    const uint32_t tru_off = img_bytes;                               // (with tokens the ONE image holds the votes, then the tokens of a step)
     uint32_t off[QMAX];
     {
         uint32_t c = (uint32_t)lane / PS, k = (uint32_t)lane - c * PS;
@@ -138,19 +138,18 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
     const int64_t wave = sv_uniform64((int64_t)blockIdx.x * NW + wid);
     const int64_t nsteps = (a.P + 63) / 64;
     const int64_t total_bytes = a.P * (int64_t)rowbytes;
-    auto issue = [&](int64_t st) {                                   // the copy of step st's 64 rows into this wave's image(s), and its truths
+    // the copy of step st's 64 rows -- its votes, or (tok) its tokens -- into this wave's image
+    auto issue = [&](int64_t st, bool tok = false) {
         const int64_t byte0 = st * 64 * (int64_t)rowbytes;
         const int64_t rem = total_bytes - byte0 - 16;
         const uint32_t lim = rem > 0x7fffffffll ? 0x7fffffffu : (uint32_t)rem;
-        const char* g = reinterpret_cast<const char*>(a.answers) + byte0;
-        const char* gt = TOK ? reinterpret_cast<const char*>(a.tokens) + byte0 : nullptr;
+        const char* g = reinterpret_cast<const char*>(tok ? a.tokens : a.answers) + byte0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) {
             if ((uint32_t)q < PS) {
                 const uint32_t o = off[q] < lim ? off[q] : lim;
                 sv_dma16(g, o, rbase + (uint32_t)q * 1024u);
-                if (TOK) sv_dma16(gt, o, rbase + img_bytes + (uint32_t)q * 1024u);
             }
         }
     };
@@ -297,51 +296,6 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
             w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
             w[NP + 4 * k] = h.x; w[NP + 4 * k + 1] = h.y; w[NP + 4 * k + 2] = h.z; w[NP + 4 * k + 3] = h.w;
         }
-        int64_t* const ctok_row = (TOK && a.cell_tokens) ? a.cell_tokens + (st * 64 + lane) * (int64_t)B : nullptr;
-        if constexpr (TOK) {
-            // running token sum in index order; the classes take their snapshots (no sort involved: written and counted right here)
-            // (the [64][B] token sums leave like the records: through the votes image -- its rows are in registers --, in memory order)
-            const bool tstaged = (uint32_t)B <= PS;
-            const uint32_t ltok = rbase + (uint32_t)lane * (uint32_t)B * 8u;
-            auto tok_class = [&](int c, long long v) {
-                if (cb[c + 1] > cb[c]) {
-                    toks[c] += live ? v : 0ll;
-                    if (a.cell_tokens) {
-                        for (int32_t j = cb[c]; j < cb[c + 1]; ++j) {
-                            const int32_t b = __builtin_amdgcn_readfirstlane(ordl[j]);
-                            if (tstaged) *reinterpret_cast<lds_v2u*>((uintptr_t)(ltok + (uint32_t)b * 8u)) = scv_v2u{(uint32_t)(unsigned long long)v, (uint32_t)((unsigned long long)v >> 32)};
-                            else if (live) ctok_row[b] = v;
-                        }
-                    }
-                }
-            };
-            tok_class(0, 0ll);
-            long long run = 0;
-#pragma unroll
-            for (int k = 0; k < RSM; ++k) {
-                if ((uint32_t)k < RS) {
-                    const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + img_bytes + 16u * k));
-                    const int32_t y[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        run += (long long)y[e];
-                        const int idx1 = 4 * k + e + 1;                   // votes summed so far (a constant after unrolling)
-                        if ((idx1 & (idx1 - 1)) == 0 && idx1 <= NP) tok_class(1 + __builtin_ctz((unsigned)idx1), run);
-                    }
-                }
-            }
-            tok_class(CF, run);
-            if (a.cell_tokens && tstaged) {
-                char* const out = reinterpret_cast<char*>(a.cell_tokens + st * 64 * (int64_t)B);
-                const uint32_t ntok = live_rows * (uint32_t)B;
-                for (int32_t i = 0; 2 * 64 * i < 64 * B; ++i) {           // 16 bytes = two sums per lane and piece
-                    const uint32_t k = (uint32_t)i * 64u + (uint32_t)lane;
-                    const scv_v4u two = *reinterpret_cast<lds_v4u*>((uintptr_t)(rbase + k * 16u));
-                    if (2u * k + 1u < ntok) __builtin_nontemporal_store(two, reinterpret_cast<scv_v4u*>(out) + k);
-                    else if (2u * k < ntok) *reinterpret_cast<scv_v2u*>(out + (size_t)k * 16u) = scv_v2u{two.x, two.y};
-                }
-            }
-        }
         uint32_t R[NP];
 #pragma unroll
         for (int r = 0; r < NP; ++r) R[r] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(w[r], w[r + NP]));
@@ -391,7 +345,8 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
         const int64_t nrem = total_bytes - nbyte0 - 16;
         const uint32_t nlim = nrem > 0x7fffffffll ? 0x7fffffffu : (nrem < 0 ? 0u : (uint32_t)nrem);
         const char* const ng = reinterpret_cast<const char*>(a.answers) + nbyte0;
-        if (have_next) {
+        if constexpr (TOK) issue(st, true);                          // this step's TOKENS follow its votes through the image while the votes are sorted
+        else if (have_next) {
             if (spread) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_truth(st + nwaves); }
             else { issue(st + nwaves); issue_truth(st + nwaves); }
         }
@@ -435,6 +390,58 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
             }
         }
         SP_STAMP(3);
+        if constexpr (TOK) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tokens have landed
+            int64_t* const ctok_row = a.cell_tokens ? a.cell_tokens + (st * 64 + lane) * (int64_t)B : nullptr;
+            {
+                // running token sum in index order: the sums of the first 1, 2, 4 ... NV / 2 tokens and of all N.  (The step's tokens were
+                // copied into the image while its votes were sorted.)  Every row is read before anything is staged: the [64][B] sums leave
+                // like the records -- through the same image, in memory order.
+                long long snap[LG + 2];
+                long long run = 0;
+#pragma unroll
+                for (int k = 0; k < RSM; ++k) {
+                    if ((uint32_t)k < RS) {
+                        const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k));
+                        const int32_t y[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            run += (long long)y[e];
+                            const int idx1 = 4 * k + e + 1;               // tokens summed so far (a constant after unrolling)
+                            if ((idx1 & (idx1 - 1)) == 0 && idx1 <= NP) snap[__builtin_ctz((unsigned)idx1)] = run;
+                        }
+                    }
+                }
+                snap[LG + 1] = run;
+                const bool tstaged = (uint32_t)B <= PS;
+                const uint32_t ltok = rbase + (uint32_t)lane * (uint32_t)B * 8u;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if (cb[c + 1] > cb[c]) {
+                        const long long v = c == 0 ? 0ll : snap[c - 1];
+                        toks[c] += live ? v : 0ll;
+                        if (a.cell_tokens) {
+                            for (int32_t j = cb[c]; j < cb[c + 1]; ++j) {
+                                const int32_t b = __builtin_amdgcn_readfirstlane(ordl[j]);
+                                if (tstaged) *reinterpret_cast<lds_v2u*>((uintptr_t)(ltok + (uint32_t)b * 8u)) = scv_v2u{(uint32_t)(unsigned long long)v, (uint32_t)((unsigned long long)v >> 32)};
+                                else if (live) ctok_row[b] = v;
+                            }
+                        }
+                    }
+                }
+                if (a.cell_tokens && tstaged) {
+                    char* const out = reinterpret_cast<char*>(a.cell_tokens + st * 64 * (int64_t)B);
+                    const uint32_t ntok = live_rows * (uint32_t)B;
+                    for (int32_t i = 0; 2 * 64 * i < 64 * B; ++i) {       // 16 bytes = two sums per lane and piece
+                        const uint32_t k = (uint32_t)i * 64u + (uint32_t)lane;
+                        const scv_v4u two = *reinterpret_cast<lds_v4u*>((uintptr_t)(rbase + k * 16u));
+                        if (2u * k + 1u < ntok) __builtin_nontemporal_store(two, reinterpret_cast<scv_v4u*>(out) + k);
+                        else if (2u * k < ntok) *reinterpret_cast<scv_v2u*>(out + (size_t)k * 16u) = scv_v2u{two.x, two.y};
+                    }
+                }
+            }
+            if (have_next) { issue(st + nwaves); issue_truth(st + nwaves); }
+        }
         if (cb[CF + 1] > cb[CF]) {
             const SortedStats s = sv_scan<NP>(R, tcmp | (tcmp << 16));
             const uint32_t n_modes = s.at_max - ((NV == 64 && s.max_run == 1u) ? (uint32_t)(NV - N) : 0u);
