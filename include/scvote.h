@@ -125,7 +125,7 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  *                         2 the cell kernels on pool rows (pools <= 4096) | 3 one streaming pass, a histogram snapshot per boundary |
  *                         4 one pass per problem over its pool row, 16 / 32 / 64 lanes per problem, every budget a snapshot of the running
  *                         mode statistics (pools <= 4096: auto above 64 votes and for budget lists too long for path 1; "reg_shape" = 16 / 32 forces the lanes per problem)
- *                         auto includes: pools of 17 .. 64 votes (N % 4 == 0) whose budgets are all 0, a power of two <= 16 (pools <= 32) / <= 32, or
+ *                         auto includes: pools of 17 .. 128 votes (N % 4 == 0) whose budgets are all 0, a power of two <= 16 / 32 / 64 (pools <= 32 / 64 / 128), or
  *                         >= N come out of ONE sort per problem (scv_sort_prefix).  A HOST-mode call reads the budgets; a DEVICE-mode call queues that
  *                         kernel in front of the general one and the two decide from n_valid which of them does the work (~4 us for the one that
  *                         leaves).  | 5 = auto, and the caller PROMISES budgets of that form for such pools: a DEVICE-mode call queues scv_sort_prefix

@@ -834,7 +834,7 @@ int launch_prefix_pool(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
     return SCV_OK;
 }
 
-// Budgets that are powers of two (and the whole row) over pools of 17 .. 64 votes: every budget out of ONE sort per problem
+// Budgets that are powers of two (and the whole row) over pools of 17 .. 128 votes: every budget out of ONE sort per problem
 // (scv_sort_prefix, scvote_sort_prefix.hip.h).  Returns through *queued whether the kernel was launched; the kernel itself leaves without
 // side effects when some budget is not of that form (the caller then queues the general kernel behind it, a.skip_sortable = *nv_out).
 int launch_sort_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, const int32_t* n_valid, const int32_t* truth,
@@ -893,7 +893,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     size_t lane_lds = 0;
     const bool lane_ok = prefix_lane_eligible(ctx, B, N, tokens != nullptr, &lane_nv, &lane_lds, &lane_threads) && (ctx->prefix_path == 0 || ctx->prefix_path == 1 || ctx->prefix_path == 5);
     const bool rows_aligned = (N % 4 == 0) && (((uintptr_t)pool & 15u) == 0) && (!tokens || ((uintptr_t)tokens & 15u) == 0);
-    // pools of 17 .. 64 votes, budgets that are powers of two (the reference's own, o1.py:274-277): every budget out of one sort per problem.
+    // pools of 17 .. 128 votes, budgets that are powers of two (the reference's own, o1.py:274-277): every budget out of one sort per problem.
     // The budgets live in n_valid: a HOST-mode call reads them; a DEVICE-mode call queues scv_sort_prefix AND the general kernel -- each
     // decides from n_valid, in its first microsecond, whether the launch is its own.
     int skip_sortable = 0;
@@ -901,7 +901,12 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     bool counters_cleared = false;
     const bool want_any_counters = tie || truth_sum || (tokens && tok_sum);
     if (ctx->path == 0 && (ctx->prefix_path == 0 || ctx->prefix_path == 5) && ctx->sort_n_max >= 64 && ctx->fused_counters_max != 0 && rows_aligned &&
-        N > 16 && N <= 128 && B <= scv::kMaxSortedB) {
+        N > 16 && N <= 128 && B <= scv::kMaxSortedB &&
+        // pools of 68 .. 128 votes (scv_sort_prefix2: two sorts, a merge and a 128-vote scan per step) pay ~36 us for a launch of one step per wave:
+        // measured against scv_prefix_pool it wins from ~1e5 pools (2e5: 64 against 84 us, 8e5: 183 against 297; 3e4: 153 against 69 in HOST-mode
+        // chunks), and with tokens (two images: four waves per CU) it does not win at all (2e5: 114 against 114) -- not used there
+        // (prefix_path = 5 selects it for any number of token-less pools)
+        (N <= 64 || (!tokens && (P >= 98304 || ctx->prefix_path == 5)))) {
         // prefix_path = 5: the caller PROMISES budgets of that form (a DEVICE-mode call then queues scv_sort_prefix alone; a list that breaks
         // the promise is an error, reported like a domain error at the next synchronisation)
         const bool promised = ctx->prefix_path == 5;

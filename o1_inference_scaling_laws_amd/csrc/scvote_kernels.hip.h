@@ -11,7 +11,7 @@
 // (scv_sort_cells -- one lane per cell, rows by LDS-DMA, packed sorting network: csrc/scvote_sort.hip.h -- 5 / 8 <= N <= 64.)
 // scv_lane_prefix, scv_prefix_hist  budgets that are prefixes of one sample pool, one pass: pools of up to 64 votes / beyond 4096
 // (scv_prefix_pool -- G lanes per problem, ranks from returning LDS atomics: csrc/scvote_prefix.hip.h -- 65 .. 4096 votes).
-// (scv_sort_prefix -- one lane per problem, power-of-two budgets out of one sort: csrc/scvote_sort_prefix.hip.h -- pools of 17 .. 64 votes.)
+// (scv_sort_prefix -- one lane per problem, power-of-two budgets out of one sort: csrc/scvote_sort_prefix.hip.h -- pools of 17 .. 128 votes; 68 .. 128 in two halves: scv_sort_prefix2.)
 // scv_reduce_cells    per-budget integer counters from the cell table when cells are short and many.
 // scv_bootstrap_k     problem-level bootstrap over the per-cell table.
 // scv_synth_fill_k    closed-form synthetic generator (spec: include/scvote.h).

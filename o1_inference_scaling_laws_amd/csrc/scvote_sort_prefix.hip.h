@@ -1,4 +1,4 @@
-// scvote_sort_prefix.hip.h -- prefix budgets over SHORT pools (17 .. 64 votes), the budgets of the reference itself: powers of two.
+// scvote_sort_prefix.hip.h -- prefix budgets over SHORT pools (17 .. 128 votes: every pool the reference forms), the budgets of the reference itself: powers of two.
 //
 // The reference's sweep (/root/reference/o1.py:274-277): the budgets of a problem are majority votes over the first 1, 2, 4 ... N samples
 // of ONE list of completions.  scv_sort_cells sorts a cell's votes in registers with Batcher's odd-even mergesort: after the merge phase
@@ -508,6 +508,9 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
 // 10 VALU per vote, no keys kept.  Per step: phase A = wait, rows A -> registers, the previous step's records leave through the image, copy B,
 // sort A with the block scans, scan 64; phase B = wait, rows B -> registers, the token sums leave through the image, copy the next A, sort B,
 // merge, scan 128.  Classes: 0 | 1 + j for 2^j votes, j = 0 .. 6 | 8 = all N votes.
+// A launch of ONE step per wave takes ~36 us (two copies, two sorts, a merge and a 128-vote dependent scan in sequence; scv_prefix_pool: 13 us):
+// the host takes this kernel from ~1e5 pools (2e5: 64 against 84 us, 8e5: 183 against 297).  The token form (a second image: four waves per CU)
+// measured equal to scv_prefix_pool at 2e5 pools (114 us both) and is not instantiated.
 template <int NP>
 __device__ __forceinline__ void sv_flip_files(uint32_t (&A)[NP], uint32_t (&Bv)[NP]) {
 #pragma unroll

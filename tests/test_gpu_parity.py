@@ -833,8 +833,8 @@ def test_prefix_budgets_over_short_pools_run_on_the_cell_kernels(hip_engine, dis
         nv = np.array(nv, dtype=np.int32)
         want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
         stat = "prefix_lane" if N <= 64 else "prefix_pool"           # one lane per problem / one pass per problem over G lanes
-        if 16 < N <= 128 and N % 4 == 0 and all(n == 0 or n >= N or (n & (n - 1) == 0 and n <= (16 if N <= 32 else (32 if N <= 64 else 64))) for n in nv.tolist()):
-            stat = "prefix_sort"                                     # powers of two (and the whole row): one sort per problem
+        if 16 < N <= 64 and N % 4 == 0 and all(n == 0 or n >= N or (n & (n - 1) == 0 and n <= (16 if N <= 32 else 32)) for n in nv.tolist()):
+            stat = "prefix_sort"                                     # powers of two (and the whole row): one sort per problem (pools of 68 .. 128: from ~1e5 pools)
         before = hip_engine.stat(stat)
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
         assert hip_engine.stat(stat) == before + 1
@@ -943,22 +943,49 @@ def test_prefix_budgets_that_are_powers_of_two_come_out_of_one_sort(hip_engine, 
     pool, tpool = a[:, 0, :], t[:, 0, :]
     dev = torch.device("cuda:0")
     dpool, dtok, dtr = torch.from_numpy(pool.copy()).to(dev), torch.from_numpy(tpool.copy()).to(dev), torch.from_numpy(tr).to(dev)
+    # pools of 68 .. 128 votes: scv_sort_prefix2 pays ~36 us for a launch of one step per wave and has no token form -- auto takes it from ~1e5
+    # token-less pools (test_prefix_pools_of_128_votes_take_the_sort_kernel_when_there_are_many), prefix_path = 5 selects it for any number
+    big = N > 64
     for mk in SORT_PREFIX_BUDGETS:
+        if big:
+            hip_engine.set_option("prefix_path", 5)                  # (every _with_options block below ends with the defaults)
         nv = np.array(mk(N), dtype=np.int32)
         want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
         before, lane0 = hip_engine.stat("prefix_sort"), hip_engine.stat("prefix_lane")
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
-        assert hip_engine.stat("prefix_sort") == before + 2 and hip_engine.stat("prefix_lane") == lane0      # HOST mode: this kernel alone
+        assert hip_engine.stat("prefix_sort") == before + (1 if big else 2) and hip_engine.stat("prefix_lane") == lane0      # HOST mode: this kernel alone
         got = hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool, want_cells=False)                       # no cell table
         assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum) and np.array_equal(got.truth_count_sum, want.truth_count_sum)
-        with _with_options(hip_engine, {"grid": 1}):                                                           # one workgroup walks every step
-            assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+        with _with_options(hip_engine, {"grid": 1, "prefix_path": 5 if big else 0}):                           # one workgroup walks every step
+            assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=None if big else tpool), want, check_tokens=not big)
+        if big:
+            hip_engine.set_option("prefix_path", 5)
         for tk in (None, dtok):                                                                                 # DEVICE mode: both kernels queued
             c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, torch.from_numpy(nv).to(dev), tokens=tk)
             hip_engine.sync()
             got = AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells), None if tk is None else ctok.cpu().numpy())
             assert_results_equal(got, want, check_tokens=tk is not None)
+    if big and P >= 3:                                              # out-of-domain votes in either half, seen only by the budgets that reach them
+        hip_engine.set_option("prefix_path", 5)
+        badp = pool.copy()
+        badp[P // 2, N - 1] = 4097
+        ok = np.array([1, 32, 64], dtype=np.int32)
+        assert_results_equal(hip_engine.aggregate_prefix(badp, tr, ok), OracleEngine().aggregate_prefix(pool, tr, ok), check_tokens=False)
+        with pytest.raises(_lib.DomainError):
+            hip_engine.aggregate_prefix(badp, tr, np.array([64, N], dtype=np.int32))
+        badp = pool.copy()
+        badp[P - 1, 40] = -3
+        assert_results_equal(hip_engine.aggregate_prefix(badp, tr, np.array([1, 32], dtype=np.int32)), OracleEngine().aggregate_prefix(pool, tr, np.array([1, 32], dtype=np.int32)), check_tokens=False)
+        with pytest.raises(_lib.DomainError):
+            hip_engine.aggregate_prefix(badp, tr, np.array([64], dtype=np.int32))
+    hip_engine.set_option("prefix_path", 0)
+    if big:                                                         # (auto: few pools of this length stay on the one-pass kernel)
+        nv = np.array(SORT_PREFIX_BUDGETS[0](N), dtype=np.int32)
+        before = hip_engine.stat("prefix_sort")
+        assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), OracleEngine().aggregate_prefix(pool, tr, nv), check_tokens=False)
+        assert hip_engine.stat("prefix_sort") == before
+        return
     # a list with a budget that is neither: HOST mode does not queue the kernel, DEVICE mode queues it and it leaves the launch alone
     nv = np.array([1, 2, 3, N], dtype=np.int32)
     want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
@@ -992,6 +1019,37 @@ def test_prefix_budgets_that_are_powers_of_two_come_out_of_one_sort(hip_engine, 
         assert_results_equal(hip_engine.aggregate_prefix(bad, tr, np.array([1, 32], dtype=np.int32)), OracleEngine().aggregate_prefix(pool, tr, np.array([1, 32], dtype=np.int32)), check_tokens=False)
         with pytest.raises(_lib.DomainError):
             hip_engine.aggregate_prefix(bad, tr, np.array([1, 32, N], dtype=np.int32))
+
+
+def test_prefix_pools_of_128_votes_take_the_sort_kernel_when_there_are_many(hip_engine):
+    """The reference's largest pool (o1.py:266-276: T = 2^18 -> N = 128 samples, budgets 1, 2, 4 ... 128): from ~1e5 token-less pools auto
+    dispatch queues scv_sort_prefix2 (DEVICE memory: a HOST-mode call of this size is staged in chunks, each a launch of its own); bit-exact vs
+    the oracle, D1 and D3; a call with tokens and a smaller call stay on the one-pass kernel."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import AggregateResult
+    dev = torch.device("cuda:0")
+    P, N = 100_032, 128
+    nv = np.array([1, 2, 4, 8, 16, 32, 64, 128], dtype=np.int32)
+    dnv = torch.from_numpy(nv).to(dev)
+    for dist in (1, 3):
+        a, t, tr = coracle.synth_fill(P, 1, N, 77 + dist, dist, want_tokens=True)
+        pool, tpool = np.ascontiguousarray(a[:, 0, :]), np.ascontiguousarray(t[:, 0, :])
+        want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
+        dpool, dtok, dtr = torch.from_numpy(pool).to(dev), torch.from_numpy(tpool).to(dev), torch.from_numpy(tr).to(dev)
+        before = hip_engine.stat("prefix_sort")
+        c, cells, _ = hip_engine.aggregate_prefix_device(dpool, dtr, dnv)
+        hip_engine.sync()
+        assert hip_engine.stat("prefix_sort") == before + 1
+        assert_results_equal(AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells)), want, check_tokens=False)
+        c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, dnv, tokens=dtok)                 # with tokens: the one-pass kernel
+        hip_engine.sync()
+        assert hip_engine.stat("prefix_sort") == before + 1
+        assert_results_equal(AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells), ctok.cpu().numpy()), want)
+        c, cells, _ = hip_engine.aggregate_prefix_device(dpool[:50_000], dtr[:50_000], dnv)               # fewer pools: the one-pass kernel
+        hip_engine.sync()
+        assert hip_engine.stat("prefix_sort") == before + 1
+        small = OracleEngine().aggregate_prefix(pool[:50_000], tr[:50_000], nv)
+        assert_results_equal(AggregateResult.from_counters(c.cpu().numpy(), 50_000, len(nv), cells_from_torch(cells)), small, check_tokens=False)
 
 
 def test_prefix_mode_device_and_errors(hip_engine):
