@@ -4,7 +4,7 @@
 namespace scv {
 // nv: votes per lane (32 / 64; 128: the two-phase kernel scv_sort_prefix2); .waves = the launch bound in waves
 RegKernel pick_sort_prefix_kernel(int nv, bool tok) {
-    if (nv == 128) return RegKernel{(KernelFn)scv_sort_prefix2<false>, sort_prefix2_threads(false) / 64};        // (no tokens: see launch_prefix)
+    if (nv == 128) return RegKernel{(KernelFn)scv_sort_prefix2, sort_prefix2_threads() / 64};                  // (no tokens: see launch_prefix)
     if (nv == 32) return tok ? RegKernel{(KernelFn)scv_sort_prefix<32, true>, sort_prefix_threads(32) / 64} : RegKernel{(KernelFn)scv_sort_prefix<32, false>, sort_prefix_threads(32) / 64};
     return tok ? RegKernel{(KernelFn)scv_sort_prefix<64, true>, sort_prefix_threads(64) / 64} : RegKernel{(KernelFn)scv_sort_prefix<64, false>, sort_prefix_threads(64) / 64};
 }

@@ -506,11 +506,10 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
 // each file is a bitonic sequence of 64: the stage between the halves of a register, five lockstep stages).  maj@N is a run scan of the 128
 // sorted values in plain 32-bit arithmetic (run lengths up to 128 do not fit the packed scan's 6-bit field): running (length, best, count, value),
 // 10 VALU per vote, no keys kept.  Per step: phase A = wait, rows A -> registers, the previous step's records leave through the image, copy B,
-// sort A with the block scans, scan 64; phase B = wait, rows B -> registers, the token sums leave through the image, copy the next A, sort B,
-// merge, scan 128.  Classes: 0 | 1 + j for 2^j votes, j = 0 .. 6 | 8 = all N votes.
+// sort A with the block scans, scan 64; phase B = wait, rows B -> registers, copy the next A, sort B, merge, scan 128.  Classes: 0 | 1 + j for 2^j votes, j = 0 .. 6 | 8 = all N votes.
 // A launch of ONE step per wave takes ~36 us (two copies, two sorts, a merge and a 128-vote dependent scan in sequence; scv_prefix_pool: 13 us):
-// the host takes this kernel from ~1e5 pools (2e5: 64 against 84 us, 8e5: 183 against 297).  The token form (a second image: four waves per CU)
-// measured equal to scv_prefix_pool at 2e5 pools (114 us both) and is not instantiated.
+// the host takes this kernel from ~1e5 pools (2e5: 64 against 84 us, 8e5: 183 against 297).  A token form (a second image: four waves per CU)
+// measured equal to scv_prefix_pool at 2e5 pools (114 us both) and was removed: calls with tokens stay on scv_prefix_pool.
 template <int NP>
 __device__ __forceinline__ void sv_flip_files(uint32_t (&A)[NP], uint32_t (&Bv)[NP]) {
 #pragma unroll
@@ -580,12 +579,11 @@ __device__ __forceinline__ BlockStats sv_scan_block_running(const uint32_t (&R)[
     return BlockStats{best, cnt, minv};
 }
 
-constexpr int sort_prefix2_threads(bool tok) { return tok ? 256 : 512; }
+constexpr int sort_prefix2_threads() { return 512; }
 
 // Host contract: 64 < N <= 128, N % 4 == 0, 16-byte aligned bases, B <= kMaxSortedB, every budget 0, a power of two <= 64 or >= N (checked
-// here: a list that is not leaves the launch to the kernel queued behind it); a.wave_lds_words = 64 * 17 * 4 (twice with tokens) + 64.
-template <bool TOK>
-__global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(const AggArgs a) {
+// here: a list that is not leaves the launch to the kernel queued behind it), no tokens stream; a.wave_lds_words = 64 * 17 * 4 + 64.
+__global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const AggArgs a) {
     constexpr int NV = 128, NH = 64, NP = 32, RSH = 16;             // votes per lane; per half; packed registers per half; 16-byte slots per half row
     constexpr uint32_t PS = 17u;                                     // slots of a padded half row in the image
     constexpr int TC = NV + 1;
@@ -603,7 +601,7 @@ __global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(co
 
     const uint32_t rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32*)(lds + (int64_t)wid * a.wave_lds_words));
     constexpr uint32_t img_bytes = 64u * PS * 16u;
-    const uint32_t tru_off = img_bytes * (TOK ? 2u : 1u);
+    const uint32_t tru_off = img_bytes;
     // slot s = 64 q + lane of the image is chunk k = s % 17 of row c = s / 17; s += 64 is (c, k) += (3, 13) with a carry: walked again by every
     // copy (17 registers of offsets held across the loop were the registers the kernel did not have)
     const uint32_t c0 = (uint32_t)lane / PS, k0 = (uint32_t)lane - c0 * PS;
@@ -617,7 +615,6 @@ __global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(co
         const int64_t rem = total_bytes - byte0 - 16;
         const uint32_t lim = rem > 0x7fffffffll ? 0x7fffffffu : (uint32_t)rem;
         const char* g = reinterpret_cast<const char*>(a.answers) + byte0;
-        const char* gt = TOK ? reinterpret_cast<const char*>(a.tokens) + byte0 : nullptr;
         const uint32_t kmax = h ? RSB - 1u : (uint32_t)RSH - 1u, add = h ? 256u : 0u;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the rows of the image's previous content are in registers, staged tables have left)
         uint32_t cr = c0 * rowbytes + add, kq = k0;
@@ -626,7 +623,6 @@ __global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(co
             uint32_t o = cr + (kq < kmax ? kq : kmax) * 16u;
             o = o < lim ? o : lim;
             sv_dma16(g, o, rbase + (uint32_t)q * 1024u);
-            if (TOK) sv_dma16(gt, o, rbase + img_bytes + (uint32_t)q * 1024u);
             kq += 64u - 3u * PS; cr += 3u * rowbytes;
             if (kq >= PS) { kq -= PS; cr += rowbytes; }
         }
@@ -697,13 +693,12 @@ __global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(co
     for (int c = 1; c < CF; ++c) if (cb[c + 1] > cb[c]) nmax = 1 << (c - 1);
     if (cb[CF + 1] > cb[CF]) nmax = N;
     const bool want_full = cb[CF + 1] > cb[CF];
-    const bool need_b = want_full || TOK;                            // (no budget beyond 64 votes and no token sums: half B is never read)
+    const bool need_b = want_full;                                   // (no budget beyond 64 votes: half B is never read)
 
     uint32_t tcs[NC];
     uint32_t h1[NC];
-    long long toks[TOK ? NC : 1];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { tcs[c] = 0; h1[c] = 0; if (TOK) toks[c] = 0; }
+    for (int c = 0; c < NC; ++c) { tcs[c] = 0; h1[c] = 0; }
     uint32_t bad = 0;
     // the previous step's records, packed: D[c] = max_count | truth_count << 8 | n_modes << 16 | hit << 31; min_mode (10 bits) of class c
     // in Dm[c / 3] at bit 10 (c % 3)
@@ -758,21 +753,6 @@ __global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(co
         for (int k = 0; k < RSH; ++k) {
             const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k));
             w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
-        }
-        long long tsnap[TOK ? 8 : 1];                                // token sums of the first 1, 2, 4 .. 64 votes; [7] grows into the whole row's
-        if constexpr (TOK) {
-            long long run = 0;
-#pragma unroll
-            for (int k = 0; k < RSH; ++k) {
-                const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + img_bytes + 16u * k));
-                const int32_t y[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    run += (long long)y[e];
-                    const int idx1 = 4 * k + e + 1;
-                    if ((idx1 & (idx1 - 1)) == 0) tsnap[__builtin_ctz((unsigned)idx1)] = run;
-                }
-            }
         }
         flush_records();                                             // the previous step's records leave through the image: its rows are in registers
         if (need_b) issue_half(st, 1);                               // half B flies while A is sorted
@@ -850,17 +830,6 @@ __global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(co
                 const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * kk));
                 v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
             }
-            if constexpr (TOK) {
-                long long run = tsnap[6];
-#pragma unroll
-                for (int k = 0; k < RSH; ++k) {
-                    if ((uint32_t)k < RSB) {
-                        const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + img_bytes + 16u * k));
-                        run += (long long)(int32_t)q.x + (long long)(int32_t)q.y + (long long)(int32_t)q.z + (long long)(int32_t)q.w;
-                    }
-                }
-                tsnap[7] = run;
-            }
 #pragma unroll
             for (int r = 0; r < NP; ++r) RB[r] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(v[r], v[r + NP]));
             uint32_t orv = 0;
@@ -886,35 +855,7 @@ __global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(co
                 }
             }
         }
-        // the image is free: this step's token sums leave through it, then the next step's half A is copied
-        if constexpr (TOK) {
-            const uint32_t ltok = rbase + (uint32_t)lane * (uint32_t)B * 8u;
-            int64_t* const ctok_row = a.cell_tokens ? a.cell_tokens + (st * 64 + lane) * (int64_t)B : nullptr;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                if (cb[c + 1] > cb[c]) {
-                    const long long v = c == 0 ? 0ll : (c == CF ? tsnap[7] : tsnap[c - 1]);
-                    toks[c] += live ? v : 0ll;
-                    if (a.cell_tokens) {
-                        for (int32_t j = cb[c]; j < cb[c + 1]; ++j) {
-                            const int32_t b = __builtin_amdgcn_readfirstlane(ordl[j]);
-                            if (staged) *reinterpret_cast<lds_v2u*>((uintptr_t)(ltok + (uint32_t)b * 8u)) = scv_v2u{(uint32_t)(unsigned long long)v, (uint32_t)((unsigned long long)v >> 32)};
-                            else if (live) ctok_row[b] = v;
-                        }
-                    }
-                }
-            }
-            if (a.cell_tokens && staged) {
-                char* const out = reinterpret_cast<char*>(a.cell_tokens + st * 64 * (int64_t)B);
-                const uint32_t ntok = live_rows * (uint32_t)B;
-                for (int32_t i = 0; 2 * 64 * i < 64 * B; ++i) {
-                    const uint32_t k = (uint32_t)i * 64u + (uint32_t)lane;
-                    const scv_v4u two = *reinterpret_cast<lds_v4u*>((uintptr_t)(rbase + k * 16u));
-                    if (2u * k + 1u < ntok) __builtin_nontemporal_store(two, reinterpret_cast<scv_v4u*>(out) + k);
-                    else if (2u * k < ntok) *reinterpret_cast<scv_v2u*>(out + (size_t)k * 16u) = scv_v2u{two.x, two.y};
-                }
-            }
-        }
+        // the image is free: the next step's half A is copied
         if (st + nwaves < nsteps) { issue_half(st + nwaves, 0); issue_truth(st + nwaves); }
         if (want_full) {
             if (nB != (uint32_t)NH) {                                // slots behind the row: distinct sentinels behind every vote
@@ -941,18 +882,15 @@ __global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(co
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     flush_records();
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
-    const bool counters = a.tie_hits || a.truth_sum || (TOK && a.token_sum);
+    const bool counters = a.tie_hits || a.truth_sum;
     if (counters) {
 #pragma unroll
         for (int c = 1; c < NC; ++c) {
             if (cb[c + 1] > cb[c]) {
                 const long long ts = wave_sum_i64((long long)tcs[c]);
-                long long tk = 0;
-                if (TOK) tk = wave_sum_i64(toks[c]);
                 if (lane == 0) {
                     if (h1[c]) atomicAdd(&tie[c * TC + 1], h1[c]);
                     if (ts) atomicAdd(&acc[c], (unsigned long long)ts);
-                    if (TOK && tk) atomicAdd(&acc[NC + c], (unsigned long long)tk);
                 }
             }
         }
@@ -968,7 +906,6 @@ __global__ __launch_bounds__(sort_prefix2_threads(TOK)) void scv_sort_prefix2(co
             int c = 0;
             while (c < NC - 1 && j >= cbeg[c + 1]) ++c;
             if (a.truth_sum && acc[c]) atomicAdd(&a.truth_sum[ordl[j]], acc[c]);
-            if (TOK && a.token_sum && acc[NC + c]) atomicAdd(&a.token_sum[ordl[j]], acc[NC + c]);
         }
     }
 }
