@@ -1021,6 +1021,35 @@ def test_prefix_budgets_that_are_powers_of_two_come_out_of_one_sort(hip_engine, 
             hip_engine.aggregate_prefix(bad, tr, np.array([1, 32, N], dtype=np.int32))
 
 
+@pytest.mark.parametrize("N,B", [(64, 65), (64, 200), (32, 130), (128, 100), (48, 512)])
+def test_sort_prefix_with_more_budgets_than_lanes(hip_engine, N, B):
+    """More than 64 budgets: the classes are worked out by the whole workgroup (ranks in LDS) instead of one wave's registers, and a list longer
+    than the image (B > N / 4 + 1 records per problem) is written straight from the lanes instead of through the image.  Budgets drawn from
+    the forms the kernel serves (0, powers of two, N, beyond N), repeated and unsorted; HOST and DEVICE memory, with tokens where the shape has
+    a token form."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import AggregateResult
+    rng = np.random.default_rng(N * 1000 + B)
+    P = 777
+    a, t, tr = coracle.synth_fill(P, 1, N, 5 + B, int(rng.integers(0, 6)), want_tokens=True)
+    pool, tpool = np.ascontiguousarray(a[:, 0, :]), np.ascontiguousarray(t[:, 0, :])
+    forms = [0, N, N + 7] + [1 << k for k in range(8) if (1 << k) <= _sort_prefix_top(N)]
+    nv = rng.choice(forms, size=B).astype(np.int32)
+    want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
+    tok = N <= 64
+    with _with_options(hip_engine, {"prefix_path": 5}):
+        before = hip_engine.stat("prefix_sort")
+        assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool if tok else None), want, check_tokens=tok)
+        assert hip_engine.stat("prefix_sort") == before + 1
+        dev = torch.device("cuda:0")
+        c, cells, ctok = hip_engine.aggregate_prefix_device(torch.from_numpy(pool).to(dev), torch.from_numpy(tr).to(dev), torch.from_numpy(nv).to(dev),
+                                                            tokens=torch.from_numpy(tpool).to(dev) if tok else None)
+        hip_engine.sync()
+        assert hip_engine.stat("prefix_sort") == before + 2
+        got = AggregateResult.from_counters(c.cpu().numpy(), P, B, cells_from_torch(cells), ctok.cpu().numpy() if tok else None)
+        assert_results_equal(got, want, check_tokens=tok)
+
+
 def test_prefix_pools_of_128_votes_take_the_sort_kernel_when_there_are_many(hip_engine):
     """The reference's largest pool (o1.py:266-276: T = 2^18 -> N = 128 samples, budgets 1, 2, 4 ... 128): from ~1e5 token-less pools auto
     dispatch queues scv_sort_prefix2 (DEVICE memory: a HOST-mode call of this size is staged in chunks, each a launch of its own); bit-exact vs
