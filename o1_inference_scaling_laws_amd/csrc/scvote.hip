@@ -860,7 +860,8 @@ int launch_sort_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
     a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
-    a.prefetch = promised ? 1 : 0; a.sorted = 1;                    // (prefetch: here "the caller promised budgets of this kernel's form")
+    a.prefetch = 0; a.sorted = 1;
+    a.budgets_promised = promised ? 1 : 0;
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.acc_classes = 0;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr;
     a.wave_lds_words = (int32_t)region_words;

@@ -90,6 +90,8 @@ struct AggArgs {
     long long* partial_tok; // split-N: [ncells * segs] partial token sums
     int32_t skip_sortable = 0;      // prefix kernels queued BEHIND scv_sort_prefix<NV> (DEVICE mode: the host cannot read n_valid): = NV; the
                                     // launch leaves at once when every budget is of the form that kernel serves (it has done the work)
+    int32_t budgets_promised = 0;   // scv_sort_prefix: != 0 = the budgets are KNOWN to be of its form (read by a HOST-mode call, or promised by the
+                                    // caller: option prefix_path = 5): a list that is not sets error bit 8 instead of leaving the launch to another kernel
 };
 
 // 64-lane reductions on the VALU (DPP), not through the LDS crossbar: __shfl_xor lowers to

@@ -99,6 +99,91 @@ __device__ unsigned long long scv_sp_timeline[8];
 #define SP_STAMP(i) do { } while (0)
 #endif
 
+// ---- shared by the two kernels ---------------------------------------------------------------------------------------------------------
+// The budget CLASSES of the launch: cb[c] = first position of class c in ordl (budgets by class, in LDS), cb[NC] = B; cbeg = the same in LDS for
+// the hand-out at the end.  Returns false when some budget has no class: the launch is not this kernel's (every workgroup finds the same
+// verdict; error bit 8 when the caller had promised such budgets).  Up to 64 budgets (every list of the reference): ONE coalesced load of
+// n_valid per wave, then everything in registers -- counts by ballot, positions by mbcnt, one barrier; longer lists: ranks by the whole
+// workgroup, counts by LDS atomics.  `zeroed` words of LDS behind ordl (the class tables) are cleared on the way.
+template <int NV, int NC>
+__device__ __forceinline__ bool sort_prefix_setup_classes(const AggArgs& a, int32_t* cbeg, int32_t* ordl, uint32_t* zero_from, int zero_words,
+                                                          int32_t (&cb)[NC + 1]) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, T = (int)blockDim.x;
+    const int32_t N = (int32_t)a.N, B = a.B;
+    if (tid < 16) cbeg[tid] = 0;
+    for (int i = tid; i < zero_words; i += T) zero_from[i] = 0;
+    if (B <= 64) {
+        const bool have = lane < B;
+        const int cls = have ? sort_prefix_class<NV>(valid_len(a, lane), N) : NC;
+        if (__any(have && cls < 0)) {                                 // (the general kernel queued behind this one takes the launch ...
+            if (a.budgets_promised && tid == 0) atomicOr(a.err_flag, 8u);   //  ... unless the budgets were promised to be of this form)
+            return false;
+        }
+        uint32_t pos = 0;
+        cb[0] = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            pos = cls == c ? (uint32_t)cb[c] + before : pos;
+            cb[c + 1] = cb[c] + (int32_t)__builtin_popcountll(m);
+        }
+        if (wid == 0 && have) ordl[pos] = lane;
+        if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c <= NC; ++c) cbeg[c] = cb[c];
+        }
+        __syncthreads();
+        return true;
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int b0 = 0; b0 < B; b0 += T) {
+        const int b = b0 + tid;
+        const bool have = b < B;
+        const int c = have ? sort_prefix_class<NV>(valid_len(a, b), N) : 0;
+        bad |= c < 0 ? 1 : 0;
+        // (a list this kernel does not serve: the ranks are not used)
+        const int rank = budget_rank_of<false>(a, b, (int64_t)c, [&](int o) { return sort_prefix_class<NV>(valid_len(a, o), N); });
+        if (have && c >= 0 && rank >= 0 && rank < B) {
+            ordl[rank] = b;
+            atomicAdd(reinterpret_cast<uint32_t*>(cbeg) + c + 1, 1u);
+        }
+    }
+    if (__syncthreads_or(bad)) {
+        if (a.budgets_promised && tid == 0) atomicOr(a.err_flag, 8u);
+        return false;
+    }
+    if (tid == 0) {
+        for (int c = 1; c <= NC; ++c) cbeg[c] += cbeg[c - 1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c <= NC; ++c) cb[c] = __builtin_amdgcn_readfirstlane(cbeg[c]);
+    return true;
+}
+// The classes' counters (tie[NC][TC] hits by tie class, acc[NC] truth sums | acc[NC ..] token sums, all in LDS and complete: call behind a
+// barrier) handed to their budgets: o1.py:238-240 as integers, one device atomic per non-zero word and budget.
+template <int NC, int TC, bool TOK>
+__device__ __forceinline__ void sort_prefix_hand_out_counters(const AggArgs& a, const int32_t* cbeg, const int32_t* ordl, const uint32_t* tie,
+                                                              const unsigned long long* acc) {
+    const int tid = threadIdx.x, T = (int)blockDim.x;
+    const int32_t B = a.B;
+    for (int64_t i = tid; i < (int64_t)B * TC; i += T) {
+        const int32_t j = (int32_t)(i / TC), k = (int32_t)(i - (int64_t)j * TC);
+        int c = 0;
+        while (c < NC - 1 && j >= cbeg[c + 1]) ++c;
+        const uint32_t v = tie[c * TC + k];
+        if (v && a.tie_hits) atomicAdd(&a.tie_hits[(int64_t)ordl[j] * SCV_TIE_CLASSES + k], (unsigned long long)v);
+    }
+    for (int j = tid; j < B; j += T) {
+        int c = 0;
+        while (c < NC - 1 && j >= cbeg[c + 1]) ++c;
+        if (a.truth_sum && acc[c]) atomicAdd(&a.truth_sum[ordl[j]], acc[c]);
+        if (TOK && a.token_sum && acc[NC + c]) atomicAdd(&a.token_sum[ordl[j]], acc[NC + c]);
+    }
+}
+
 // NV: capacity of the shape (32 / 64); host contract: NV / 2 < N <= NV, N % 4 == 0, 16-byte aligned bases, B <= kMaxSortedB,
 // a.wave_lds_words = 64 * PS * 4 + 64, PS = (N / 4) | 1 (one image: with tokens it holds a step's votes, then its tokens).  LDS behind the waves' regions: class offsets [16] |
 // budgets by class [B rounded to 4] | tie classes [classes][NV + 1] | truth sums [classes] | token sums [classes] (64-bit).
@@ -162,62 +247,10 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
 
     int64_t st = wave;
     int32_t cb[NC + 1];
-    if (tid < 16) cbeg[tid] = 0;
-    for (int i = tid; i < NC * TC; i += T) tie[i] = 0;
-    for (int i = tid; i < 2 * NC; i += T) acc[i] = 0;
-    bool issued = false;
-    if (B <= 64) {
-        // Up to 64 budgets (every list of the reference): ONE coalesced load of n_valid per wave, then everything about the classes in
-        // registers -- counts by ballot, positions by mbcnt -- with the first copy already in flight (no further load, one barrier).
-        const bool have = lane < B;
-        int cls = have ? sort_prefix_class<NV>(valid_len(a, lane), N) : NC;
-        if (__any(have && cls < 0)) {                                 // (the general kernel queued behind this one takes the launch ...
-            if (a.prefetch && tid == 0) atomicOr(a.err_flag, 8u);    //  ... unless the caller promised such budgets: option prefix_path = 5)
-            return;
-        }
-        // (the load has returned -- the verdict needed it --: nothing the compiler would wait for with vmcnt(0) follows the copy)
-        if (st < nsteps) { issue(st); issue_truth(st); issued = true; }
-        uint32_t pos = 0;
-        cb[0] = 0;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const unsigned long long m = __ballot(cls == c);
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            pos = cls == c ? (uint32_t)cb[c] + before : pos;
-            cb[c + 1] = cb[c] + (int32_t)__builtin_popcountll(m);
-        }
-        if (wid == 0 && have) ordl[pos] = lane;
-        if (tid == 0) {
-#pragma unroll
-            for (int c = 0; c <= NC; ++c) cbeg[c] = cb[c];
-        }
-        __syncthreads();
-    } else {
-        __syncthreads();
-        int bad = 0;
-        for (int b0 = 0; b0 < B; b0 += T) {
-            const int b = b0 + tid;
-            const bool have = b < B;
-            const int c = have ? sort_prefix_class<NV>(valid_len(a, b), N) : 0;
-            bad |= c < 0 ? 1 : 0;
-            // (a list this kernel does not serve: the ranks are not used)
-            const int rank = budget_rank_of<false>(a, b, (int64_t)c, [&](int o) { return sort_prefix_class<NV>(valid_len(a, o), N); });
-            if (have && c >= 0 && rank >= 0 && rank < B) {
-                ordl[rank] = b;
-                atomicAdd(reinterpret_cast<uint32_t*>(cbeg) + c + 1, 1u);
-            }
-        }
-        if (__syncthreads_or(bad)) {
-            if (a.prefetch && tid == 0) atomicOr(a.err_flag, 8u);
-            return;
-        }
-        if (tid == 0) {
-            for (int c = 1; c <= NC; ++c) cbeg[c] += cbeg[c - 1];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c <= NC; ++c) cb[c] = __builtin_amdgcn_readfirstlane(cbeg[c]);
-    }
+    // (tie and acc are adjacent: [NC][TC] words rounded to an even count, then 2 NC 64-bit sums)
+    if (!sort_prefix_setup_classes<NV, NC>(a, cbeg, ordl, tie, ((NC * TC + 1) & ~1) + 4 * NC, cb)) return;
+    // (the load of n_valid has returned -- the verdict needed it --: nothing the compiler would wait for with vmcnt(0) follows the copy)
+    if (st < nsteps) { issue(st); issue_truth(st); }
     // votes the longest budget sees (the domain check looks no further)
     int32_t nmax = 0;
 #pragma unroll
@@ -272,7 +305,6 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
         Dlive = 0;
     };
 
-    if (!issued && st < nsteps) { issue(st); issue_truth(st); }
 #ifdef SCV_SP_TIMELINE
     unsigned long long tl[7] = {0, 0, 0, 0, 0, 0, 0}, tl_steps = 0;
     unsigned long long t_last = __builtin_readcyclecounter();
@@ -479,20 +511,7 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
             }
         }
         __syncthreads();
-        // the classes' counters to their budgets
-        for (int64_t i = tid; i < (int64_t)B * TC; i += T) {
-            const int32_t j = (int32_t)(i / TC), k = (int32_t)(i - (int64_t)j * TC);
-            int c = 0;
-            while (c < NC - 1 && j >= cbeg[c + 1]) ++c;
-            const uint32_t v = tie[c * TC + k];
-            if (v && a.tie_hits) atomicAdd(&a.tie_hits[(int64_t)ordl[j] * SCV_TIE_CLASSES + k], (unsigned long long)v);
-        }
-        for (int j = tid; j < B; j += T) {
-            int c = 0;
-            while (c < NC - 1 && j >= cbeg[c + 1]) ++c;
-            if (a.truth_sum && acc[c]) atomicAdd(&a.truth_sum[ordl[j]], acc[c]);
-            if (TOK && a.token_sum && acc[NC + c]) atomicAdd(&a.token_sum[ordl[j]], acc[NC + c]);
-        }
+        sort_prefix_hand_out_counters<NC, TC, TOK>(a, cbeg, ordl, tie, acc);
     }
 }
 
@@ -636,58 +655,8 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
 
     int64_t st = wave;
     int32_t cb[NC + 1];
-    if (tid < 16) cbeg[tid] = 0;
-    for (int i = tid; i < NC * TC; i += T) tie[i] = 0;
-    for (int i = tid; i < 2 * NC; i += T) acc[i] = 0;
-    bool issued = false;
-    if (B <= 64) {                                                   // (as in scv_sort_prefix: one load of n_valid per wave, the classes in registers)
-        const bool have = lane < B;
-        int cls = have ? sort_prefix_class<NV>(valid_len(a, lane), N) : NC;
-        if (__any(have && cls < 0)) {
-            if (a.prefetch && tid == 0) atomicOr(a.err_flag, 8u);
-            return;
-        }
-        if (st < nsteps) { issue_half(st, 0); issue_truth(st); issued = true; }
-        uint32_t pos = 0;
-        cb[0] = 0;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const unsigned long long m = __ballot(cls == c);
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            pos = cls == c ? (uint32_t)cb[c] + before : pos;
-            cb[c + 1] = cb[c] + (int32_t)__builtin_popcountll(m);
-        }
-        if (wid == 0 && have) ordl[pos] = lane;
-        if (tid == 0) {
-#pragma unroll
-            for (int c = 0; c <= NC; ++c) cbeg[c] = cb[c];
-        }
-        __syncthreads();
-    } else {
-        __syncthreads();
-        int bad = 0;
-        for (int b0 = 0; b0 < B; b0 += T) {
-            const int b = b0 + tid;
-            const bool have = b < B;
-            const int c = have ? sort_prefix_class<NV>(valid_len(a, b), N) : 0;
-            bad |= c < 0 ? 1 : 0;
-            const int rank = budget_rank_of<false>(a, b, (int64_t)c, [&](int o) { return sort_prefix_class<NV>(valid_len(a, o), N); });
-            if (have && c >= 0 && rank >= 0 && rank < B) {
-                ordl[rank] = b;
-                atomicAdd(reinterpret_cast<uint32_t*>(cbeg) + c + 1, 1u);
-            }
-        }
-        if (__syncthreads_or(bad)) {
-            if (a.prefetch && tid == 0) atomicOr(a.err_flag, 8u);
-            return;
-        }
-        if (tid == 0) {
-            for (int c = 1; c <= NC; ++c) cbeg[c] += cbeg[c - 1];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c <= NC; ++c) cb[c] = __builtin_amdgcn_readfirstlane(cbeg[c]);
-    }
+    if (!sort_prefix_setup_classes<NV, NC>(a, cbeg, ordl, tie, ((NC * TC + 1) & ~1) + 4 * NC, cb)) return;
+    if (st < nsteps) { issue_half(st, 0); issue_truth(st); }
     int32_t nmax = 0;                                                // votes the longest budget sees (the domain check looks no further)
 #pragma unroll
     for (int c = 1; c < CF; ++c) if (cb[c + 1] > cb[c]) nmax = 1 << (c - 1);
@@ -738,7 +707,6 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
         Dlive = 0;
     };
 
-    if (!issued && st < nsteps) { issue_half(st, 0); issue_truth(st); }
     for (; st < nsteps; st += nwaves) {
         // ================================ phase A: votes 0 .. 63 ================================
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // half A and the truths have landed (and every older store)
@@ -895,18 +863,7 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
             }
         }
         __syncthreads();
-        for (int64_t i = tid; i < (int64_t)B * TC; i += T) {
-            const int32_t j = (int32_t)(i / TC), k = (int32_t)(i - (int64_t)j * TC);
-            int c = 0;
-            while (c < NC - 1 && j >= cbeg[c + 1]) ++c;
-            const uint32_t v = tie[c * TC + k];
-            if (v && a.tie_hits) atomicAdd(&a.tie_hits[(int64_t)ordl[j] * SCV_TIE_CLASSES + k], (unsigned long long)v);
-        }
-        for (int j = tid; j < B; j += T) {
-            int c = 0;
-            while (c < NC - 1 && j >= cbeg[c + 1]) ++c;
-            if (a.truth_sum && acc[c]) atomicAdd(&a.truth_sum[ordl[j]], acc[c]);
-        }
+        sort_prefix_hand_out_counters<NC, TC, false>(a, cbeg, ordl, tie, acc);
     }
 }
 
