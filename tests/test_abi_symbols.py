@@ -104,6 +104,41 @@ def test_no_kernel_spills_to_scratch():
     assert head and head[0][1] <= 128 and head[0][4] == 0            # the headline kernel: 16 waves per CU need <= 128 VGPRs
 
 
+def test_copy_pipelines_keep_their_waits():
+    """The one-lane-per-cell kernels copy a step's rows HBM -> LDS by LDS-DMA and keep the NEXT copy in flight while the current rows are sorted.
+    hipcc does not count those copies (inline asm), so every `s_waitcnt vmcnt` behind the first copy is one the source put there on purpose; a
+    load the compiler can see inside the step loop would make it add a vmcnt(0) of its own and drain the copy in flight (how the truth gather
+    became a 4-byte LDS-DMA in round 4, and why round 5's prefix kernels work out the budget classes before their first copy).  Device-only
+    compile, no GPU: the waits behind the first `global_load_lds` of each kernel are counted in its ISA."""
+    import re
+    import subprocess
+    import tempfile
+    csrc = os.path.join(REPO, "o1_inference_scaling_laws_amd", "csrc")
+    expect = {                                                       # kernel (mangled-name fragment) -> vmcnt waits behind its first copy: (least, most)
+        "scv_sort_prefixILi64ELb0EE": (1, 1), "scv_sort_prefixILi32ELb0EE": (1, 1),      # the top of a step
+        "scv_sort_prefixILi64ELb1EE": (2, 2), "scv_sort_prefixILi32ELb1EE": (2, 2),      # + the step's tokens, behind the sort
+        "scv_sort_prefix2": (2, 2),                                                          # half A, half B
+        "scv_sort_cellsILi64ELb0ELb0EE": (3, 5), "scv_sort_cellsILi16ELb0ELb0EE": (3, 5),  # vmcnt(0) / (1) / (2) by the stores left in flight
+    }
+    with tempfile.TemporaryDirectory() as d:
+        isa = ""
+        for unit in ("scvote_sort_prefix.hip", "scvote_sort.hip"):
+            out = os.path.join(d, unit + ".s")
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", out, os.path.join(csrc, unit)],
+                           check=True, stderr=subprocess.DEVNULL)
+            isa += open(out).read()
+    for frag, (least, most) in expect.items():
+        m = re.search(r"^(_ZN3scv\d+" + re.escape(frag) + r"\w*):[^\n]*\n(.*?)s_endpgm", isa, re.S | re.M)
+        assert m, frag
+        body = m.group(2)
+        assert "scratch_" not in body, frag
+        behind = body[body.index("global_load_lds_dword"):]
+        waits = re.findall(r"vmcnt\(\d+\)", behind)
+        assert least <= len(waits) <= most, (frag, waits)
+        if "sort_prefix" in frag:                                    # (scv_sort_cells keeps a load for budget lists beyond its n_valid cache, in a branch of its own)
+            assert not re.search(r"\b(global|flat|buffer)_load_dword", behind.replace("global_load_lds_dword", "")), frag      # no load the compiler counts
+
+
 def test_communicator_refuses_without_a_device():
     """scv_comm_create on a box without a GPU: SCV_ERR_NO_DEVICE, no communicator, no crash (and no RCCL needed to say so)."""
     import torch
