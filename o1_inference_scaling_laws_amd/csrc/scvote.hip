@@ -7,6 +7,7 @@
 #define SCV_TU_MAIN 1   // the non-template kernels are emitted by this translation unit only
 #include "scvote_kernels.hip.h"
 #include "scvote_dispatch.h"
+#include "scvote_hostpool.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -50,15 +51,18 @@ int guarded(F&& body) noexcept {
     }
 }
 
-// TEST HOOK (tests/test_gpu_parity.py): SCV_TEST_FAULT in the environment makes the HOST-mode staging path fail the way a
-// starved container would -- "thread": every worker-thread creation raises std::system_error (the pipeline must run on the calling
-// thread alone); "alloc": std::bad_alloc while the copy pieces are built; "throw": a std::runtime_error.  Read per HOST-mode call.
+// TEST HOOK, compiled only with -DSCV_TEST_HOOKS (the `hooks` variant of _build.py: csrc/libscvote_hooks.so, which only
+// tests/test_gpu_parity.py loads; libscvote.so, the product, never reads the environment): SCV_TEST_FAULT makes the HOST-mode staging
+// path fail the way a starved container would -- "thread": every worker-thread creation raises std::system_error (the pipeline must
+// run on the calling thread alone); "alloc": std::bad_alloc while the copy pieces are built; "throw": a std::runtime_error.
 int test_fault() {
+#ifdef SCV_TEST_HOOKS
     const char* f = getenv("SCV_TEST_FAULT");
     if (!f || !*f) return 0;
     if (!strcmp(f, "thread")) return 1;
     if (!strcmp(f, "alloc")) return 2;
     if (!strcmp(f, "throw")) return 3;
+#endif
     return 0;
 }
 
@@ -92,67 +96,13 @@ struct HostPipe {
     size_t bounce_bytes = 0;
     void* dslot[kSlots] = {nullptr, nullptr};            // HBM
     size_t dslot_bytes = 0;
-    // worker threads for the pageable -> pinned copies
-    std::vector<std::thread> workers;
-    std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::vector<std::function<void()>> jobs;
-    size_t next_job = 0, jobs_done = 0;
-    bool stop = false;
-
-    void worker_loop() {
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            cv_work.wait(lk, [&] { return stop || next_job < jobs.size(); });
-            if (stop) return;
-            const size_t j = next_job++;
-            lk.unlock();
-            jobs[j]();
-            lk.lock();
-            if (++jobs_done == jobs.size()) cv_done.notify_all();
-        }
-    }
-    // Fewer threads than asked for is fine (run() makes the calling thread a worker too): a container at its thread limit raises
-    // std::system_error from std::thread's constructor; the pipeline then runs with the workers it already has, possibly none.
-    int start_failures = 0;
-    void start(int nthreads, bool fail_for_test = false) noexcept {
-        for (int i = (int)workers.size(); i < nthreads; ++i) {
-            try {
-                if (fail_for_test) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "test hook");
-                workers.emplace_back([this] { worker_loop(); });
-            } catch (const std::exception&) {
-                ++start_failures;
-                break;
-            }
-        }
-    }
-    // run the pieces on the workers (the caller takes pieces too) and return when all are done
-    void run(std::vector<std::function<void()>>&& pieces) {
-        if (pieces.empty()) return;
-        if (workers.empty()) { for (auto& f : pieces) f(); return; }
-        std::unique_lock<std::mutex> lk(mu);
-        jobs = std::move(pieces);
-        next_job = 0; jobs_done = 0;
-        cv_work.notify_all();
-        while (next_job < jobs.size()) {                 // the calling thread is a worker too
-            const size_t j = next_job++;
-            lk.unlock();
-            jobs[j]();
-            lk.lock();
-            ++jobs_done;
-        }
-        cv_done.wait(lk, [&] { return jobs_done == jobs.size(); });
-        jobs.clear();
-        next_job = 0; jobs_done = 0;
-    }
+    // worker threads for the pageable -> pinned copies: plain C++ with no HIP in it (scvote_hostpool.h), so that gcc's
+    // -fsanitize=thread / address can be pointed at it on the CPU (tests/hostpool_sanitize.cpp)
+    scv::CopyPool pool;
+    void start(int nthreads, bool fail_for_test = false) noexcept { pool.start(nthreads, fail_for_test); }
+    void run(std::vector<std::function<void()>>&& pieces) { pool.run(std::move(pieces)); }
     void shutdown() {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-        }
-        cv_work.notify_all();
-        for (auto& t : workers) t.join();
-        workers.clear();
+        pool.join_all();
         for (int k = 0; k < kSlots; ++k) {
             if (landed[k]) (void)hipEventDestroy(landed[k]);
             if (consumed[k]) (void)hipEventDestroy(consumed[k]);
@@ -1099,7 +1049,11 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 extern "C" {
 
 const char* scv_last_error(void) { return g_err; }
-const char* scv_version(void) { return "scvote 0.1 (gfx950)"; }
+#ifdef SCV_TEST_HOOKS
+const char* scv_version(void) { return "scvote 0.2 (gfx950) +testhooks"; }
+#else
+const char* scv_version(void) { return "scvote 0.2 (gfx950)"; }
+#endif
 
 int scv_device_count(void) {
     return guarded([&]() -> int {
@@ -1223,6 +1177,12 @@ int scv_set_option(scv_ctx* ctx, const char* key, int64_t value) {
     return guarded([&]() -> int {
         if (!ctx || !key) return fail(SCV_ERR_ARG, "NULL argument");
         if (!strcmp(key, "overwrite_counters")) ctx->overwrite_counters = value != 0;
+        else if (!strcmp(key, "auto_geometry")) {
+            // DEPRECATED alias (rounds 1-4 documented this key; round 5 replaced it by scv_set_tuning(ctx, -1, -1, -1, -1)): 1 = the library
+            // picks the streaming geometry from the shape again; 0 = keep whatever scv_set_tuning set (and pin the current geometry)
+            if (value) { ctx->copies = 16; ctx->threads = 1024; ctx->wg_per_cu = 1; ctx->unroll = 4; ctx->user_tuned = false; }
+            else ctx->user_tuned = true;
+        }
         else if (!strcmp(key, "path")) { if (value < 0 || value > 5 || value == 3) return fail(SCV_ERR_ARG, "path must be 0, 1, 2, 4 or 5"); ctx->path = (int)value; }
         else if (!strcmp(key, "sort_n_min")) { if (value < 1 || value > 65) return fail(SCV_ERR_ARG, "sort_n_min must be 1..65"); ctx->sort_n_min = (int)value; }
         else if (!strcmp(key, "sort_n_max")) { if (value < 0 || value > 64) return fail(SCV_ERR_ARG, "sort_n_max must be 0..64"); ctx->sort_n_max = (int)value; }
@@ -1285,19 +1245,7 @@ int ensure_pipe(scv_ctx* ctx, size_t bounce_bytes, size_t dslot_bytes) {
     return SCV_OK;
 }
 
-// memcpy split over the pipe's worker threads (pieces of >= 1 MiB, 64-byte aligned cuts)
-void add_copy_pieces(std::vector<std::function<void()>>& pieces, void* dst, const void* src, size_t bytes, int parts) {
-    if (!bytes) return;
-    size_t piece = (bytes + parts - 1) / parts;
-    if (piece < ((size_t)1 << 20)) piece = (size_t)1 << 20;
-    piece = (piece + 63) & ~(size_t)63;
-    for (size_t off = 0; off < bytes; off += piece) {
-        const size_t n = bytes - off < piece ? bytes - off : piece;
-        char* d = static_cast<char*>(dst) + off;
-        const char* c = static_cast<const char*>(src) + off;
-        pieces.emplace_back([d, c, n] { memcpy(d, c, n); });
-    }
-}
+using scv::add_copy_pieces;     // memcpy split over the pipe's worker threads (scvote_hostpool.h)
 
 // HOST mode: the three-stage ingestion pipeline described at HostPipe.
 int host_pipelined(scv_ctx* ctx, bool prefix, const int32_t* answers, const int32_t* tokens, const int32_t* n_valid,
@@ -1706,7 +1654,7 @@ int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
         else if (!strcmp(key, "few_votes")) *out = ctx->stat_few_votes;
         else if (!strcmp(key, "host_small_calls")) *out = ctx->stat_small_calls;
         else if (!strcmp(key, "host_pipelined_calls")) *out = ctx->stat_pipelined_calls;
-        else if (!strcmp(key, "host_thread_start_failures")) *out = ctx->pipe ? ctx->pipe->start_failures : 0;
+        else if (!strcmp(key, "host_thread_start_failures")) *out = ctx->pipe ? ctx->pipe->pool.start_failures : 0;
         else return fail(SCV_ERR_ARG, "unknown stat '%s'", key);
         return SCV_OK;
     });

@@ -150,11 +150,15 @@ int guarded(F&& body) noexcept {
     }
 }
 
-// TEST HOOK: SCV_TEST_FAULT=peer makes the self-test of a SCV_COMM_PEER communicator fail (every expectation skewed), and makes it run
+// TEST HOOK (only in builds with -DSCV_TEST_HOOKS: csrc/libscvote_hooks.so): SCV_TEST_FAULT=peer makes the self-test of a SCV_COMM_PEER communicator fail (every expectation skewed), and makes it run
 // for one rank too -- so that a 1-GPU box can exercise "self-test failed -> RCCL" (MultiDeviceEngine, tests/test_gpu_parity.py).
 static bool peer_fault_for_test() {
+#ifdef SCV_TEST_HOOKS
     const char* f = getenv("SCV_TEST_FAULT");
     return f && !strcmp(f, "peer");
+#else
+    return false;
+#endif
 }
 
 #define COMM_HIP(expr)                                                                                     \

@@ -1856,9 +1856,13 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_
         const int32_t* row = a.answers + t.rowi * a.N;
         t.sh = VEC ? 0u : ((uint32_t)(uintptr_t)row & 15u) >> 2;
         const int4* row4 = reinterpret_cast<const int4*>(row - t.sh);          // 16-byte aligned (a vector never crosses a page)
+        // a lane whose vector lies beyond the row re-reads the row's LAST vector: in a row that ends inside a wave instruction (N = 96 in
+        // the 128-slot shape) that is the 16 bytes a neighbouring lane reads in the SAME instruction -- one request, no second fetch
+        // (round 5 re-read vector 0 there: a non-temporal line is not kept, FETCH_SIZE was 1.36x the row bytes at N = 96)
+        const uint32_t vlast = t.n + t.sh ? (t.n + t.sh - 1u) >> 2 : 0u;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const uint32_t vi = element(k, 0) < t.n + t.sh ? (uint32_t)(k * G + l) : 0u;
+            const uint32_t vi = (uint32_t)(k * G + l) < vlast ? (uint32_t)(k * G + l) : vlast;
             const int4 x = stream_load(row4 + vi);
             t.v[4 * k] = (uint32_t)x.x; t.v[4 * k + 1] = (uint32_t)x.y; t.v[4 * k + 2] = (uint32_t)x.z; t.v[4 * k + 3] = (uint32_t)x.w;
         }
@@ -2062,9 +2066,10 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_
                 const uint32_t tsh = VEC ? 0u : ((uint32_t)(uintptr_t)trow & 15u) >> 2;
                 const int4* trow4 = reinterpret_cast<const int4*>(trow - tsh);
                 const uint32_t hi = n + tsh;
+                const uint32_t tlast = hi ? (hi - 1u) >> 2 : 0u;
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    const uint32_t vi = element(k, 0) < hi ? (uint32_t)(k * G + l) : 0u;
+                    const uint32_t vi = (uint32_t)(k * G + l) < tlast ? (uint32_t)(k * G + l) : tlast;
                     const int4 y = stream_load(trow4 + vi);
                     // slot e is token e - tsh: valid iff tsh <= e < n + tsh (unsigned: e - tsh < n)
                     tsum += (element(k, 0) - tsh < n ? (long long)y.x : 0) + (element(k, 1) - tsh < n ? (long long)y.y : 0)

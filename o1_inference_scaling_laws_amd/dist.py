@@ -82,22 +82,31 @@ def aggregate_sharded(engine, answers_local, truth_local, num_problems: int, tok
 
     ``prefix=True``: ``answers_local`` / ``tokens_local`` are this rank's block of ONE sample pool per problem,
     ``[P_local, N]``, and budget b votes over its first ``n_valid[b]`` samples (the reference's shape, o1.py:274-277);
-    the block goes through ``engine.aggregate_prefix_device`` and everything else is the same."""
+    the block goes through ``engine.aggregate_prefix_device`` and everything else is the same.  ``n_valid`` may then be a
+    HOST sequence (list / numpy array) instead of a device tensor: the budgets are known at the call, and a list of the served
+    form (powers of two over pools of 17 .. 128 votes) is promised to the library -- one launch, no decision on the device."""
     import torch
     from ._lib import ERR_DOMAIN, DomainError, ScvError
     from .engine import AggregateResult, cells_from_torch, counters_size
+    budgets_host = None
     if prefix:
         if n_valid is None:
             raise ValueError("prefix=True needs n_valid[B]")
+        if not hasattr(n_valid, "is_cuda"):
+            # the budgets as a HOST sequence (list / numpy): the rank knows them, so the engine may promise them to the library
+            # (one launch instead of two deciding from device memory; Engine.aggregate_prefix_device) -- and puts them on the device
+            budgets_host = [int(x) for x in n_valid]
+            n_valid = torch.tensor(budgets_host, dtype=torch.int32, device=answers_local.device)
         P_local, B = int(answers_local.shape[0]), int(n_valid.shape[0])
     else:
         P_local, B = int(answers_local.shape[0]), int(answers_local.shape[1])
     ncount = counters_size(B)
     packed = torch.zeros(ncount + 1, dtype=torch.int64, device=answers_local.device)     # counters | error word
     if prefix:
+        kw = {"budgets_host": budgets_host} if budgets_host is not None else {}
         _, cells, cell_tokens = engine.aggregate_prefix_device(
             answers_local, truth_local, n_valid, tokens=tokens_local, counters=packed[:ncount],
-            cells=None if want_cells else False)
+            cells=None if want_cells else False, **kw)
     else:
         _, cells, cell_tokens = engine.aggregate_device(
             answers_local, truth_local, tokens=tokens_local, n_valid=n_valid, counters=packed[:ncount],

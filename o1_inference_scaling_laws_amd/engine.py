@@ -112,6 +112,7 @@ class Engine:
         self.num_cus, self.lds_bytes, self.clock_khz, self.hbm_bytes = (int(x) for x in info)
         self._bound_stream = None
         self._overwrite = False
+        self._options = {}
         self.timing = timing
 
     def close(self):
@@ -139,6 +140,17 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         check(self._L.scv_set_option(self._ctx, key.encode(), int(value)))
+        self._options[key] = int(value)
+
+    @staticmethod
+    def budgets_come_out_of_one_sort(budgets, N: int) -> bool:
+        """True when a DEVICE-mode prefix call over pools of N votes with these budgets may PROMISE them to the library
+        (option "prefix_path" = 5, include/scvote.h): pools of 17 .. 128 votes (N % 4 == 0) whose budgets are all 0, a power of
+        two <= 16 / 32 / 64 (pools <= 32 / 64 / 128) or >= N -- the reference's own lists (o1.py:274-277: 1, 2, 4 ... N)."""
+        if not (16 < N <= 128) or N % 4:
+            return False
+        cap = 16 if N <= 32 else (32 if N <= 64 else 64)
+        return all(n <= 0 or n >= N or ((n & (n - 1)) == 0 and n <= cap) for n in (int(x) for x in budgets))
 
     def _check_device(self, tensor, name="tensor"):
         if self.device >= 0 and tensor.device.index != self.device:
@@ -312,12 +324,28 @@ class Engine:
         return counters, cells, cell_tokens, out
 
     def aggregate_prefix_device(self, pool, truth, n_valid, tokens=None, counters=None, cells=None, cell_tokens=None,
-                                overwrite=False):
-        """pool torch.int32 cuda [P,N], n_valid torch.int32 cuda [B].  Asynchronous; see aggregate_device."""
+                                overwrite=False, budgets_host=None):
+        """pool torch.int32 cuda [P,N], n_valid torch.int32 cuda [B].  Asynchronous; see aggregate_device.
+
+        ``budgets_host``: the same budgets as a host sequence, when the caller has them (it usually built ``n_valid`` from one).
+        The library cannot read device memory at launch time, so in auto mode a DEVICE-mode call over pools of 17 .. 128 votes queues
+        two kernels that decide from ``n_valid`` which of them works (2-4 us); with the budgets known here and of the served form
+        (``budgets_come_out_of_one_sort``) the call PROMISES them instead (option "prefix_path" = 5 for this call: one launch)."""
         P, B, N, counters, cells, cell_tokens, ptr, cptrs = self._device_call(pool, "pool", (0,), truth, tokens, n_valid, counters, cells,
                                                                               cell_tokens, overwrite)
-        check(self._L.scv_aggregate_prefix_i32(self._ctx, ptr(pool), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, _lib.MEM_DEVICE,
-                                               ptr(cells), ptr(cell_tokens), *cptrs))
+        promise = False
+        if budgets_host is not None and self._options.get("prefix_path", 0) == 0:
+            if len(budgets_host) != B:
+                raise ValueError("budgets_host must list the B budgets of n_valid")
+            promise = self.budgets_come_out_of_one_sort(budgets_host, N)
+        if promise:
+            check(self._L.scv_set_option(self._ctx, b"prefix_path", 5))
+        try:
+            check(self._L.scv_aggregate_prefix_i32(self._ctx, ptr(pool), ptr(tokens), ptr(n_valid), ptr(truth), P, B, N, _lib.MEM_DEVICE,
+                                                   ptr(cells), ptr(cell_tokens), *cptrs))
+        finally:
+            if promise:
+                check(self._L.scv_set_option(self._ctx, b"prefix_path", 0))
         return counters, cells, cell_tokens
 
     def synth_fill_device(self, answers=None, tokens=None, truth=None, *, P, B, N, seed, dist, p_offset=0):

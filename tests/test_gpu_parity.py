@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from o1_inference_scaling_laws_amd import _lib, o1_dropin, synth
+from o1_inference_scaling_laws_amd import _build, _lib, o1_dropin, synth
 from o1_inference_scaling_laws_amd.engine import (AggregateResult, cells_from_torch, counters_size)
 from o1_inference_scaling_laws_amd.extract import build_vote_tensors
 from oracle import coracle
@@ -231,7 +231,7 @@ def test_no_cpp_exception_crosses_the_abi(mode):
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", FAULT_SCRIPT.format(repo=repo, mode=mode)], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, SCV_TEST_FAULT=mode), cwd=repo)
+                         env=dict(os.environ, SCV_TEST_FAULT=mode, SCV_LIB_PATH=_build.variant_path("hooks")), cwd=repo)
     assert out.returncode == 0, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
     if mode == "thread":
         assert "RESULT-OK" in out.stdout and int(out.stdout.split("RESULT-OK")[1].split()[0]) >= 1 and "STILL-ALIVE" in out.stdout
