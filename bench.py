@@ -99,6 +99,10 @@ def parse():
     ap.add_argument("--share-device", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 (1-GPU box, with --backend gloo) to exercise the multi-process path")
     ap.add_argument("--dump", default=None, help="rank 0 writes the last step's integer outputs (.npz) for bit-exact comparisons")
+    ap.add_argument("--full-pass", dest="full_pass", action="store_true", default=True,
+                    help="c3 on ONE GPU (default on): after the timed region, aggregate ALL 8 chunks of the workload (the 8th is generated into a "
+                         "freed slot) into one counter buffer and print c3_full = C3's RESULT (accuracy per budget, sums, sha256 of the counters)")
+    ap.add_argument("--no-full-pass", dest="full_pass", action="store_false")
     return ap.parse_args()
 
 
@@ -130,6 +134,7 @@ def check_cells_vs_c_oracle(gpu_cells, P_check, B, N, seed, dist, p_offset, toke
 
 # ---- the N > 1 line proves its own exchange step (BASELINE C4: "bit-exact at every GPU count"; o1.py:232-245) ----------------------
 
+WARNINGS = []                   # things a reader of the line must see (rank 0): legs that did not run, ratios that should prompt a check
 RANK_PARITY_PROBLEMS = 32       # problems of EVERY rank's last timed chunk that go through the oracle (rank-local, in parallel)
 
 
@@ -173,6 +178,61 @@ def closed_form_check(counters_np, B, N, total_problems, dist_id):
             return None, (f"closed form of dist {dist_id} violated at budget {b}: tie_class_hits[b][1] = {int(tie[b, 1])} (want {want_tie1}), "
                           f"row sum {int(tie[b].sum())}, truth_count_sum[b] = {int(tcs[b])} (want {want_tcs})")
     return (f"D{dist_id}: tie_class_hits[b][1] == {want_tie1} (= ranks x problems per rank) and truth_count_sum[b] == {want_tcs} for all {B} budgets", None)
+
+
+def counters_digest(counters_np, ncount):
+    """sha256 of the packed int64 counters (little-endian, tie_class_hits | token_sum | truth_count_sum): two runs that print the same digest
+    computed the same 8216 words -- how a 1-GPU full pass and an 8-rank line are compared without a dump."""
+    import hashlib
+    import numpy as np
+    return hashlib.sha256(np.ascontiguousarray(np.asarray(counters_np, dtype="<i8")[:ncount]).tobytes()).hexdigest()
+
+
+def full_pass_c3(eng, torch, slots, Pc, B, N, args, cells, ctok, nchunks=8):
+    """ONE GPU, all of C3: the timed region cycles the chunks that fit in HBM (7 of 8 at the default shape), so problems 8750 .. 9999 are never
+    aggregated there and no 1-GPU line could print C3's RESULT (VERDICT r5 missing #5).  Here, outside the timed region: every chunk s = 0 .. 7
+    (global problems [s Pc, (s+1) Pc)) is accumulated into ONE counter buffer -- resident chunks as they are, the others generated into a slot that
+    is no longer needed -- which is the sum o1.py:236-245 takes over ALL problems.  -> dict for the line (and the counters for --dump)."""
+    import numpy as np
+    from o1_inference_scaling_laws_amd.engine import AggregateResult, counters_size
+    dev = slots[0][0].device
+    ncount = counters_size(B)
+    full = torch.zeros(ncount, dtype=torch.int64, device=dev)
+    resident = {sl[3] // Pc: k for k, sl in enumerate(slots) if sl[3] % Pc == 0}
+    generated = []
+    eng.sync()
+    t0 = time.perf_counter()
+    for s_ in range(nchunks):
+        if s_ in resident:
+            ans, tok, tr, _ = slots[resident[s_]]
+        else:
+            k = min(resident.values()) if resident else 0          # reuse the slot of a chunk that has already been accumulated (chunk 0's)
+            ans, tok, tr, _ = slots[k]
+            eng.synth_fill_device(ans, tok, tr, P=Pc, B=B, N=N, seed=args.seed, dist=args.dist, p_offset=s_ * Pc)
+            slots[k] = (ans, tok, tr, s_ * Pc)
+            resident = {c: kk for c, kk in resident.items() if kk != k}
+            generated.append(s_)
+        eng.aggregate_device(ans, tr, tokens=tok, counters=full, cells=cells, cell_tokens=ctok, overwrite=False)   # DEVICE mode accumulates (+=)
+    eng.sync()
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) * 1e3
+    host = full.cpu().numpy()
+    total = nchunks * Pc
+    res = AggregateResult.from_counters(host, total, B, num_problems=total)
+    cf_what, cf_msg = closed_form_check(host, B, N, total, args.dist)
+    if cf_msg:
+        sys.exit("FULL PASS FAILURE: " + cf_msg)
+    return {
+        "what": (f"all {nchunks} chunks of {Pc} problems = global problems 0..{total - 1} x {B} budgets x {N} votes accumulated into ONE counter buffer on one GPU, "
+                 f"outside the timed region (chunks {generated} generated into a freed slot); equals the all-reduced counters of an {nchunks}-rank step over the same problems"),
+        "problems": total, "chunks": nchunks, "chunks_generated_after_the_timed_region": generated,
+        "accuracy": [res.accuracy(b) for b in range(B)],
+        "avg_tokens_used": [float(res.avg_tokens_used(b)) for b in range(B)] if args.tokens else None,
+        "token_sum": [int(x) for x in res.token_sum], "truth_count_sum": [int(x) for x in res.truth_count_sum],
+        "strict_wins": [int(res.tie_class_hits[b, 1]) for b in range(B)],
+        "counters_sha256": counters_digest(host, ncount), "counters_words": ncount,
+        "closed_form": cf_what, "ms_including_generation": ms,
+    }, host
 
 
 def judge_exchange(rank, ncount, reduced_np, local_parts, gathered_cells_np=None, local_cell_parts=None):
@@ -280,6 +340,11 @@ def cpu_baseline(args, B, N, gpu_first_cells, first_off, gpu_last_cells, last_of
             # both driver families of the reference end to end (o1.py:314-315: 19 budgets at P = 30), reference vs drop-in
             dropin_loop["family"] = ref.get("family")
             fam = ref.get("family") or {}
+            if "error" in fam or not fam:
+                #  the family leg raised: the keys below would simply be absent and the parity exit skipped -- say so in the line
+                dropin_loop["family_error"] = fam.get("error", "oracle.refbaseline returned no family record")
+                WARNINGS.append("cpu_baseline.dropin_loop.family did not run (" + dropin_loop["family_error"] + "): the reference's own 19-budget "
+                                "family was NOT compared with the drop-in in this run")
             for k in ("dropin_unbatched", "dropin_batched"):
                 if k in fam and not fam[k]["records_equal_to_reference"]:
                     sys.exit(f"PARITY FAILURE: {k} records of the reference's driver families differ from the live reference's")
@@ -511,7 +576,7 @@ def main_single_process(args):
     def step(i, timed_slot=None):
         if c5:
             shards = [(slots[g][0][0], slots[g][0][2], slots[g][0][1]) for g in range(world)]
-            out = mde.evaluate_c5(shards, args.resamples, c5_state["boot_seed"], M=c5_state["M"])
+            out = mde.evaluate_c5(shards, args.resamples, c5_state["boot_seed"], M=c5_state["M"], keep_all_ranks=True)
             c5_state["M"], c5_state["last"] = out[3], out
             return out[0][:ncount]
         cur = []
@@ -904,10 +969,40 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         kmax = torch.tensor([kern_ns / max(launches, 1)], dtype=torch.float64, device=dev)
+        kmin = kmax.clone()
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kmin, op=dist.ReduceOp.MIN)
         kern_avg_ns = float(kmax.item())
+        kern_rank_min_ms, kern_rank_max_ms = float(kmin.item()) / 1e6, float(kmax.item()) / 1e6
+        # the exposed all-reduce, measured OUTSIDE the timed region (so that a first multi-GPU run below 6x explains itself: kernel imbalance
+        # between the ranks, or the exchange): a few more steps in which the step's stream waits for its collective right behind the vote
+        # kernel -- torch events around that wait = from the end of THIS rank's kernel to its buffer holding the sum, the wait for the slowest
+        # rank included.  In the timed region the all-reduce of step i runs on RCCL's stream under the kernel of step i + 1.
+        exposed_us = None
+        if not c5 and not use_graph and args.steps > 0:
+            samples = []
+            for j in range(6):
+                i = args.warmup + args.steps + j
+                ans_, tok_, tr_, _ = slots[i % R]
+                buf = pipe.acquire(i, zero=True)
+                eng.aggregate_device(ans_, tr_, tokens=tok_, counters=buf, cells=cells, cell_tokens=ctok, overwrite=False)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+                w.wait()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                if j:
+                    samples.append(e0.elapsed_time(e1) * 1e3)
+            xm = torch.tensor([sorted(samples)[len(samples) // 2]], dtype=torch.float64, device=dev)
+            dist.all_reduce(xm, op=dist.ReduceOp.MAX)
+            exposed_us = float(xm.item())
+            if not no_events:
+                eng.drain_kernel_ns()
     else:
         kern_avg_ns = kern_ns / max(launches, 1)
+        kern_rank_min_ms = kern_rank_max_ms = kern_avg_ns / 1e6
+        exposed_us = None
     last_slot = slots[(args.warmup + args.steps - 1) % R] if args.steps > 0 else slots[0]
 
     # ---- the exchange step proves itself (outside the timed region; BASELINE C4 "bit-exact at every GPU count") -----------------
@@ -974,6 +1069,11 @@ def main():
     bytes_per_launch = votes_per_step_per_gpu * BYTES_PER_VOTE * (2 if args.tokens else 1)
     achieved = bytes_per_launch / (kern_avg_ns * 1e-9) / 1e9
     ev = committed_evidence() if (Pc, B, N, args.tokens, args.workload) == (1250, 8, 1 << 20, False, "c3") else {}
+    c3_full = full_host = None
+    if args.workload == "c3" and world == 1 and not force and args.full_pass and not use_graph and rank == 0:
+        c3_full, full_host = full_pass_c3(eng, torch, slots, Pc, B, N, args, cells, ctok)
+        if not no_events:
+            eng.drain_kernel_ns()
     # the read ceiling of THIS box, measured now (rank 0 of a single-GPU default run; the probe allocates its own 41.9 GB)
     if rank == 0 and world == 1 and ev and not args.no_read_ceiling:
         last_off_kept = last_slot[3]
@@ -1046,11 +1146,21 @@ def main():
             "traffic_source": ev.get("traffic_source"),
             "kernel": "scv_hist_argmax",
             "kernel_avg_ms": kern_avg_ns / 1e6,
+            "kernel_avg_ms_per_rank_min": kern_rank_min_ms,
+            "kernel_avg_ms_per_rank_max": kern_rank_max_ms,
+            "exposed_allreduce_us": exposed_us,
+            "exposed_allreduce_what": ("median of 5 steps AFTER the timed region in which the rank's stream waits for the step's all-reduce right behind its vote kernel "
+                                       "(torch events around the wait; max over ranks; the wait for the slowest rank included) -- in the timed region the all-reduce "
+                                       "of step i overlaps the kernel of step i + 1") if exposed_us is not None else None,
             "kernel_timed_in": kernel_timed_in,
             "launches_timed": launches,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "measured_read_ceiling_gbs": ev.get("read_ceiling_gbs"),
-            "frac_of_measured_read_ceiling": (min(1.0, achieved / ev["read_ceiling_gbs"]) if ev.get("read_ceiling_is_lower_bound") else achieved / ev["read_ceiling_gbs"]) if ev.get("read_ceiling_gbs") else None,
+            # the RAW ratio (round 5 clamped it at 1.0, which would have hidden a wrong byte count or a broken probe): the quick probe is a lower
+            # bound of the box's ceiling, so a ratio a little above 1 is probe noise; beyond 1.03 the line says so instead of looking perfect
+            "frac_of_measured_read_ceiling": achieved / ev["read_ceiling_gbs"] if ev.get("read_ceiling_gbs") else None,
+            "read_ceiling_warning": ("kernel faster than 1.03x the measured pure-read rate: check the probe, the byte count and the timing before quoting this fraction"
+                                     if ev.get("read_ceiling_gbs") and achieved / ev["read_ceiling_gbs"] > 1.03 else None),
             "read_ceiling_is_lower_bound": bool(ev.get("read_ceiling_is_lower_bound")),
             "read_ceiling_source": ev.get("read_ceiling_source"),
         },
@@ -1059,6 +1169,8 @@ def main():
         "allreduce_verified": exchange["allreduce_verified"] if exchange else None,
         "exchange_check": exchange,
         "accuracy_last_step": [round(final.accuracy(b), 6) for b in range(B)],
+        "counters_sha256_last_step": counters_digest(last_host, counters_size(B)),
+        "c3_full": c3_full,
         "device": {"cus": eng.num_cus, "hbm_gb": round(eng.hbm_bytes / 1e9, 1)},
     }
     if rank == 0 and not args.no_cpu_baseline:
@@ -1112,8 +1224,9 @@ def main():
             if args.dump:
                 np.savez(args.dump, counters=d.counters.cpu().numpy(), cells=d.cells.cpu().numpy(), boot=boot_all.cpu().numpy())
     elif rank == 0 and args.dump:
-        np.savez(args.dump, counters=last_host)
+        np.savez(args.dump, counters=last_host, **({"full": full_host} if full_host is not None else {}))
     if rank == 0:
+        out["warnings"] = list(WARNINGS) or None
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1 or force:

@@ -114,8 +114,12 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  *   "sort_n_min" / "sort_n_max"   defaults 8 / 64: cells of that many votes run one lane per cell, the wave's rows staged through LDS
  *                         by LDS-DMA and sorted in registers (rows that are not 16-byte aligned: from 5); "sort_n_max" = 0: off
  *   "reg_n_max"           default 8192 = its maximum: 32 < N <= this uses the register-resident cell kernels; 0: the streaming kernel
- *   "reg_shape"           force a register-resident shape: g * 100 + v (g lanes per cell, v vectors per lane: 1601 1602 1604 3204 6404)
- *                         or 1000 + 40 + h (dense scan, h = 1, 2, 4, 8 parts of 4 KiB)
+ *   "reg_shape"           force a register-resident shape: g * 100 + v (g lanes per cell, v vectors per lane: 1601 803 804 1602 1604 3204 6404;
+ *                         803 / 804 = 8 lanes x 3 / 4 vectors with 8-bit LDS bins, the auto choice for 65 .. 96 / 97 .. 128 slots since round 6 --
+ *                         1602 there is round 5's 128-slot shape) or 1041 / 1042 / 1044 / 1048 (dense scan, 1, 2, 4, 8 parts of 4 KiB); a shape too
+ *                         small for N is ignored
+ *   "auto_geometry"       DEPRECATED alias kept for callers of rounds 1-4: 1 = scv_set_tuning(ctx, -1, -1, -1, -1) (the library picks the
+ *                         streaming geometry from the shape), 0 = pin the current geometry
  *   "fused_counters_max"  default 4096: streaming kernel -- at or below this many cells (or problem rows >= 4 MiB) per-cell atomics inside
  *                         the hot kernel, otherwise a separate reduction of the cell table; 0: EVERY kernel leaves the counters to that
  *                         reduction (the cell kernels otherwise keep per-workgroup LDS tables and flush them in the same launch)
@@ -125,12 +129,14 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  *                         2 the cell kernels on pool rows (pools <= 4096) | 3 one streaming pass, a histogram snapshot per boundary |
  *                         4 one pass per problem over its pool row, 16 / 32 / 64 lanes per problem, every budget a snapshot of the running
  *                         mode statistics (pools <= 4096: auto above 64 votes and for budget lists too long for path 1; "reg_shape" = 16 / 32 forces the lanes per problem)
- *                         auto includes: pools of 17 .. 128 votes (N % 4 == 0) whose budgets are all 0, a power of two <= 16 / 32 / 64 (pools <= 32 / 64 / 128), or
- *                         >= N come out of ONE sort per problem (scv_sort_prefix).  A HOST-mode call reads the budgets; a DEVICE-mode call queues that
+ *                         auto includes: pools of 17 .. 128 votes (N % 4 == 0, 16-byte aligned bases) whose budgets are all 0, a power of two <= 16 / 32 / 64
+ *                         (pools <= 32 / 64 / 128), or >= N come out of ONE sort per problem (scv_sort_prefix) -- pools of 17 .. 64 votes always, pools of
+ *                         68 .. 128 votes (scv_sort_prefix2: ~36 us for a launch of one step per wave) from 98 304 pools per call; with tokens their sums
+ *                         come from scv_prefix_tokens queued behind it.  A HOST-mode call reads the budgets; a DEVICE-mode call queues that
  *                         kernel in front of the general one and the two decide from n_valid which of them does the work (~4 us for the one that
- *                         leaves).  | 5 = auto, and the caller PROMISES budgets of that form for such pools: a DEVICE-mode call queues scv_sort_prefix
- *                         alone; a list that breaks the promise computes nothing and is SCV_ERR_ARG (at the call in HOST mode, at the next
- *                         synchronisation in DEVICE mode).  1 .. 4 switch the kernel off
+ *                         leaves).  | 5 = auto, and the caller PROMISES budgets of that form for such pools (any number of them, with or without
+ *                         tokens): a DEVICE-mode call queues scv_sort_prefix alone; a list that breaks the promise computes nothing and is
+ *                         SCV_ERR_ARG (at the call in HOST mode, at the next synchronisation in DEVICE mode).  1 .. 4 switch the kernel off
  *   "boot_path"           scv_aggregate_bootstrap_i32: 0 auto (ONE cooperative launch when the shape allows it) | 1 one ORDINARY launch |
  *                         2 two launches, LDS-resident code table | 3 two launches, global gathers (also scv_bootstrap's kernel)
  *   "boot_spin_limit"     default 2^20: polls at the grid barrier before a workgroup of an ordinary one-launch form gives up and leaves
@@ -336,7 +342,8 @@ int scv_host_free(void* p);
  * overwritten by the vote kernel's last workgroup), "lds_counters" (register-resident launches that produced their counters
  * themselves), "sort_cells" (sorted-cells launches), "few_votes" (launches of the kernel for cells of exactly 1, 2 or 4 votes), "prefix_cells" / "prefix_lane" / "prefix_pool" (prefix calls served by the cell kernels / by
  * the one-lane-per-problem kernel / by the one-pass-per-problem kernel), "prefix_sort" (launches of scv_sort_prefix: every power-of-two budget out of one
- * sort per problem -- queued, that is: a DEVICE-mode launch may find budgets it does not serve and leave them to the kernel behind it), "host_small_calls" / "host_pipelined_calls" (HOST-mode calls served by the one-block small path / by
+ * sort per problem -- queued, that is: a DEVICE-mode launch may find budgets it does not serve and leave them to the kernel behind it), "prefix_tokens" (launches of
+ * scv_prefix_tokens: the token sums of pools of 68 .. 128 votes, queued behind scv_sort_prefix2), "host_small_calls" / "host_pipelined_calls" (HOST-mode calls served by the one-block small path / by
  * the staging pipeline), "host_thread_start_failures" (worker threads of the staging pipeline the system refused to start: the
  * pipeline runs with the threads it has, the calling thread at least). */
 int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out);

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(CSRC, "libscvote.so")
 UNITS = ["scvote.hip", "scvote_stream_c4.hip", "scvote_stream_c8.hip", "scvote_stream_c16.hip",
-         "scvote_reg_g16.hip", "scvote_reg_g32.hip", "scvote_reg_g64.hip", "scvote_dense.hip", "scvote_comm.hip", "scvote_sort.hip", "scvote_prefix.hip", "scvote_sort_prefix.hip"]
+         "scvote_reg_g8.hip", "scvote_reg_g16.hip", "scvote_reg_g32.hip", "scvote_reg_g64.hip", "scvote_dense.hip", "scvote_comm.hip", "scvote_sort.hip", "scvote_prefix.hip", "scvote_sort_prefix.hip"]
 HEADERS = [os.path.join(CSRC, "scvote_kernels.hip.h"), os.path.join(CSRC, "scvote_dispatch.h"), os.path.join(CSRC, "scvote_hostpool.h"),
            os.path.join(os.path.dirname(HERE), "include", "scvote.h")]
 UNIT_HEADERS = {"scvote_sort.hip": [os.path.join(CSRC, "scvote_sort.hip.h"), os.path.join(CSRC, "scvote_sortnet.h")],

@@ -128,6 +128,7 @@ struct scv_ctx {
     // options (scv_set_option; include/scvote.h documents every key)
     int path = 0;            // 0 auto | 1 streaming, whole cells | 2 streaming, split-N | 4 register-resident cells | 5 sorted cells
     int segs_override = 0;   // > 0: segments per cell for path 2
+    int split_seg_kb = 256;  // split-N: smallest segment the auto choice cuts (KiB)
     int overwrite_counters = 0;  // DEVICE mode: per-budget outputs are overwritten instead of accumulated into (no caller memset)
     int sort_n_min = 8;      // sorted cells (scv_sort_cells): sort_n_min <= N <= sort_n_max (rows that are not 16-byte aligned: from 5); shorter
     int sort_n_max = 64;     // cells stay on scv_lane_cells, longer ones go to the register-resident kernels; sort_n_max = 0: off
@@ -151,7 +152,7 @@ struct scv_ctx {
     // the last fused request, kept so that a grid-barrier timeout can be repaired at scv_sync by a separate bootstrap launch
     struct BootLast { const scv_cell* cells = nullptr; int64_t P = 0; int32_t B = 0, r0 = 0, r1 = 0, M = 0; uint64_t seed = 0; int64_t* out = nullptr; bool valid = false; } boot_last;
     int64_t stat_boot_recovered = 0, stat_boot_cooperative = 0, stat_sort_cells = 0, stat_few_votes = 0, stat_prefix_pool = 0;
-    int64_t stat_prefix_sort = 0;
+    int64_t stat_prefix_sort = 0, stat_prefix_tokens = 0;
     const int32_t* nv_host = nullptr;   // HOST-mode calls: the caller's n_valid (host memory) for the duration of the call -- launch_prefix reads the budgets
     // split-N scratch (grown on demand)
     void* d_partial = nullptr;
@@ -248,12 +249,15 @@ int ensure_cells(scv_ctx* ctx, size_t bytes) {
 // Arrival counters of the single-launch modes (overwrite-counters, vote + bootstrap): 4 words, zero when allocated at scv_create,
 // and every counter is reset by the workgroup that completes it, so they are all-zero again whenever no launch is in flight.
 // Nothing allocates on the launch path: legal inside hipGraph capture and independent of later scv_set_stream calls.
-constexpr size_t kTicketWords = 64;
+constexpr size_t kTicketWords = 8 + scv::kSplitTickets;     // [0 .. 2] the single-launch epilogues | [8 + cell] split-N arrival counters
 
+// split-N scratch: the split cells' histograms and token sums in memory.  All zero whenever no launch is in flight (the workgroup that
+// finishes a cell clears what it read), so it is cleared here once, when it is (re)allocated.
 int ensure_partial(scv_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->d_partial_bytes) return SCV_OK;
-    if (ctx->d_partial) { SCV_HIP(hipFree(ctx->d_partial)); ctx->d_partial = nullptr; ctx->d_partial_bytes = 0; }
+    if (ctx->d_partial) { SCV_HIP(hipStreamSynchronize(ctx->stream)); SCV_HIP(hipFree(ctx->d_partial)); ctx->d_partial = nullptr; ctx->d_partial_bytes = 0; }
     SCV_HIP(hipMalloc(&ctx->d_partial, bytes));
+    SCV_HIP(hipMemset(ctx->d_partial, 0, bytes));
     ctx->d_partial_bytes = bytes;
     return SCV_OK;
 }
@@ -264,7 +268,7 @@ int ensure_partial(scv_ctx* ctx, size_t bytes) {
 //   lane      N <= 4 (and pool rows <= 32)  one lane per cell, registers only                (scv_lane_cells)
 //   sorted    5 / 8 <= N <= 64              one lane per cell, rows by LDS-DMA, sorted       (scv_sort_cells)
 //   register  up to 8192                    a cell in the registers of 16 / 32 / 64 lanes    (scv_reg_cells, scv_reg_dense)
-//   split-N   cells <= CUs/2, big N         several workgroups per cell + merge kernel       (scv_hist_argmax + scv_merge_partials)
+//   split-N   cells <= CUs/2, big N         several workgroups per cell, merged in the launch  (scv_hist_argmax: device atomics + a ticket per cell)
 //   stream    everything else               one persistent workgroup streams whole cells     (scv_hist_argmax)
 // plus scv_reduce_cells behind the streaming kernel when the per-budget counters are not fused.
 // lds bytes of the one-lane-per-cell kernel (tie classes 0..nv and two sums per budget)
@@ -415,7 +419,8 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         // A/B runs: g*100 + v (sparse: g lanes per cell, v vectors per lane) or 1000 + v*10 + h (dense: h parts of v vectors)
         int g = 0, v = 0, h = 0;
         if (Nreg <= 64) { g = 16; v = 1; }
-        else if (Nreg <= 128) { g = 16; v = 2; }
+        else if (Nreg <= 96) { g = 8; v = 3; }        // round 6: 96 slots for 65 ... 96 votes (8 lanes x 3 vectors, 8-bit bins), not 128 ("reg_shape" = 1602: round 5's shape)
+        else if (Nreg <= 128) { g = 8; v = 4; }       // ... and 8 lanes x 4 vectors for 97 ... 128 (3-10 % over 16 lanes x 2: eight cells per wave share the fixed work)
         else if (Nreg <= 256) { g = 16; v = 4; }
         else if (Nreg <= 512) { g = 32; v = 4; }
         else if (Nreg <= 896) { g = 64; v = 4; }
@@ -423,13 +428,15 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         else if (Nreg <= 2048) { v = 4; h = 2; }      // 4 KiB parts: 126-136 VGPRs, 3 waves per SIMD (8 KiB parts: 200, 2 waves; measured 73 vs 79 us)
         else if (Nreg <= 4096) { v = 4; h = 4; }
         else { v = 4; h = 8; }                        // 4096 < N <= 8192: 4.5 -> 5.4 TB/s at N = 4608 against the streaming kernel, equal at 8192
-        if (ctx->reg_shape >= 1000) {
+        // (round 6: the dense codes are 1041 ... 1048 ONLY -- until now every value >= 1000 was read as a dense code, so 1601 / 1602 / 1604 / 3204 /
+        //  6404 were never honoured: a forced sparse shape silently ran the auto choice)
+        if (ctx->reg_shape >= 1040 && ctx->reg_shape < 1050) {
             const int fv = (ctx->reg_shape - 1000) / 10, fh = ctx->reg_shape % 10;
             if (fv == 4 && (fh == 1 || fh == 2 || fh == 4 || fh == 8) && (int64_t)256 * fv * fh >= Nreg) { g = 0; v = fv; h = fh; }
         } else if (ctx->reg_shape > 0) {
             const int fg = ctx->reg_shape / 100, fv = ctx->reg_shape % 100;
-            const bool have = (fg == 16 && (fv == 1 || fv == 2 || fv == 4)) || ((fg == 32 || fg == 64) && fv == 4);
-            if (have && (int64_t)4 * fg * fv >= Nreg) { g = fg; v = fv; h = 0; }
+            const bool have = (fg == 16 && (fv == 1 || fv == 2 || fv == 4)) || ((fg == 32 || fg == 64) && fv == 4) || (fg == 8 && (fv == 3 || fv == 4));
+            if (have && (int64_t)4 * fg * fv >= Nreg && (fg != 8 || scv::pick_reg_g8(fv, tok, vec).fn)) { g = fg; v = fv; h = 0; }   // ((8, 4): A/B builds only)
         }
         const int64_t cpw = h ? 1 : 64 / g;
         const int64_t nbatches = (ncells + cpw - 1) / cpw;
@@ -549,12 +556,15 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     // split-N when whole cells cannot fill the chip: S workgroups per cell, then one merge launch.
     // Measured (tools/segs_sweep.py): best is ONE round of items (at most one per workgroup slot) with
     // segments of at least 512 KiB -- more, smaller segments only add fold/publish/merge work.
+    // Round 6: the segments of a cell are merged INSIDE the launch (device atomics into the cell's histogram in memory, the last segment to
+    // arrive runs the epilogue), so a segment costs its fold + 16 atomic instructions, not 4 KiB of traffic and a share of a second kernel:
+    // segments of 256 KiB, one round over every workgroup slot (a single cell of 2^24 votes: 128 x 512 KiB + merge launch = 27.8 us in round 5).
     int64_t S = 1;
-    if (ctx->path == 2 || (ctx->path == 0 && 2 * ncells <= slots && N * 4 >= (1 << 20))) {
+    if ((ctx->path == 2 || (ctx->path == 0 && 2 * ncells <= slots && N * 4 >= (1 << 20))) && ncells <= scv::kSplitTickets) {
         if (ctx->segs_override > 0) S = ctx->segs_override;
         else {
             S = slots / ncells;
-            const int64_t by_size = (N * 4) / (512 << 10);
+            const int64_t by_size = (N * 4) / (ctx->split_seg_kb << 10);
             if (S > by_size) S = by_size;
         }
         if (S > 4096) S = 4096;
@@ -563,21 +573,21 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     if (S > 1) {
         a.segs = (int32_t)S;
         a.seg_len = ((N + S - 1) / S + 3) & ~(int64_t)3;     // multiple of 4 votes: segments start 16-byte aligned in aligned rows
-        a.sorted = 0;                                        // merge kernel indexes partials by cell
-        const size_t items = (size_t)ncells * (size_t)S;
-        const size_t hist_bytes = items * scv::kBins * sizeof(uint32_t);
-        if (int rc = ensure_partial(ctx, hist_bytes + items * sizeof(long long) + 256)) return rc;
+        a.sorted = 0;                                        // split items are numbered cell-major
+        const size_t hist_bytes = (size_t)ncells * scv::kBins * sizeof(uint32_t);
+        if (int rc = ensure_partial(ctx, hist_bytes + (size_t)ncells * sizeof(long long) + 256)) return rc;
         a.partial = static_cast<uint32_t*>(ctx->d_partial);
         a.partial_tok = reinterpret_cast<long long*>(static_cast<char*>(ctx->d_partial) + ((hist_bytes + 255) / 256) * 256);
+        a.tickets = static_cast<uint32_t*>(ctx->d_tickets);
     }
     // the single-launch epilogues exist for the geometries the library picks itself (scvote_dispatch.h)
     const bool have_xtra = pick_kernel(copies, threads, unroll, tok, true) != nullptr;
     if (a.overwrite && (S > 1 || !have_xtra)) {
-        // split cells are finished by the merge KERNEL (the main launch's last workgroup would read an unfinished cell table), and a
+        // split cells use the tickets for their own hand-off (kept simple: no second epilogue behind it), and a
         // hand-tuned geometry may have no epilogue variant: overwrite = memset node + accumulate here.
         a.overwrite = 0;
         overwrite_fused = false;
-        a.tickets = nullptr;
+        if (S == 1) a.tickets = nullptr;
         a.ow_tie = a.ow_tok = a.ow_truth = nullptr;
         a.cells = cells; a.cell_tokens = cell_tokens;
         a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
@@ -652,12 +662,6 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     }
     if (!launched) hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)threads), lds, ctx->stream, a);
     SCV_HIP(hipGetLastError());
-    if (S > 1) {
-        int64_t mgrid = ncells < (int64_t)ctx->num_cus * 8 ? ncells : (int64_t)ctx->num_cus * 8;
-        if (tok) hipLaunchKernelGGL((scv::scv_merge_partials<true>), dim3((unsigned)mgrid), dim3(1024), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((scv::scv_merge_partials<false>), dim3((unsigned)mgrid), dim3(1024), 0, ctx->stream, a);
-        SCV_HIP(hipGetLastError());
-    }
     return finish(ev);
 }
 
@@ -791,27 +795,31 @@ int launch_sort_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
                        int64_t P, int32_t B, int64_t N, scv_cell* cells, int64_t* cell_tokens, int64_t* tie, int64_t* tok_sum,
                        int64_t* truth_sum, bool promised, bool* queued, int* nv_out) {
     *queued = false;
-    const bool tok = tokens != nullptr;
     const int nv = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
+    // pools of 68 .. 128 votes WITH tokens (the reference's largest pool, o1.py:266-276, and its drop-in always sums tokens, o1.py:195): the votes
+    // go through scv_sort_prefix2 as without tokens, the token sums come from scv_prefix_tokens queued right behind it -- the token rows read as one
+    // contiguous stream, no image (round 6; scvote_sort_prefix.hip.h)
+    const bool tok_sep = tokens != nullptr && nv == 128;
+    const bool tok = tokens != nullptr && !tok_sep;
     const RegKernel rk = pick_sort_prefix_kernel(nv, tok);
     const int64_t ps = nv == 128 ? 17 : ((N / 4) | 1);                 // (128: the row goes through the image in two halves of up to 64 votes)
-    // one image per wave (scv_sort_prefix: a step's tokens follow its votes through it; scv_sort_prefix2 keeps a tokens image of its own)
-    const int64_t region_words = 64 * ps * 4 * ((tok && nv == 128) ? 2 : 1) + 64;
+    // one image per wave (scv_sort_prefix: a step's tokens follow its votes through it)
+    const int64_t region_words = 64 * ps * 4 + 64;
     const int64_t tail_words = scv::sort_prefix_tail_words(nv, B);
     int W = rk.waves;
     while (W > 2 && (W * region_words + tail_words) * 4 + 1024 > ctx->lds_max) --W;
     if ((W * region_words + tail_words) * 4 + 1024 > ctx->lds_max) return SCV_OK;
     scv::AggArgs a;
     a.pool_rows = 1;
-    a.answers = pool; a.tokens = tokens; a.n_valid = n_valid; a.truth = truth;
+    a.answers = pool; a.tokens = tok ? tokens : nullptr; a.n_valid = n_valid; a.truth = truth;
     a.ncells = P * (int64_t)B; a.N = N; a.B = B; a.P = P;
-    a.cells = cells; a.cell_tokens = cell_tokens;
+    a.cells = cells; a.cell_tokens = tok ? cell_tokens : nullptr;
     a.tie_hits = reinterpret_cast<unsigned long long*>(tie);
-    a.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
+    a.token_sum = tok ? reinterpret_cast<unsigned long long*>(tok_sum) : nullptr;
     a.truth_sum = reinterpret_cast<unsigned long long*>(truth_sum);
     a.err_flag = ctx->d_err;
     a.prefetch = 0; a.sorted = 1;
-    a.budgets_promised = promised ? 1 : 0;
+    a.budgets_promised = promised ? 1 : 0;     // the list is KNOWN to be of the served form (promised by the caller: option prefix_path = 5, or read by a HOST-mode call)
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.acc_classes = 0;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr;
     a.wave_lds_words = (int32_t)region_words;
@@ -827,6 +835,27 @@ int launch_sort_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
     hipLaunchKernelGGL(rk.fn, dim3((unsigned)grid), dim3((unsigned)(W * 64)), lds, ctx->stream, a);
     SCV_HIP(hipGetLastError());
     ctx->stat_prefix_sort += 1;
+    if (tok_sep && (cell_tokens || tok_sum)) {
+        scv::AggArgs t = a;
+        t.tokens = tokens; t.cells = nullptr; t.cell_tokens = cell_tokens;
+        t.tie_hits = nullptr; t.truth_sum = nullptr;
+        t.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
+        t.only_if_sortable = nv;                              // (a list the sort kernel leaves to the general kernel: that one sums the tokens too)
+        const KernelFn tf = scv::pick_prefix_tokens_kernel(32);
+        const int tw = 4;
+        const size_t tlds = (size_t)scv::prefix_tokens_lds_words_host(32, B, tw) * sizeof(uint32_t);
+        SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+        const int64_t tsteps = (P + 2 * scv::kPrefixTokensGroups - 1) / (2 * scv::kPrefixTokensGroups);   // a step = 4 groups of 2 rows per wave
+        int64_t tgrid = (tsteps + tw * 4 - 1) / (tw * 4);     // >= 4 steps per wave before the grid grows
+        int per_cu = (int)(ctx->lds_max / (int64_t)(tlds + 512));
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        if (tgrid > (int64_t)ctx->num_cus * per_cu) tgrid = (int64_t)ctx->num_cus * per_cu;
+        if (tgrid < 1) tgrid = 1;
+        hipLaunchKernelGGL(tf, dim3((unsigned)tgrid), dim3((unsigned)(tw * 64)), tlds, ctx->stream, t);
+        SCV_HIP(hipGetLastError());
+        ctx->stat_prefix_tokens += 1;
+    }
     ctx->err_dirty = true;
     *queued = true;
     *nv_out = nv;
@@ -855,9 +884,9 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
         N > 16 && N <= 128 && B <= scv::kMaxSortedB &&
         // pools of 68 .. 128 votes (scv_sort_prefix2: two sorts, a merge and a 128-vote scan per step) pay ~36 us for a launch of one step per wave:
         // measured against scv_prefix_pool it wins from ~1e5 pools (2e5: 64 against 84 us, 8e5: 183 against 297; 3e4: 153 against 69 in HOST-mode
-        // chunks), and with tokens (two images: four waves per CU) it does not win at all (2e5: 114 against 114) -- not used there
-        // (prefix_path = 5 selects it for any number of token-less pools)
-        (N <= 64 || (!tokens && (P >= 98304 || ctx->prefix_path == 5)))) {
+        // chunks); with tokens (round 6) the sums come from scv_prefix_tokens queued behind it (round 5 tried a second image: 114 against 114 us,
+        // and left such calls on scv_prefix_pool); prefix_path = 5 selects it for any number of pools
+        (N <= 64 || P >= 98304 || ctx->prefix_path == 5)) {
         // prefix_path = 5: the caller PROMISES budgets of that form (a DEVICE-mode call then queues scv_sort_prefix alone; a list that breaks
         // the promise is an error, reported like a domain error at the next synchronisation)
         const bool promised = ctx->prefix_path == 5;
@@ -881,7 +910,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
             }
             if (ev_open) SCV_HIP(hipEventRecord(ev_open->a, ctx->stream));
             bool queued = false;
-            if (int rc = launch_sort_prefix(ctx, pool, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, promised, &queued, &skip_sortable)) return rc;
+            if (int rc = launch_sort_prefix(ctx, pool, tokens, n_valid, truth, P, B, N, cells, cell_tokens, tie, tok_sum, truth_sum, known, &queued, &skip_sortable)) return rc;
             if (queued && known) {
                 if (ev_open) SCV_HIP(hipEventRecord(ev_open->b, ctx->stream));
                 return SCV_OK;
@@ -1650,6 +1679,7 @@ int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
         else if (!strcmp(key, "prefix_lane")) *out = ctx->stat_prefix_lane;
     else if (!strcmp(key, "prefix_pool")) *out = ctx->stat_prefix_pool;
     else if (!strcmp(key, "prefix_sort")) *out = ctx->stat_prefix_sort;
+    else if (!strcmp(key, "prefix_tokens")) *out = ctx->stat_prefix_tokens;
         else if (!strcmp(key, "sort_cells")) *out = ctx->stat_sort_cells;
         else if (!strcmp(key, "few_votes")) *out = ctx->stat_few_votes;
         else if (!strcmp(key, "host_small_calls")) *out = ctx->stat_small_calls;
@@ -1697,6 +1727,7 @@ KernelFn pick_kernel(int copies, int t, int u, bool tok, bool xtra) {
     }
 }
 RegKernel pick_reg_kernel(int g, int v, bool tok, bool vec) {
+    if (g == 8) return pick_reg_g8(v, tok, vec);
     if (g == 16) return pick_reg_g16(v, tok, vec);
     if (g == 32) return pick_reg_g32(v, tok, vec);
     return pick_reg_g64(v, tok, vec);

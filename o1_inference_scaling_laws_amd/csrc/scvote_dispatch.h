@@ -1,7 +1,7 @@
 // scvote_dispatch.h -- host-side tables that map a launch geometry to a kernel instantiation.
 //
 // The kernel family is ~120 template instantiations.  They are spread over several translation units
-// (scvote_stream_c{4,8,16}.hip: the streaming kernel by LDS replication; scvote_reg_g{16,32,64}.hip: register-resident
+// (scvote_stream_c{4,8,16}.hip: the streaming kernel by LDS replication; scvote_reg_g{8,16,32,64}.hip: register-resident
 // cells by lanes per cell; scvote_dense.hip: register-streamed long cells; scvote_sort.hip: sorted cells) so that hipcc compiles
 // them in parallel (_build.py) and an edit to one kernel rebuilds one table.  scvote.hip (the C ABI) only sees these prototypes.
 #pragma once
@@ -23,8 +23,9 @@ KernelFn pick_stream_c8(int threads, int unroll, bool tok, bool xtra);
 KernelFn pick_stream_c16(int threads, int unroll, bool tok, bool xtra);
 
 // scv_reg_cells<g lanes per cell, v vectors per lane, ...>: capacity 4 * g * v votes per cell; the shapes the dispatch uses:
-// (16, 1) (16, 2) (16, 4) (32, 4) (64, 4)
+// (16, 1) (8, 3) (16, 2) (16, 4) (32, 4) (64, 4)
 RegKernel pick_reg_kernel(int g, int v, bool tok, bool vec);
+RegKernel pick_reg_g8(int v, bool tok, bool vec);      // (8, 3): 65 ... 96 votes in 96 slots, 8-bit bins; (8, 4): an A/B shape for 97 ... 128
 RegKernel pick_reg_g16(int v, bool tok, bool vec);
 RegKernel pick_reg_g32(int v, bool tok, bool vec);
 RegKernel pick_reg_g64(int v, bool tok, bool vec);
@@ -54,6 +55,11 @@ RegKernel pick_prefix_pool_kernel(int g, bool tok, bool vec);
 constexpr int sort_prefix_classes(int nv) { int l = 0; while ((1 << l) < nv / 2) ++l; return l + 3; }
 constexpr long long sort_prefix_tail_words(int nv, int B) { return 16 + ((B + 3) & ~3) + ((sort_prefix_classes(nv) * (nv + 1) + 1) & ~1) + 4 * sort_prefix_classes(nv); }
 RegKernel pick_sort_prefix_kernel(int nv, bool tok);
+// scv_prefix_tokens<16 / 32 lanes per row> (scvote_sort_prefix.hip.h): token sums of prefix budgets, rows of up to 64 / 128 tokens; 256 threads;
+// dynamic LDS = prefix_tokens_lds_words(lanes, B, 4) words
+KernelFn pick_prefix_tokens_kernel(int lanes);
+constexpr int kPrefixTokensGroups = 4;            // = kPrefixTokensU of the kernel: row groups a wave has in flight per step
+constexpr long long prefix_tokens_lds_words_host(int L, int B, int waves) { return ((B + 3) & ~3) + 2ll * ((B + 1) & ~1) + (long long)waves * kPrefixTokensGroups * (64 / L) * 4 * L * 2; }
 
 // ---- shared by the table translation units ------------------------------------------------------------------------
 template <int RL2, int T, int U>

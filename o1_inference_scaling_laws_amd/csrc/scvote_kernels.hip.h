@@ -4,7 +4,7 @@
 //                     Replaces, per (problem, budget) cell, /root/reference/o1.py:181-195 (collect N
 //                     votes, sum tokens), o1.py:202 (statistics.multimode) and o1.py:204-213 (tie-aware
 //                     score), and accumulates the integer part of the per-budget reduction o1.py:229-245.
-// scv_merge_partials  finishes cells that were split over several workgroups.
+// (split cells -- several workgroups per cell -- are merged inside the scv_hist_argmax launch: device atomics + a ticket per cell, round 6)
 // scv_few_votes       cells of exactly 1 / 2 / 4 votes in whole blocks (the reference's most common sizes, o1.py:276, 302).
 // scv_lane_cells      one lane per cell, registers only: N = 3, 5 .. 7, partial blocks, pool rows of up to 32 votes.
 // scv_reg_cells, scv_reg_dense      a cell in the registers of 16 / 32 / 64 lanes, 16-bit bins in LDS (64 < N <= 8192).
@@ -48,6 +48,7 @@ namespace scv {
 
 constexpr int kBins = SCV_NUM_BINS;
 constexpr int kRedWords = 96;  // cross-wave scratch behind the histogram
+constexpr int kSplitTickets = 512;  // split-N in one launch: one arrival counter per split cell (tickets[8 + cell]; a launch splits at most this many cells)
 
 struct AggArgs {
     const int32_t* answers;
@@ -86,10 +87,12 @@ struct AggArgs {
                             // as a separate launch at the next scv_sync)
     uint64_t boot_seed;
     unsigned long long* boot_out;   // [r1 - r0][B][M]
-    uint32_t* partial;      // split-N: [ncells * segs][1024] partial histograms
-    long long* partial_tok; // split-N: [ncells * segs] partial token sums
+    uint32_t* partial;      // split-N: [ncells][1024] the cells' histograms in memory, summed by device atomics (all zero between launches)
+    long long* partial_tok; // split-N: [ncells] the cells' token sums, likewise
     int32_t skip_sortable = 0;      // prefix kernels queued BEHIND scv_sort_prefix<NV> (DEVICE mode: the host cannot read n_valid): = NV; the
                                     // launch leaves at once when every budget is of the form that kernel serves (it has done the work)
+    int32_t only_if_sortable = 0;   // scv_prefix_tokens queued NEXT TO scv_sort_prefix<NV> (DEVICE mode): = NV; the launch leaves at once unless every budget
+                                    // is of the form that kernel serves (otherwise the general kernel behind them does votes and tokens)
     int32_t budgets_promised = 0;   // scv_sort_prefix: != 0 = the budgets are KNOWN to be of its form (read by a HOST-mode call, or promised by the
                                     // caller: option prefix_path = 5): a list that is not sets error bit 8 instead of leaving the launch to another kernel
 };
@@ -778,23 +781,41 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
         uint32_t cnt[NB];
         fold_copies<RL2, T, true>(hist, tid, cnt);     // and zero them for the next item
         if (S > 1) {
-            // split-N: publish the partial histogram; scv_merge_partials finishes the cell
-            uint32_t* out = a.partial + (item << 10);
+            // split-N, ONE launch (round 6; round 5 published 4 KiB per segment and a second kernel merged them: 27.8 us for one cell of
+            // 2^24 votes): the segment's folded counts are ADDED into the cell's histogram in memory -- device atomics at L2, a wave's 64
+            // consecutive bins = two 128-byte requests --, the token sum into the cell's 64-bit word; the workgroup that arrives last at the
+            // cell's ticket reads the sums back (agent-scope loads), clears histogram, token word and ticket for the next launch, and runs the
+            // common epilogue.  Nothing but the votes is read twice; the scratch is all-zero whenever no launch is in flight.
+            uint32_t* gh = a.partial + (cell << 10);            // (split items are numbered cell-major and the sorted traversal is off: item / S == cell)
 #pragma unroll
-            for (int k = 0; k < NB; ++k) out[tid + k * T] = cnt[k];
+            for (int k = 0; k < NB; ++k)
+                if (cnt[k]) __hip_atomic_fetch_add(gh + tid + k * T, cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (TOK) {
                 const long long wt = wave_sum_i64(tsum);
-                if (lane == 0) {
-                    red[64 + 2 * (tid >> 6)] = (uint32_t)((unsigned long long)wt & 0xffffffffull);
-                    red[65 + 2 * (tid >> 6)] = (uint32_t)((unsigned long long)wt >> 32);
-                }
+                if (lane == 0 && wt) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(a.partial_tok) + cell, (unsigned long long)wt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __syncthreads();  // histogram zero again; wave token sums visible
-            if (TOK && tid == 0) {
-                long long tok = 0;
-                for (int w = 0; w < T / 64; ++w)
-                    tok += (long long)(((unsigned long long)red[65 + 2 * w] << 32) | red[64 + 2 * w]);
-                a.partial_tok[item] = tok;
+            drain_stores();                                   // this wave's atomics have been performed at L2 ...
+            __syncthreads();                                  // ... and every wave's (and the histogram is zero again)
+            if (tid == 0) {
+                const uint32_t arrived = __hip_atomic_fetch_add(a.tickets + 8 + cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                red[52] = (arrived == (uint32_t)S - 1u) ? 1u : 0u;
+                red[48] = 0;
+            }
+            __syncthreads();
+            if (red[52]) {                                    // the last segment of the cell: every other segment's sums are in memory
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    cnt[k] = ld_agent(gh + tid + k * T);
+                    st_agent(gh + tid + k * T, 0u);
+                }
+                long long tsum_all = 0;
+                if (TOK && tid == 0) {
+                    unsigned long long* tw = reinterpret_cast<unsigned long long*>(a.partial_tok) + cell;
+                    tsum_all = (long long)ld_agent(tw);
+                    st_agent(tw, 0ull);
+                }
+                if (tid == 0) st_agent(a.tickets + 8 + cell, 0u);
+                finalize_cell<T, TOK, XTRA>(a, red, cnt, tsum_all, tid, cell, b, a.truth[p]);
             }
         } else {
             finalize_cell<T, TOK, XTRA>(a, red, cnt, tsum, tid, cell, b, a.truth[p]);
@@ -842,46 +863,6 @@ __global__ __launch_bounds__(T) void scv_hist_argmax(const AggArgs a) {
         bool overflow = false;
         if (red[51]) bootstrap_in_launch<T>(a, hist, tid, overflow);
         if (overflow) atomicOr(a.err_flag, 2u);
-    }
-}
-
-// ---- kernel 1b: merge the partial histograms of split cells -------------------------------------
-// 1024 threads per cell: thread (g = tid >> 8, q = tid & 255) sums bins 4q..4q+3 over segments
-// s == g (mod 4) with 16-byte loads (4 independent streams, 64+ KiB in flight), LDS combines the four
-// groups, then the common epilogue runs with one bin per thread.
-template <bool TOK>
-__global__ __launch_bounds__(1024) void scv_merge_partials(const AggArgs a) {
-    constexpr int T = 1024;
-    __shared__ __attribute__((aligned(16))) uint32_t part[4 * kBins];
-    __shared__ uint32_t red[kRedWords];
-    const int tid = threadIdx.x, g = tid >> 8, q = tid & 255;
-    const int32_t S = a.segs;
-    for (int64_t cell = blockIdx.x; cell < a.ncells; cell += gridDim.x) {
-        const int64_t p = cell / a.B;
-        const int32_t b = (int32_t)(cell - p * a.B);
-        // the streaming kernel numbers split items cell-major (sorted traversal is off when segs > 1)
-        const uint4* in = reinterpret_cast<const uint4*>(a.partial + ((cell * S) << 10)) + q;
-        uint4 acc = make_uint4(0, 0, 0, 0);
-        int32_t s = g;
-        for (; s + 12 < S; s += 16) {
-            const uint4 x0 = in[(int64_t)s << 8], x1 = in[(int64_t)(s + 4) << 8];
-            const uint4 x2 = in[(int64_t)(s + 8) << 8], x3 = in[(int64_t)(s + 12) << 8];
-            acc.x += x0.x + x1.x + x2.x + x3.x; acc.y += x0.y + x1.y + x2.y + x3.y;
-            acc.z += x0.z + x1.z + x2.z + x3.z; acc.w += x0.w + x1.w + x2.w + x3.w;
-        }
-        for (; s < S; s += 4) {
-            const uint4 x = in[(int64_t)s << 8];
-            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-        }
-        reinterpret_cast<uint4*>(part + g * kBins)[q] = acc;
-        long long tsum = 0;
-        if (TOK) for (int32_t t = tid; t < S; t += T) tsum += a.partial_tok[cell * S + t];
-        if (tid == 0) red[48] = 0;
-        __syncthreads();
-        uint32_t cnt[1];
-        cnt[0] = part[tid] + part[kBins + tid] + part[2 * kBins + tid] + part[3 * kBins + tid];
-        finalize_cell<T, TOK>(a, red, cnt, tsum, tid, cell, b, a.truth[p]);
-        // `part` is rewritten only after the other threads pass finalize_cell's barriers
     }
 }
 
@@ -1626,7 +1607,7 @@ __device__ __forceinline__ uint32_t cellgroup_max(uint32_t v) {
     t = dpp_mov<kQuadXor1>(v); v = v > t ? v : t;
     t = dpp_mov<kQuadXor2>(v); v = v > t ? v : t;
     t = dpp_mov<kHalfMirror>(v); v = v > t ? v : t;
-    t = dpp_mov<kRowMirror>(v); v = v > t ? v : t;
+    if (G >= 16) { t = dpp_mov<kRowMirror>(v); v = v > t ? v : t; }
     if (G >= 32) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); v = r[0] > r[1] ? r[0] : r[1]; }
     if (G >= 64) { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); v = r[0] > r[1] ? r[0] : r[1]; }
     return v;
@@ -1636,7 +1617,7 @@ __device__ __forceinline__ uint32_t cellgroup_sum(uint32_t v) {
     v += dpp_mov<kQuadXor1>(v);
     v += dpp_mov<kQuadXor2>(v);
     v += dpp_mov<kHalfMirror>(v);
-    v += dpp_mov<kRowMirror>(v);
+    if (G >= 16) v += dpp_mov<kRowMirror>(v);
     if (G >= 32) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); v = r[0] + r[1]; }
     if (G >= 64) { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); v = r[0] + r[1]; }
     return v;
@@ -1660,6 +1641,12 @@ constexpr int kRegLaneWords = 64 + 128 + 64;         // + per lane: the first pi
 // end-of-launch counter flush then costs 256 device atomics per counter (12 ns each on one address), not 1024.
 template <int G, int V, bool TOK, bool VEC = true>
 constexpr int reg_cells_waves() {
+#ifdef SCV_G8_WAVES
+    if (G == 8) return SCV_G8_WAVES;           // (A/B builds)
+#endif
+    // 8 lanes per cell, 8-bit bins: 8 cells x 1026 bytes = the same 8 KiB per wave.  (8, 3) runs K = 2 batches per iteration at 12 waves (136-157
+    // VGPRs; measured on one box, N = 96, D1 / D0 / D3 / D5: 80.6 / 74.9 / 75.9 / 72.1 us against 82.7 / 78.8 / 79.5 / 77.3 with K = 1 at 16 waves)
+    if (G == 8) return (V == 3 || TOK) ? 12 : 16;
     if (!VEC && V == 1) return 12;             // unaligned rows, K = 4 batches in flight: 12-28 B of scratch at 128 VGPRs
     // (with tokens the one-vector shapes run K = 4 batches per iteration, each with its token loads in flight: they
     // spill at 128 VGPRs -- tools/kernel_resources.py -- and get 12 waves = 168 VGPRs like the four-vector shapes)
@@ -1706,6 +1693,13 @@ __device__ __forceinline__ void lds_add(uint32_t addr, uint32_t inc) {
     __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>((uintptr_t)addr), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+// 8-bit bins (G = 8): the increment of the byte A & 3 of its word: 1 << (8 * (A & 3)) = v_bfm_b32(1, A << 3) (bfm reads 5 bits of the shift)
+__device__ __forceinline__ uint32_t byte_inc(uint32_t A) {
+    uint32_t inc;
+    asm("v_lshlrev_b32 %0, 3, %1\n\tv_bfm_b32 %0, 1, %0" : "=&v"(inc) : "v"(A));
+    return inc;
+}
 __device__ __forceinline__ uint32_t sum_halves(uint32_t w, uint32_t acc) {      // acc + w.lo + w.hi: v_dot2_u32_u16
     return __builtin_amdgcn_udot2(__builtin_bit_cast(scv_v2h, w), scv_v2h{1, 1}, acc, false);
 }
@@ -1768,6 +1762,23 @@ __device__ __forceinline__ uint32_t pivot_select_h16(uint32_t A, uint32_t ap0, u
     return W;
 }
 
+// 8-bit bins (G = 8): the word that holds the bin (A & ~3) and the increment 1 << 8 (A & 3); a pivot's word collects the same increments
+__device__ __forceinline__ uint32_t pivot_select_b8(uint32_t A, uint32_t ap0, uint32_t ap1, uint32_t tw, uint32_t tw2, uint32_t& inc) {
+    uint32_t W;
+    unsigned long long m1;
+    asm("v_cmp_eq_u32_e64 %[m1], %[a], %[p1]\n\t"
+        "v_cmp_eq_u32_e32 vcc, %[a], %[p0]\n\t"
+        "v_lshlrev_b32 %[i], 3, %[a]\n\t"
+        "v_cndmask_b32_e64 %[w], %[a], %[t2], %[m1]\n\t"
+        "v_cndmask_b32_e32 %[w], %[w], %[t1], vcc\n\t"
+        "v_bfm_b32 %[i], 1, %[i]\n\t"
+        "v_and_b32_e32 %[w], -4, %[w]"
+        : [w] "=&v"(W), [i] "=&v"(inc), [m1] "=&s"(m1)
+        : [a] "v"(A), [p0] "v"(ap0), [p1] "v"(ap1), [t1] "v"(tw), [t2] "v"(tw2)
+        : "vcc");
+    return W;
+}
+
 // G lanes per cell, V 16-byte vectors per lane, K batches of C cells per loop iteration (short cells: more
 // bytes in flight per wave), TOK tokens stream.  VEC: every row is 16-byte aligned (N % 4 == 0 and aligned bases).  !VEC: rows
 // start anywhere (the reference's N is arbitrary, o1.py:276): a cell reads the 16-byte-aligned SUPERSET of its row with the same
@@ -1777,7 +1788,7 @@ __device__ __forceinline__ uint32_t pivot_select_h16(uint32_t A, uint32_t ap0, u
 template <int G, int V, int K, bool TOK, bool VEC>
 __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_reg_cells(const AggArgs a) {
     constexpr int C = 64 / G;                 // cells per wave per batch
-    constexpr int R = G / 16;                 // histogram copies per cell
+    constexpr int R = G >= 16 ? G / 16 : 1;   // histogram copies per cell
     // 16-bit counters for every sparse shape (a cell slot holds <= 1024 votes): 8 KiB of LDS per wave instead of
     // 16, so 3-4 waves per SIMD are resident instead of 2 (measured +15-19 % at N = 64 ... 256).
     //  H16 (G = 16, one copy): a cell = 1026 u16 bins; a vote adds 1 << 16 (bin parity) to the WORD holding its bin
@@ -1785,11 +1796,16 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_
     //  P16 (G = 32 / 64, 2 / 4 copies): the copies of a bin sit side by side (one / two words per bin); a lane's
     //      increment (1 or 1 << 16) and word are constants of the lane, the read is one b32 / b64 + v_dot2_u32_u16.
     //      Two copies share a word, so all-equal votes serialise 32 deep instead of 16 (truth votes never do).
-    constexpr bool H16 = G == 16;
+    //  B8  (G = 8, round 6: 65 ... 96 votes in a 96-slot shape -- 8 lanes x 3 vectors -- instead of the 128 slots of 16 x 2): a cell =
+    //      1026 u8 bins, EIGHT cells per wave in the same 8 KiB; a vote adds 1 << 8 (A & 3) to the word holding its bin (one VALU more
+    //      than H16: v_lshlrev + v_bfm instead of v_alignbyte), reads and clears are 8-bit.  A bin holds <= 255: cells of up to 128 votes.
+    constexpr bool B8 = G == 8;
+    constexpr bool H16 = G <= 16;             // one copy per cell, sub-word bins (B8 is the 8-bit form of it)
     constexpr bool P16 = G > 16;
-    constexpr int S = H16 ? 1 : (R == 4 ? 3 : 2);   // log2(bytes between consecutive bins)
+    constexpr int S = B8 ? 0 : (H16 ? 1 : (R == 4 ? 3 : 2));   // log2(bytes between consecutive bins)
     constexpr int WW = kRegWaveWords16;
-    constexpr uint32_t CELLBYTES = (uint32_t)(kRegCopyBytes16 * R);
+    constexpr uint32_t CELLBYTES = B8 ? 1026u : (uint32_t)(kRegCopyBytes16 * R);
+    static_assert(!B8 || 4 * G * V <= 255, "8-bit bins hold at most 255 votes");
     constexpr int E = 4 * V;                  // votes per lane per batch
     constexpr uint32_t CAP = 4u * G * V;      // votes per cell slot
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_wg[];
@@ -1939,7 +1955,16 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_
         uint32_t ap1 = A[1] != ap0 ? A[1] : (A[2] != ap0 ? A[2] : A[3]);
 #pragma unroll
         for (int i = 0; i < EL; ++i) {
-            if (H16) {
+            if (B8) {
+                uint32_t inc, W;
+#ifdef SCV_G8_NOPIVOT
+                W = A[i] & ~3u; inc = byte_inc(A[i]);               // (A/B builds: every vote straight to its bin)
+#else
+                if (i == 0) { W = TW; inc = byte_inc(A[0]); }
+                else W = pivot_select_b8(A[i], ap0, ap1, TW, TW2, inc);
+#endif
+                lds_add(W, inc);
+            } else if (H16) {
                 uint32_t inc, W;
                 if (i == 0) { W = TW; inc = __builtin_amdgcn_alignbyte(1u, 1u, A[0]); }
                 else W = pivot_select_h16(A[i], ap0, ap1, TW, TW2, inc);
@@ -1950,6 +1975,9 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_
             }
         }
         // move the pivot words into the pivots' bins (LDS operations of a wave execute in order: the reads of pass 2 see them)
+#ifdef SCV_G8_NOPIVOT
+        if (!B8)
+#endif
         {
             const uint32_t w0 = __hip_atomic_exchange(reinterpret_cast<lds_u32*>((uintptr_t)TW), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint32_t w1 = __hip_atomic_exchange(reinterpret_cast<lds_u32*>((uintptr_t)TW2), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1971,14 +1999,14 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_
         // h[truth] (o1.py:206): every lane of the cell reads the truth's bin (same address: a broadcast).  Issued first, so it
         // has returned when the counts of pass 2 have (LDS answers in order); pinned before the clears of pass 4 below.
         const uint32_t ATt = (c.truth >= 0 && c.truth < kBins) ? KB - ((uint32_t)c.truth << S) : ATR;   // no such bin: the lane's trash
-        tc = H16 ? lds_count16<R>(ATt) : lds_count_packed<R>(ATt);
+        tc = B8 ? (uint32_t)*reinterpret_cast<lds_u8*>((uintptr_t)ATt) : (H16 ? lds_count16<R>(ATt) : lds_count_packed<R>(ATt));
 #pragma unroll
         for (int i0 = 0; i0 < EL; i0 += CH) {
             // all CH reads are issued before the first count is consumed (left alone, the scheduler keeps only
             // two ds_reads in flight and the pass becomes a chain of LDS latencies: measured 48 % wave-wait)
             uint32_t cn[CH];
 #pragma unroll
-            for (int i = i0; i < i0 + CH; ++i) cn[i - i0] = H16 ? lds_count16<R>(c.v[i]) : lds_count_packed<R>(c.v[i]);
+            for (int i = i0; i < i0 + CH; ++i) cn[i - i0] = B8 ? (uint32_t)*reinterpret_cast<lds_u8*>((uintptr_t)c.v[i]) : (H16 ? lds_count16<R>(c.v[i]) : lds_count_packed<R>(c.v[i]));
             __builtin_amdgcn_sched_group_barrier(0x100 /* DS read */, CH, 0);
             __builtin_amdgcn_sched_group_barrier(0x2 /* VALU */, CH * 6, 0);
 #pragma unroll
@@ -2004,7 +2032,8 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_
 #pragma unroll
         for (int i = 0; i < EL; ++i) {
             at_max += c.v[i] >= thr ? 1u : 0u;                      // inactive keys have count 0: they only count when max_count == 0
-            if (H16) *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) + copy4)) = (uint16_t)0;
+            if (B8) *reinterpret_cast<lds_u8*>((uintptr_t)(c.v[i] & kKeyMask)) = (uint8_t)0;
+            else if (H16) *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) + copy4)) = (uint16_t)0;
             else *reinterpret_cast<lds_u16*>((uintptr_t)((c.v[i] & kKeyMask) | copy2)) = (uint16_t)0;
         }
         __builtin_amdgcn_wave_barrier();

@@ -8,6 +8,9 @@ RegKernel pick_sort_prefix_kernel(int nv, bool tok) {
     if (nv == 32) return tok ? RegKernel{(KernelFn)scv_sort_prefix<32, true>, sort_prefix_threads(32) / 64} : RegKernel{(KernelFn)scv_sort_prefix<32, false>, sort_prefix_threads(32) / 64};
     return tok ? RegKernel{(KernelFn)scv_sort_prefix<64, true>, sort_prefix_threads(64) / 64} : RegKernel{(KernelFn)scv_sort_prefix<64, false>, sort_prefix_threads(64) / 64};
 }
+// scv_prefix_tokens<lanes per row>: the token sums of prefix budgets over pools of up to 64 / 128 tokens per row
+static_assert(kPrefixTokensU == kPrefixTokensGroups, "the host sizes the token kernel's LDS from kPrefixTokensGroups");
+KernelFn pick_prefix_tokens_kernel(int lanes) { (void)lanes; return (KernelFn)scv_prefix_tokens<32>; }   // (the 16-lane form -- rows of up to 64 tokens -- is not instantiated: those pools send their tokens through scv_sort_prefix's image)
 }  // namespace scv
 #ifdef SCV_SP_TIMELINE
 // measurement build only: read (and clear) the phase sums of scv_sort_prefix

@@ -867,4 +867,120 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
     }
 }
 
+
+// ---- the tokens of prefix budgets over short pools (round 6) ---------------------------------------------------------------------------------
+//
+// scv_prefix_tokens: cell_tokens[p][b] = sum of tokens[p][0 .. min(n_valid[b], N) - 1] (o1.py:195 over the budget's prefix), token_sum[b] = its
+// sum over the problems (o1.py:240).  The tokens of a sample never influence the vote, so the sums need nothing of the sort kernel's: not its
+// one-lane-per-problem layout (rows 512 bytes apart), not its 17 KiB image (scv_sort_prefix<64> sends a step's tokens through the image behind
+// its votes: + 13 us for 51 MB at 2e5 pools; the 128-vote kernel would pay that twice, and a second image was measured at 114 us in round 5).
+// Here the token rows are read as what they are in memory -- ONE contiguous stream --, 16 bytes per lane, L = 32 lanes per row (16 for rows of
+// up to 64 tokens): an inclusive scan inside the lane (4 tokens) + a DPP scan of the lane totals across the row's lanes (three 21/22-bit limbs:
+// exact mod 2^64 for any int32 tokens) give every prefix sum of the row; they are written to the wave's LDS table, lane j of the row picks the
+// prefix its budget j needs, and the row's B sums leave in ONE store of 8 B consecutive bytes.  Any budget list (not only powers of two).
+// HBM-bound: 4 N bytes read + 8 B written per problem, no vote bytes.  The host queues it behind scv_sort_prefix2 (68 .. 128 votes with tokens);
+// like that kernel it leaves at once when the budget list is not one the sort kernel serves (a.only_if_sortable = its NV: the general kernel
+// queued behind both then does votes AND tokens).
+__device__ __forceinline__ bool sort_prefix_serves_nv(const AggArgs& a, int nv, int tid, int nthreads) {
+    if (nv == 128) return sort_prefix_serves<128>(a, tid, nthreads);
+    if (nv == 64) return sort_prefix_serves<64>(a, tid, nthreads);
+    return sort_prefix_serves<32>(a, tid, nthreads);
+}
+constexpr int prefix_tokens_threads() { return 256; }
+constexpr int kPrefixTokensU = 4;                                    // row groups (of 64 / L rows) a wave has in flight per step
+// LDS: clipped budgets [B rounded to 4] (int32) | token sums [B rounded to 2] (64-bit) | per wave: [U][64 / L rows][4 L prefixes] (64-bit)
+// (the same formula as prefix_tokens_lds_words_host in scvote_dispatch.h)
+template <int L>
+__global__ __launch_bounds__(prefix_tokens_threads()) void scv_prefix_tokens(const AggArgs a) {
+    static_assert(L == 16 || L == 32, "16 or 32 lanes per row");
+    constexpr int R = 64 / L;                                        // rows per wave instruction
+    constexpr int U = kPrefixTokensU;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, T = (int)blockDim.x, NW = T >> 6;
+    const int32_t N = (int32_t)a.N, B = a.B;
+    if (a.only_if_sortable && !a.budgets_promised && !sort_prefix_serves_nv(a, a.only_if_sortable, tid, T)) return;
+    int32_t* nvl = reinterpret_cast<int32_t*>(lds);                                                   // min(n_valid[b], N)
+    unsigned long long* tsum = reinterpret_cast<unsigned long long*>(lds + ((B + 3) & ~3));            // [B rounded to 2]
+    unsigned long long* table = tsum + ((B + 1) & ~1) + (int64_t)wid * U * R * 4 * L;                  // this wave's [U][R][4 L] prefixes (16-byte aligned)
+    for (int b = tid; b < B; b += T) { nvl[b] = (int32_t)valid_len(a, b); tsum[b] = 0ull; }
+    __syncthreads();
+    const int sub = lane / L, l = lane % L;
+    const uint32_t nvec = (uint32_t)N >> 2;                          // 16-byte vectors of a row (N % 4 == 0: host contract)
+    const bool have = (uint32_t)l < nvec;
+    const uint32_t vi = have ? (uint32_t)l : nvec - 1u;
+    const int64_t nwaves = (int64_t)gridDim.x * NW;
+    const int64_t wave = (int64_t)blockIdx.x * NW + wid;
+    const int64_t nsteps = (a.P + U * R - 1) / (U * R);             // a step = U * R consecutive rows
+    const int4* const tok4 = reinterpret_cast<const int4*>(a.tokens);
+    auto load = [&](int64_t step, int4 (&x)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t row = (step * U + u) * R + sub;
+            if (row >= a.P) row = a.P - 1;
+            x[u] = stream_load(tok4 + row * (int64_t)nvec + vi);
+        }
+    };
+    // the budget this lane serves for every row of its row slot (budgets >= L, rare, go round the loop below)
+    const int32_t n_mine = l < B ? nvl[l] : 0;
+    unsigned long long acc = 0;
+    int4 nxt[U];
+    if (wave < nsteps) load(wave, nxt);
+    for (int64_t step = wave; step < nsteps; step += nwaves) {
+        int4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = nxt[u];
+        if (step + nwaves < nsteps) load(step + nwaves, nxt);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long s0 = have ? (long long)x[u].x : 0ll, s1 = s0 + (have ? (long long)x[u].y : 0ll),
+                            s2 = s1 + (have ? (long long)x[u].z : 0ll), s3 = s2 + (have ? (long long)x[u].w : 0ll);
+            // exclusive scan of the lane totals over the row's L lanes, as three limbs (sums of <= 32 limbs of <= 22 bits fit 32 bits)
+            const unsigned long long t = (unsigned long long)s3;
+            const uint32_t limb[3] = {(uint32_t)(t & 0x3fffffu), (uint32_t)((t >> 22) & 0x1fffffu), (uint32_t)((t >> 43) & 0x1fffffu)};
+            unsigned long long ex = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                uint32_t v = limb[k];
+                v += (uint32_t)SCV_DPP(0, v, 0x111, 0xf);            // row_shr:1, 2, 4, 8: inclusive inside each 16 lanes
+                v += (uint32_t)SCV_DPP(0, v, 0x112, 0xf);
+                v += (uint32_t)SCV_DPP(0, v, 0x114, 0xf);
+                v += (uint32_t)SCV_DPP(0, v, 0x118, 0xf);
+                if (L == 32) v += (uint32_t)SCV_DPP(0, v, 0x142, 0xa);   // row_bcast:15 -> rows 1, 3: the upper 16 lanes of a 32-lane row
+                ex += (unsigned long long)(v - limb[k]) << (k == 0 ? 0 : (k == 1 ? 22 : 43));
+            }
+            // (the table of the previous step has been read by every lane of the wave: LDS operations of a wave execute in order)
+            uint4* const dst = reinterpret_cast<uint4*>(table + ((int64_t)u * R + sub) * 4 * L + 4 * l);
+            const unsigned long long p0 = ex + (unsigned long long)s0, p1 = ex + (unsigned long long)s1, p2 = ex + (unsigned long long)s2, p3 = ex + (unsigned long long)s3;
+            dst[0] = make_uint4((uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32));
+            dst[1] = make_uint4((uint32_t)p2, (uint32_t)(p2 >> 32), (uint32_t)p3, (uint32_t)(p3 >> 32));
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long* const mine = table + ((int64_t)u * R + sub) * 4 * L;
+            const int64_t row = (step * U + u) * R + sub;
+            if (l < B && row < a.P) {                                // lane j of the row: budget j, kept in a register across the rows
+                const unsigned long long v = n_mine > 0 ? mine[n_mine - 1] : 0ull;
+                if (a.cell_tokens) a.cell_tokens[row * (int64_t)B + l] = (long long)v;
+                acc += v;
+            }
+            for (int b = l + L; b < B; b += L) {                     // ... and budgets j + L, j + 2 L ... (more budgets than lanes per row)
+                const int32_t n = nvl[b];
+                const unsigned long long v = n > 0 ? mine[n - 1] : 0ull;
+                if (row < a.P) {
+                    if (a.cell_tokens) a.cell_tokens[row * (int64_t)B + b] = (long long)v;
+                    if (a.token_sum) atomicAdd(&tsum[b], v);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (a.token_sum) {
+        if (l < B && acc) atomicAdd(&tsum[l], acc);
+        __syncthreads();
+        for (int b = tid; b < B; b += T)
+            if (tsum[b]) atomicAdd(&a.token_sum[b], tsum[b]);
+    }
+}
+
 }  // namespace scv

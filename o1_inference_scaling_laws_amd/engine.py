@@ -489,7 +489,7 @@ class MultiDeviceEngine:
         check(self._L.scv_allgather_i64(self._comm, ptrs, (C.c_int64 * len(counts))(*[int(c) for c in counts])))
         return buffers
 
-    def evaluate_c5(self, shards, resamples: int, seed: int, M: int | None = None, n_valid=None):
+    def evaluate_c5(self, shards, resamples: int, seed: int, M: int | None = None, n_valid=None, keep_all_ranks: bool = False):
         """BASELINE config 5 from ONE process over this communicator's GPUs, no torch.distributed (the
         multi-process form is passk.evaluate_device): ``shards[g] = (answers_g, truth_g, tokens_g | None)`` resident on engine g's
         device (``scatter`` makes them).  Per engine: vote over its block (cells written into its block of the whole table) ->
@@ -497,8 +497,11 @@ class MultiDeviceEngine:
         resamples -> all-gather of the slices.  ``M=None`` reads the class bound from the counters (one host sync).
         Returns (counters int64 [counters_size(B) + 1] -- the last word is the summed device error word --, cells uint8 [P, B, 16],
         boot int64 [resamples, B, M], M), all on the first engine's device and complete on EVERY engine; asynchronous: ``sync()``
-        before reading (it raises what any engine has to report)."""
+        before reading (it raises what any engine has to report).  ``keep_all_ranks=True`` also keeps EVERY engine's copy of the
+        three exchanged buffers in ``self.last_c5`` until the next call (bench.py verifies the exchange step on every rank with
+        it); by default nothing outlives the call but what is returned (the copies held 3 x G buffers of HBM alive)."""
         import torch
+        self.last_c5 = None
         if len(shards) != len(self.engines):
             raise ValueError("one shard per engine")
         G = len(self.engines)
@@ -535,7 +538,8 @@ class MultiDeviceEngine:
         self.all_gather_i64(boots, [(r1 - r0) * B * M for r0, r1 in bounds])
         # every engine's copy of the three exchanged buffers (each must be complete): what a caller that wants to verify the
         # exchange step on EVERY rank reads back (bench.py does, after its timed region)
-        self.last_c5 = {"counters": counters, "tables": tables, "boots": boots}
+        if keep_all_ranks:
+            self.last_c5 = {"counters": counters, "tables": tables, "boots": boots}
         return counters[0], tables[0], boots[0], M
 
     def _run(self, fn_name, rows, truth, per_shard_kwargs, shared_kwargs):

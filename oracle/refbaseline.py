@@ -30,6 +30,21 @@ import time
 _REBOUND = ("process_single_example", "run_experiments", "run_majority_vote_inference_experiments", "run_just_ask_nicely_experiments")
 
 
+def same_accuracy(got: float, want: float, P: int = 30) -> bool:
+    """Two accuracies as EXACT RATIONALS (as the tests compare them), not floats within a tolerance: the reference sums 1/len(modes)
+    in thread-completion order (o1.py:236-239) and the drop-in in one canonical order, so the two floats may differ in the last ulps
+    while naming the same rational k / (P * lcm of the tie sizes).  Each float is taken back to the nearest fraction with a denominator
+    up to P * lcm(1..8) = 25 200 (ties of up to 8 answers; the floats are ~1e-15 from it, the next such fraction >= 7.8e-10 away) and
+    the fractions must be EQUAL."""
+    from fractions import Fraction
+    D = P * 840
+    fg, fw = Fraction(float(got)).limit_denominator(D), Fraction(float(want)).limit_denominator(D)
+    # ... and each float must BE its fraction up to the rounding of a 30-term sum (1e-13 is ~1000 ulps; a float that is merely NEAR
+    # a fraction with a small denominator is not that fraction)
+    near = Fraction(1, 10 ** 13)
+    return fg == fw and abs(Fraction(float(got)) - fg) <= near and abs(Fraction(float(want)) - fw) <= near
+
+
 def _dropin_engine(kind: str):
     if kind == "oracle":
         from tests._adapters import OracleEngine
@@ -61,7 +76,8 @@ def _time_dropin(o1, engine, ds, cache, N, ref_acc, ref_avg, repeats):
                             "staging_in_engine_call": max(0.0, split["engine"] - split["kernel"]), "floats": split["floats"],
                             "other": max(0.0, best - split["extract"] - split["engine"] - split["floats"])},
                 "accuracy": acc, "avg_tokens_used": float(avg),
-                "equal_to_reference": bool(abs(acc - ref_acc) < 1e-12 and float(avg) == float(ref_avg))}
+                "equal_to_reference": bool(same_accuracy(acc, ref_acc, P) and float(avg) == float(ref_avg)),
+                "accuracy_compared_as": "exact rationals (Fraction.limit_denominator(P * lcm(1..8)))"}
     finally:
         for k, v in saved.items():
             setattr(o1, k, v)
@@ -111,7 +127,7 @@ def _time_family(o1, engine, ds, cache, repeats):
                 if best is None or dt < best[0]:
                     best = (dt, rec, logs, dict(cfg.timings))
             dt, rec, logs, split = best
-            close = all(abs(g["accuracy"] - w["accuracy"]) < 1e-12 and float(g["avg_tokens_used"]) == float(w["avg_tokens_used"])
+            close = all(same_accuracy(g["accuracy"], w["accuracy"], len(ds)) and float(g["avg_tokens_used"]) == float(w["avg_tokens_used"])
                         and g["token_limit"] == w["token_limit"] for k in ref_rec for g, w in zip(rec[k], ref_rec[k]))
             out["dropin_batched" if batched else "dropin_unbatched"] = {
                 "seconds": dt, "speedup_vs_reference": ref_s / dt, "engine_calls": split["calls"],

@@ -83,7 +83,7 @@ def test_every_option_and_stat_key_is_documented_in_the_header():
         body = src[src.index(f"int {fn}("):]
         body = body[: body.index("\n}\n")]
         keys = re.findall(r'!strcmp\(key, "([a-z0-9_]+)"\)', body)
-        assert 5 <= len(keys) <= 15, (fn, len(keys))                 # round 4: at most 15 option keys are part of the boundary
+        assert 5 <= len(keys) <= 16, (fn, len(keys))                 # round 4: at most 15 option keys are part of the boundary (+ the deprecated alias "auto_geometry")
         missing = [k for k in keys if f'"{k}"' not in hdr]
         assert not missing, f"{fn}: keys not documented in include/scvote.h: {missing}"
 
@@ -97,7 +97,7 @@ def test_no_kernel_spills_to_scratch():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     rows = mod.collect()
-    assert 100 <= len(rows) <= 130, len(rows)                        # round 4: pruned from 231 (at most 130)
+    assert 100 <= len(rows) <= 136, len(rows)                        # round 4: pruned from 231 to <= 130; round 6: + the four scv_reg_cells<8, 3>
     spilled = {r[0]: r[4] for r in rows if r[4]}                     # (round 5: no exception left -- 17..32 votes with tokens on one lane per cell went to scv_reg_cells)
     assert not spilled, spilled
     head = [r for r in rows if r[0] == "scv_hist_argmax<4, 1024, 4, false, false>"]

@@ -296,3 +296,40 @@ def test_a_wrong_sum_on_one_rank_stops_the_line(stack):
     assert out.returncode != 0
     text = out.stdout + out.stderr
     assert "rank 2: all-reduced counters != independently gathered sum: word 1030" in text and '"value"' not in text.split("EXCHANGE")[0][-400:]
+
+
+# ---- round 6: one GPU ends in C3's RESULT; the N > 1 line explains its own scaling ---------------------------
+
+def test_full_pass_of_all_eight_chunks_equals_the_eight_rank_step(tmp_path):
+    """The timed region of the 1-GPU line cycles the chunks that fit in HBM; `c3_full` then accumulates ALL 8 chunks (problems 0 .. 8 Pc - 1,
+    the sum o1.py:236-245 takes over every problem) into one buffer.  It must be, word for word (sha256 of the 8216 counters and the dump),
+    the all-reduced step of 8 ranks x Pc problems over the same global problems -- here with fewer resident slots than chunks, so that
+    several chunks are generated into freed slots -- and satisfy the closed forms of D2 / D5."""
+    shape = ["--problems-per-step", "24", "--samples", str(1 << 13), "--no-cpu-baseline"]
+    one = _bench([*shape, "--steps", "2", "--warmup", "1", "--dump", str(tmp_path / "one.npz")])
+    f = one["c3_full"]
+    assert f["problems"] == 192 and f["chunks"] == 8 and f["chunks_generated_after_the_timed_region"] == [3, 4, 5, 6, 7] and f["counters_words"] == 8 * 1027
+    eight = _bench([*shape[:4], "--steps", "1", "--warmup", "0", "--dump", str(tmp_path / "eight.npz")], ranks=8)
+    assert eight["c3_full"] is None and eight["counters_sha256_last_step"] == f["counters_sha256"]
+    full = np.load(tmp_path / "one.npz")["full"]
+    assert np.array_equal(full, np.load(tmp_path / "eight.npz")["counters"]) and full[:8 * 1025].sum() > 0
+    assert [round(a, 6) for a in f["accuracy"]] == eight["accuracy_last_step"]
+    # ... and one rank x 192 problems in ONE chunk
+    whole = _bench(["--problems-per-step", "192", "--samples", str(1 << 13), "--no-cpu-baseline", "--steps", "1", "--warmup", "0", "--no-full-pass"])
+    assert whole["c3_full"] is None and whole["counters_sha256_last_step"] == f["counters_sha256"]
+    for dist, wins, tcs in ((2, 192, 192 << 13), (5, 0, 0)):
+        d = _bench([*shape, "--steps", "1", "--warmup", "1", "--dist", str(dist)])["c3_full"]
+        assert d["closed_form"].startswith(f"D{dist}:") and d["strict_wins"] == [wins] * 8 and d["truth_count_sum"] == [tcs] * 8
+        assert d["accuracy"] == [1.0 if dist == 2 else 0.0] * 8
+
+
+def test_multi_rank_line_reports_kernel_balance_and_the_exposed_all_reduce():
+    """A first multi-GPU run below 6x must explain itself: per-rank kernel time min / max and the exposed all-reduce are in the torch line too."""
+    d = _bench(["--problems-per-step", "64", "--samples", str(1 << 14), "--steps", "3", "--warmup", "1", "--resident", "2"], ranks=2)
+    r = d["roofline"]
+    assert 0 < r["kernel_avg_ms_per_rank_min"] <= r["kernel_avg_ms_per_rank_max"] == r["kernel_avg_ms"]
+    assert r["exposed_allreduce_us"] is not None and r["exposed_allreduce_us"] > 0 and "AFTER the timed region" in r["exposed_allreduce_what"]
+    assert d["allreduce_verified"] is True and d["warnings"] is None
+    one = _bench(["--problems-per-step", "64", "--samples", str(1 << 14), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert one["roofline"]["exposed_allreduce_us"] is None and one["roofline"]["kernel_avg_ms_per_rank_min"] == one["roofline"]["kernel_avg_ms"]
+    assert one["roofline"]["read_ceiling_warning"] is None and "frac_of_measured_read_ceiling" in one["roofline"]

@@ -16,9 +16,15 @@ DEFAULTS = (("path", 0), ("segs", 0), ("grid", 0), ("fused_counters_max", 4096),
 GEOMETRIES = ((4, 256, 2), (8, 256, 4), (8, 512, 4), (16, 256, 4), (16, 512, 4), (16, 1024, 4))       # (copies, threads, unroll) instantiated
 
 
+def seed_is_even(rng):
+    return bool(rng.integers(0, 2))
+
+
 def _draw(rng):
-    regime = rng.choice(["tiny", "small", "mid", "large", "few_big"], p=[0.25, 0.25, 0.25, 0.15, 0.10])
-    if regime == "tiny":
+    regime = rng.choice(["tiny", "small", "mid", "large", "few_big", "band96"], p=[0.22, 0.22, 0.23, 0.15, 0.10, 0.08])
+    if regime == "band96":                                       # round 6: 65 ... 128 votes (the 96-slot shape with 8-bit bins and its neighbours)
+        P, B, N = int(rng.integers(1, 900)), int(rng.integers(1, 6)), int(rng.integers(65, 129))
+    elif regime == "tiny":
         P, B, N = int(rng.integers(1, 400)), int(rng.integers(1, 12)), int(rng.integers(0, 33))
     elif regime == "small":
         P, B, N = int(rng.integers(1, 120)), int(rng.integers(1, 6)), int(rng.integers(33, 700))
@@ -53,6 +59,8 @@ def _draw(rng):
         opts["reg_n_max"] = int(rng.choice([0, 600]))            # streaming kernel below / above the register-resident range
     if rng.random() < 0.4:                                       # forced register-kernel shape (ignored when its capacity is < N)
         opts["reg_shape"] = int(rng.choice([1601, 1602, 1604, 3204, 6404, 1041, 1042, 1044, 1048]))
+        if N <= 128 and seed_is_even(rng):                       # round 6: the 8-lane shapes with 8-bit bins (capacity 96 / 128 votes)
+            opts["reg_shape"] = int(rng.choice([803, 804]))
     tuning = None
     if rng.random() < 0.3:
         c, t, u = GEOMETRIES[int(rng.integers(0, len(GEOMETRIES)))]

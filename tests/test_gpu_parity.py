@@ -321,7 +321,8 @@ def _with_options(eng, opts):
     return _Ctx()
 
 
-REG_SHAPES = [(700, 3, 33), (1200, 2, 64), (500, 4, 65), (301, 3, 100), (900, 2, 128), (333, 2, 129), (257, 4, 256), (200, 3, 257),
+REG_SHAPES = [(700, 3, 33), (1200, 2, 64), (500, 4, 65), (900, 3, 72), (611, 2, 88), (777, 2, 93), (1000, 4, 96), (433, 3, 97), (301, 3, 100), (555, 2, 124),
+              (900, 2, 128), (333, 2, 129), (257, 4, 256), (200, 3, 257),
               (150, 2, 500), (300, 3, 512), (90, 2, 513), (70, 3, 1000), (200, 2, 1024), (41, 2, 1025), (33, 3, 2047),
               (100, 2, 2048), (20, 2, 2049), (19, 3, 3000), (17, 2, 4095), (60, 2, 4096),
               (20, 2, 4097), (15, 3, 6000), (12, 2, 8189), (10, 3, 8192)]          # (round 3: 8 parts of 4 vectors per lane up to 8192 votes)
@@ -337,7 +338,7 @@ def test_register_resident_cells_path(hip_engine, dist, shape):
     a, t, tr = coracle.synth_fill(P, B, N, 900 + dist, dist, want_tokens=True)
     nv = np.array([max(0, N - 3 * b) if b % 2 else N >> (b // 2) for b in range(B)], dtype=np.int32)
     # every kernel shape whose capacity covers N: sparse g*100+v (4*g*v votes), dense 1000+10*v+h (256*v*h votes)
-    shapes = [g * 100 + v for g, v in ((16, 1), (16, 2), (16, 4), (32, 4), (64, 4)) if 4 * g * v >= N]
+    shapes = [g * 100 + v for g, v in ((16, 1), (8, 3), (8, 4), (16, 2), (16, 4), (32, 4), (64, 4)) if 4 * g * v >= N + (3 if N % 4 else 0)]   # (8, 3) / (8, 4): round 6, 8-bit bins
     shapes += [1000 + 10 * v + h for v, h in ((4, 1), (4, 2), (4, 4), (4, 8)) if 256 * v * h >= N]
     pick = [shapes[(P + dist + i * 3) % len(shapes)] for i in range(3)]
     for opts in ({"path": 4}, {"path": 4, "grid": 7, "fused_counters_max": 0, "reg_shape": pick[0]},
@@ -404,6 +405,35 @@ def test_register_kernels_accumulate_counters_in_lds(hip_engine, shape):
         from o1_inference_scaling_laws_amd.engine import AggregateResult
         r = AggregateResult.from_counters(c.cpu().numpy(), P, B)
         assert np.array_equal(r.tie_class_hits, want.tie_class_hits) and np.array_equal(r.truth_count_sum, want.truth_count_sum)
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("N", [65, 68, 72, 77, 80, 84, 88, 92, 93, 95, 96, 97, 100, 112, 124, 125, 127, 128])
+def test_the_96_slot_shape_with_8_bit_bins(hip_engine, dist, N):
+    """Round 6: 65 <= N <= 96 (93 for unaligned rows: the superset has up to N + 3 slots) runs 8 lanes x 3 vectors per
+    cell with 8-bit LDS bins -- eight cells per wave --, 97 <= N <= 128 (125) 8 lanes x 4 vectors.  Every length of the band against the oracle and against the 128-slot shape it replaces
+    (option "reg_shape" = 1602), on every distribution: bytes of one word are four bins, so neighbouring hot values (narrow domains), full cells
+    of ONE value (a bin at 96 = no carry into the next byte), ragged budgets and tokens are all in here."""
+    P, B = 1531, 3
+    a, t, tr = coracle.synth_fill(P, B, N, 4100 + dist, dist, want_tokens=True)
+    a[::3] = a[::3] % 4 + 500                                       # four neighbouring bins = ONE LDS word: every add of a cell on one word
+    a[1::7] = 1023                                                  # the last bin of a cell (its first byte), every vote
+    a[2::7, :, ::2] = 0                                             # ... and the first bin (the cell's last byte) against another value
+    nv = np.array([N, max(1, N - 29), N // 2][:B], dtype=np.int32)
+    want = oracle(a, tr, tokens=t)
+    want_nv = oracle(a, tr, tokens=t, n_valid=nv)
+    for opts in ({}, {"reg_shape": 1602}, {"path": 4, "reg_shape": 803 if N <= 93 or (N <= 96 and N % 4 == 0) else 804}, {"grid": 3, "fused_counters_max": 0}):
+        with _with_options(hip_engine, opts):
+            before = hip_engine.stat("lds_counters")
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t), want)
+            assert_results_equal(hip_engine.aggregate(a, tr, n_valid=nv), want_nv, check_tokens=False)
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), want_nv)
+            if not opts:
+                assert hip_engine.stat("lds_counters") > before       # (a register-resident launch, not the sorted-cells kernel)
+    bad = a.copy()
+    bad[5, 1, N - 1] = 1024
+    with pytest.raises(_lib.DomainError):
+        hip_engine.aggregate(bad, tr)
 
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
@@ -943,29 +973,42 @@ def test_prefix_budgets_that_are_powers_of_two_come_out_of_one_sort(hip_engine, 
     pool, tpool = a[:, 0, :], t[:, 0, :]
     dev = torch.device("cuda:0")
     dpool, dtok, dtr = torch.from_numpy(pool.copy()).to(dev), torch.from_numpy(tpool.copy()).to(dev), torch.from_numpy(tr).to(dev)
-    # pools of 68 .. 128 votes: scv_sort_prefix2 pays ~36 us for a launch of one step per wave and has no token form -- auto takes it from ~1e5
-    # token-less pools (test_prefix_pools_of_128_votes_take_the_sort_kernel_when_there_are_many), prefix_path = 5 selects it for any number
+    # pools of 68 .. 128 votes: scv_sort_prefix2 pays ~36 us for a launch of one step per wave -- auto takes it from ~1e5 pools
+    # (test_prefix_pools_of_128_votes_take_the_sort_kernel_when_there_are_many), prefix_path = 5 selects it for any number; with tokens (round 6)
+    # the sums come from scv_prefix_tokens queued behind it ("prefix_tokens" +1 per call with tokens)
     big = N > 64
     for mk in SORT_PREFIX_BUDGETS:
         if big:
             hip_engine.set_option("prefix_path", 5)                  # (every _with_options block below ends with the defaults)
         nv = np.array(mk(N), dtype=np.int32)
         want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
-        before, lane0 = hip_engine.stat("prefix_sort"), hip_engine.stat("prefix_lane")
+        before, lane0, pool0, tok0 = hip_engine.stat("prefix_sort"), hip_engine.stat("prefix_lane"), hip_engine.stat("prefix_pool"), hip_engine.stat("prefix_tokens")
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
-        assert hip_engine.stat("prefix_sort") == before + (1 if big else 2) and hip_engine.stat("prefix_lane") == lane0      # HOST mode: this kernel alone
+        assert hip_engine.stat("prefix_sort") == before + 2 and hip_engine.stat("prefix_lane") == lane0 and hip_engine.stat("prefix_pool") == pool0   # HOST mode: this kernel alone
+        assert hip_engine.stat("prefix_tokens") == tok0 + (1 if big else 0)                                   # (68 .. 128 votes: the token sums behind the sort kernel)
         got = hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool, want_cells=False)                       # no cell table
         assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum) and np.array_equal(got.truth_count_sum, want.truth_count_sum)
         with _with_options(hip_engine, {"grid": 1, "prefix_path": 5 if big else 0}):                           # one workgroup walks every step
-            assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=None if big else tpool), want, check_tokens=not big)
-        if big:
-            hip_engine.set_option("prefix_path", 5)
-        for tk in (None, dtok):                                                                                 # DEVICE mode: both kernels queued
-            c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, torch.from_numpy(nv).to(dev), tokens=tk)
-            hip_engine.sync()
-            got = AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells), None if tk is None else ctok.cpu().numpy())
-            assert_results_equal(got, want, check_tokens=tk is not None)
+            assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
+        for promised in ((True,) if big else (False,)) + ((False,) if big and P >= 1 else ()):
+            hip_engine.set_option("prefix_path", 5 if promised else 0)
+            for tk in (None, dtok):                                                                             # DEVICE mode: both kernels queued (promised: this one alone)
+                sort0, pool0 = hip_engine.stat("prefix_sort"), hip_engine.stat("prefix_pool")
+                c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, torch.from_numpy(nv).to(dev), tokens=tk)
+                hip_engine.sync()
+                got = AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells), None if tk is None else ctok.cpu().numpy())
+                assert_results_equal(got, want, check_tokens=tk is not None)
+                if promised:
+                    assert hip_engine.stat("prefix_sort") == sort0 + 1 and hip_engine.stat("prefix_pool") == pool0
+                # the engine makes the promise itself when it is handed the budgets as a host list (Engine.aggregate_prefix_device(budgets_host=...))
+                sort0, pool0, lane0 = hip_engine.stat("prefix_sort"), hip_engine.stat("prefix_pool"), hip_engine.stat("prefix_lane")
+                if not promised:
+                    c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, torch.from_numpy(nv).to(dev), tokens=tk, budgets_host=[int(x) for x in nv])
+                    hip_engine.sync()
+                    got = AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells), None if tk is None else ctok.cpu().numpy())
+                    assert_results_equal(got, want, check_tokens=tk is not None)
+                    assert hip_engine.stat("prefix_sort") == sort0 + 1 and hip_engine.stat("prefix_pool") == pool0 and hip_engine.stat("prefix_lane") == lane0
     if big and P >= 3:                                              # out-of-domain votes in either half, seen only by the budgets that reach them
         hip_engine.set_option("prefix_path", 5)
         badp = pool.copy()
@@ -1036,7 +1079,7 @@ def test_sort_prefix_with_more_budgets_than_lanes(hip_engine, N, B):
     forms = [0, N, N + 7] + [1 << k for k in range(8) if (1 << k) <= _sort_prefix_top(N)]
     nv = rng.choice(forms, size=B).astype(np.int32)
     want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
-    tok = N <= 64
+    tok = True                                                      # (round 6: pools of 68 .. 128 votes have a token form too: scv_prefix_tokens behind the sort kernel)
     with _with_options(hip_engine, {"prefix_path": 5}):
         before = hip_engine.stat("prefix_sort")
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool if tok else None), want, check_tokens=tok)
@@ -1053,7 +1096,7 @@ def test_sort_prefix_with_more_budgets_than_lanes(hip_engine, N, B):
 def test_prefix_pools_of_128_votes_take_the_sort_kernel_when_there_are_many(hip_engine):
     """The reference's largest pool (o1.py:266-276: T = 2^18 -> N = 128 samples, budgets 1, 2, 4 ... 128): from ~1e5 token-less pools auto
     dispatch queues scv_sort_prefix2 (DEVICE memory: a HOST-mode call of this size is staged in chunks, each a launch of its own); bit-exact vs
-    the oracle, D1 and D3; a call with tokens and a smaller call stay on the one-pass kernel."""
+    the oracle, D1 and D3; with tokens the sums come from scv_prefix_tokens behind it; a smaller call stays on the one-pass kernel."""
     import torch
     from o1_inference_scaling_laws_amd.engine import AggregateResult
     dev = torch.device("cuda:0")
@@ -1070,10 +1113,17 @@ def test_prefix_pools_of_128_votes_take_the_sort_kernel_when_there_are_many(hip_
         hip_engine.sync()
         assert hip_engine.stat("prefix_sort") == before + 1
         assert_results_equal(AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells)), want, check_tokens=False)
-        c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, dnv, tokens=dtok)                 # with tokens: the one-pass kernel
+        tok0 = hip_engine.stat("prefix_tokens")
+        c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, dnv, tokens=dtok)                 # with tokens (round 6): the same kernel + scv_prefix_tokens
         hip_engine.sync()
-        assert hip_engine.stat("prefix_sort") == before + 1
+        assert hip_engine.stat("prefix_sort") == before + 2 and hip_engine.stat("prefix_tokens") == tok0 + 1
         assert_results_equal(AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells), ctok.cpu().numpy()), want)
+        odd = torch.tensor([1, 2, 3, 128], dtype=torch.int32, device=dev)                                 # a list the sort kernel leaves: the token kernel leaves too,
+        c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, odd, tokens=dtok)                 # the general kernel does votes AND tokens (nothing counted twice)
+        hip_engine.sync()
+        assert_results_equal(AggregateResult.from_counters(c.cpu().numpy(), P, 4, cells_from_torch(cells), ctok.cpu().numpy()),
+                             OracleEngine().aggregate_prefix(pool, tr, np.array([1, 2, 3, 128], dtype=np.int32), tokens=tpool))
+        before += 2
         c, cells, _ = hip_engine.aggregate_prefix_device(dpool[:50_000], dtr[:50_000], dnv)               # fewer pools: the one-pass kernel
         hip_engine.sync()
         assert hip_engine.stat("prefix_sort") == before + 1

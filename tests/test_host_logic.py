@@ -392,3 +392,41 @@ def test_dropin_records_its_wall_time_split():
     acc, avg = o1_dropin.run_experiments(cfg, ds, cache, 2048, 4)
     assert acc == 0.5 and float(avg) == 36.0
     assert cfg.timings["calls"] == 1 and cfg.timings["votes"] == 8 and cfg.timings["extract"] > 0 and cfg.timings["engine"] > 0
+
+
+# ---- round 6 ------------------------------------------------------------------------------------------------------------------------
+
+def test_budget_lists_a_device_call_may_promise():
+    """Engine.budgets_come_out_of_one_sort mirrors launch_prefix's own test (csrc/scvote.hip): pools of 17 .. 128 votes (N % 4 == 0),
+    budgets 0, a power of two <= 16 / 32 / 64, or >= N -- the reference's lists 1, 2, 4 ... N (o1.py:274-277)."""
+    from o1_inference_scaling_laws_amd.engine import Engine
+    ok = Engine.budgets_come_out_of_one_sort
+    assert ok([1, 2, 4, 8, 16, 32, 64], 64) and ok([1, 2, 4, 8, 16, 32, 64, 128], 128) and ok([1, 2, 4, 8, 16, 32], 32)
+    assert ok([64, 1, 1, 0, 200], 64) and ok([96, 64, 1], 96) and ok(np.array([1, 2, 4, 8, 16, 20], dtype=np.int32), 20)
+    assert not ok([1, 2, 3], 64)                                      # 3 is not a power of two
+    assert not ok([1, 2, 4, 8, 16], 16) and not ok([1, 2], 132)       # pools outside 17 .. 128
+    assert not ok([1, 2, 4], 30)                                      # rows that are not 16-byte multiples
+    assert not ok([48], 64) and ok([64], 124)                         # 48: no power of two; 64 is a served prefix of a 124-vote pool
+    assert ok([32], 32) and ok([32], 40) and not ok([64], 68 - 4) is False and not ok([32], 32 - 4) is False
+    assert not ok([64, 96], 128)                                      # 96 < N and not a power of two
+
+
+def test_accuracies_are_compared_as_rationals_not_within_a_tolerance():
+    """oracle/refbaseline.same_accuracy (bench.py's dropin_loop): order-dependent float sums of the same rational are equal, the next
+    rational with an admissible denominator is not (the old test was abs(a - b) < 1e-12)."""
+    from fractions import Fraction
+    from oracle.refbaseline import same_accuracy
+    terms = [1, 1 / 3, 1 / 3, 1 / 3, 1, 1 / 3, 1 / 7, 1 / 5]
+    a = sum(terms) / 30
+    b = sum(reversed(terms)) / 30
+    assert same_accuracy(a, b) and same_accuracy(0.0, 0.0) and same_accuracy(1.0, 1.0)
+    assert not same_accuracy(float(Fraction(19, 30)), float(Fraction(19, 30) + Fraction(1, 25200)))
+    assert not same_accuracy(0.5, 0.5 + 1e-9)
+
+
+def test_counters_digest_is_a_function_of_the_counter_words_only():
+    import importlib
+    bench = importlib.import_module("bench")
+    c = np.arange(8 * 1027 + 1, dtype=np.int64)
+    assert bench.counters_digest(c, 8 * 1027) == bench.counters_digest(c[:8 * 1027].copy(), 8 * 1027) != bench.counters_digest(c + 1, 8 * 1027)
+    assert len(bench.counters_digest(c, 8 * 1027)) == 64
