@@ -103,6 +103,8 @@ def parse():
                     help="c3 on ONE GPU (default on): after the timed region, aggregate ALL 8 chunks of the workload (the 8th is generated into a "
                          "freed slot) into one counter buffer and print c3_full = C3's RESULT (accuracy per budget, sums, sha256 of the counters)")
     ap.add_argument("--no-full-pass", dest="full_pass", action="store_false")
+    ap.add_argument("--no-live-traffic", dest="live_traffic", action="store_false", default=True,
+                    help="default c3 run on one GPU: do not re-run the command under rocprofv3 --pmc for roofline.traffic (the committed profiles/ figure is quoted instead)")
     return ap.parse_args()
 
 
@@ -475,6 +477,47 @@ def measure_read_ceiling(cells: int):
         if line.startswith("READ_CEILING_GBPS"):
             return float(line.split()[1])
     return None
+
+
+def measure_traffic_live(args):
+    """HBM bytes per launch of the dominant kernel, MEASURED IN THIS RUN (the line used to quote a committed file): the same
+    command is run once more as a child under `rocprofv3 --pmc FETCH_SIZE` and once under `--pmc WRITE_SIZE` (separate passes, counters only -- no
+    trace domain next to --pmc, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), a few steps over resident chunks, after this process has handed
+    its HBM back.  FETCH_SIZE is in KiB and reads 1/2 on gfx950 for wide coalesced streams (x2; calibrated on a known-bytes read:
+    profiles/r02_fetch_size_calibration.json); WRITE_SIZE x 1024.  -> (bytes per launch | None, note)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--resident", "2", "--no-cpu-baseline", "--no-read-ceiling",
+             "--no-full-pass", "--no-live-traffic", "--seed", str(args.seed), "--dist", str(args.dist)]
+    got = {}
+    launches = 0
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(prefix="scv_pmc_") as d:
+                out = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", *child], capture_output=True, text=True, timeout=300,
+                                     cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+                if out.returncode != 0:
+                    return None, f"rocprofv3 --pmc {counter} failed (rc {out.returncode}): " + out.stderr[-300:].replace("\n", " | ")
+                vals = []
+                for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if "scv_hist_argmax" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                            vals.append(float(r["Counter_Value"]))
+                if not vals:
+                    return None, f"no {counter} rows for scv_hist_argmax in the child's counter_collection.csv"
+                got[counter] = sum(vals) / len(vals)
+                launches = len(vals)
+    except (OSError, subprocess.TimeoutExpired) as e:
+        return None, f"{type(e).__name__}: {e}"
+    return got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024, (
+        f"measured in THIS run: child `bench.py --steps 2 --warmup 1` under rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes, {launches} launches "
+        f"of scv_hist_argmax each); FETCH_SIZE {got['FETCH_SIZE']:.0f} KiB x 1024 x 2 (gfx950 correction, profiles/r02_fetch_size_calibration.json) + WRITE_SIZE "
+        f"{got['WRITE_SIZE']:.0f} KiB x 1024")
 
 
 def committed_evidence():
@@ -1089,6 +1132,19 @@ def main():
                                          "profiles/r04_hbm_probe.log) -- a fraction slightly above 1 of it is probe noise, not a result")
             ev["read_ceiling_is_lower_bound"] = True
 
+    traffic_live = None
+    if rank == 0 and world == 1 and not force and ev and args.live_traffic and not use_graph:
+        last_off_kept = last_slot[3]
+        slots.clear()                           # the child allocates its own chunks: hand the resident ones back first
+        last_slot = (None, None, None, last_off_kept)
+        ans = tok = tr = None
+        torch.cuda.empty_cache()
+        t_pm = time.perf_counter()
+        traffic_live, traffic_note = measure_traffic_live(args)
+        if traffic_live is not None:
+            ev["traffic"], ev["traffic_source"] = traffic_live, traffic_note + f" ({time.perf_counter() - t_pm:.0f} s)"
+        else:
+            WARNINGS.append("roofline.traffic could not be measured in this run (" + str(traffic_note) + "): the committed figure of profiles/ is quoted")
     final = AggregateResult.from_counters(last_host[:counters_size(B)], Pc, B, num_problems=args.problems if c5 else Pc * world)
     if c5:
         workload = (f"C5: P={args.problems} x N={N} sharded by problem over {world} GPU(s) ({Pc} problems = {bytes_per_launch / 1e9:.2f} GB on rank 0); "
@@ -1142,7 +1198,8 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": ev.get("traffic"),
-            "traffic_measured_in_this_run": False if ev.get("traffic") is not None else None,
+            "traffic_measured_in_this_run": (traffic_live is not None) if ev.get("traffic") is not None else None,
+            "traffic_over_algorithmic": (ev["traffic"] / bytes_per_launch) if ev.get("traffic") else None,
             "traffic_source": ev.get("traffic_source"),
             "kernel": "scv_hist_argmax",
             "kernel_avg_ms": kern_avg_ns / 1e6,

@@ -45,6 +45,13 @@ extern "C" {
 /* scv_create flags */
 #define SCV_FLAG_TIMING 0x1u      /* record hipEvents around every aggregation kernel launch    */
 #define SCV_FLAG_CLAMP_TO_INVALID_BIN 0x2u /* out-of-domain votes go to bin 1023, no error      */
+#define SCV_FLAG_PACKED_CELLS 0x4u /* OPT-IN: scv_aggregate_i32 (DEVICE memory, N <= 127) writes its cell table as uint32_t [P, B], 4 bytes per cell:
+                                      max_count | truth_count << 7 | n_modes << 14 | min_mode << 21 | hit << 31 (7 + 7 + 7 + 10 + 1 bits; an empty cell
+                                      -- max_count 0 -- has min_mode field 1023 and means -1).  The reference's most common call is N = 1
+                                      (o1.py:302) and N = 1, 2, 4, 8 (o1.py:276): a 16-byte scv_cell per 4-byte vote is 80 % of such a launch's traffic.
+                                      Everything else (counters, cell_tokens) is unchanged; a call the flag does not cover (prefix budgets, HOST memory,
+                                      N > 127, a forced streaming path, vote + bootstrap) with cells_out != NULL is SCV_ERR_ARG.  Decoder:
+                                      o1_inference_scaling_laws_amd/engine.py unpack_cells */
 
 /* synthetic distributions */
 #define SCV_DIST_UNIFORM 0        /* D0: uniform over 0..999                                    */
@@ -120,7 +127,7 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  *                         small for N is ignored
  *   "auto_geometry"       DEPRECATED alias kept for callers of rounds 1-4: 1 = scv_set_tuning(ctx, -1, -1, -1, -1) (the library picks the
  *                         streaming geometry from the shape), 0 = pin the current geometry
- *   "fused_counters_max"  default 4096: streaming kernel -- at or below this many cells (or problem rows >= 4 MiB) per-cell atomics inside
+ *   "fused_counters_max"  default 512 (4096 until round 6; re-measured by tools/crossovers.py): streaming kernel -- at or below this many cells (or problem rows >= 4 MiB) per-cell atomics inside
  *                         the hot kernel, otherwise a separate reduction of the cell table; 0: EVERY kernel leaves the counters to that
  *                         reduction (the cell kernels otherwise keep per-workgroup LDS tables and flush them in the same launch)
  *   "grid"                > 0: exact persistent grid (0: from the CU count, balanced so that all workgroups stream the same number of items)

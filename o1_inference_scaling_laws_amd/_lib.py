@@ -10,7 +10,7 @@ _lib = None
 
 # include/scvote.h constants
 MEM_HOST, MEM_DEVICE = 0, 1
-FLAG_TIMING, FLAG_CLAMP = 0x1, 0x2
+FLAG_TIMING, FLAG_CLAMP, FLAG_PACKED_CELLS = 0x1, 0x2, 0x4
 COMM_PEER, COMM_RCCL = 0x0, 0x1
 DIST_UNIFORM, DIST_PEAKED, DIST_DEGENERATE, DIST_TIE, DIST_PEAKED_WRONG, DIST_DEGENERATE_WRONG = 0, 1, 2, 3, 4, 5
 NUM_BINS, TIE_CLASSES = 1024, 1025

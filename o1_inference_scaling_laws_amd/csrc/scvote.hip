@@ -134,7 +134,9 @@ struct scv_ctx {
     int sort_n_max = 64;     // cells stay on scv_lane_cells, longer ones go to the register-resident kernels; sort_n_max = 0: off
     int reg_n_max = 8192;    // auto: 32 < N <= this -> register-resident cells (scv_reg_cells / scv_reg_dense); 0 = off (streaming kernel)
     int reg_shape = 0;       // force a register-resident shape (parity tests, A/B runs), see launch_aggregate
-    int fused_counters_max = 4096;  // cells: at or below, counters inside the hot kernel; above, scv_reduce_cells; 0: always the reduction
+    int fused_counters_max = 512;   // cells: at or below, counters inside the hot kernel; above, scv_reduce_cells; 0: always the reduction.  (Round 6, tools/crossovers.py:
+                                    // 4096 until then -- at 2048 / 4096 / 8192 cells of 64 KiB the per-cell atomics cost 41 / 73 / 138 us against 29 / 50 / 89 with the reduction;
+                                    // equal at 512 cells, 4 % better at 256)
     int grid_override = 0;   // > 0: exact persistent grid size
     int prefix_path = 0;     // prefix budgets: 0 auto | 1 one lane per problem | 2 cell kernels on pool rows | 3 one-pass streaming snapshots |
                              // 4 one pass per problem, G lanes per problem (scv_prefix_pool; "reg_shape" 16 / 32 / 64 forces G)
@@ -294,6 +296,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
     a.sorted = 1;
     a.segs = 1; a.seg_len = N; a.partial = nullptr; a.partial_tok = nullptr; a.wave_lds_words = 0; a.acc_classes = 0;
     a.tickets = nullptr; a.overwrite = 0; a.ow_tie = a.ow_tok = a.ow_truth = nullptr; a.boot = 0; a.boot_r0 = a.boot_r1 = 0; a.boot_M = 1; a.boot_spins = 0; a.boot_seed = 0; a.boot_out = nullptr;
+    a.packed_cells = ((ctx->flags & SCV_FLAG_PACKED_CELLS) && cells && !pool_rows) ? 1 : 0;   // (aggregate_common has checked the shape: N <= 127, cell kernels only)
     const bool tok = tokens != nullptr;
     const bool want_counters = tie || truth_sum || (tok && tok_sum);
     const bool rows_aligned = (N % 4 == 0) && (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0);
@@ -1468,6 +1471,12 @@ int aggregate_common(scv_ctx* ctx, bool prefix, const int32_t* answers, const in
     if (prefix && B > 0 && !n_valid) return fail(SCV_ERR_ARG, "prefix mode needs n_valid");
     if (prefix && B > scv::kMaxSortedB) return fail(SCV_ERR_ARG, "prefix mode supports at most %d budgets", scv::kMaxSortedB);
     if (mem_kind != SCV_MEM_HOST && mem_kind != SCV_MEM_DEVICE) return fail(SCV_ERR_ARG, "bad mem_kind %d", mem_kind);
+    if ((ctx->flags & SCV_FLAG_PACKED_CELLS) && cells_out) {
+        // 4-byte records: DEVICE-mode scv_aggregate_i32 over cells of up to 127 votes (every count fits 7 bits) on the kernels that serve such cells
+        if (prefix || mem_kind != SCV_MEM_DEVICE || N > 127 || ctx->path == 1 || ctx->path == 2 || ctx->fused_counters_max == 0 || ctx->boot_req)
+            return fail(SCV_ERR_ARG, "SCV_FLAG_PACKED_CELLS: cells_out is uint32 [P, B] only for scv_aggregate_i32 on DEVICE memory with N <= 127 "
+                                     "(auto dispatch; no prefix budgets, no bootstrap in the call); got prefix=%d mem_kind=%d N=%lld", (int)prefix, mem_kind, (long long)N);
+    }
     SCV_ENTER(ctx);
     auto launch = prefix ? launch_prefix : launch_dense;
 
@@ -1567,6 +1576,7 @@ int scv_aggregate_bootstrap_i32(scv_ctx* ctx, const int32_t* answers, const int3
     return guarded([&]() -> int {
         if (!ctx) return fail(SCV_ERR_ARG, "ctx is NULL");
         if (!cells_out || !counts_out) return fail(SCV_ERR_ARG, "aggregate_bootstrap: cells_out and counts_out are required");
+        if (ctx->flags & SCV_FLAG_PACKED_CELLS) return fail(SCV_ERR_ARG, "SCV_FLAG_PACKED_CELLS: vote + bootstrap in one call reads 16-byte records (use a ctx without the flag)");
         if (P <= 0 || P > 0xFFFFFFFFll || B <= 0 || M <= 0 || r_end < r_begin || r_begin < 0)
             return fail(SCV_ERR_ARG, "aggregate_bootstrap: bad shape P=%lld B=%d M=%d r=[%d,%d)", (long long)P, B, M, r_begin, r_end);
         if ((size_t)B * M * sizeof(uint32_t) > 64 * 1024) return fail(SCV_ERR_ARG, "bootstrap: B*M=%lld counters exceed 64 KiB of LDS", (long long)B * M);

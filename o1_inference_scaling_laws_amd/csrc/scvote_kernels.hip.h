@@ -91,11 +91,19 @@ struct AggArgs {
     long long* partial_tok; // split-N: [ncells] the cells' token sums, likewise
     int32_t skip_sortable = 0;      // prefix kernels queued BEHIND scv_sort_prefix<NV> (DEVICE mode: the host cannot read n_valid): = NV; the
                                     // launch leaves at once when every budget is of the form that kernel serves (it has done the work)
+    int32_t packed_cells = 0;       // SCV_FLAG_PACKED_CELLS: cells is uint32 [P, B] (cells of up to 127 votes; pack_cell below), not scv_cell [P, B]
     int32_t only_if_sortable = 0;   // scv_prefix_tokens queued NEXT TO scv_sort_prefix<NV> (DEVICE mode): = NV; the launch leaves at once unless every budget
                                     // is of the form that kernel serves (otherwise the general kernel behind them does votes and tokens)
     int32_t budgets_promised = 0;   // scv_sort_prefix: != 0 = the budgets are KNOWN to be of its form (read by a HOST-mode call, or promised by the
                                     // caller: option prefix_path = 5): a list that is not sets error bit 8 instead of leaving the launch to another kernel
 };
+
+// SCV_FLAG_PACKED_CELLS (include/scvote.h): one record in 4 bytes -- max_count | truth_count << 7 | n_modes << 14 | min_mode << 21 | hit << 31; every count
+// of a cell of up to 127 votes fits 7 bits; an empty cell (max_count == 0) has min_mode field 1023 and decodes to -1.  The reference's most common
+// call is N = 1 (o1.py:302): a 16-byte record per 4-byte vote made the cell table 80 % of that launch's traffic.
+__device__ __forceinline__ uint32_t pack_cell(uint32_t maxc, uint32_t tc, uint32_t n_modes, uint32_t mm, uint32_t hit) {
+    return (maxc & 0x7fu) | ((tc & 0x7fu) << 7) | ((n_modes & 0x7fu) << 14) | ((maxc ? (mm & 0x3ffu) : 0x3ffu) << 21) | (hit << 31);
+}
 
 // 64-lane reductions on the VALU (DPP), not through the LDS crossbar: __shfl_xor lowers to
 // ds_bpermute_b32, which has LDS latency and queues behind the histogram atomics.  gfx9 scan idiom:
@@ -1094,7 +1102,8 @@ __global__ __launch_bounds__(T) void scv_lane_cells(const AggArgs a) {
                 rec.y = tc;
                 rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
                 rec.w = hit;
-                reinterpret_cast<uint4*>(a.cells)[c.cell] = rec;
+                if (a.packed_cells) reinterpret_cast<uint32_t*>(a.cells)[c.cell] = pack_cell(maxc, tc, n_modes, mm, hit);
+                else reinterpret_cast<uint4*>(a.cells)[c.cell] = rec;
             }
             if (TOK && a.cell_tokens) a.cell_tokens[c.cell] = tok;
             if (fixed_b) {                                                        // o1.py:238-240 as integers
@@ -1193,10 +1202,17 @@ __global__ __launch_bounds__(1024) void scv_few_votes(const AggArgs a) {
     // (p, b) of each cell slot of the lane, then add-and-carry: a step moves every slot by nwaves * BLK cells = (dp, db)
     const uint32_t dcell = nwaves * BLK, dp = dcell / B, db = dcell - dp * B;
     const bool fixed_b = db == 0;                                    // the host rounds the grid: a lane's cells keep their budgets
+    // Which cells of the block a lane owns.  With 16-byte records (the default cell table) lane l owns block + l, block + 64 + l ...: every record store
+    // of the wave then touches consecutive bytes.  Round 6: with the 4-byte records of SCV_FLAG_PACKED_CELLS lane l owns the CPL consecutive cells
+    // block + CPL l ...: its votes are ONE 16-byte load (N = 1: four cells, N = 2: two) instead of four / two 4- / 8-byte loads, its packed records one
+    // 16- / 8-byte store (N = 1, 1.02e8 cells: 264 -> 241 us; 401 with 16-byte records).  Counters-only launches keep the first layout: they are bound by
+    // their ~50 VALU per cell, not by the loads (the consecutive layout measured 131 -> 155 us there: more registers, fewer waves).
+    const bool consec = NV < 4 && a.cells && a.packed_cells;
+    auto slot_cell = [&](uint32_t bk, int j) -> uint64_t { return (uint64_t)bk * BLK + (consec ? (uint32_t)CPL * (uint32_t)lane + (uint32_t)j : 64u * (uint32_t)j + (uint32_t)lane); };
     uint32_t pj[CPL], bj[CPL], nj[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-        const uint32_t c = blk * BLK + 64u * j + (uint32_t)lane;
+        const uint32_t c = (uint32_t)slot_cell(blk, j);
         pj[j] = c / B;
         bj[j] = c - pj[j] * B;
         const int64_t n = valid_len(a, (int32_t)bj[j]);
@@ -1216,7 +1232,30 @@ __global__ __launch_bounds__(1024) void scv_few_votes(const AggArgs a) {
     // its 16-byte records (5.3 TB/s of reads + writes at N = 1) and ran 7-9 % SLOWER with the extra loads in flight (r04_ab_few_truth.log).
     // Nor for cells of 4 votes (one truth per 16 bytes of votes: 91 -> 94 us with it).
     const bool pre = NV < 4 && !a.cells;
-    auto load = [&](uint32_t bk, Votes& o, bool ahead) {            // every instruction: 64 lanes x 4 NV consecutive bytes
+    auto load = [&](uint32_t bk, Votes& o, bool ahead) {            // every instruction: 64 lanes x 4 NV (consec: 16) consecutive bytes
+        if constexpr (NV < 4) {
+            if (consec) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j)
+                    if (pre) o.truth[j] = a.truth[ahead ? pj[j] + dp + (bj[j] + db >= B ? 1u : 0u) : pj[j]];
+                const uint64_t v16 = (uint64_t)bk * 64u + (uint32_t)lane;        // this lane's 16 bytes of the block (CPL cells x NV votes)
+                const int4 q = stream_load(reinterpret_cast<const int4*>(a.answers) + v16);
+                const uint32_t qq[4] = {(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w};
+#pragma unroll
+                for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) o.w[j][i] = qq[j * NV + i];
+                if (TOK) {
+                    const int4 y = stream_load(reinterpret_cast<const int4*>(a.tokens) + v16);
+                    const int32_t yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) o.tk[j][i] = yy[j * NV + i];
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             const uint64_t c = (uint64_t)bk * BLK + 64u * j + (uint32_t)lane;
@@ -1240,6 +1279,7 @@ __global__ __launch_bounds__(1024) void scv_few_votes(const AggArgs a) {
     if (blk < nblocks) load(blk, cur, false);
     for (; blk < nblocks; blk += nwaves) {
         if (blk + nwaves < nblocks) load(blk + nwaves, nxt, true);   // one step ahead
+        uint32_t pk[CPL];                                            // (consec + packed records: the lane's CPL records leave in one store)
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             const uint32_t b = bj[j];
@@ -1280,9 +1320,12 @@ __global__ __launch_bounds__(1024) void scv_few_votes(const AggArgs a) {
             }
             const bool any = maxc > 0;
             const uint32_t hit = (any && tc == maxc) ? 1u : 0u;                   // o1.py:206
-            const uint64_t c = (uint64_t)blk * BLK + 64u * j + (uint32_t)lane;
-            if (a.cells)
-                __builtin_nontemporal_store(scv_v4u{maxc, tc, (n_modes & 0xffffu) | ((any ? mm : 0xffffu) << 16), hit}, reinterpret_cast<scv_v4u*>(a.cells) + c);
+            const uint64_t c = slot_cell(blk, j);
+            pk[j] = pack_cell(maxc, tc, n_modes, mm, hit);
+            if (a.cells) {
+                if (a.packed_cells) { if (NV == 4) __builtin_nontemporal_store(pk[j], reinterpret_cast<uint32_t*>(a.cells) + c); }
+                else __builtin_nontemporal_store(scv_v4u{maxc, tc, (n_modes & 0xffffu) | ((any ? mm : 0xffffu) << 16), hit}, reinterpret_cast<scv_v4u*>(a.cells) + c);
+            }
             if (TOK && a.cell_tokens) a.cell_tokens[c] = tok;
             if (fixed_b) {                                                        // o1.py:238-240 as integers, in registers
                 h1[j] += (hit && n_modes == 1u) ? 1u : 0u;
@@ -1296,6 +1339,13 @@ __global__ __launch_bounds__(1024) void scv_few_votes(const AggArgs a) {
             }
             pj[j] += dp; bj[j] += db;
             if (bj[j] >= B) { bj[j] -= B; pj[j] += 1u; }
+        }
+        if constexpr (NV < 4) {
+            if (a.cells && a.packed_cells) {                         // (consec: 4 / 2 consecutive 4-byte records per lane)
+                uint32_t* const out = reinterpret_cast<uint32_t*>(a.cells) + (uint64_t)blk * BLK + (uint32_t)CPL * (uint32_t)lane;
+                if constexpr (NV == 1) __builtin_nontemporal_store(scv_v4u{pk[0], pk[1], pk[2], pk[3]}, reinterpret_cast<scv_v4u*>(out));
+                else __builtin_nontemporal_store(scv_v2u{pk[0], pk[1]}, reinterpret_cast<scv_v2u*>(out));
+            }
         }
         cur = nxt;
     }
@@ -2063,7 +2113,8 @@ __global__ __launch_bounds__((64 * reg_cells_waves<G, V, TOK, VEC>())) void scv_
             rec.y = o.tc;
             rec.z = (n_modes & 0xffffu) | ((any ? (mm & 0xffffu) : 0xffffu) << 16);
             rec.w = hit;
-            reinterpret_cast<uint4*>(a.cells)[o.cell] = rec;
+            if (a.packed_cells) reinterpret_cast<uint32_t*>(a.cells)[o.cell] = pack_cell(maxc, o.tc, n_modes, mm, hit);
+            else reinterpret_cast<uint4*>(a.cells)[o.cell] = rec;
         }
         if (a.cell_tokens) a.cell_tokens[o.cell] = o.tok;
         if (wgc.tcl > 0) wg_counters_add<TOK>(a, wgc, o.b, hit, n_modes, o.tc, o.tok);

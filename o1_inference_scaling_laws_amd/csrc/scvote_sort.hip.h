@@ -544,7 +544,8 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
         }
         SV_STAMP(1);
         // the next step's copy flies while this step is counted
-        uint4* const cells_out = a.cells ? reinterpret_cast<uint4*>(a.cells) + c0 : nullptr;     // (scalar bases of this step's outputs)
+        // (scalar bases of this step's outputs; a record is 16 bytes, or 4 under SCV_FLAG_PACKED_CELLS)
+        char* const cells_out = a.cells ? reinterpret_cast<char*>(a.cells) + c0 * (a.packed_cells ? 4 : 16) : nullptr;
         int64_t* const ctok_out = (TOK && a.cell_tokens) ? a.cell_tokens + c0 : nullptr;
         advance();
         // The next step's copy goes into the image just read.  Votes only, 16 votes or more: its pieces are issued one every few
@@ -615,7 +616,8 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
                 rec.y = tc;
                 rec.z = (n_modes & 0xffffu) | ((any ? (s.min_at_max & 0xffffu) : 0xffffu) << 16);
                 rec.w = hit;
-                __builtin_nontemporal_store(scv_v4u{rec.x, rec.y, rec.z, rec.w}, reinterpret_cast<scv_v4u*>(cells_out) + (uint32_t)lane);
+                if (a.packed_cells) __builtin_nontemporal_store(pack_cell(maxc, tc, n_modes, s.min_at_max, hit), reinterpret_cast<uint32_t*>(cells_out) + (uint32_t)lane);
+                else __builtin_nontemporal_store(scv_v4u{rec.x, rec.y, rec.z, rec.w}, reinterpret_cast<scv_v4u*>(cells_out) + (uint32_t)lane);
             }
             if (TOK && a.cell_tokens) ctok_out[(uint32_t)lane] = tok;
             if (fixed_b) {                                                        // o1.py:238-240 as integers

@@ -94,10 +94,14 @@ def pinned_empty(shape, dtype=np.int32) -> np.ndarray:
 class Engine:
     """One context per GPU per process (one process per GPU under torch.distributed)."""
 
-    def __init__(self, device: int | None = None, timing: bool = False, clamp_to_invalid_bin: bool = False, _adopt=None):
+    def __init__(self, device: int | None = None, timing: bool = False, clamp_to_invalid_bin: bool = False, packed_cells: bool = False, _adopt=None):
+        """``packed_cells=True`` (SCV_FLAG_PACKED_CELLS, opt-in): ``aggregate_device`` over cells of up to 127 votes writes 4-byte records --
+        its ``cells`` tensor is uint8 [P, B, 4] and ``cells_from_torch`` decodes it (``unpack_cells``); every other call form of such an engine
+        must be made without a cell table (``cells=False``)."""
         self._L = _lib.load()            # raises ImportError when csrc/libscvote.so is missing
         self._ctx = C.c_void_p()
-        flags = (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_CLAMP if clamp_to_invalid_bin else 0)
+        self.packed_cells = bool(packed_cells)
+        flags = (_lib.FLAG_TIMING if timing else 0) | (_lib.FLAG_CLAMP if clamp_to_invalid_bin else 0) | (_lib.FLAG_PACKED_CELLS if packed_cells else 0)
         if device is None:
             import torch
             device = torch.cuda.current_device() if torch.cuda.is_available() else -1
@@ -280,7 +284,7 @@ class Engine:
         elif not (counters.is_cuda and counters.dtype == torch.int64 and counters.numel() == counters_size(B) and counters.is_contiguous()):
             raise ValueError("counters must be int64 [counters_size(B)] on the device")
         if cells is None:
-            cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev)
+            cells = torch.empty((P, B, 4 if getattr(self, "packed_cells", False) else 16), dtype=torch.uint8, device=dev)
         elif cells is False:
             if not want_no_cells:
                 raise ValueError("this call needs the cell table")
@@ -626,7 +630,23 @@ class MultiDeviceEngine:
         return self._run("aggregate_prefix", pool, truth, {"tokens": tokens}, {"n_valid": n_valid, "want_cells": want_cells})
 
 
+def unpack_cells(packed_u32: np.ndarray) -> np.ndarray:
+    """SCV_FLAG_PACKED_CELLS records (include/scvote.h: max_count | truth_count << 7 | n_modes << 14 | min_mode << 21 | hit << 31) -> CELL_DTYPE,
+    field for field what the 16-byte record of the same cell holds (min_mode = -1 for an empty cell)."""
+    w = np.ascontiguousarray(packed_u32).astype(np.uint32, copy=False)
+    out = np.zeros(w.shape, dtype=CELL_DTYPE)
+    out["max_count"] = w & 0x7F
+    out["truth_count"] = (w >> 7) & 0x7F
+    out["n_modes"] = (w >> 14) & 0x7F
+    mm = ((w >> 21) & 0x3FF).astype(np.int16)
+    out["min_mode"] = np.where(out["max_count"] == 0, np.int16(-1), mm)
+    out["hit"] = (w >> 31).astype(np.uint8)
+    return out
+
+
 def cells_from_torch(cells_u8) -> np.ndarray:
-    """uint8 cuda/cpu [P,B,16] -> CELL_DTYPE [P,B] on the host."""
-    arr = cells_u8.detach().cpu().numpy()
-    return np.ascontiguousarray(arr).view(CELL_DTYPE).reshape(arr.shape[0], arr.shape[1])
+    """uint8 cuda/cpu [P,B,16] (or [P,B,4]: packed records of an Engine(packed_cells=True)) -> CELL_DTYPE [P,B] on the host."""
+    arr = np.ascontiguousarray(cells_u8.detach().cpu().numpy())
+    if arr.shape[-1] == 4:
+        return unpack_cells(arr.view(np.uint32).reshape(arr.shape[0], arr.shape[1]))
+    return arr.view(CELL_DTYPE).reshape(arr.shape[0], arr.shape[1])

@@ -11,7 +11,7 @@ from tests._adapters import OracleEngine, assert_results_equal
 
 pytestmark = pytest.mark.gpu
 
-DEFAULTS = (("path", 0), ("segs", 0), ("grid", 0), ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0),
+DEFAULTS = (("path", 0), ("segs", 0), ("grid", 0), ("fused_counters_max", 512), ("reg_n_max", 8192), ("reg_shape", 0),
             ("prefix_path", 0), ("sort_n_min", 8), ("sort_n_max", 64), ("host_small_kb", 1024))
 GEOMETRIES = ((4, 256, 2), (8, 256, 4), (8, 512, 4), (16, 256, 4), (16, 512, 4), (16, 1024, 4))       # (copies, threads, unroll) instantiated
 
@@ -52,7 +52,7 @@ def _draw(rng):
         if opts["path"] == 2:
             opts["segs"] = int(rng.choice([0, 2, 3, 5, 16, 40]))
     if rng.random() < 0.3:
-        opts["fused_counters_max"] = int(rng.choice([0, 1, 4096]))   # 0: every kernel leaves the counters to scv_reduce_cells
+        opts["fused_counters_max"] = int(rng.choice([0, 1, 512, 4096]))   # 0: every kernel leaves the counters to scv_reduce_cells
     if rng.random() < 0.2:
         opts["grid"] = int(rng.integers(1, 40))
     if rng.random() < 0.25:

@@ -314,7 +314,7 @@ def _with_options(eng, opts):
             for k, v in opts.items():
                 eng.set_option(k, v)
         def __exit__(self_, *exc):
-            for k, v in (("path", 0), ("segs", 0), ("grid", 0), ("fused_counters_max", 4096), ("reg_n_max", 8192), ("reg_shape", 0),
+            for k, v in (("path", 0), ("segs", 0), ("grid", 0), ("fused_counters_max", 512), ("reg_n_max", 8192), ("reg_shape", 0),
                          ("prefix_path", 0), ("boot_path", 0), ("sort_n_min", 8), ("sort_n_max", 64)):
                 eng.set_option(k, v)
             eng.set_tuning(-1, -1, -1, -1)
@@ -2043,3 +2043,72 @@ def test_multi_device_engine_all_reduce_is_the_library_communicator():
         me.all_reduce_counters(cs)
         me.sync()
         assert cs[0].tolist() == cs[1].tolist() == [3 * i for i in range(10)]
+
+
+# ---- round 6: 4-byte cell records (SCV_FLAG_PACKED_CELLS) -----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [(4096, 8, 1), (4096, 4, 2), (2048, 3, 4), (1000, 5, 1), (333, 2, 3), (900, 7, 8), (700, 3, 16), (500, 2, 31), (400, 4, 48),
+                                   (300, 3, 64), (250, 2, 65), (200, 4, 96), (150, 3, 127), (64, 200, 2), (1, 1, 127)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("dist", [1, 3, 5])
+def test_packed_cell_records_decode_to_the_16_byte_records(dist, shape):
+    """the opt-in 4-byte record (7 + 7 + 7 + 10 + 1 bits) of every kernel family that serves cells of up to 127 votes -- few votes
+    (the reference's N = 1, 2, 4: o1.py:302, 276), one lane per cell, sorted cells, register-resident cells -- decodes field for field to the 16-byte
+    record of the default engine and to the oracle's, with ragged budgets (empty cells: min_mode -1), tokens, counters unchanged."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine
+    P, B, N = shape
+    dev = torch.device("cuda:0")
+    a, t, tr = coracle.synth_fill(P, B, N, 7000 + N, dist, want_tokens=True)
+    a[::5, :, :] = 1023                                              # the last bin as the mode (10 bits of min_mode)
+    nv = np.array([(N if b % 3 == 0 else (0 if b % 3 == 1 else max(1, N // 2))) for b in range(B)], dtype=np.int32)
+    da, dt, dtr, dnv = (torch.from_numpy(x).to(dev) for x in (a, t, tr, nv))
+    with Engine(packed_cells=True) as packed, Engine() as plain:
+        for (tok, nvx) in ((None, None), (dt, dnv), (None, dnv)):
+            c1, cells1, ctok1 = packed.aggregate_device(da, dtr, tokens=tok, n_valid=nvx)
+            c2, cells2, ctok2 = plain.aggregate_device(da, dtr, tokens=tok, n_valid=nvx)
+            packed.sync(); plain.sync()
+            assert tuple(cells1.shape) == (P, B, 4) and tuple(cells2.shape) == (P, B, 16)
+            got, ref = cells_from_torch(cells1), cells_from_torch(cells2)
+            want = coracle.aggregate(a, tr, tokens=None if tok is None else t, n_valid=None if nvx is None else nv)
+            for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+                assert np.array_equal(got[f], ref[f]) and np.array_equal(got[f], want["cells"][f]), f
+            assert torch.equal(c1, c2)
+            if tok is not None:
+                assert torch.equal(ctok1, ctok2)
+        # counters only: nothing about the records matters
+        c3, none, _ = packed.aggregate_device(da, dtr, cells=False)
+        packed.sync()
+        assert none is None and np.array_equal(c3.cpu().numpy()[: B * 1025], want_counters(a, tr, B))
+
+
+def want_counters(a, tr, B):
+    return coracle.aggregate(a, tr)["tie_class_hits"].reshape(-1)
+
+
+def test_packed_cell_records_refuse_what_they_do_not_cover():
+    """A packed engine with a cell table asked for: prefix budgets, HOST memory, cells of more than 127 votes, vote + bootstrap -> SCV_ERR_ARG, not a
+    table in the wrong format; the same calls WITHOUT a cell table are served."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine
+    dev = torch.device("cuda:0")
+    a, _, tr = coracle.synth_fill(50, 2, 128, 1, 1)
+    da, dtr = torch.from_numpy(a).to(dev), torch.from_numpy(tr).to(dev)
+    with Engine(packed_cells=True) as eng:
+        with pytest.raises(_lib.ScvError):
+            eng.aggregate_device(da, dtr)                                        # N = 128
+        c, none, _ = eng.aggregate_device(da, dtr, cells=False)                  # ... without a table: fine
+        eng.sync()
+        assert np.array_equal(c.cpu().numpy()[: 2 * 1025], want_counters(a, tr, 2))
+        with pytest.raises(_lib.ScvError):
+            eng.aggregate(a[:, :, :64], tr)                                      # HOST memory
+        with pytest.raises(_lib.ScvError):
+            eng.aggregate_prefix_device(da[:, 0, :64].contiguous(), dtr, torch.tensor([1, 64], dtype=torch.int32, device=dev))
+        with pytest.raises(_lib.ScvError):
+            eng.aggregate_bootstrap_device(da[:, :, :64].contiguous(), dtr, 0, 10, 1, 4)
+        eng.set_option("path", 1)
+        with pytest.raises(_lib.ScvError):
+            eng.aggregate_device(da[:, :, :64].contiguous(), dtr)                # a forced streaming path
+        eng.set_option("path", 0)
+        _, cells, _ = eng.aggregate_device(da[:, :, :64].contiguous(), dtr)      # (the ctx is still good)
+        eng.sync()
+        assert np.array_equal(cells_from_torch(cells)["max_count"], coracle.aggregate(a[:, :, :64], tr)["cells"]["max_count"])

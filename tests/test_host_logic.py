@@ -430,3 +430,24 @@ def test_counters_digest_is_a_function_of_the_counter_words_only():
     c = np.arange(8 * 1027 + 1, dtype=np.int64)
     assert bench.counters_digest(c, 8 * 1027) == bench.counters_digest(c[:8 * 1027].copy(), 8 * 1027) != bench.counters_digest(c + 1, 8 * 1027)
     assert len(bench.counters_digest(c, 8 * 1027)) == 64
+
+
+def test_packed_cell_records_round_trip_on_the_host():
+    """SCV_FLAG_PACKED_CELLS (include/scvote.h): max_count | truth_count << 7 | n_modes << 14 | min_mode << 21 | hit << 31 -- the decoder of engine.py
+    gives back every field of every record a cell of up to 127 votes can have (an empty cell: min_mode -1, whatever its 10 bits hold)."""
+    from o1_inference_scaling_laws_amd.engine import CELL_DTYPE, unpack_cells
+    rng = np.random.default_rng(3)
+    n = 5000
+    ref = np.zeros(n, dtype=CELL_DTYPE)
+    ref["max_count"] = rng.integers(0, 128, n)
+    ref["max_count"][:50] = 0
+    ref["truth_count"] = np.minimum(rng.integers(0, 128, n), ref["max_count"])
+    ref["n_modes"] = np.where(ref["max_count"] > 0, rng.integers(1, 128, n), 0)
+    ref["min_mode"] = np.where(ref["max_count"] > 0, rng.integers(0, 1024, n), -1)
+    ref["hit"] = (ref["truth_count"] == ref["max_count"]) & (ref["max_count"] > 0)
+    w = (ref["max_count"].astype(np.uint32) | (ref["truth_count"].astype(np.uint32) << 7) | (ref["n_modes"].astype(np.uint32) << 14)
+         | (np.where(ref["max_count"] > 0, ref["min_mode"], 1023).astype(np.uint32) << 21) | (ref["hit"].astype(np.uint32) << 31))
+    got = unpack_cells(w.reshape(100, 50))
+    for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+        assert np.array_equal(got[f].reshape(-1), ref[f]), f
+    assert got.dtype == CELL_DTYPE and got.shape == (100, 50)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Re-check the dispatch thresholds of csrc/scvote.hip ON THIS BOX (the constants were measured on one box of a pool whose
+read ceilings differ by 5 %).  For every threshold the two kernels that meet there are timed on the same cold buffers, at the threshold and one
+step to either side; the table says which side wins and by how much, and whether the constant in the library still points at the faster one.
+A measurement tool: nothing in the product reads its output.  Usage: python tools/crossovers.py  (-> gpurun_out/crossovers.md)"""
+from __future__ import annotations
+
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine
+    from one_case import run_prefix
+    from regimes import run
+    DEFAULTS = {"path": 0, "segs": 0, "reg_n_max": 8192, "reg_shape": 0, "fused_counters_max": 512, "sort_n_min": 8, "sort_n_max": 64, "prefix_path": 0}
+    eng = Engine(device=0, timing=True)
+
+    def timed(shape, opts, prefix=False, tokens=False, dist=1):
+        for k, v in DEFAULTS.items():
+            eng.set_option(k, v)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        P, B, N = shape
+        r = run_prefix(eng, torch, P, N, tokens, dist, 5) if prefix else run(eng, torch, P, B, N, tokens, dist=dist, rounds=5)
+        torch.cuda.empty_cache()
+        return r["median_us"]
+
+    # (what the library does at this shape, the other side of the threshold, the shapes, the constant)
+    checks = [
+        ("sorted cells up to 64 votes, register-resident beyond (sort_n_max = 64)", {}, {"sort_n_max": 0}, [(400000, 4, 48), (400000, 4, 64)], "sorted"),
+        ("... the first length beyond: 8 lanes x 3 vectors (auto) against 16 lanes x 2 (round 5)", {}, {"reg_shape": 1602}, [(300000, 4, 68), (200000, 4, 96)], "8 x 3"),
+        ("8 lanes x 4 vectors for 97 .. 128 slots against 16 lanes x 2", {}, {"reg_shape": 1602}, [(200000, 4, 100), (200000, 4, 128)], "8 x 4"),
+        ("sparse read-back up to 896 votes, one dense part beyond", {"reg_shape": 6404}, {"reg_shape": 1041}, [(60000, 4, 768), (55000, 4, 896), (50000, 4, 1024)], "sparse <= 896"),
+        ("register-resident up to 8192 votes, streaming beyond (reg_n_max = 8192)", {}, {"reg_n_max": 0}, [(20000, 4, 4096), (10000, 4, 8192)], "register"),
+        ("streaming kernel: per-cell atomics up to 512 cells (round 5: 4096), cell-table reduction beyond", {"fused_counters_max": 1 << 30}, {"fused_counters_max": 1}, [(32, 8, 32768), (64, 8, 32768), (128, 8, 32768), (256, 8, 16384), (512, 8, 16384)], "fused <= 512 cells"),
+        ("few cells of >= 1 MiB: split-N against whole cells (2 cells <= slots)", {"path": 2}, {"path": 1}, [(30, 1, 1 << 20), (100, 1, 1 << 20), (128, 1, 1 << 20)], "split when 2 x cells <= 256"),
+    ]
+    lines = ["# dispatch thresholds re-checked on this box (tools/crossovers.py; median of 5 cold passes, us)", "",
+             "| threshold (csrc/scvote.hip) | shape [P, B, N] | library's side | other side | ratio other / library |", "|---|---|---|---|---|"]
+    for what, mine, other, shapes, _ in checks:
+        for sh in shapes:
+            a, b = timed(sh, mine), timed(sh, other)
+            lines.append(f"| {what} | {list(sh)} | {a:.1f} | {b:.1f} | {b / a:.2f} |")
+            print(lines[-1], flush=True)
+    # prefix budgets: scv_sort_prefix2 from 98 304 pools of 68 .. 128 votes, scv_prefix_pool below
+    for P in (49152, 98304, 196608):
+        for tok in (False, True):
+            a, b = timed((P, 8, 128), {"prefix_path": 5}, prefix=True, tokens=tok), timed((P, 8, 128), {"prefix_path": 4}, prefix=True, tokens=tok)
+            lines.append(f"| prefix budgets over 128-vote pools{' with tokens' if tok else ''}: one sort per problem from 98 304 pools, one pass per problem below | [{P}, 8, 128] | sort {a:.1f} | one pass {b:.1f} | {b / a:.2f} |")
+            print(lines[-1], flush=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    open("gpurun_out/crossovers.md", "w").write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()

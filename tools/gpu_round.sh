@@ -10,10 +10,10 @@ export TMPDIR=/tmp
 cd $R
 echo "== torch-free load"; timeout 120 python -c "import ctypes; L=ctypes.CDLL('o1_inference_scaling_laws_amd/csrc/libscvote.so'); print('devices visible without torch:', L.scv_device_count())" 2>&1 | tail -2
 echo "== bench (the driver's command)"; timeout 900 python bench.py 2> gpurun_out/bench.err | tee gpurun_out/bench.json | cut -c1-500; tail -2 gpurun_out/bench.err
-echo "== rocprof kernel-trace of the same command"; (cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_trace.log 2>&1); tail -2 gpurun_out/prof_trace.log | cut -c1-300
-echo "== rocprof pmc FETCH_SIZE"; (cd /tmp; timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-read-ceiling > $R/gpurun_out/prof_fetch.log 2>&1); tail -1 gpurun_out/prof_fetch.log | cut -c1-200
-echo "== rocprof pmc WRITE_SIZE"; (cd /tmp; timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-read-ceiling > $R/gpurun_out/prof_write.log 2>&1); tail -1 gpurun_out/prof_write.log | cut -c1-200
-echo "== rocprof pmc LDS"; (cd /tmp; timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/prof_lds -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-read-ceiling > $R/gpurun_out/prof_lds.log 2>&1); tail -1 gpurun_out/prof_lds.log | cut -c1-200
+echo "== rocprof kernel-trace of the same command"; (cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-live-traffic > $R/gpurun_out/prof_trace.log 2>&1); tail -2 gpurun_out/prof_trace.log | cut -c1-300
+echo "== rocprof pmc FETCH_SIZE"; (cd /tmp; timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-read-ceiling --no-live-traffic --no-full-pass > $R/gpurun_out/prof_fetch.log 2>&1); tail -1 gpurun_out/prof_fetch.log | cut -c1-200
+echo "== rocprof pmc WRITE_SIZE"; (cd /tmp; timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-read-ceiling --no-live-traffic --no-full-pass > $R/gpurun_out/prof_write.log 2>&1); tail -1 gpurun_out/prof_write.log | cut -c1-200
+echo "== rocprof pmc LDS"; (cd /tmp; timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/prof_lds -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-read-ceiling --no-live-traffic --no-full-pass > $R/gpurun_out/prof_lds.log 2>&1); tail -1 gpurun_out/prof_lds.log | cut -c1-200
 echo "== probe"; timeout 300 ./tools/hbm_probe.bin 10000 2>&1 | tee gpurun_out/hbm_probe.log | tail -4
 echo "== probe --percu"; timeout 300 ./tools/hbm_probe.bin 1000 --percu 2>&1 | tee gpurun_out/hbm_probe_percu.log | tail -6
 echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 --tb=short 2>&1 | tail -12 | tee gpurun_out/pytest_gpu.log
@@ -25,7 +25,7 @@ timeout 600 python bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-basel
 timeout 600 python bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline --graph 2>/dev/null > gpurun_out/bench_c2_graph.json
 timeout 600 python bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline --graph --graph-steps 10 2>/dev/null > gpurun_out/bench_c2_graph10.json
 for f in bench_c2 bench_c2_one_launch bench_c2_graph bench_c2_graph10; do python -c "import json; d=json.load(open('gpurun_out/$f.json')); print('$f', round(d['ms_per_step']*1e3, 2), 'us/step', d['config']['launch'], 'kernel', round(d['roofline']['kernel_avg_ms']*1e3, 2), 'us')"; done
-echo "== bench dists"; for d in 0 2 3 4 5; do timeout 600 python bench.py --dist $d --no-cpu-baseline --steps 6 --no-read-ceiling 2>/dev/null; done > gpurun_out/bench_dists.jsonl; python -c "
+echo "== bench dists"; for d in 0 2 3 4 5; do timeout 600 python bench.py --dist $d --no-cpu-baseline --steps 6 --no-read-ceiling --no-live-traffic 2>/dev/null; done > gpurun_out/bench_dists.jsonl; python -c "
 import json
 for l in open('gpurun_out/bench_dists.jsonl'):
     d = json.loads(l); print(d['config']['distribution'], round(d['roofline']['achieved']), 'GB/s', '%.3e' % d['value'])"
@@ -44,14 +44,20 @@ for f in ('bench_comm_peer_2ctx', 'bench_comm_rccl_1gpu'):
     print(f, 'kernel ms per rank min/max', round(r['kernel_avg_ms_per_rank_min'], 3), round(r['kernel_avg_ms_per_rank_max'], 3), 'exposed all-reduce us', r['exposed_allreduce_us'], 'selftest words', d['config']['comm_selftest_words_per_rank'], 'create s', round(d['config']['comm_create_s'], 3))"
 echo "== regimes"; timeout 1200 python tools/regimes.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/regimes.log | tail -8
 echo "== PMC per regime (sorted cells 48 / 64, register-resident 96 / 128 / 256 / 1024, dense 2048 / 8192, lane 3, few votes 1 / 4)"
-SHAPES="6400000:4:1 1600000:4:4 1000000:4:3 400000:4:48 400000:4:64 270000:4:96 200000:4:128 100000:4:256 50000:4:1024 40000:4:2048 10000:4:8192" timeout 1500 bash tools/prof_regimes.sh r05 > gpurun_out/prof_regimes_r05.log 2>&1; tail -3 gpurun_out/prof_regimes_r05.log
+SHAPES="6400000:4:1 1600000:4:4 1000000:4:3 400000:4:48 400000:4:64 300000:4:72 200000:4:96 200000:4:128 100000:4:256 50000:4:1024 40000:4:2048 10000:4:8192" timeout 1500 bash tools/prof_regimes.sh r06 > gpurun_out/prof_regimes_r06.log 2>&1; tail -3 gpurun_out/prof_regimes_r06.log
 echo "== PMC of the prefix-budget kernels (budgets 1, 2, 4 ... N over one pool: scv_sort_prefix 32 / 64, scv_prefix_pool 256 / 1024 / 4096)"
-MODE=prefix SHAPES="200000:1:32 200000:1:64 100000:1:256 50000:1:1024 20000:1:4096" timeout 900 bash tools/prof_regimes.sh r05_prefix > gpurun_out/prof_regimes_r05_prefix.log 2>&1; tail -3 gpurun_out/prof_regimes_r05_prefix.log
+MODE=prefix SHAPES="200000:1:32 200000:1:64 200000:1:128 100000:1:256 50000:1:1024 20000:1:4096" timeout 900 bash tools/prof_regimes.sh r06_prefix > gpurun_out/prof_regimes_r06_prefix.log 2>&1; tail -3 gpurun_out/prof_regimes_r06_prefix.log
 echo "== prefix budgets over short pools (auto: DEVICE mode queues scv_sort_prefix and the general kernel for pools of 17 .. 64 votes)"; timeout 600 python tools/prefix_small.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/prefix_small.log | cut -c1-140 | tail -14
 echo "== ... with the budgets promised to be powers of two (prefix_path = 5: one launch)"; timeout 600 python tools/prefix_small.py prefix_path=5 2>&1 | grep -v amdgpu.ids | tee gpurun_out/prefix_small_promised.log | cut -c1-140 | sed -n 3,4p
 echo "== ... the general kernels alone (prefix_path = 1: one lane per problem up to 64 votes)"; timeout 600 python tools/prefix_small.py prefix_path=1 2>&1 | grep -v amdgpu.ids | tee gpurun_out/prefix_small_lane.log | cut -c1-140 | sed -n 3,4p
 echo "== prefix pools over the distributions D0 .. D5"; timeout 600 bash tools/prefix_dists.sh 2>&1 | tee gpurun_out/prefix_dists.log | tail -18
 echo "== ranks from returning atomics against the register-resident cell kernels (dense cells of 96 .. 1024 votes, D0 .. D5)"; timeout 900 python tools/rtn_ab.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/rtn_ab.log | cut -c1-200 | tail -6
 echo "== phase timeline of scv_sort_prefix (measurement build)"; timeout 300 python tools/sort_prefix_timeline.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/sort_prefix_timeline.log | cut -c1-260 | tail -8
+echo "== dispatch thresholds re-checked on this box"; timeout 1500 python tools/crossovers.py 2>&1 | grep -v amdgpu.ids | tail -40
+echo "== packed 4-byte records against 16-byte records against counters only (N = 1, 2, 4, 8)"
+for s in "12800000 8 1" "12800000 4 2" "6400000 4 4" "3200000 4 8"; do set -- $s; for m in "" "--packed" "--no-cells"; do timeout 300 python tools/one_case.py --P $1 --B $2 --N $3 --rounds 6 $m 2>/dev/null | grep "^{" | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('%-12s records=%-10s %8.1f us %8.1f GB/s of votes' % (str(d['shape']), sys.argv[1] or '16-byte', d['median_us'], d['GBps']))" "$m"; done; done | tee gpurun_out/packed_records.log
+echo "== TSAN build of the host code under the HIP runtime (best effort: the binding check is tests/test_host_sanitizers.py on the CPU)"; timeout 400 bash tools/tsan_host.sh > gpurun_out/tsan_host.log 2>&1; tail -4 gpurun_out/tsan_host.log
 echo "== host mode"; timeout 600 python tools/host_mode_bench.py 2>&1 | grep -v amdgpu | tee gpurun_out/host_mode.log | tail -12
 cd $R; du -sh gpurun_out

@@ -49,12 +49,13 @@ def main():
     ap.add_argument("--no-cells", action="store_true", help="counters only: no cell table is written")
     ap.add_argument("--nv", default="", help="prefix mode: the budgets, comma separated (default 1, 2, 4 ... N)")
     ap.add_argument("--prefix", action="store_true", help="prefix budgets 1, 2, 4 ... N over one pool [P, N] (B is ignored)")
+    ap.add_argument("--packed", action="store_true", help="SCV_FLAG_PACKED_CELLS: 4-byte cell records (N <= 127)")
     args = ap.parse_args()
     import torch
     from o1_inference_scaling_laws_amd.engine import Engine
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from regimes import run
-    eng = Engine(device=0, timing=True)
+    eng = Engine(device=0, timing=True, packed_cells=args.packed)
     for kv in args.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v))

@@ -26,7 +26,7 @@ def run(eng, torch, P, B, N, tokens, dist=1, nbuf=None, rounds=6, n_valid=None, 
         bufs.append((a, t, tr))
     nv = None if n_valid is None else torch.tensor(n_valid, dtype=torch.int32, device=dev)
     counters = torch.zeros(counters_size(B), dtype=torch.int64, device=dev)
-    cells = torch.empty((P, B, 16), dtype=torch.uint8, device=dev) if want_cells else False   # False: counters only, no cell table
+    cells = torch.empty((P, B, 4 if getattr(eng, "packed_cells", False) else 16), dtype=torch.uint8, device=dev) if want_cells else False   # False: counters only, no cell table
     eng.sync(); eng.drain_kernel_ns()
     times = []
     for r in range(rounds + 1):

@@ -93,7 +93,7 @@ for name in ("bench.json", "hbm_probe.log", "hbm_probe_percu.log", "hbm_probe_dm
              "bench_c2_graph10.json", "bench_dists.jsonl", "bench_tokens.jsonl", "bench_comm_peer_2ctx.json", "bench_comm_rccl_1gpu.json", "bench_2ranks_shared_gpu.json",
              "regimes.log", "regimes.json", "sort_check.log", "prefix_small.log", "host_mode.log", "pytest_gpu.log", "smoke.log",
              "valu_probe.log", "sort_timeline.log", "sort_timeline_nospread.log", "hbm_probe_dmawork.log", "hbm_probe_vmemq.log",
-             "prefix_small_promised.log", "prefix_small_lane.log", "prefix_small_general.log", "prefix_dists.log", "rtn_ab.log", "sort_prefix_timeline.log", "gpu_round_" + tag + ".log"):
+             "crossovers.md", "packed_records.log", "tsan_host.log", "prefix_small_promised.log", "prefix_small_lane.log", "prefix_small_general.log", "prefix_dists.log", "rtn_ab.log", "sort_prefix_timeline.log", "gpu_round_" + tag + ".log"):
     src = os.path.join(G, name)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name.replace('bench_c5.json', 'bench_c5_1gpu.json')}"))
