@@ -52,7 +52,6 @@ echo "== ... with the budgets promised to be powers of two (prefix_path = 5: one
 echo "== ... the general kernels alone (prefix_path = 1: one lane per problem up to 64 votes)"; timeout 600 python tools/prefix_small.py prefix_path=1 2>&1 | grep -v amdgpu.ids | tee gpurun_out/prefix_small_lane.log | cut -c1-140 | sed -n 3,4p
 echo "== prefix pools over the distributions D0 .. D5"; timeout 600 bash tools/prefix_dists.sh 2>&1 | tee gpurun_out/prefix_dists.log | tail -18
 echo "== ranks from returning atomics against the register-resident cell kernels (dense cells of 96 .. 1024 votes, D0 .. D5)"; timeout 900 python tools/rtn_ab.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/rtn_ab.log | cut -c1-200 | tail -6
-echo "== phase timeline of scv_sort_prefix (measurement build)"; timeout 300 python tools/sort_prefix_timeline.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/sort_prefix_timeline.log | cut -c1-260 | tail -8
 echo "== dispatch thresholds re-checked on this box"; timeout 1500 python tools/crossovers.py 2>&1 | grep -v amdgpu.ids | tail -40
 echo "== packed 4-byte records against 16-byte records against counters only (N = 1, 2, 4, 8)"
 for s in "12800000 8 1" "12800000 4 2" "6400000 4 4" "3200000 4 8"; do set -- $s; for m in "" "--packed" "--no-cells"; do timeout 300 python tools/one_case.py --P $1 --B $2 --N $3 --rounds 6 $m 2>/dev/null | grep "^{" | python -c "
