@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """The numbers DESIGN.md / README.md quote, read back from profiles/<tag>_* (one evidence session): print them in the order of the documents'
-tables so that the text can be checked against the files.  Usage: design_numbers.py [r05]"""
+tables so that the text can be checked against the files.  Usage: design_numbers.py [r06]"""
 import json
 import os
 import re
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 f = lambda n: os.path.join(P, f"{tag}_{n}")  # noqa: E731
 
@@ -45,9 +45,12 @@ for name in ("prefix_small", "prefix_small_promised", "prefix_small_lane"):
     for l in open(f(name + ".log")):
         if l.startswith("{"):
             x = json.loads(l); print(f"  {x['shape']} tokens={x['tokens']}: {x['prefix_us']:.1f} us (dense {x.get('dense_us', float('nan')):.1f})")
-for name in ("prefix_dists.log", "sort_prefix_scaling.log"):
-    print("---", name); print(open(f(name)).read().rstrip())
-print("--- latency"); print("".join(l[:215] + "\n" for l in open(f("prefix_latency.log")) if "P=    30" in l or "P=   300" in l).rstrip())
+for name in ("prefix_dists.log", "crossovers.md", "packed_records.log"):
+    if os.path.exists(f(name)):
+        print("---", name); print(open(f(name)).read().rstrip())
+r = d["roofline"]
+print(f"traffic: {r['traffic']} B measured in this run: {r['traffic_measured_in_this_run']}, over algorithmic {r['traffic_over_algorithmic']}")
+print("c3_full:", json.dumps(d.get("c3_full"))[:400])
 rows = [json.loads(l) for l in open(f("rtn_ab.log")) if l.startswith("{")]
 for N in sorted({x["N"] for x in rows}):
     rr = [x for x in rows if x["N"] == N]
