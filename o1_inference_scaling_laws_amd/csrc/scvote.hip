@@ -154,7 +154,7 @@ struct scv_ctx {
     // the last fused request, kept so that a grid-barrier timeout can be repaired at scv_sync by a separate bootstrap launch
     struct BootLast { const scv_cell* cells = nullptr; int64_t P = 0; int32_t B = 0, r0 = 0, r1 = 0, M = 0; uint64_t seed = 0; int64_t* out = nullptr; bool valid = false; } boot_last;
     int64_t stat_boot_recovered = 0, stat_boot_cooperative = 0, stat_sort_cells = 0, stat_few_votes = 0, stat_prefix_pool = 0;
-    int64_t stat_prefix_sort = 0, stat_prefix_tokens = 0;
+    int64_t stat_prefix_sort = 0, stat_prefix_tokens = 0, stat_one_vote = 0;
     const int32_t* nv_host = nullptr;   // HOST-mode calls: the caller's n_valid (host memory) for the duration of the call -- launch_prefix reads the budgets
     // split-N scratch (grown on demand)
     void* d_partial = nullptr;
@@ -491,26 +491,40 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         return finish(ev);
     }
 
-    if (kind == LANE && (N == 1 || N == 2 || N == 4) && !pool_rows && ncells < (1ll << 29) && ncells % (256 / N) == 0 &&
+    if (kind == LANE && (N == 1 || N == 2 || N == 4) && !pool_rows && ncells < (1ll << 29) &&
         (((uintptr_t)answers & 15u) == 0) && (!tok || ((uintptr_t)tokens & 15u) == 0) && lane_kernel_lds(B, (int)N) <= (size_t)60 * 1024) {
         // ---- cells of exactly 1, 2 or 4 votes (the reference's most common sizes, o1.py:276,302): a block of 256 / 128 / 64 cells per wave and step
-        const int64_t nblocks = ncells / (256 / N);
+        const int64_t nblocks = ncells / (256 / N);                // whole blocks
         const int threads = 1024;
         const size_t lds = lane_kernel_lds(B, (int)N);
         int64_t grid = (nblocks + threads / 64 - 1) / (threads / 64);
+        if (grid < 1) grid = 1;
         const int64_t cap = (int64_t)ctx->num_cus * 2;             // two workgroups per CU: 32 waves, each with a block in flight behind the one it counts
         if (grid > cap) grid = cap;
         // cells per grid step a multiple of B: every cell slot of a lane then keeps its budget and its counters stay in registers
         if ((grid * (threads / 64) * 256) % B != 0 && grid > B) grid -= grid % B;
         if (ctx->grid_override > 0) grid = ctx->grid_override;
-        ctx->stat_few_votes += 1;
-        if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+        // N = 1 (o1.py:302, 276: the reference's most common call): a kernel whose loop body is one compare per cell (round 6), when the grid
+        // step is a multiple of B (it is, unless the launch is smaller than B workgroups or the grid is forced); it also takes the cells behind the
+        // last whole block (large launches only: a few hundred cells are the general kernel's)
+        const bool one = N == 1 && (grid * (threads / 64) * 256) % B == 0 && (size_t)B * 16 <= (size_t)60 * 1024 && (ncells % 256 == 0 || ncells >= 65536);
+        if (one || ncells % (256 / N) == 0) {
+            ctx->stat_few_votes += 1;
+            if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
+            if (one) {
+                const size_t lds1 = (size_t)B * 2 * sizeof(unsigned long long);
+                if (tok) hipLaunchKernelGGL((scv::scv_one_vote<true>), dim3((unsigned)grid), dim3(threads), lds1, ctx->stream, a);
+                else hipLaunchKernelGGL((scv::scv_one_vote<false>), dim3((unsigned)grid), dim3(threads), lds1, ctx->stream, a);
+                ctx->stat_one_vote += 1;
+            } else {
 #define SCV_FEW(NVV) do { if (tok) hipLaunchKernelGGL((scv::scv_few_votes<NVV, true>), dim3((unsigned)grid), dim3(threads), lds, ctx->stream, a); \
                           else hipLaunchKernelGGL((scv::scv_few_votes<NVV, false>), dim3((unsigned)grid), dim3(threads), lds, ctx->stream, a); } while (0)
-        if (N == 1) SCV_FEW(1); else if (N == 2) SCV_FEW(2); else SCV_FEW(4);
+                if (N == 1) SCV_FEW(1); else if (N == 2) SCV_FEW(2); else SCV_FEW(4);
 #undef SCV_FEW
-        SCV_HIP(hipGetLastError());
-        return finish(ev);
+            }
+            SCV_HIP(hipGetLastError());
+            return finish(ev);
+        }
     }
 
     if (kind == LANE) {
@@ -1690,6 +1704,7 @@ int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out) {
     else if (!strcmp(key, "prefix_pool")) *out = ctx->stat_prefix_pool;
     else if (!strcmp(key, "prefix_sort")) *out = ctx->stat_prefix_sort;
     else if (!strcmp(key, "prefix_tokens")) *out = ctx->stat_prefix_tokens;
+    else if (!strcmp(key, "one_vote")) *out = ctx->stat_one_vote;
         else if (!strcmp(key, "sort_cells")) *out = ctx->stat_sort_cells;
         else if (!strcmp(key, "few_votes")) *out = ctx->stat_few_votes;
         else if (!strcmp(key, "host_small_calls")) *out = ctx->stat_small_calls;

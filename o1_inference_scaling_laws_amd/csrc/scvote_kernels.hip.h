@@ -1374,6 +1374,146 @@ __global__ __launch_bounds__(1024) void scv_few_votes(const AggArgs a) {
     }
 }
 
+
+// ---- kernel 1f1: cells of exactly ONE vote -- the reference's most common call (round 6) -------------------------------------------
+//
+// o1.py:302 runs every ask-nicely budget with N = 1, o1.py:276 the first eight majority budgets: a cell IS its vote.  statistics.multimode([x]) = [x]:
+// max_count = 1, one mode, min_mode = x, truth_count = hit = (x == truth); an empty cell (n_valid = 0) has no mode.  scv_few_votes<1> serves such cells
+// with its general machinery -- 62 VALU + 47 SALU per cell in the ISA (tools: the main loop of scv_few_votes<1, false>): the launch is bound by its
+// instructions, not by HBM (counters only: 139 us for 1.02e8 cells = 2.9 TB/s).  Here the loop body of a cell is a clamp, one compare and one
+// add: hits with one mode and truth votes are the SAME number at N = 1, so one 32-bit accumulator per cell slot feeds both tie_hits[b][1] and
+// truth_sum[b].  A wave takes 256 consecutive cells per step; with 16-byte records lane l owns block + l, block + 64 + l ... (every store instruction
+// of the wave touches consecutive bytes), without them -- counters only, or the 4-byte records of SCV_FLAG_PACKED_CELLS -- lane l owns the four
+// consecutive cells block + 4 l ...: ONE 16-byte load, one 16-byte store of four packed records.  The last ncells % 256 cells (no whole block) are
+// taken one per lane by one wave, with guarded loads.  Host contract: N == 1, 16-byte aligned bases, ncells < 2^29, no pool rows, and
+// (grid * 16 * 256) % B == 0: a lane's cell slots keep their budgets for the whole launch.
+template <bool TOK>
+__global__ __launch_bounds__(1024) void scv_one_vote(const AggArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds);        // [B] hits = truth votes | [B] token sums
+    const int tid = threadIdx.x, T = (int)blockDim.x, lane = tid & 63;
+    const uint32_t B = (uint32_t)a.B;
+    const bool counters = a.tie_hits || a.truth_sum || (TOK && a.token_sum);
+    if (counters) {
+        for (int i = tid; i < 2 * (int)B; i += T) acc[i] = 0;
+        __syncthreads();
+    }
+    const bool consec = !a.cells || a.packed_cells;
+    const uint32_t nblocks = (uint32_t)(a.ncells >> 8);
+    const uint32_t nwaves = (uint32_t)gridDim.x * (uint32_t)(T >> 6);
+    uint32_t blk = (uint32_t)blockIdx.x * (uint32_t)(T >> 6) + (uint32_t)(tid >> 6);
+    const uint32_t dp = (nwaves * 256u) / B;                         // (the host rounds the grid: nwaves * 256 is a multiple of B)
+    uint32_t pj[4], nj[4], bj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t c = blk * 256u + (consec ? 4u * (uint32_t)lane + (uint32_t)j : 64u * (uint32_t)j + (uint32_t)lane);
+        pj[j] = c / B;
+        bj[j] = c - pj[j] * B;
+        nj[j] = valid_len(a, (int32_t)bj[j]) > 0 ? 0xffffffffu : 0u;              // all ones: the cell has its vote
+    }
+    uint32_t hits[4] = {0u, 0u, 0u, 0u};
+    long long toks[4] = {0ll, 0ll, 0ll, 0ll};
+    uint32_t bad = 0;
+    struct Step { uint32_t w[4]; int32_t tk[4]; int32_t truth[4]; };
+    auto load = [&](uint32_t bk, Step& o, uint32_t pstep) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.truth[j] = a.truth[pj[j] + pstep];
+        if (consec) {
+            const int4 q = stream_load(reinterpret_cast<const int4*>(a.answers) + ((uint64_t)bk * 64u + (uint32_t)lane));
+            o.w[0] = (uint32_t)q.x; o.w[1] = (uint32_t)q.y; o.w[2] = (uint32_t)q.z; o.w[3] = (uint32_t)q.w;
+            if (TOK) {
+                const int4 y = stream_load(reinterpret_cast<const int4*>(a.tokens) + ((uint64_t)bk * 64u + (uint32_t)lane));
+                o.tk[0] = y.x; o.tk[1] = y.y; o.tk[2] = y.z; o.tk[3] = y.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t c = (uint64_t)bk * 256u + 64u * (uint32_t)j + (uint32_t)lane;
+                o.w[j] = (uint32_t)__builtin_nontemporal_load(a.answers + c);
+                if (TOK) o.tk[j] = __builtin_nontemporal_load(a.tokens + c);
+            }
+        }
+    };
+    // the cells behind the last whole block: one per lane, by one wave, BEFORE its main loop (here few registers are live: behind the loop this
+    // code cost the votes-only kernel 4 VGPRs = its second workgroup per CU)
+    const uint32_t tail = (uint32_t)(a.ncells & 255);
+    if (tail && blk == nblocks % nwaves) {
+        for (uint32_t i = (uint32_t)lane; i < tail; i += 64u) {
+            const uint32_t c = (nblocks << 8) + i;                  // (ncells < 2^29: 32-bit arithmetic)
+            const uint32_t p = c / B, b = c - p * B;
+            const uint32_t have = valid_len(a, (int32_t)b) > 0 ? 0xffffffffu : 0u;
+            const uint32_t x = (uint32_t)a.answers[c];
+            bad |= x & have;
+            const uint32_t w = x < 1023u ? x : 1023u;
+            const uint32_t tc = ((uint32_t)a.truth[p] == w ? 1u : 0u) & have;
+            long long tv = 0;
+            if (TOK) tv = have ? (long long)a.tokens[c] : 0ll;
+            if (a.cells) {
+                if (a.packed_cells) reinterpret_cast<uint32_t*>(a.cells)[c] = have ? (1u | (tc << 7) | (1u << 14) | (w << 21) | (tc << 31)) : (0x3ffu << 21);
+                else reinterpret_cast<scv_v4u*>(a.cells)[c] = scv_v4u{have & 1u, tc, have ? (1u | (w << 16)) : 0xffff0000u, tc};
+            }
+            if (TOK && a.cell_tokens) a.cell_tokens[c] = tv;
+            if (counters) {
+                if (tc) atomicAdd(&acc[b], 1ull);
+                if (TOK && tv) atomicAdd(&acc[B + b], (unsigned long long)tv);
+            }
+        }
+    }
+    Step cur{}, nxt{};
+    if (blk < nblocks) load(blk, cur, 0u);
+    for (; blk < nblocks; blk += nwaves) {
+        if (blk + nwaves < nblocks) load(blk + nwaves, nxt, dp);     // one step ahead (its problems: this step's + dp)
+        uint32_t pk[4];
+        long long tv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t have = nj[j];
+            bad |= cur.w[j] & have;
+            const uint32_t w = cur.w[j] < 1023u ? cur.w[j] : 1023u;                // (an out-of-domain vote counts for bin 1023 and raises the error word)
+            const uint32_t tc = ((uint32_t)cur.truth[j] == w ? 1u : 0u) & have;    // o1.py:206 (a truth outside the bins equals no clamped vote ... except
+            hits[j] += tc;                                                         //  1023 itself, which IS bin 1023: the same rule as every kernel)
+            if (TOK) { tv[j] = have ? (long long)cur.tk[j] : 0ll; toks[j] += tv[j]; }
+            if (a.cells) {
+                if (a.packed_cells) pk[j] = have ? (1u | (tc << 7) | (1u << 14) | (w << 21) | (tc << 31)) : (0x3ffu << 21);
+                else {
+                    const uint64_t c = (uint64_t)blk * 256u + 64u * (uint32_t)j + (uint32_t)lane;
+                    __builtin_nontemporal_store(scv_v4u{have & 1u, tc, have ? (1u | (w << 16)) : 0xffff0000u, tc}, reinterpret_cast<scv_v4u*>(a.cells) + c);
+                }
+            }
+            pj[j] += dp;
+        }
+        if (a.cells && a.packed_cells)
+            __builtin_nontemporal_store(scv_v4u{pk[0], pk[1], pk[2], pk[3]}, reinterpret_cast<scv_v4u*>(reinterpret_cast<uint32_t*>(a.cells) + (uint64_t)blk * 256u) + (uint32_t)lane);
+        if (TOK && a.cell_tokens) {
+            if (consec) {
+                scv_v4u* const out = reinterpret_cast<scv_v4u*>(a.cell_tokens + (uint64_t)blk * 256u + 4u * (uint32_t)lane);
+                out[0] = scv_v4u{(uint32_t)tv[0], (uint32_t)((unsigned long long)tv[0] >> 32), (uint32_t)tv[1], (uint32_t)((unsigned long long)tv[1] >> 32)};
+                out[1] = scv_v4u{(uint32_t)tv[2], (uint32_t)((unsigned long long)tv[2] >> 32), (uint32_t)tv[3], (uint32_t)((unsigned long long)tv[3] >> 32)};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a.cell_tokens[(uint64_t)blk * 256u + 64u * (uint32_t)j + (uint32_t)lane] = tv[j];
+            }
+        }
+        cur = nxt;
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+    if (counters) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (hits[j]) atomicAdd(&acc[bj[j]], (unsigned long long)hits[j]);
+            if (TOK && toks[j]) atomicAdd(&acc[B + bj[j]], (unsigned long long)toks[j]);
+        }
+        __syncthreads();
+        for (int i = tid; i < (int)B; i += T) {
+            if (acc[i]) {
+                if (a.tie_hits) atomicAdd(&a.tie_hits[(int64_t)i * SCV_TIE_CLASSES + 1], acc[i]);
+                if (a.truth_sum) atomicAdd(&a.truth_sum[i], acc[i]);
+            }
+            if (TOK && a.token_sum && acc[B + i]) atomicAdd(&a.token_sum[i], acc[B + i]);
+        }
+    }
+}
+
 // Per-workgroup accumulation of the per-budget counters (o1.py:238-240 as integers) for the register-resident
 // kernels: [B][TCL] tie-class hits (u32) and [B] truth-vote | [B] token sums (u64) live behind the waves' private
 // regions; one lane per cell adds to them with LDS atomics and the workgroup flushes the non-zero words with one

@@ -603,8 +603,8 @@ def test_cells_of_exactly_1_2_4_votes(hip_engine, dist, shape):
             want = oracle(a2, tr2, tokens=t)
             assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum)
             assert np.array_equal(got.truth_count_sum, want.truth_count_sum)
-    if (P * B * N) % 256 == 0:
-        assert hip_engine.stat("few_votes") > before
+    if (P * B * N) % 256 == 0 or (N == 1 and P * B >= 65536):
+        assert hip_engine.stat("few_votes") > before                   # (round 6: scv_one_vote also takes the cells behind the last whole block of a large launch)
     else:
         assert hip_engine.stat("few_votes") == before                  # not whole blocks of 64 lanes x 16 bytes: the general one-lane-per-cell kernel
     bad = a.copy()
@@ -1336,10 +1336,12 @@ def test_hot_path_is_hipgraph_capturable():
             assert rc == 0 and np.array_equal(boot.cpu().numpy(), wb)
 
 
-@pytest.mark.parametrize("P,B,N", [(300, 4, 1024), (500, 3, 200), (90, 2, 4096), (700, 4, 16)])
+@pytest.mark.parametrize("P,B,N", [(300, 4, 1024), (500, 3, 200), (90, 2, 4096), (700, 4, 16), (900, 3, 96), (700, 2, 128), (4096, 8, 1), (9001, 8, 1), (3, 2, 1 << 20)])
 def test_cell_kernels_are_hipgraph_capturable(P, B, N):
     """The register-resident kernels (counters accumulated in the launch) and the one-lane-per-cell kernel replay from a
-    hipGraph: their host side queries occupancy and sets function attributes, but enqueues nothing but the launch."""
+    hipGraph: their host side queries occupancy and sets function attributes, but enqueues nothing but the launch.  Round 6: the 8-lane
+    shapes, scv_one_vote (whole blocks and a ragged tail) and split-N merged inside the launch (its scratch is all-zero between launches, so a
+    replay needs no memset node of the library's own)."""
     import torch
     from o1_inference_scaling_laws_amd.engine import Engine
     dev = torch.device("cuda:0")
@@ -1367,6 +1369,46 @@ def test_cell_kernels_are_hipgraph_capturable(P, B, N):
             a, _, trc = coracle.synth_fill(P, B, N, seed, 1)
             got = AggregateResult.from_counters(counters.cpu().numpy(), P, B, cells_from_torch(cells))
             assert_results_equal(got, oracle(a, trc), check_tokens=False)
+
+
+def test_prefix_sort_and_token_kernels_are_hipgraph_capturable():
+    """The reference's largest pool with tokens (o1.py:266-276, 195): scv_sort_prefix2 + scv_prefix_tokens, the budgets promised from a host list,
+    captured once and replayed on new pools and tokens."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine
+    dev = torch.device("cuda:0")
+    P, N = 5000, 128
+    nvl = [1, 2, 4, 8, 16, 32, 64, 128]
+    with Engine(device=0) as eng:
+        pool = torch.empty((P, 1, N), dtype=torch.int32, device=dev)
+        tpool = torch.empty((P, 1, N), dtype=torch.int32, device=dev)
+        tr = torch.empty((P,), dtype=torch.int32, device=dev)
+        nv = torch.tensor(nvl, dtype=torch.int32, device=dev)
+        counters = torch.zeros(counters_size(len(nvl)), dtype=torch.int64, device=dev)
+        cells = torch.empty((P, len(nvl), 16), dtype=torch.uint8, device=dev)
+        ctok = torch.empty((P, len(nvl)), dtype=torch.int64, device=dev)
+        eng.synth_fill_device(pool, tpool, tr, P=P, B=1, N=N, seed=1, dist=1)
+        side = torch.cuda.Stream()
+        eng.set_option("prefix_path", 5)
+        with torch.cuda.stream(side):
+            counters.zero_()
+            eng.aggregate_prefix_device(pool.view(P, N), tr, nv, tokens=tpool.view(P, N), counters=counters, cells=cells, cell_tokens=ctok)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            counters.zero_()
+            eng.aggregate_prefix_device(pool.view(P, N), tr, nv, tokens=tpool.view(P, N), counters=counters, cells=cells, cell_tokens=ctok)
+        assert eng.stat("prefix_sort") == 2 and eng.stat("prefix_tokens") == 2 and eng.stat("prefix_pool") == 0
+        for seed in (9, 10):
+            eng.use_torch_stream()
+            eng.synth_fill_device(pool, tpool, tr, P=P, B=1, N=N, seed=seed, dist=3)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            a, t, trc = coracle.synth_fill(P, 1, N, seed, 3, want_tokens=True)
+            want = OracleEngine().aggregate_prefix(a[:, 0, :], trc, np.array(nvl, dtype=np.int32), tokens=t[:, 0, :])
+            got = AggregateResult.from_counters(counters.cpu().numpy(), P, len(nvl), cells_from_torch(cells), ctok.cpu().numpy())
+            assert_results_equal(got, want)
 
 
 def test_prefix_lane_kernel_is_hipgraph_capturable():
@@ -2112,3 +2154,64 @@ def test_packed_cell_records_refuse_what_they_do_not_cover():
         _, cells, _ = eng.aggregate_device(da[:, :, :64].contiguous(), dtr)      # (the ctx is still good)
         eng.sync()
         assert np.array_equal(cells_from_torch(cells)["max_count"], coracle.aggregate(a[:, :, :64], tr)["cells"]["max_count"])
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 5])
+@pytest.mark.parametrize("shape", [(4096, 8, 1), (8192, 3, 1), (30 * 256, 19, 1), (65536, 1, 1), (3 * 4096, 11, 1), (512, 1024, 1),
+                                   (4099, 19, 1), (65537, 1, 1), (21846, 3, 1), (9001, 8, 1)], ids=lambda s: "x".join(map(str, s)))   # (the last four: cells behind the last whole block of 256)
+def test_cells_of_one_vote_have_a_kernel_of_their_own(hip_engine, dist, shape):
+    """Round 6: N = 1 is the reference's most common call (o1.py:302: every ask-nicely budget; o1.py:276: the first eight majority budgets) and
+    multimode([x]) = [x]: scv_one_vote's loop body is a clamp and one compare per cell.  Against the oracle with 16-byte records, packed records and
+    counters only; tokens; budgets with no votes (empty cells); truths outside the bins and at bin 1023; out-of-domain and negative votes (bin 1023 +
+    the error word); DEVICE and HOST memory; and the same cells through scv_few_votes<1> (a grid that is not a multiple of B)."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine
+    P, B, N = shape
+    dev = torch.device("cuda:0")
+    a, t, tr = coracle.synth_fill(P, B, N, 9000 + B, dist, want_tokens=True)
+    tr[::7] = 1023
+    a[::7, ::2, 0] = 1023
+    tr[3::11] = 2000                                                # a truth no vote can equal
+    nv = np.array([(0 if b % 4 == 1 else 1 + b % 3) for b in range(B)], dtype=np.int32)
+    da, dt, dtr, dnv = (torch.from_numpy(x).to(dev) for x in (a, t, tr, nv))
+    before = hip_engine.stat("one_vote")
+    for (tok, nvx) in ((None, None), (dt, dnv), (None, dnv), (dt, None)):
+        want = coracle.aggregate(a, tr, tokens=None if tok is None else t, n_valid=None if nvx is None else nv)
+        c, cells, ctok = hip_engine.aggregate_device(da, dtr, tokens=tok, n_valid=nvx)
+        hip_engine.sync()
+        got = AggregateResult.from_counters(c.cpu().numpy(), P, B, cells_from_torch(cells), None if tok is None else ctok.cpu().numpy())
+        for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+            assert np.array_equal(got.cells[f], want["cells"][f]), f
+        assert np.array_equal(got.tie_class_hits, want["tie_class_hits"]) and np.array_equal(got.truth_count_sum, want["truth_count_sum"])
+        if tok is not None:
+            assert np.array_equal(got.token_sum, want["token_sum"]) and np.array_equal(got.cell_tokens, want["cell_tokens"])
+        c2, none, _ = hip_engine.aggregate_device(da, dtr, tokens=tok, n_valid=nvx, cells=False)            # counters only: consecutive cells per lane
+        hip_engine.sync()
+        assert none is None and torch.equal(c2, c)
+    assert hip_engine.stat("one_vote") == before + 8
+    with Engine(packed_cells=True) as packed:
+        c3, cells3, ctok3 = packed.aggregate_device(da, dtr, tokens=dt, n_valid=dnv)
+        packed.sync()
+        want = coracle.aggregate(a, tr, tokens=t, n_valid=nv)
+        got = cells_from_torch(cells3)
+        for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+            assert np.array_equal(got[f], want["cells"][f]), ("packed", f)
+        assert np.array_equal(ctok3.cpu().numpy(), want["cell_tokens"]) and packed.stat("one_vote") == 1
+    # HOST memory (the pipeline's chunks / the small path), and the general kernel on the same cells
+    assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+    if B not in (1, 2, 4, 8, 16, 1024):
+        with _with_options(hip_engine, {"grid": 1}):                 # 1 x 4096 cells per step is not a multiple of B: scv_few_votes<1>
+            before = hip_engine.stat("one_vote")
+            assert_results_equal(hip_engine.aggregate(a, tr, tokens=t, n_valid=nv), oracle(a, tr, tokens=t, n_valid=nv))
+            assert hip_engine.stat("one_vote") == before
+    bad = a.copy()
+    bad[P // 2, B - 1, 0] = 5000
+    bad[P - 1, 0, 0] = -4
+    with pytest.raises(_lib.DomainError):
+        hip_engine.aggregate(bad, tr)
+    with Engine(clamp_to_invalid_bin=True) as clamp:
+        got = clamp.aggregate(bad, tr)
+        want = coracle.aggregate(bad, tr, clamp=True)
+        assert want["rc"] == 0
+        for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+            assert np.array_equal(got.cells[f], want["cells"][f]), ("clamp", f)
