@@ -347,7 +347,7 @@ int scv_host_free(void* p);
  * (scv_aggregate_bootstrap_i32: one launch / two), "boot_cooperative" (one-launch forms started as cooperative launches),
  * "boot_recovered" (grid-barrier timeouts repaired by scv_sync with a separate bootstrap launch), "overwrite_fused" (counters
  * overwritten by the vote kernel's last workgroup), "lds_counters" (register-resident launches that produced their counters
- * themselves), "sort_cells" (sorted-cells launches), "few_votes" (launches of the kernels for cells of exactly 1, 2 or 4 votes), "one_vote" (those of them served by scv_one_vote: N = 1), "prefix_cells" / "prefix_lane" / "prefix_pool" (prefix calls served by the cell kernels / by
+ * themselves), "sort_cells" (sorted-cells launches), "few_votes" (launches of the kernels for cells of exactly 1, 2 or 4 votes), "one_vote" (those of them served by scv_one_vote / scv_two_votes: N = 1, 2), "prefix_cells" / "prefix_lane" / "prefix_pool" (prefix calls served by the cell kernels / by
  * the one-lane-per-problem kernel / by the one-pass-per-problem kernel), "prefix_sort" (launches of scv_sort_prefix: every power-of-two budget out of one
  * sort per problem -- queued, that is: a DEVICE-mode launch may find budgets it does not serve and leave them to the kernel behind it), "prefix_tokens" (launches of
  * scv_prefix_tokens: the token sums of pools of 68 .. 128 votes, queued behind scv_sort_prefix2), "host_small_calls" / "host_pipelined_calls" (HOST-mode calls served by the one-block small path / by

@@ -502,19 +502,25 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         const int64_t cap = (int64_t)ctx->num_cus * 2;             // two workgroups per CU: 32 waves, each with a block in flight behind the one it counts
         if (grid > cap) grid = cap;
         // cells per grid step a multiple of B: every cell slot of a lane then keeps its budget and its counters stay in registers
-        if ((grid * (threads / 64) * 256) % B != 0 && grid > B) grid -= grid % B;
+        if ((grid * (threads / 64) * (256 / N)) % B != 0 && grid > B) grid -= grid % B;
         if (ctx->grid_override > 0) grid = ctx->grid_override;
         // N = 1 (o1.py:302, 276: the reference's most common call): a kernel whose loop body is one compare per cell (round 6), when the grid
         // step is a multiple of B (it is, unless the launch is smaller than B workgroups or the grid is forced); it also takes the cells behind the
         // last whole block (large launches only: a few hundred cells are the general kernel's)
-        const bool one = N == 1 && (grid * (threads / 64) * 256) % B == 0 && (size_t)B * 16 <= (size_t)60 * 1024 && (ncells % 256 == 0 || ncells >= 65536);
+        // (N = 2, o1.py:276 at T = 4096: scv_two_votes, the same idea with blocks of 128 cells)
+        const bool one = N <= 2 && (grid * (threads / 64) * (256 / N)) % B == 0 && (size_t)B * 32 <= (size_t)60 * 1024 && (ncells % (256 / N) == 0 || ncells >= 65536);
         if (one || ncells % (256 / N) == 0) {
             ctx->stat_few_votes += 1;
             if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
-            if (one) {
+            if (one && N == 1) {
                 const size_t lds1 = (size_t)B * 2 * sizeof(unsigned long long);
                 if (tok) hipLaunchKernelGGL((scv::scv_one_vote<true>), dim3((unsigned)grid), dim3(threads), lds1, ctx->stream, a);
                 else hipLaunchKernelGGL((scv::scv_one_vote<false>), dim3((unsigned)grid), dim3(threads), lds1, ctx->stream, a);
+                ctx->stat_one_vote += 1;
+            } else if (one) {
+                const size_t lds2 = (size_t)B * 4 * sizeof(unsigned long long);
+                if (tok) hipLaunchKernelGGL((scv::scv_two_votes<true>), dim3((unsigned)grid), dim3(threads), lds2, ctx->stream, a);
+                else hipLaunchKernelGGL((scv::scv_two_votes<false>), dim3((unsigned)grid), dim3(threads), lds2, ctx->stream, a);
                 ctx->stat_one_vote += 1;
             } else {
 #define SCV_FEW(NVV) do { if (tok) hipLaunchKernelGGL((scv::scv_few_votes<NVV, true>), dim3((unsigned)grid), dim3(threads), lds, ctx->stream, a); \

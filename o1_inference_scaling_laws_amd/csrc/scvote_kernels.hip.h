@@ -1514,6 +1514,157 @@ __global__ __launch_bounds__(1024) void scv_one_vote(const AggArgs a) {
     }
 }
 
+// ---- kernel 1f2: cells of exactly TWO votes (o1.py:276: the budget T = 4096) -- the same idea as scv_one_vote ---------------------------------
+//
+// multimode([x, y]) is [x] when x == y and [x, y] otherwise: max_count = 1 + (x == y), modes = 2 - (x == y), min_mode = min(x, y),
+// truth_count = (x == t) + (y == t), hit = (truth_count == max_count) -- a budget that sees only the first vote (n_valid = 1) is the one-vote case on x.
+// Two 32-bit accumulators per cell slot (hits with one mode, hits with two) + the truth votes.  A wave takes 128 consecutive cells per step: with
+// 16-byte records lane l owns block + l and block + 64 + l (two 8-byte loads), without them the two consecutive cells block + 2 l, + 1 (one
+// 16-byte load, one 8-byte store of two packed records).  Host contract as scv_one_vote's with blocks of 128 cells.
+template <bool TOK>
+__global__ __launch_bounds__(1024) void scv_two_votes(const AggArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds);        // [B] hits, one mode | [B] hits, two modes | [B] truth votes | [B] token sums
+    const int tid = threadIdx.x, T = (int)blockDim.x, lane = tid & 63;
+    const uint32_t B = (uint32_t)a.B;
+    const bool counters = a.tie_hits || a.truth_sum || (TOK && a.token_sum);
+    if (counters) {
+        for (int i = tid; i < 4 * (int)B; i += T) acc[i] = 0;
+        __syncthreads();
+    }
+    const bool consec = !a.cells || a.packed_cells;
+    const uint32_t nblocks = (uint32_t)(a.ncells >> 7);
+    const uint32_t nwaves = (uint32_t)gridDim.x * (uint32_t)(T >> 6);
+    uint32_t blk = (uint32_t)blockIdx.x * (uint32_t)(T >> 6) + (uint32_t)(tid >> 6);
+    const uint32_t dp = (nwaves * 128u) / B;                         // (the host rounds the grid: nwaves * 128 is a multiple of B)
+    uint32_t pj[2], bj[2], m0[2], m1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t c = blk * 128u + (consec ? 2u * (uint32_t)lane + (uint32_t)j : 64u * (uint32_t)j + (uint32_t)lane);
+        pj[j] = c / B;
+        bj[j] = c - pj[j] * B;
+        const int64_t n = valid_len(a, (int32_t)bj[j]);
+        m0[j] = n >= 1 ? 0xffffffffu : 0u;
+        m1[j] = n >= 2 ? 0xffffffffu : 0u;
+    }
+    uint32_t h1[2] = {0u, 0u}, h2[2] = {0u, 0u}, tcs[2] = {0u, 0u};
+    long long toks[2] = {0ll, 0ll};
+    uint32_t bad = 0;
+    // one cell: everything the record and the counters need
+    struct Out { uint32_t maxc, tc, n_modes, mm, hit; };
+    auto count = [&](uint32_t x0, uint32_t x1, uint32_t t, uint32_t k0, uint32_t k1) -> Out {
+        bad |= (x0 & k0) | (x1 & k1);
+        const uint32_t w0 = x0 < 1023u ? x0 : 1023u, w1 = x1 < 1023u ? x1 : 1023u;
+        const uint32_t eq = (w0 == w1 ? 1u : 0u) & k1;
+        Out o;
+        o.maxc = (1u + eq) & k0;
+        o.n_modes = ((k1 & 1u) + 1u - eq) & k0;
+        o.mm = (k1 && w1 < w0) ? w1 : w0;
+        o.tc = ((t == w0 ? 1u : 0u) & k0) + ((t == w1 ? 1u : 0u) & k1);
+        o.hit = (o.tc == o.maxc ? 1u : 0u) & k0;
+        return o;
+    };
+    // the cells behind the last whole block: one per lane, by one wave, before its main loop (few registers are live here)
+    const uint32_t tail = (uint32_t)(a.ncells & 127);
+    if (tail && blk == nblocks % nwaves) {
+        for (uint32_t i = (uint32_t)lane; i < tail; i += 64u) {
+            const uint32_t c = (nblocks << 7) + i;
+            const uint32_t p = c / B, b = c - p * B;
+            const int64_t n = valid_len(a, (int32_t)b);
+            const uint32_t k0 = n >= 1 ? 0xffffffffu : 0u, k1 = n >= 2 ? 0xffffffffu : 0u;
+            const Out o = count((uint32_t)a.answers[2u * (uint64_t)c], (uint32_t)a.answers[2u * (uint64_t)c + 1u], (uint32_t)a.truth[p], k0, k1);
+            long long tv = 0;
+            if (TOK) tv = (k0 ? (long long)a.tokens[2u * (uint64_t)c] : 0ll) + (k1 ? (long long)a.tokens[2u * (uint64_t)c + 1u] : 0ll);
+            if (a.cells) {
+                if (a.packed_cells) reinterpret_cast<uint32_t*>(a.cells)[c] = pack_cell(o.maxc, o.tc, o.n_modes, o.mm, o.hit);
+                else reinterpret_cast<scv_v4u*>(a.cells)[c] = scv_v4u{o.maxc, o.tc, o.n_modes | ((k0 ? o.mm : 0xffffu) << 16), o.hit};
+            }
+            if (TOK && a.cell_tokens) a.cell_tokens[c] = tv;
+            if (counters) {
+                if (o.hit) atomicAdd(&acc[(o.n_modes == 2u ? B : 0u) + b], 1ull);
+                if (o.tc) atomicAdd(&acc[2 * B + b], (unsigned long long)o.tc);
+                if (TOK && tv) atomicAdd(&acc[3 * B + b], (unsigned long long)tv);
+            }
+        }
+    }
+    struct Step { uint32_t w[2][2]; int32_t tk[2][2]; int32_t truth[2]; };
+    typedef int v2i32 __attribute__((ext_vector_type(2)));
+    auto load = [&](uint32_t bk, Step& o, uint32_t pstep) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o.truth[j] = a.truth[pj[j] + pstep];
+        if (consec) {
+            const int4 q = stream_load(reinterpret_cast<const int4*>(a.answers) + ((uint64_t)bk * 64u + (uint32_t)lane));
+            o.w[0][0] = (uint32_t)q.x; o.w[0][1] = (uint32_t)q.y; o.w[1][0] = (uint32_t)q.z; o.w[1][1] = (uint32_t)q.w;
+            if (TOK) {
+                const int4 y = stream_load(reinterpret_cast<const int4*>(a.tokens) + ((uint64_t)bk * 64u + (uint32_t)lane));
+                o.tk[0][0] = y.x; o.tk[0][1] = y.y; o.tk[1][0] = y.z; o.tk[1][1] = y.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint64_t c = (uint64_t)bk * 128u + 64u * (uint32_t)j + (uint32_t)lane;
+                const v2i32 q = __builtin_nontemporal_load(reinterpret_cast<const v2i32*>(a.answers) + c);
+                o.w[j][0] = (uint32_t)q.x; o.w[j][1] = (uint32_t)q.y;
+                if (TOK) { const v2i32 y = __builtin_nontemporal_load(reinterpret_cast<const v2i32*>(a.tokens) + c); o.tk[j][0] = y.x; o.tk[j][1] = y.y; }
+            }
+        }
+    };
+    Step cur{}, nxt{};
+    if (blk < nblocks) load(blk, cur, 0u);
+    for (; blk < nblocks; blk += nwaves) {
+        if (blk + nwaves < nblocks) load(blk + nwaves, nxt, dp);     // one step ahead
+        uint32_t pk[2];
+        long long tv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const Out o = count(cur.w[j][0], cur.w[j][1], (uint32_t)cur.truth[j], m0[j], m1[j]);
+            h1[j] += o.hit & (o.n_modes == 1u ? 1u : 0u);
+            h2[j] += o.hit & (o.n_modes == 2u ? 1u : 0u);
+            tcs[j] += o.tc;
+            if (TOK) { tv[j] = (m0[j] ? (long long)cur.tk[j][0] : 0ll) + (m1[j] ? (long long)cur.tk[j][1] : 0ll); toks[j] += tv[j]; }
+            if (a.cells) {
+                if (a.packed_cells) pk[j] = pack_cell(o.maxc, o.tc, o.n_modes, o.mm, o.hit);
+                else {
+                    const uint64_t c = (uint64_t)blk * 128u + 64u * (uint32_t)j + (uint32_t)lane;
+                    __builtin_nontemporal_store(scv_v4u{o.maxc, o.tc, o.n_modes | ((m0[j] ? o.mm : 0xffffu) << 16), o.hit}, reinterpret_cast<scv_v4u*>(a.cells) + c);
+                }
+            }
+            pj[j] += dp;
+        }
+        if (a.cells && a.packed_cells)
+            __builtin_nontemporal_store(scv_v2u{pk[0], pk[1]}, reinterpret_cast<scv_v2u*>(reinterpret_cast<uint32_t*>(a.cells) + (uint64_t)blk * 128u) + (uint32_t)lane);
+        if (TOK && a.cell_tokens) {
+            if (consec) {
+                scv_v4u* const out = reinterpret_cast<scv_v4u*>(a.cell_tokens + (uint64_t)blk * 128u + 2u * (uint32_t)lane);
+                out[0] = scv_v4u{(uint32_t)tv[0], (uint32_t)((unsigned long long)tv[0] >> 32), (uint32_t)tv[1], (uint32_t)((unsigned long long)tv[1] >> 32)};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) a.cell_tokens[(uint64_t)blk * 128u + 64u * (uint32_t)j + (uint32_t)lane] = tv[j];
+            }
+        }
+        cur = nxt;
+    }
+    if (bad > 1023u) atomicOr(a.err_flag, 1u);
+    if (counters) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (h1[j]) atomicAdd(&acc[bj[j]], (unsigned long long)h1[j]);
+            if (h2[j]) atomicAdd(&acc[B + bj[j]], (unsigned long long)h2[j]);
+            if (tcs[j]) atomicAdd(&acc[2 * B + bj[j]], (unsigned long long)tcs[j]);
+            if (TOK && toks[j]) atomicAdd(&acc[3 * B + bj[j]], (unsigned long long)toks[j]);
+        }
+        __syncthreads();
+        for (int i = tid; i < (int)B; i += T) {
+            if (a.tie_hits) {
+                if (acc[i]) atomicAdd(&a.tie_hits[(int64_t)i * SCV_TIE_CLASSES + 1], acc[i]);
+                if (acc[B + i]) atomicAdd(&a.tie_hits[(int64_t)i * SCV_TIE_CLASSES + 2], acc[B + i]);
+            }
+            if (a.truth_sum && acc[2 * B + i]) atomicAdd(&a.truth_sum[i], acc[2 * B + i]);
+            if (TOK && a.token_sum && acc[3 * B + i]) atomicAdd(&a.token_sum[i], acc[3 * B + i]);
+        }
+    }
+}
+
 // Per-workgroup accumulation of the per-budget counters (o1.py:238-240 as integers) for the register-resident
 // kernels: [B][TCL] tie-class hits (u32) and [B] truth-vote | [B] token sums (u64) live behind the waves' private
 // regions; one lane per cell adds to them with LDS atomics and the workgroup flushes the non-zero words with one

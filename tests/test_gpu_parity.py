@@ -603,7 +603,7 @@ def test_cells_of_exactly_1_2_4_votes(hip_engine, dist, shape):
             want = oracle(a2, tr2, tokens=t)
             assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum)
             assert np.array_equal(got.truth_count_sum, want.truth_count_sum)
-    if (P * B * N) % 256 == 0 or (N == 1 and P * B >= 65536):
+    if (P * B * N) % 256 == 0 or (N <= 2 and P * B >= 65536):
         assert hip_engine.stat("few_votes") > before                   # (round 6: scv_one_vote also takes the cells behind the last whole block of a large launch)
     else:
         assert hip_engine.stat("few_votes") == before                  # not whole blocks of 64 lanes x 16 bytes: the general one-lane-per-cell kernel
@@ -2215,3 +2215,58 @@ def test_cells_of_one_vote_have_a_kernel_of_their_own(hip_engine, dist, shape):
         assert want["rc"] == 0
         for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
             assert np.array_equal(got.cells[f], want["cells"][f]), ("clamp", f)
+
+
+@pytest.mark.parametrize("dist", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("shape", [(4096, 8, 2), (8192, 3, 2), (15 * 256, 19, 2), (32768, 1, 2), (3 * 2048, 11, 2), (256, 1024, 2),
+                                   (4099, 19, 2), (65537, 1, 2), (21846, 3, 2), (9001, 8, 2)], ids=lambda s: "x".join(map(str, s)))
+def test_cells_of_two_votes_have_a_kernel_of_their_own(hip_engine, dist, shape):
+    """scv_two_votes (o1.py:276 at T = 4096): multimode([x, y]) in five instructions.  Equal and unequal pairs (votes folded into three bins), budgets
+    that see none / only the first / both votes, tokens, truths outside the bins, the three record forms, cells behind the last whole block of 128,
+    out-of-domain votes in either slot, and the same cells on scv_few_votes<2> (a grid that is not a multiple of B)."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine
+    P, B, N = shape
+    dev = torch.device("cuda:0")
+    a, t, tr = coracle.synth_fill(P, B, N, 9500 + B, dist, want_tokens=True)
+    a2 = (a % 3).astype(np.int32)
+    tr2 = (tr % 4).astype(np.int32)
+    tr2[::7] = 1023
+    a2[::7, ::2, 1] = 1023
+    tr2[3::11] = -9
+    nv = np.array([b % 4 for b in range(B)], dtype=np.int32)       # 0, 1, 2, 3 (-> 2) votes
+    before = hip_engine.stat("one_vote")
+    for (x, xt) in ((a, tr), (a2, tr2)):
+        dx, dt, dtr, dnv = (torch.from_numpy(v).to(dev) for v in (x, t, xt, nv))
+        for (tok, nvx) in ((None, None), (dt, dnv), (None, dnv)):
+            want = coracle.aggregate(x, xt, tokens=None if tok is None else t, n_valid=None if nvx is None else nv)
+            c, cells, ctok = hip_engine.aggregate_device(dx, dtr, tokens=tok, n_valid=nvx)
+            hip_engine.sync()
+            got = AggregateResult.from_counters(c.cpu().numpy(), P, B, cells_from_torch(cells), None if tok is None else ctok.cpu().numpy())
+            for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+                assert np.array_equal(got.cells[f], want["cells"][f]), f
+            assert np.array_equal(got.tie_class_hits, want["tie_class_hits"]) and np.array_equal(got.truth_count_sum, want["truth_count_sum"])
+            if tok is not None:
+                assert np.array_equal(got.token_sum, want["token_sum"]) and np.array_equal(got.cell_tokens, want["cell_tokens"])
+            c2, none, _ = hip_engine.aggregate_device(dx, dtr, tokens=tok, n_valid=nvx, cells=False)
+            hip_engine.sync()
+            assert none is None and torch.equal(c2, c)
+    assert hip_engine.stat("one_vote") == before + 12
+    with Engine(packed_cells=True) as packed:
+        dx, dt, dtr, dnv = (torch.from_numpy(v).to(dev) for v in (a2, t, tr2, nv))
+        _, cells3, ctok3 = packed.aggregate_device(dx, dtr, tokens=dt, n_valid=dnv)
+        packed.sync()
+        want = coracle.aggregate(a2, tr2, tokens=t, n_valid=nv)
+        got = cells_from_torch(cells3)
+        for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+            assert np.array_equal(got[f], want["cells"][f]), ("packed", f)
+        assert np.array_equal(ctok3.cpu().numpy(), want["cell_tokens"]) and packed.stat("one_vote") == 1
+    assert_results_equal(hip_engine.aggregate(a2, tr2, tokens=t, n_valid=nv), oracle(a2, tr2, tokens=t, n_valid=nv))
+    bad = a.copy()
+    bad[P // 2, B - 1, 1] = 5000
+    with pytest.raises(_lib.DomainError):
+        hip_engine.aggregate(bad, tr)
+    hip_engine.aggregate(bad, tr, n_valid=np.ones(B, dtype=np.int32))             # the second vote is beyond every budget: not an error
+    bad[P - 1, 0, 0] = -4
+    with pytest.raises(_lib.DomainError):
+        hip_engine.aggregate(bad, tr, n_valid=np.ones(B, dtype=np.int32))

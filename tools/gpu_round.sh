@@ -44,7 +44,7 @@ for f in ('bench_comm_peer_2ctx', 'bench_comm_rccl_1gpu'):
     print(f, 'kernel ms per rank min/max', round(r['kernel_avg_ms_per_rank_min'], 3), round(r['kernel_avg_ms_per_rank_max'], 3), 'exposed all-reduce us', r['exposed_allreduce_us'], 'selftest words', d['config']['comm_selftest_words_per_rank'], 'create s', round(d['config']['comm_create_s'], 3))"
 echo "== regimes"; timeout 1200 python tools/regimes.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/regimes.log | tail -8
 echo "== PMC per regime (sorted cells 48 / 64, register-resident 96 / 128 / 256 / 1024, dense 2048 / 8192, lane 3, few votes 1 / 4)"
-SHAPES="6400000:4:1 1600000:4:4 1000000:4:3 400000:4:48 400000:4:64 300000:4:72 200000:4:96 200000:4:128 100000:4:256 50000:4:1024 40000:4:2048 10000:4:8192" timeout 1500 bash tools/prof_regimes.sh r06 > gpurun_out/prof_regimes_r06.log 2>&1; tail -3 gpurun_out/prof_regimes_r06.log
+SHAPES="6400000:4:1 3200000:4:2 1600000:4:4 1000000:4:3 400000:4:48 400000:4:64 300000:4:72 200000:4:96 200000:4:128 100000:4:256 50000:4:1024 40000:4:2048 10000:4:8192" timeout 1500 bash tools/prof_regimes.sh r06 > gpurun_out/prof_regimes_r06.log 2>&1; tail -3 gpurun_out/prof_regimes_r06.log
 echo "== PMC of the prefix-budget kernels (budgets 1, 2, 4 ... N over one pool: scv_sort_prefix 32 / 64, scv_prefix_pool 256 / 1024 / 4096)"
 MODE=prefix SHAPES="200000:1:32 200000:1:64 200000:1:128 100000:1:256 50000:1:1024 20000:1:4096" timeout 900 bash tools/prof_regimes.sh r06_prefix > gpurun_out/prof_regimes_r06_prefix.log 2>&1; tail -3 gpurun_out/prof_regimes_r06_prefix.log
 echo "== prefix budgets over short pools (auto: DEVICE mode queues scv_sort_prefix and the general kernel for pools of 17 .. 64 votes)"; timeout 600 python tools/prefix_small.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/prefix_small.log | cut -c1-140 | tail -14
@@ -54,9 +54,9 @@ echo "== prefix pools over the distributions D0 .. D5"; timeout 600 bash tools/p
 echo "== ranks from returning atomics against the register-resident cell kernels (dense cells of 96 .. 1024 votes, D0 .. D5)"; timeout 900 python tools/rtn_ab.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/rtn_ab.log | cut -c1-200 | tail -6
 echo "== dispatch thresholds re-checked on this box"; timeout 1500 python tools/crossovers.py 2>&1 | grep -v amdgpu.ids | tail -40
 echo "== packed 4-byte records against 16-byte records against counters only (N = 1, 2, 4, 8)"
-for s in "12800000 8 1" "12800000 4 2" "6400000 4 4" "3200000 4 8"; do set -- $s; for m in "" "--packed" "--no-cells"; do timeout 300 python tools/one_case.py --P $1 --B $2 --N $3 --rounds 6 $m 2>/dev/null | grep "^{" | python -c "
+for s in "12800000 8 1" "5000000 19 1" "12800000 4 2" "6400000 4 4" "3200000 4 8"; do set -- $s; for m in "" "--packed" "--no-cells"; do timeout 300 python tools/one_case.py --P $1 --B $2 --N $3 --rounds 6 $m 2>/dev/null | grep "^{" | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('%-12s records=%-10s %8.1f us %8.1f GB/s of votes' % (str(d['shape']), sys.argv[1] or '16-byte', d['median_us'], d['GBps']))" "$m"; done; done | tee gpurun_out/packed_records.log
+d=json.loads(sys.stdin.read()); print('%-18s records=%-10s %8.1f us %8.1f GB/s of votes' % (str(d['shape']), sys.argv[1] or '16-byte', d['median_us'], d['GBps']))" "$m"; done; done | tee gpurun_out/packed_records.log
 echo "== TSAN build of the host code under the HIP runtime (best effort: the binding check is tests/test_host_sanitizers.py on the CPU)"; timeout 400 bash tools/tsan_host.sh > gpurun_out/tsan_host.log 2>&1; tail -4 gpurun_out/tsan_host.log
 echo "== host mode"; timeout 600 python tools/host_mode_bench.py 2>&1 | grep -v amdgpu | tee gpurun_out/host_mode.log | tail -12
 cd $R; du -sh gpurun_out
