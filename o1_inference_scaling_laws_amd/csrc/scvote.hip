@@ -62,6 +62,7 @@ int test_fault() {
     if (!strcmp(f, "thread")) return 1;
     if (!strcmp(f, "alloc")) return 2;
     if (!strcmp(f, "throw")) return 3;
+    if (!strcmp(f, "race")) return 4;          // a DELIBERATE data race among the copy pieces: proves that a sanitizer run would see one
 #endif
     return 0;
 }
@@ -1361,7 +1362,13 @@ int host_pipelined(scv_ctx* ctx, bool prefix, const int32_t* answers, const int3
         char* db = static_cast<char*>(hp->dslot[k]);
         // stage 1: caller memory -> pinned bounce slot (worker threads); overlaps the DMA of the previous chunk
         std::vector<std::function<void()>> pieces;
-        if (const int tf = test_fault(); tf >= 2) { if (tf == 2) throw std::bad_alloc(); throw std::runtime_error("test hook: SCV_TEST_FAULT=throw"); }
+        if (const int tf = test_fault(); tf == 2 || tf == 3) { if (tf == 2) throw std::bad_alloc(); throw std::runtime_error("test hook: SCV_TEST_FAULT=throw"); }
+#ifdef SCV_TEST_HOOKS
+        if (test_fault() == 4) {                               // (test builds only) unsynchronised increments from the copy workers
+            static volatile long racy = 0;
+            for (int r = 0; r < 8; ++r) pieces.emplace_back([] { for (int k = 0; k < 20000; ++k) racy = racy + 1; });
+        }
+#endif
         if (!pin_a) add_copy_pieces(pieces, bb + o_ans, answers + (size_t)p0 * row_elems, (size_t)pc * row_bytes, parts);
         if (tokens && !pin_t) add_copy_pieces(pieces, bb + o_tok, tokens + (size_t)p0 * row_elems, (size_t)pc * row_bytes, parts);
         memcpy(bb + o_truth, truth + p0, (size_t)pc * sizeof(int32_t));

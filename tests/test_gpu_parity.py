@@ -2270,3 +2270,20 @@ def test_cells_of_two_votes_have_a_kernel_of_their_own(hip_engine, dist, shape):
     bad[P - 1, 0, 0] = -4
     with pytest.raises(_lib.DomainError):
         hip_engine.aggregate(bad, tr, n_valid=np.ones(B, dtype=np.int32))
+
+
+def test_host_code_is_clean_under_tsan_on_the_gpu_box():
+    """the host side of the library under ThreadSanitizer ON the GPU box (tools/tsan_host.sh: csrc/libscvote_tsan.so driven by
+    tools/tsan_host_driver.py without torch -- the staging pipeline with its worker threads, pinned sources, the small path, the fault injections):
+    no report from the library's own code, and the deliberately planted race of the last run IS reported, so "no report" means something."""
+    import glob
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(_build.variant_path("tsan")) or not glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so"):
+        pytest.skip("libscvote_tsan.so or the TSAN runtime is not there (build(): _build.build_variant('tsan'))")
+    out = subprocess.run(["bash", os.path.join(repo, "tools", "tsan_host.sh")], capture_output=True, text=True, timeout=1500, cwd=repo,
+                         env={k: v for k, v in os.environ.items() if k not in ("SCV_LIB_PATH", "SCV_TEST_FAULT", "LD_PRELOAD")})
+    text = out.stdout + out.stderr
+    assert "TSAN VERDICT: clean" in text, text[-4000:]
+    assert text.count("TSAN-DRIVER-OK") == 5 and "ThreadSanitizer runtime: present in this process" in text
+    assert "SCV_TEST_FAULT=none: 0 warning(s)" in text and "SCV_TEST_FAULT=race: 0 warning(s)" not in text
