@@ -1,1 +1,1 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; timeout 1500 bash tools/tsan_host.sh 2>&1 | tee gpurun_out/tsan_host.log | tail -60
+cd $GRAFT_REPO_ROOT; timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -k "tsan or no_cpp_exception" 2>&1 | tail -5
