@@ -195,3 +195,64 @@ def test_random_prefix_configuration_is_bit_exact(hip_engine, seed):
     finally:
         for k, v in DEFAULTS:
             hip_engine.set_option(k, v)
+
+
+# ---- round 6: DEVICE-mode cells of up to 127 votes, both record forms ----------------------------------------------------------------------------
+
+_PACKED = {}
+
+
+def _packed_engine():
+    if "eng" not in _PACKED:
+        from o1_inference_scaling_laws_amd.engine import Engine
+        _PACKED["eng"] = Engine(packed_cells=True)
+    return _PACKED["eng"]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SCV_FUZZ_FIRST", "0")), int(os.environ.get("SCV_FUZZ_FIRST", "0")) + int(os.environ.get("SCV_FUZZ_CELL_SEEDS", "300"))))
+def test_random_short_cells_in_device_memory_both_record_forms(hip_engine, seed):
+    """Seeded draws over what round 6 added below 128 votes: cells of 1 / 2 votes on scv_one_vote / scv_two_votes (whole blocks and ragged tails, grids
+    that are and are not multiples of B), the 8-lane shapes, 16-byte and 4-byte records (SCV_FLAG_PACKED_CELLS) and counters only -- DEVICE memory,
+    every distribution, ragged budgets incl. empty ones, tokens; cells, cell tokens and counters against the oracle."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import AggregateResult, cells_from_torch
+    rng = np.random.default_rng(880_000 + seed)
+    kind = rng.choice(["one", "two", "few", "sorted", "band"], p=[0.3, 0.2, 0.15, 0.15, 0.2])
+    N = {"one": 1, "two": 2, "few": int(rng.choice([3, 4, 5, 7, 8])), "sorted": int(rng.integers(9, 65)), "band": int(rng.integers(65, 128))}[kind]
+    B = int(rng.choice([1, 2, 3, 4, 7, 8, 11, 19, 32, 40]))
+    cells_target = int(rng.choice([300, 5000, 70000, 200000])) if N <= 8 else int(rng.choice([300, 3000, 20000]))
+    P = max(1, cells_target // B + int(rng.integers(0, 3)))
+    dist = int(rng.integers(0, 6))
+    a, t, tr = coracle.synth_fill(P, B, N, 50_000 + seed, dist, want_tokens=True)
+    if rng.random() < 0.4:
+        a = (a % int(rng.choice([2, 3, 5]))).astype(np.int32); tr = (tr % 4).astype(np.int32)
+    if rng.random() < 0.3:
+        tr[:: int(rng.integers(2, 9))] = int(rng.choice([1023, -3, 2000]))
+    nv = None if rng.random() < 0.4 else rng.integers(0, N + 2, size=B).astype(np.int32)
+    tokens = bool(rng.integers(0, 2))
+    packed = bool(rng.integers(0, 2))
+    want_cells = bool(rng.random() < 0.75)
+    eng = _packed_engine() if packed else hip_engine
+    dev = torch.device("cuda:0")
+    da, dtr = torch.from_numpy(a).to(dev), torch.from_numpy(tr).to(dev)
+    dtk = torch.from_numpy(t).to(dev) if tokens else None
+    dnv = None if nv is None else torch.from_numpy(nv).to(dev)
+    grid = int(rng.integers(1, 40)) if rng.random() < 0.25 else 0
+    try:
+        eng.set_option("grid", grid)
+        c, cells, ctok = eng.aggregate_device(da, dtr, tokens=dtk, n_valid=dnv, cells=None if want_cells else False)
+        eng.sync()
+    finally:
+        eng.set_option("grid", 0)
+    want = coracle.aggregate(a, tr, tokens=t if tokens else None, n_valid=nv)
+    got = AggregateResult.from_counters(c.cpu().numpy(), P, B)
+    assert np.array_equal(got.tie_class_hits, want["tie_class_hits"]) and np.array_equal(got.truth_count_sum, want["truth_count_sum"]), (seed, kind, P, B, N)
+    if tokens:
+        assert np.array_equal(got.token_sum, want["token_sum"]), (seed, "token_sum")
+    if want_cells:
+        assert tuple(cells.shape) == (P, B, 4 if packed else 16)
+        gc = cells_from_torch(cells)
+        for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
+            assert np.array_equal(gc[f], want["cells"][f]), (seed, kind, P, B, N, packed, f)
+        if tokens:
+            assert np.array_equal(ctok.cpu().numpy(), want["cell_tokens"]), (seed, "cell_tokens")
