@@ -1,5 +1,4 @@
 set -u
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_fuzz.py -m gpu -q --maxfail=5 --tb=short -k "short_cells" 2>&1 | tail -15
-echo "== ... 6000 further seeds of test_random_short_cells_in_device_memory_both_record_forms (DEVICE memory, N <= 127, 16-byte / 4-byte records / counters only)" | tee -a gpurun_out/fuzz_extended.log
-SCV_FUZZ_FIRST=300 SCV_FUZZ_CELL_SEEDS=6000 timeout 3000 python -m pytest tests/test_gpu_fuzz.py -m gpu -q --maxfail=5 --tb=short -k "short_cells" 2>&1 | tail -4 | tee -a gpurun_out/fuzz_extended.log
+timeout 3000 python -m pytest tests -m gpu -q --maxfail=10 --tb=short 2>&1 | tail -8 | tee gpurun_out/pytest_gpu_final.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | cut -c1-400
