@@ -384,7 +384,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         // The reference's own range (N = 1 ... 128, o1.py:267,276).  Rows that are not all 16-byte aligned (N % 4 != 0, unaligned
         // bases) take the linear-image form (dword reads).
         const bool sort_lin = !rows_aligned;
-        const int nv = N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : (N <= 48 ? 48 : 64)));
+        const int nv = N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : (N <= 40 ? 40 : (N <= 48 ? 48 : 64))));
         const RegKernel rk = pick_sort_kernel(nv, tok, sort_lin);
         const int64_t ps = (N / 4) | 1;
         const int64_t image_words = sort_lin ? ((64 * N * 4 + 16 + 1023) >> 10) * 256 : 64 * ps * 4;

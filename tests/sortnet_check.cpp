@@ -311,15 +311,18 @@ int main() {
     bool ok = true;
     ok &= network_sorts_all_01<2>() && network_sorts_all_01<4>() && network_sorts_all_01<8>() && network_sorts_all_01<16>();
     ok &= network_sorts_all_01<24>();                                   // the 48-vote shape's lockstep network: exhaustive (2^24 inputs)
+    ok &= network_sorts_all_01<20>();                                   // the 40-vote shape's (round 6): exhaustive (2^20 inputs)
     ok &= network_sorts_all_01<32>();                                   // (sampled: 2^20 random 0-1 inputs; all 2^32 below, bit-sliced)
     printf("network: %s (exchanges on 4 / 8 / 16 / 24 / 32 wires: %d %d %d %d %d; exhaustive up to 24 wires, 32 sampled here and exhaustive below)\n", ok ? "sorts" : "FAILS", sv_make_network<4>().n,
            sv_make_network<8>().n, sv_make_network<16>().n, sv_make_network<24>().n, sv_make_network<32>().n);
     const bool okv = valley_merge_sorts_all_01_valleys<6>() && valley_merge_sorts_all_01_valleys<12>() && valley_merge_sorts_all_01_valleys<24>() &&
-                     valley_merge_sorts_all_01_valleys<16>() && valley_merge_sorts_all_01_valleys<48>();
+                     valley_merge_sorts_all_01_valleys<16>() && valley_merge_sorts_all_01_valleys<48>() && valley_merge_sorts_all_01_valleys<20>() &&
+                     valley_merge_sorts_all_01_valleys<40>();
     printf("valley merge: %s (exchanges on 24 wires: %d)\n", okv ? "sorts every 0-1 valley" : "FAILS", sv_make_valley_merge<24>().n);
     ok &= okv;
     bool ok2 = packed_count_matches_bruteforce<8>(20000) && packed_count_matches_bruteforce<16>(20000) && packed_count_matches_bruteforce<32>(20000) &&
-               packed_count_matches_bruteforce<48>(60000) && packed_count_matches_bruteforce<64>(20000) && packed_count_matches_bruteforce<24>(20000);
+               packed_count_matches_bruteforce<48>(60000) && packed_count_matches_bruteforce<64>(20000) && packed_count_matches_bruteforce<24>(20000) &&
+               packed_count_matches_bruteforce<40>(60000);
     printf("packed sort + scan: %s\n", ok2 ? "equals statistics.multimode" : "DIFFERS");
     const bool ok3 = network_sorts_all_01_bitsliced_with_phase_blocks<32>() && network_sorts_all_01_bitsliced_with_phase_blocks<16>();
     printf("32 wires, all 2^32 inputs, every aligned block of 2 p wires after phase p: %s\n", ok3 ? "sorted" : "FAILS");

@@ -98,7 +98,7 @@ def test_no_kernel_spills_to_scratch():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     rows = mod.collect()
-    assert 100 <= len(rows) <= 142, len(rows)                        # round 4: pruned from 231 to <= 130; round 6: + scv_reg_cells<8, 3 | 4>, scv_prefix_tokens, scv_one_vote, - scv_merge_partials
+    assert 100 <= len(rows) <= 146, len(rows)                        # round 4: pruned from 231 to <= 130; round 6: + scv_reg_cells<8, 3 | 4>, scv_prefix_tokens, scv_one_vote, - scv_merge_partials
     spilled = {r[0]: r[4] for r in rows if r[4]}                     # (round 5: no exception left -- 17..32 votes with tokens on one lane per cell went to scv_reg_cells)
     assert not spilled, spilled
     head = [r for r in rows if r[0] == "scv_hist_argmax<4, 1024, 4, false, false>"]

@@ -1,10 +1,4 @@
 set -u
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-for i in 1 2 3; do
-  for lib in new r05; do
-    if [ $lib = r05 ]; then export SCV_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/libscvote_r05.so; else unset SCV_LIB_PATH; fi
-    timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-full-pass --no-live-traffic --no-read-ceiling 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); r=d['roofline']; print('$lib', round(d['ms_per_step'],4), 'ms/step  kernel', round(r['kernel_avg_ms'],4), 'ms', round(r['achieved']), 'GB/s')"
-  done
-done
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -q --tb=short -x -k "sorted or sort_cells or random or short_and_mid or packed" 2>&1 | tail -6
+python tools/regimes.py --only="small N=36" --only="small N=40" --only="small N=44" --only="small N=48 P=400k" --only="N=45" --only="tiny N=32 P=800k" 2>&1 | grep -v amdgpu.ids
