@@ -492,6 +492,8 @@ def measure_traffic_live(args):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    if os.environ.get("ROCPROFILER_LIBRARY_CTOR") or any(k.startswith("ROCPROF_") for k in os.environ):
+        return None, "this process is itself running under rocprofv3 (its environment would reach the child's profiler)"
     child = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--resident", "2", "--no-cpu-baseline", "--no-read-ceiling",
              "--no-full-pass", "--no-live-traffic", "--seed", str(args.seed), "--dist", str(args.dist)]
     got = {}

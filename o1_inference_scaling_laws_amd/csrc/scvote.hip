@@ -398,18 +398,21 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             const size_t lds = (size_t)(W * region_words + tail_words) * sizeof(uint32_t);
             SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rk.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const int64_t nsteps = (ncells + 63) / 64;
-            int64_t grid = (nsteps + W - 1) / W;
             // persistent: one workgroup per CU (or as many as the LDS lets be resident), 16 waves per CU at most
             int per_cu = (int)(ctx->lds_max / (int64_t)lds);
             if (per_cu < 1) per_cu = 1;
             if (per_cu * W > 16) per_cu = 16 / W > 0 ? 16 / W : 1;
+            // (few steps: smaller workgroups on more CUs, scvote_dispatch.h)
+            const int Wl = scv::spread_waves(nsteps, W, ctx->num_cus);
+            const size_t lds_l = (size_t)(Wl * region_words + tail_words) * sizeof(uint32_t);
+            int64_t grid = (nsteps + Wl - 1) / Wl;
             if (grid > (int64_t)ctx->num_cus * per_cu) grid = (int64_t)ctx->num_cus * per_cu;
             // cells per grid step a multiple of B: every lane slot then sees one budget and keeps its counters in registers
-            if ((grid * W * 64) % B != 0 && grid > B) grid -= grid % B;
+            if ((grid * Wl * 64) % B != 0 && grid > B) grid -= grid % B;
             if (ctx->grid_override > 0) grid = ctx->grid_override;
             ctx->stat_sort_cells += 1;
             if (ev) SCV_HIP(hipEventRecord(ev->a, ctx->stream));
-            hipLaunchKernelGGL(rk.fn, dim3((unsigned)grid), dim3((unsigned)(W * 64)), lds, ctx->stream, a);
+            hipLaunchKernelGGL(rk.fn, dim3((unsigned)grid), dim3((unsigned)(Wl * 64)), lds_l, ctx->stream, a);
             SCV_HIP(hipGetLastError());
             return finish(ev);
         }
@@ -820,11 +823,10 @@ int launch_sort_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
                        int64_t* truth_sum, bool promised, bool* queued, int* nv_out) {
     *queued = false;
     const int nv = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
-    // pools of 68 .. 128 votes WITH tokens (the reference's largest pool, o1.py:266-276, and its drop-in always sums tokens, o1.py:195): the votes
-    // go through scv_sort_prefix2 as without tokens, the token sums come from scv_prefix_tokens queued right behind it -- the token rows read as one
-    // contiguous stream, no image (round 6; scvote_sort_prefix.hip.h)
-    const bool tok_sep = tokens != nullptr && nv == 128;
-    const bool tok = tokens != nullptr && !tok_sep;
+    // pools of 68 .. 128 votes WITH tokens (the reference's largest pool, o1.py:266-276, and its drop-in always sums tokens, o1.py:195): scv_sort_prefix2<true> --
+    // the votes as without tokens, the token rows in token steps of their own that the waves without a sort step in the last, partial round take first
+    // (round 6; scvote_sort_prefix.hip.h)
+    const bool tok = tokens != nullptr;
     const RegKernel rk = pick_sort_prefix_kernel(nv, tok);
     const int64_t ps = nv == 128 ? 17 : ((N / 4) | 1);                 // (128: the row goes through the image in two halves of up to 64 votes)
     // one image per wave (scv_sort_prefix: a step's tokens follow its votes through it)
@@ -853,33 +855,17 @@ int launch_sort_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens,
     SCV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rk.fn), W * 64, lds));
     if (per_cu < 1) per_cu = 1;
     const int64_t nsteps = (P + 63) / 64;
-    int64_t grid = (nsteps + W - 1) / W;
+    // fewer steps than the chip has wave slots: every CU gets a workgroup before any CU gets a second wave per SIMD (a step is ~1400 VALU instructions
+    // per wave; two waves of a SIMD in the same step take turns: 4.9 against 2.6 us for the sort of a one-step launch)
+    const int Wl = scv::spread_waves(nsteps, W, ctx->num_cus);
+    const size_t lds_l = (size_t)(Wl * region_words + tail_words) * sizeof(uint32_t);
+    int64_t grid = (nsteps + Wl - 1) / Wl;
     if (grid > (int64_t)ctx->num_cus * per_cu) grid = (int64_t)ctx->num_cus * per_cu;
     if (ctx->grid_override > 0) grid = ctx->grid_override;
-    hipLaunchKernelGGL(rk.fn, dim3((unsigned)grid), dim3((unsigned)(W * 64)), lds, ctx->stream, a);
+    hipLaunchKernelGGL(rk.fn, dim3((unsigned)grid), dim3((unsigned)(Wl * 64)), lds_l, ctx->stream, a);
     SCV_HIP(hipGetLastError());
     ctx->stat_prefix_sort += 1;
-    if (tok_sep && (cell_tokens || tok_sum)) {
-        scv::AggArgs t = a;
-        t.tokens = tokens; t.cells = nullptr; t.cell_tokens = cell_tokens;
-        t.tie_hits = nullptr; t.truth_sum = nullptr;
-        t.token_sum = reinterpret_cast<unsigned long long*>(tok_sum);
-        t.only_if_sortable = nv;                              // (a list the sort kernel leaves to the general kernel: that one sums the tokens too)
-        const KernelFn tf = scv::pick_prefix_tokens_kernel(32);
-        const int tw = 4;
-        const size_t tlds = (size_t)scv::prefix_tokens_lds_words_host(32, B, tw) * sizeof(uint32_t);
-        SCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-        const int64_t tsteps = (P + 2 * scv::kPrefixTokensGroups - 1) / (2 * scv::kPrefixTokensGroups);   // a step = 4 groups of 2 rows per wave
-        int64_t tgrid = (tsteps + tw * 4 - 1) / (tw * 4);     // >= 4 steps per wave before the grid grows
-        int per_cu = (int)(ctx->lds_max / (int64_t)(tlds + 512));
-        if (per_cu > 8) per_cu = 8;
-        if (per_cu < 1) per_cu = 1;
-        if (tgrid > (int64_t)ctx->num_cus * per_cu) tgrid = (int64_t)ctx->num_cus * per_cu;
-        if (tgrid < 1) tgrid = 1;
-        hipLaunchKernelGGL(tf, dim3((unsigned)tgrid), dim3((unsigned)(tw * 64)), tlds, ctx->stream, t);
-        SCV_HIP(hipGetLastError());
-        ctx->stat_prefix_tokens += 1;
-    }
+    if (tok && nv == 128 && (cell_tokens || tok_sum)) ctx->stat_prefix_tokens += 1;   // (launches with the token steps of scv_sort_prefix2<true>)
     ctx->err_dirty = true;
     *queued = true;
     *nv_out = nv;
@@ -908,7 +894,7 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
         N > 16 && N <= 128 && B <= scv::kMaxSortedB &&
         // pools of 68 .. 128 votes (scv_sort_prefix2: two sorts, a merge and a 128-vote scan per step) pay ~36 us for a launch of one step per wave:
         // measured against scv_prefix_pool it wins from ~1e5 pools (2e5: 64 against 84 us, 8e5: 183 against 297; 3e4: 153 against 69 in HOST-mode
-        // chunks); with tokens (round 6) the sums come from scv_prefix_tokens queued behind it (round 5 tried a second image: 114 against 114 us,
+        // chunks); with tokens (round 6) the sums come from token steps of the same launch (round 5 tried a second image: 114 against 114 us,
         // and left such calls on scv_prefix_pool); prefix_path = 5 selects it for any number of pools
         (N <= 64 || P >= 98304 || ctx->prefix_path == 5)) {
         // prefix_path = 5: the caller PROMISES budgets of that form (a DEVICE-mode call then queues scv_sort_prefix alone; a list that breaks

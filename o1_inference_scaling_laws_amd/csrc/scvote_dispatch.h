@@ -13,6 +13,17 @@ namespace scv {
 using KernelFn = void (*)(const AggArgs);
 struct RegKernel { KernelFn fn; int waves; };   // + the workgroup size (waves) the kernel was compiled for
 
+// Waves per workgroup of a one-wave-per-step kernel (scv_sort_cells, scv_sort_prefix, scv_sort_prefix2) when the launch has fewer steps than the chip
+// has wave slots: every SIMD of a CU gets a wave before any gets a second one (two waves of a SIMD in the same VALU-bound step take turns: 4.9 against
+// 3.0 us for the sort of a one-step launch of 64-vote pools) -- but never fewer than one wave per SIMD: every workgroup ends in one device atomic per
+// counter word, ~13 ns each on ONE word whoever sends it (391 one-wave workgroups: 5 us of epilogue; 98 of four waves: 1.3; profiles/r06_sort_prefix_wall.log).
+inline int spread_waves(int64_t nsteps, int waves, int num_cus) {
+    if (nsteps >= (int64_t)num_cus * waves) return waves;
+    int w = (int)((nsteps + num_cus - 1) / num_cus);
+    if (w < 4) w = 4;
+    return w < waves ? w : waves;
+}
+
 // streaming kernel scv_hist_argmax<log2(copies), threads, unroll, tokens, xtra>.  Instantiated geometries (copies, threads):
 // (4, 256) (8, 256) (8, 512) (16, 256) (16, 512) (16, 1024), 4 loads in flight per lane ((4, 256): 2 -- the short-cell band);
 // xtra (single-launch epilogues: overwrite-counters, bootstrap behind a grid barrier) for the four the library picks itself:
@@ -55,11 +66,6 @@ RegKernel pick_prefix_pool_kernel(int g, bool tok, bool vec);
 constexpr int sort_prefix_classes(int nv) { int l = 0; while ((1 << l) < nv / 2) ++l; return l + 3; }
 constexpr long long sort_prefix_tail_words(int nv, int B) { return 16 + ((B + 3) & ~3) + ((sort_prefix_classes(nv) * (nv + 1) + 1) & ~1) + 4 * sort_prefix_classes(nv); }
 RegKernel pick_sort_prefix_kernel(int nv, bool tok);
-// scv_prefix_tokens<16 / 32 lanes per row> (scvote_sort_prefix.hip.h): token sums of prefix budgets, rows of up to 64 / 128 tokens; 256 threads;
-// dynamic LDS = prefix_tokens_lds_words(lanes, B, 4) words
-KernelFn pick_prefix_tokens_kernel(int lanes);
-constexpr int kPrefixTokensGroups = 4;            // = kPrefixTokensU of the kernel: row groups a wave has in flight per step
-constexpr long long prefix_tokens_lds_words_host(int L, int B, int waves) { return ((B + 3) & ~3) + 2ll * ((B + 1) & ~1) + (long long)waves * kPrefixTokensGroups * (64 / L) * 4 * L * 2; }
 
 // ---- shared by the table translation units ------------------------------------------------------------------------
 template <int RL2, int T, int U>

@@ -92,8 +92,6 @@ struct AggArgs {
     int32_t skip_sortable = 0;      // prefix kernels queued BEHIND scv_sort_prefix<NV> (DEVICE mode: the host cannot read n_valid): = NV; the
                                     // launch leaves at once when every budget is of the form that kernel serves (it has done the work)
     int32_t packed_cells = 0;       // SCV_FLAG_PACKED_CELLS: cells is uint32 [P, B] (cells of up to 127 votes; pack_cell below), not scv_cell [P, B]
-    int32_t only_if_sortable = 0;   // scv_prefix_tokens queued NEXT TO scv_sort_prefix<NV> (DEVICE mode): = NV; the launch leaves at once unless every budget
-                                    // is of the form that kernel serves (otherwise the general kernel behind them does votes and tokens)
     int32_t budgets_promised = 0;   // scv_sort_prefix: != 0 = the budgets are KNOWN to be of its form (read by a HOST-mode call, or promised by the
                                     // caller: option prefix_path = 5): a list that is not sets error bit 8 instead of leaving the launch to another kernel
 };

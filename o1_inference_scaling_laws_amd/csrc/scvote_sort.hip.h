@@ -374,7 +374,8 @@ __global__ __launch_bounds__(sort_cells_threads(NV)) void scv_sort_cells(const A
         }
     }
     const int64_t nwaves = (int64_t)gridDim.x * NW;
-    const int64_t wave = sv_uniform64((int64_t)blockIdx.x * NW + wid);
+    // (wave-major over the grid: the steps of the last, partial round go to one wave of every CU before any CU gets a second one)
+    const int64_t wave = sv_uniform64((int64_t)wid * gridDim.x + blockIdx.x);
     constexpr int64_t SC = 64;                                       // cells per step
     const int64_t nsteps = (a.ncells + SC - 1) / SC;
     const int64_t total_bytes = a.ncells * (int64_t)rowbytes;

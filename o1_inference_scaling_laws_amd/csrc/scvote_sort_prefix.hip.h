@@ -98,6 +98,20 @@ __device__ unsigned long long scv_sp_timeline[8];
 #else
 #define SP_STAMP(i) do { } while (0)
 #endif
+#ifdef SCV_SP_WALL
+// the same launch on the 100 MHz wall clock: [0] = the first wave's start (min), [i] = the LAST wave to pass mark i (max): 1 a wave starts | 2 classes set up |
+// 3 the first image has landed | 4 rows in registers | 5 sorted | 6 final scan | 7 all steps done | 8 last records out | 9 counters handed out
+// (one row of 16 marks per wave, plain stores: atomics on one word serialise the launch)
+constexpr int kSpWallWaves = 4096;
+__device__ unsigned long long scv_sp_wall[kSpWallWaves * 16];
+#define SP_WALL(i) do { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0) scv_sp_wall[sp_wall_row * 16 + (i)] = (unsigned long long)wall_clock64(); \
+                        __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SP_WALL_START() const int sp_wall_row = (int)(((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kSpWallWaves); SP_WALL(0); SP_WALL(1); \
+    if ((threadIdx.x & 63) == 0) { uint32_t hw_id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id)); scv_sp_wall[sp_wall_row * 16 + 10] = 0x100000000ull | hw_id; }
+#else
+#define SP_WALL(i) do { } while (0)
+#define SP_WALL_START() do { } while (0)
+#endif
 
 // ---- shared by the two kernels ---------------------------------------------------------------------------------------------------------
 // The budget CLASSES of the launch: cb[c] = first position of class c in ordl (budgets by class, in LDS), cb[NC] = B; cbeg = the same in LDS for
@@ -220,7 +234,8 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
         }
     }
     const int64_t nwaves = (int64_t)gridDim.x * NW;
-    const int64_t wave = sv_uniform64((int64_t)blockIdx.x * NW + wid);
+    // (wave-major over the grid: the steps of the last, partial round go to one wave of every CU before any CU gets a second one)
+    const int64_t wave = sv_uniform64((int64_t)wid * gridDim.x + blockIdx.x);
     const int64_t nsteps = (a.P + 63) / 64;
     const int64_t total_bytes = a.P * (int64_t)rowbytes;
     // the copy of step st's 64 rows -- its votes, or (tok) its tokens -- into this wave's image
@@ -247,10 +262,20 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
 
     int64_t st = wave;
     int32_t cb[NC + 1];
+    SP_WALL_START();
     // (tie and acc are adjacent: [NC][TC] words rounded to an even count, then 2 NC 64-bit sums)
-    if (!sort_prefix_setup_classes<NV, NC>(a, cbeg, ordl, tie, ((NC * TC + 1) & ~1) + 4 * NC, cb)) return;
+    // A list KNOWN to be this kernel's (a HOST-mode call has read it, a DEVICE-mode caller has promised it): the first copy starts before the classes
+    // are worked out, n_valid travels beside the image instead of in front of it (-1.3 us per launch: profiles/r06_sort_prefix_wall.log).  Otherwise the
+    // verdict comes first: a list this kernel does not serve would wait for an image nobody reads.
+    const bool early = a.budgets_promised != 0;
+    if (early && st < nsteps) { issue(st); issue_truth(st); }
+    if (!sort_prefix_setup_classes<NV, NC>(a, cbeg, ordl, tie, ((NC * TC + 1) & ~1) + 4 * NC, cb)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (a broken promise, error bit 8: no copy may land in LDS this wave no longer owns)
+        return;
+    }
+    SP_WALL(2);
     // (the load of n_valid has returned -- the verdict needed it --: nothing the compiler would wait for with vmcnt(0) follows the copy)
-    if (st < nsteps) { issue(st); issue_truth(st); }
+    if (!early && st < nsteps) { issue(st); issue_truth(st); }
     // votes the longest budget sees (the domain check looks no further)
     int32_t nmax = 0;
 #pragma unroll
@@ -309,10 +334,12 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
     unsigned long long tl[7] = {0, 0, 0, 0, 0, 0, 0}, tl_steps = 0;
     unsigned long long t_last = __builtin_readcyclecounter();
 #endif
+    asm volatile("; SCV_STEP_LOOP" ::: "memory");                    // (tests/test_abi_symbols.py counts the vmcnt waits behind this line)
     for (; st < nsteps; st += nwaves) {
         SP_STAMP(6);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this step's images and truths have landed (and every older store)
         SP_STAMP(0);
+        if (st == wave) SP_WALL(3);
         const int64_t left = a.P - st * 64;
         const uint32_t live_rows = left >= 64 ? 64u : (uint32_t)left;
         const bool live = (uint32_t)lane < live_rows;
@@ -367,6 +394,7 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
             }
         }
         SP_STAMP(1);
+        if (st == wave) SP_WALL(4);
         // the previous step's records leave now: a whole sort lies between these stores and the next wait
         flush_records();
         SP_STAMP(2);
@@ -422,6 +450,7 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
             }
         }
         SP_STAMP(3);
+        if (st == wave) SP_WALL(5);
         if constexpr (TOK) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tokens have landed
             int64_t* const ctok_row = a.cell_tokens ? a.cell_tokens + (st * 64 + lane) * (int64_t)B : nullptr;
@@ -483,10 +512,12 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
         Dp0 = st * 64;
         Dlive = live_rows;
         SP_STAMP(5);
+        if (st == wave) SP_WALL(6);
 #ifdef SCV_SP_TIMELINE
         ++tl_steps;
 #endif
     }
+    SP_WALL(7);
 #ifdef SCV_SP_TIMELINE
     if (lane == 0) {
         for (int i = 0; i < 7; ++i) atomicAdd(&scv_sp_timeline[i], tl[i]);
@@ -494,6 +525,8 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
     }
 #endif
     flush_records();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SP_WALL(8);
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
     const bool counters = a.tie_hits || a.truth_sum || (TOK && a.token_sum);
     if (counters) {
@@ -513,6 +546,10 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
         __syncthreads();
         sort_prefix_hand_out_counters<NC, TC, TOK>(a, cbeg, ordl, tie, acc);
     }
+#ifdef SCV_SP_WALL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SP_WALL(9);
 }
 
 
@@ -602,6 +639,10 @@ constexpr int sort_prefix2_threads() { return 512; }
 
 // Host contract: 64 < N <= 128, N % 4 == 0, 16-byte aligned bases, B <= kMaxSortedB, every budget 0, a power of two <= 64 or >= N (checked
 // here: a list that is not leaves the launch to the kernel queued behind it), no tokens stream; a.wave_lds_words = 64 * 17 * 4 + 64.
+#ifndef SCV_TOK_PASSES
+#define SCV_TOK_PASSES 2
+#endif
+template <bool TOK>
 __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const AggArgs a) {
     constexpr int NV = 128, NH = 64, NP = 32, RSH = 16;             // votes per lane; per half; packed registers per half; 16-byte slots per half row
     constexpr uint32_t PS = 17u;                                     // slots of a padded half row in the image
@@ -625,15 +666,16 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
     // copy (17 registers of offsets held across the loop were the registers the kernel did not have)
     const uint32_t c0 = (uint32_t)lane / PS, k0 = (uint32_t)lane - c0 * PS;
     const int64_t nwaves = (int64_t)gridDim.x * NW;
-    const int64_t wave = sv_uniform64((int64_t)blockIdx.x * NW + wid);
+    // (wave-major over the grid: the steps of the last, partial round go to one wave of every CU before any CU gets a second one)
+    const int64_t wave = sv_uniform64((int64_t)wid * gridDim.x + blockIdx.x);
     const int64_t nsteps = (a.P + 63) / 64;
     const int64_t total_bytes = a.P * (int64_t)rowbytes;
     // the copy of half h (0: votes 0 .. 63, 1: votes 64 .. N - 1) of step st's 64 rows into this wave's image(s)
-    auto issue_half = [&](int64_t st, int h) {
+    auto issue_half = [&](int64_t st, int h, bool tok = false) {
         const int64_t byte0 = st * 64 * (int64_t)rowbytes;
         const int64_t rem = total_bytes - byte0 - 16;
         const uint32_t lim = rem > 0x7fffffffll ? 0x7fffffffu : (uint32_t)rem;
-        const char* g = reinterpret_cast<const char*>(a.answers) + byte0;
+        const char* g = reinterpret_cast<const char*>(tok ? a.tokens : a.answers) + byte0;
         const uint32_t kmax = h ? RSB - 1u : (uint32_t)RSH - 1u, add = h ? 256u : 0u;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the rows of the image's previous content are in registers, staged tables have left)
         uint32_t cr = c0 * rowbytes + add, kq = k0;
@@ -655,8 +697,13 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
 
     int64_t st = wave;
     int32_t cb[NC + 1];
-    if (!sort_prefix_setup_classes<NV, NC>(a, cbeg, ordl, tie, ((NC * TC + 1) & ~1) + 4 * NC, cb)) return;
-    if (st < nsteps) { issue_half(st, 0); issue_truth(st); }
+    const bool early = a.budgets_promised != 0;                      // (as in scv_sort_prefix: a promised list's first copy does not wait for the classes)
+    if (early && st < nsteps) { issue_half(st, 0); issue_truth(st); }
+    if (!sort_prefix_setup_classes<NV, NC>(a, cbeg, ordl, tie, ((NC * TC + 1) & ~1) + 4 * NC, cb)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    if (!early && st < nsteps) { issue_half(st, 0); issue_truth(st); }
     int32_t nmax = 0;                                                // votes the longest budget sees (the domain check looks no further)
 #pragma unroll
     for (int c = 1; c < CF; ++c) if (cb[c + 1] > cb[c]) nmax = 1 << (c - 1);
@@ -707,6 +754,7 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
         Dlive = 0;
     };
 
+    asm volatile("; SCV_STEP_LOOP" ::: "memory");
     for (; st < nsteps; st += nwaves) {
         // ================================ phase A: votes 0 .. 63 ================================
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // half A and the truths have landed (and every older store)
@@ -850,136 +898,111 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     flush_records();
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
-    const bool counters = a.tie_hits || a.truth_sum;
+    // ================================ the token sums (round 6) ================================
+    // cell_tokens[p][b] = sum of tokens[p][0 .. min(n_valid[b], N) - 1] (o1.py:195 over the budget's prefix), token_sum[b] = its sum over the problems
+    // (o1.py:240).  A token step = the 64 token rows of 64 problems, one lane per row, through the wave's image in the same two halves as the votes: a
+    // running 64-bit sum in index order, snapshots behind 1, 2, 4 ... 64 tokens and behind all N.  The tokens of a sample never influence its vote, so
+    // ANY wave can take ANY token step -- and the sort leaves waves idle: its last round is partial (2e5 pools: 3125 steps on 2048 waves, 971 waves
+    // have nothing to sort while the others sort their second step).  Those waves take the token steps first, SCV_TOK_PASSES each; what is left is dealt
+    // to all waves.  (Round 6 first read the token rows in a kernel of its own behind this one, scv_prefix_tokens: 62 + 27 us + a launch gap at 2e5 pools.)
+    long long toks[TOK ? NC : 1];
+    if constexpr (TOK) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) toks[c] = 0;
+        if (a.cell_tokens || a.token_sum) {
+            const int64_t Lw = nsteps % nwaves;                       // waves 0 .. Lw - 1 sort one step more than the others
+            const int64_t Iw = Lw == 0 ? 0 : nwaves - Lw;             // waves without a step in the sort's last round
+            const int64_t v = wave >= Lw ? wave - Lw : wave + Iw;     // those first
+            const bool tstaged = (uint32_t)B <= PS;
+            const uint32_t ra = rbase + (uint32_t)lane * (PS * 16u);
+            const uint32_t ltok = rbase + (uint32_t)lane * (uint32_t)B * 8u;
+            int pass = v < Iw ? 0 : SCV_TOK_PASSES;
+            auto step_of = [&](int p) -> int64_t { return p < SCV_TOK_PASSES ? (int64_t)p * Iw + v : (int64_t)SCV_TOK_PASSES * Iw + (int64_t)(p - SCV_TOK_PASSES) * nwaves + v; };
+            int64_t t = step_of(pass);
+            if (t < nsteps) issue_half(t, 0, true);
+            while (t < nsteps) {
+                const int64_t left = a.P - t * 64;
+                const uint32_t live_rows = left >= 64 ? 64u : (uint32_t)left;
+                const bool live = (uint32_t)lane < live_rows;
+                long long snap[8];
+                long long run = 0;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tokens 0 .. 63 of the step's rows have landed
+                {
+                    int32_t y[NH];
+#pragma unroll
+                    for (int k = 0; k < RSH; ++k) {
+                        const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k));
+                        y[4 * k] = (int32_t)q.x; y[4 * k + 1] = (int32_t)q.y; y[4 * k + 2] = (int32_t)q.z; y[4 * k + 3] = (int32_t)q.w;
+                    }
+                    if (want_full) issue_half(t, 1, true);           // tokens 64 .. N - 1 fly while the first 64 are summed
+#pragma unroll
+                    for (int i = 0; i < NH; ++i) {
+                        run += (long long)y[i];
+                        const int idx1 = i + 1;
+                        if ((idx1 & (idx1 - 1)) == 0) snap[__builtin_ctz((unsigned)idx1)] = run;
+                    }
+                }
+                if (want_full) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int k = 0; k < RSH; ++k) {
+                        if ((uint32_t)k < RSB) {                     // (whole slots under a scalar branch, as for the votes)
+                            const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k));
+                            run += (long long)(int32_t)q.x + (long long)(int32_t)q.y + (long long)(int32_t)q.z + (long long)(int32_t)q.w;
+                        }
+                    }
+                }
+                snap[7] = run;
+                // the [64][B] sums leave like the records: through the image, in memory order (every row has been read)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                int64_t* const ctok_row = a.cell_tokens ? a.cell_tokens + (t * 64 + lane) * (int64_t)B : nullptr;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if (cb[c + 1] > cb[c]) {
+                        const long long sv = c == 0 ? 0ll : snap[c - 1];
+                        toks[c] += live ? sv : 0ll;
+                        if (a.cell_tokens) {
+                            for (int32_t j = cb[c]; j < cb[c + 1]; ++j) {
+                                const int32_t b = __builtin_amdgcn_readfirstlane(ordl[j]);
+                                if (tstaged) *reinterpret_cast<lds_v2u*>((uintptr_t)(ltok + (uint32_t)b * 8u)) = scv_v2u{(uint32_t)(unsigned long long)sv, (uint32_t)((unsigned long long)sv >> 32)};
+                                else if (live) ctok_row[b] = sv;
+                            }
+                        }
+                    }
+                }
+                if (a.cell_tokens && tstaged) {
+                    char* const out = reinterpret_cast<char*>(a.cell_tokens + t * 64 * (int64_t)B);
+                    const uint32_t ntok = live_rows * (uint32_t)B;
+                    for (int32_t i = 0; 2 * 64 * i < 64 * B; ++i) {   // 16 bytes = two sums per lane and piece
+                        const uint32_t k = (uint32_t)i * 64u + (uint32_t)lane;
+                        const scv_v4u two = *reinterpret_cast<lds_v4u*>((uintptr_t)(rbase + k * 16u));
+                        if (2u * k + 1u < ntok) __builtin_nontemporal_store(two, reinterpret_cast<scv_v4u*>(out) + k);
+                        else if (2u * k < ntok) *reinterpret_cast<scv_v2u*>(out + (size_t)k * 16u) = scv_v2u{two.x, two.y};
+                    }
+                }
+                ++pass;
+                t = step_of(pass);
+                if (t < nsteps) issue_half(t, 0, true);
+            }
+        }
+    }
+    const bool counters = a.tie_hits || a.truth_sum || (TOK && a.token_sum);
     if (counters) {
 #pragma unroll
         for (int c = 1; c < NC; ++c) {
             if (cb[c + 1] > cb[c]) {
                 const long long ts = wave_sum_i64((long long)tcs[c]);
+                long long tk = 0;
+                if (TOK) tk = wave_sum_i64(toks[c]);
                 if (lane == 0) {
                     if (h1[c]) atomicAdd(&tie[c * TC + 1], h1[c]);
                     if (ts) atomicAdd(&acc[c], (unsigned long long)ts);
+                    if (TOK && tk) atomicAdd(&acc[NC + c], (unsigned long long)tk);
                 }
             }
         }
         __syncthreads();
-        sort_prefix_hand_out_counters<NC, TC, false>(a, cbeg, ordl, tie, acc);
-    }
-}
-
-
-// ---- the tokens of prefix budgets over short pools (round 6) ---------------------------------------------------------------------------------
-//
-// scv_prefix_tokens: cell_tokens[p][b] = sum of tokens[p][0 .. min(n_valid[b], N) - 1] (o1.py:195 over the budget's prefix), token_sum[b] = its
-// sum over the problems (o1.py:240).  The tokens of a sample never influence the vote, so the sums need nothing of the sort kernel's: not its
-// one-lane-per-problem layout (rows 512 bytes apart), not its 17 KiB image (scv_sort_prefix<64> sends a step's tokens through the image behind
-// its votes: + 13 us for 51 MB at 2e5 pools; the 128-vote kernel would pay that twice, and a second image was measured at 114 us in round 5).
-// Here the token rows are read as what they are in memory -- ONE contiguous stream --, 16 bytes per lane, L = 32 lanes per row (16 for rows of
-// up to 64 tokens): an inclusive scan inside the lane (4 tokens) + a DPP scan of the lane totals across the row's lanes (three 21/22-bit limbs:
-// exact mod 2^64 for any int32 tokens) give every prefix sum of the row; they are written to the wave's LDS table, lane j of the row picks the
-// prefix its budget j needs, and the row's B sums leave in ONE store of 8 B consecutive bytes.  Any budget list (not only powers of two).
-// HBM-bound: 4 N bytes read + 8 B written per problem, no vote bytes.  The host queues it behind scv_sort_prefix2 (68 .. 128 votes with tokens);
-// like that kernel it leaves at once when the budget list is not one the sort kernel serves (a.only_if_sortable = its NV: the general kernel
-// queued behind both then does votes AND tokens).
-__device__ __forceinline__ bool sort_prefix_serves_nv(const AggArgs& a, int nv, int tid, int nthreads) {
-    if (nv == 128) return sort_prefix_serves<128>(a, tid, nthreads);
-    if (nv == 64) return sort_prefix_serves<64>(a, tid, nthreads);
-    return sort_prefix_serves<32>(a, tid, nthreads);
-}
-constexpr int prefix_tokens_threads() { return 256; }
-constexpr int kPrefixTokensU = 4;                                    // row groups (of 64 / L rows) a wave has in flight per step
-// LDS: clipped budgets [B rounded to 4] (int32) | token sums [B rounded to 2] (64-bit) | per wave: [U][64 / L rows][4 L prefixes] (64-bit)
-// (the same formula as prefix_tokens_lds_words_host in scvote_dispatch.h)
-template <int L>
-__global__ __launch_bounds__(prefix_tokens_threads()) void scv_prefix_tokens(const AggArgs a) {
-    static_assert(L == 16 || L == 32, "16 or 32 lanes per row");
-    constexpr int R = 64 / L;                                        // rows per wave instruction
-    constexpr int U = kPrefixTokensU;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, T = (int)blockDim.x, NW = T >> 6;
-    const int32_t N = (int32_t)a.N, B = a.B;
-    if (a.only_if_sortable && !a.budgets_promised && !sort_prefix_serves_nv(a, a.only_if_sortable, tid, T)) return;
-    int32_t* nvl = reinterpret_cast<int32_t*>(lds);                                                   // min(n_valid[b], N)
-    unsigned long long* tsum = reinterpret_cast<unsigned long long*>(lds + ((B + 3) & ~3));            // [B rounded to 2]
-    unsigned long long* table = tsum + ((B + 1) & ~1) + (int64_t)wid * U * R * 4 * L;                  // this wave's [U][R][4 L] prefixes (16-byte aligned)
-    for (int b = tid; b < B; b += T) { nvl[b] = (int32_t)valid_len(a, b); tsum[b] = 0ull; }
-    __syncthreads();
-    const int sub = lane / L, l = lane % L;
-    const uint32_t nvec = (uint32_t)N >> 2;                          // 16-byte vectors of a row (N % 4 == 0: host contract)
-    const bool have = (uint32_t)l < nvec;
-    const uint32_t vi = have ? (uint32_t)l : nvec - 1u;
-    const int64_t nwaves = (int64_t)gridDim.x * NW;
-    const int64_t wave = (int64_t)blockIdx.x * NW + wid;
-    const int64_t nsteps = (a.P + U * R - 1) / (U * R);             // a step = U * R consecutive rows
-    const int4* const tok4 = reinterpret_cast<const int4*>(a.tokens);
-    auto load = [&](int64_t step, int4 (&x)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int64_t row = (step * U + u) * R + sub;
-            if (row >= a.P) row = a.P - 1;
-            x[u] = stream_load(tok4 + row * (int64_t)nvec + vi);
-        }
-    };
-    // the budget this lane serves for every row of its row slot (budgets >= L, rare, go round the loop below)
-    const int32_t n_mine = l < B ? nvl[l] : 0;
-    unsigned long long acc = 0;
-    int4 nxt[U];
-    if (wave < nsteps) load(wave, nxt);
-    for (int64_t step = wave; step < nsteps; step += nwaves) {
-        int4 x[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = nxt[u];
-        if (step + nwaves < nsteps) load(step + nwaves, nxt);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long long s0 = have ? (long long)x[u].x : 0ll, s1 = s0 + (have ? (long long)x[u].y : 0ll),
-                            s2 = s1 + (have ? (long long)x[u].z : 0ll), s3 = s2 + (have ? (long long)x[u].w : 0ll);
-            // exclusive scan of the lane totals over the row's L lanes, as three limbs (sums of <= 32 limbs of <= 22 bits fit 32 bits)
-            const unsigned long long t = (unsigned long long)s3;
-            const uint32_t limb[3] = {(uint32_t)(t & 0x3fffffu), (uint32_t)((t >> 22) & 0x1fffffu), (uint32_t)((t >> 43) & 0x1fffffu)};
-            unsigned long long ex = 0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                uint32_t v = limb[k];
-                v += (uint32_t)SCV_DPP(0, v, 0x111, 0xf);            // row_shr:1, 2, 4, 8: inclusive inside each 16 lanes
-                v += (uint32_t)SCV_DPP(0, v, 0x112, 0xf);
-                v += (uint32_t)SCV_DPP(0, v, 0x114, 0xf);
-                v += (uint32_t)SCV_DPP(0, v, 0x118, 0xf);
-                if (L == 32) v += (uint32_t)SCV_DPP(0, v, 0x142, 0xa);   // row_bcast:15 -> rows 1, 3: the upper 16 lanes of a 32-lane row
-                ex += (unsigned long long)(v - limb[k]) << (k == 0 ? 0 : (k == 1 ? 22 : 43));
-            }
-            // (the table of the previous step has been read by every lane of the wave: LDS operations of a wave execute in order)
-            uint4* const dst = reinterpret_cast<uint4*>(table + ((int64_t)u * R + sub) * 4 * L + 4 * l);
-            const unsigned long long p0 = ex + (unsigned long long)s0, p1 = ex + (unsigned long long)s1, p2 = ex + (unsigned long long)s2, p3 = ex + (unsigned long long)s3;
-            dst[0] = make_uint4((uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32));
-            dst[1] = make_uint4((uint32_t)p2, (uint32_t)(p2 >> 32), (uint32_t)p3, (uint32_t)(p3 >> 32));
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned long long* const mine = table + ((int64_t)u * R + sub) * 4 * L;
-            const int64_t row = (step * U + u) * R + sub;
-            if (l < B && row < a.P) {                                // lane j of the row: budget j, kept in a register across the rows
-                const unsigned long long v = n_mine > 0 ? mine[n_mine - 1] : 0ull;
-                if (a.cell_tokens) a.cell_tokens[row * (int64_t)B + l] = (long long)v;
-                acc += v;
-            }
-            for (int b = l + L; b < B; b += L) {                     // ... and budgets j + L, j + 2 L ... (more budgets than lanes per row)
-                const int32_t n = nvl[b];
-                const unsigned long long v = n > 0 ? mine[n - 1] : 0ull;
-                if (row < a.P) {
-                    if (a.cell_tokens) a.cell_tokens[row * (int64_t)B + b] = (long long)v;
-                    if (a.token_sum) atomicAdd(&tsum[b], v);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (a.token_sum) {
-        if (l < B && acc) atomicAdd(&tsum[l], acc);
-        __syncthreads();
-        for (int b = tid; b < B; b += T)
-            if (tsum[b]) atomicAdd(&a.token_sum[b], tsum[b]);
+        sort_prefix_hand_out_counters<NC, TC, TOK>(a, cbeg, ordl, tie, acc);
     }
 }
 

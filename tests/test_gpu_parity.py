@@ -975,7 +975,7 @@ def test_prefix_budgets_that_are_powers_of_two_come_out_of_one_sort(hip_engine, 
     dpool, dtok, dtr = torch.from_numpy(pool.copy()).to(dev), torch.from_numpy(tpool.copy()).to(dev), torch.from_numpy(tr).to(dev)
     # pools of 68 .. 128 votes: scv_sort_prefix2 pays ~36 us for a launch of one step per wave -- auto takes it from ~1e5 pools
     # (test_prefix_pools_of_128_votes_take_the_sort_kernel_when_there_are_many), prefix_path = 5 selects it for any number; with tokens (round 6)
-    # the sums come from scv_prefix_tokens queued behind it ("prefix_tokens" +1 per call with tokens)
+    # the sums come from the token steps of the same launch, scv_sort_prefix2<true> ("prefix_tokens" +1 per call with tokens)
     big = N > 64
     for mk in SORT_PREFIX_BUDGETS:
         if big:
@@ -986,7 +986,7 @@ def test_prefix_budgets_that_are_powers_of_two_come_out_of_one_sort(hip_engine, 
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool), want)
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv), want, check_tokens=False)
         assert hip_engine.stat("prefix_sort") == before + 2 and hip_engine.stat("prefix_lane") == lane0 and hip_engine.stat("prefix_pool") == pool0   # HOST mode: this kernel alone
-        assert hip_engine.stat("prefix_tokens") == tok0 + (1 if big else 0)                                   # (68 .. 128 votes: the token sums behind the sort kernel)
+        assert hip_engine.stat("prefix_tokens") == tok0 + (1 if big else 0)                                   # (68 .. 128 votes: the token steps of the sort kernel)
         got = hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool, want_cells=False)                       # no cell table
         assert np.array_equal(got.tie_class_hits, want.tie_class_hits) and np.array_equal(got.token_sum, want.token_sum) and np.array_equal(got.truth_count_sum, want.truth_count_sum)
         with _with_options(hip_engine, {"grid": 1, "prefix_path": 5 if big else 0}):                           # one workgroup walks every step
@@ -1079,7 +1079,7 @@ def test_sort_prefix_with_more_budgets_than_lanes(hip_engine, N, B):
     forms = [0, N, N + 7] + [1 << k for k in range(8) if (1 << k) <= _sort_prefix_top(N)]
     nv = rng.choice(forms, size=B).astype(np.int32)
     want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
-    tok = True                                                      # (round 6: pools of 68 .. 128 votes have a token form too: scv_prefix_tokens behind the sort kernel)
+    tok = True                                                      # (round 6: pools of 68 .. 128 votes have a token form too: token steps in the sort kernel's launch)
     with _with_options(hip_engine, {"prefix_path": 5}):
         before = hip_engine.stat("prefix_sort")
         assert_results_equal(hip_engine.aggregate_prefix(pool, tr, nv, tokens=tpool if tok else None), want, check_tokens=tok)
@@ -1096,7 +1096,7 @@ def test_sort_prefix_with_more_budgets_than_lanes(hip_engine, N, B):
 def test_prefix_pools_of_128_votes_take_the_sort_kernel_when_there_are_many(hip_engine):
     """The reference's largest pool (o1.py:266-276: T = 2^18 -> N = 128 samples, budgets 1, 2, 4 ... 128): from ~1e5 token-less pools auto
     dispatch queues scv_sort_prefix2 (DEVICE memory: a HOST-mode call of this size is staged in chunks, each a launch of its own); bit-exact vs
-    the oracle, D1 and D3; with tokens the sums come from scv_prefix_tokens behind it; a smaller call stays on the one-pass kernel."""
+    the oracle, D1 and D3; with tokens the sums come from token steps of the same launch; a smaller call stays on the one-pass kernel."""
     import torch
     from o1_inference_scaling_laws_amd.engine import AggregateResult
     dev = torch.device("cuda:0")
@@ -1114,7 +1114,7 @@ def test_prefix_pools_of_128_votes_take_the_sort_kernel_when_there_are_many(hip_
         assert hip_engine.stat("prefix_sort") == before + 1
         assert_results_equal(AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells)), want, check_tokens=False)
         tok0 = hip_engine.stat("prefix_tokens")
-        c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, dnv, tokens=dtok)                 # with tokens (round 6): the same kernel + scv_prefix_tokens
+        c, cells, ctok = hip_engine.aggregate_prefix_device(dpool, dtr, dnv, tokens=dtok)                 # with tokens (round 6): the same kernel with its token steps
         hip_engine.sync()
         assert hip_engine.stat("prefix_sort") == before + 2 and hip_engine.stat("prefix_tokens") == tok0 + 1
         assert_results_equal(AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells), ctok.cpu().numpy()), want)
@@ -1129,6 +1129,32 @@ def test_prefix_pools_of_128_votes_take_the_sort_kernel_when_there_are_many(hip_
         assert hip_engine.stat("prefix_sort") == before + 1
         small = OracleEngine().aggregate_prefix(pool[:50_000], tr[:50_000], nv)
         assert_results_equal(AggregateResult.from_counters(c.cpu().numpy(), 50_000, len(nv), cells_from_torch(cells)), small, check_tokens=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 63, 1920, 65_536 + 7, 131_072, 131_072 + 64 * 5 + 3, 200_000, 262_144 - 64, 262_144 + 1])
+@pytest.mark.parametrize("N", [72, 128])
+def test_token_steps_of_the_128_vote_sort_kernel_whoever_takes_them(hip_engine, P, N):
+    """scv_sort_prefix2<true> deals the token steps (64 token rows each) to the waves WITHOUT a sort step in the sort's last, partial round first, two
+    each, and the rest to all waves: the numbers of pools here leave no / five / half / all but one / one of the waves without a step in that round
+    (2048 waves on an MI355X; any other chip only shifts the cases), a last step of 1 ... 63 live rows, fewer steps than waves, one pool.  Votes,
+    records, counters and every token sum against the oracle (o1.py:195, 240 over each budget's prefix), budgets promised from a host list."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import AggregateResult
+    dev = torch.device("cuda:0")
+    nvl = [1, 2, 4, 8, 16, 32, 64, N] if P % 2 else [N, 64, 0, 16, 16, 1, 4]        # (the second list: classes with two budgets, none, out of order)
+    nv = np.array(nvl, dtype=np.int32)
+    a, t, tr = coracle.synth_fill(P, 1, N, 1000 + P % 997 + N, 3 if P % 3 == 0 else 1, want_tokens=True)
+    pool, tpool = np.ascontiguousarray(a[:, 0, :]), np.ascontiguousarray(t[:, 0, :])
+    tpool[::7, ::5] *= -1                                                            # (any int32: the running sums are 64-bit, signed)
+    tpool[P // 2, :] = np.iinfo(np.int32).max
+    want = OracleEngine().aggregate_prefix(pool, tr, nv, tokens=tpool)
+    s0, t0 = hip_engine.stat("prefix_sort"), hip_engine.stat("prefix_tokens")
+    c, cells, ctok = hip_engine.aggregate_prefix_device(torch.from_numpy(pool).to(dev), torch.from_numpy(tr).to(dev), torch.from_numpy(nv).to(dev),
+                                                        tokens=torch.from_numpy(tpool).to(dev), budgets_host=nvl)
+    hip_engine.sync()
+    assert hip_engine.stat("prefix_sort") == s0 + 1 and hip_engine.stat("prefix_tokens") == t0 + 1
+    assert_results_equal(AggregateResult.from_counters(c.cpu().numpy(), P, len(nv), cells_from_torch(cells), ctok.cpu().numpy()), want)
 
 
 def test_prefix_mode_device_and_errors(hip_engine):
@@ -1372,7 +1398,7 @@ def test_cell_kernels_are_hipgraph_capturable(P, B, N):
 
 
 def test_prefix_sort_and_token_kernels_are_hipgraph_capturable():
-    """The reference's largest pool with tokens (o1.py:266-276, 195): scv_sort_prefix2 + scv_prefix_tokens, the budgets promised from a host list,
+    """The reference's largest pool with tokens (o1.py:266-276, 195): scv_sort_prefix2<true> (sort steps + token steps in one launch), the budgets promised from a host list,
     captured once and replayed on new pools and tokens."""
     import torch
     from o1_inference_scaling_laws_amd.engine import Engine
