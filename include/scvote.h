@@ -138,8 +138,8 @@ int scv_set_tuning(scv_ctx* ctx, int copies, int threads, int wg_per_cu, int unr
  *                         mode statistics (pools <= 4096: auto above 64 votes and for budget lists too long for path 1; "reg_shape" = 16 / 32 forces the lanes per problem)
  *                         auto includes: pools of 17 .. 128 votes (N % 4 == 0, 16-byte aligned bases) whose budgets are all 0, a power of two <= 16 / 32 / 64
  *                         (pools <= 32 / 64 / 128), or >= N come out of ONE sort per problem (scv_sort_prefix) -- pools of 17 .. 64 votes always, pools of
- *                         68 .. 128 votes (scv_sort_prefix2: ~36 us for a launch of one step per wave) from 98 304 pools per call; with tokens their sums
- *                         come from scv_prefix_tokens queued behind it.  A HOST-mode call reads the budgets; a DEVICE-mode call queues that
+ *                         68 .. 128 votes (scv_sort_prefix2: ~27 us for a launch of one step per wave) from 57 344 pools per call; with tokens their sums
+ *                         come from token steps of the same launch (scv_sort_prefix2<true>).  A HOST-mode call reads the budgets; a DEVICE-mode call queues that
  *                         kernel in front of the general one and the two decide from n_valid which of them does the work (~4 us for the one that
  *                         leaves).  | 5 = auto, and the caller PROMISES budgets of that form for such pools (any number of them, with or without
  *                         tokens): a DEVICE-mode call queues scv_sort_prefix alone; a list that breaks the promise computes nothing and is
@@ -350,7 +350,7 @@ int scv_host_free(void* p);
  * themselves), "sort_cells" (sorted-cells launches), "few_votes" (launches of the kernels for cells of exactly 1, 2 or 4 votes), "one_vote" (those of them served by scv_one_vote / scv_two_votes: N = 1, 2), "prefix_cells" / "prefix_lane" / "prefix_pool" (prefix calls served by the cell kernels / by
  * the one-lane-per-problem kernel / by the one-pass-per-problem kernel), "prefix_sort" (launches of scv_sort_prefix: every power-of-two budget out of one
  * sort per problem -- queued, that is: a DEVICE-mode launch may find budgets it does not serve and leave them to the kernel behind it), "prefix_tokens" (launches of
- * scv_prefix_tokens: the token sums of pools of 68 .. 128 votes, queued behind scv_sort_prefix2), "host_small_calls" / "host_pipelined_calls" (HOST-mode calls served by the one-block small path / by
+ * scv_sort_prefix2<true>: the token sums of pools of 68 .. 128 votes out of token steps of the sort kernel's launch), "host_small_calls" / "host_pipelined_calls" (HOST-mode calls served by the one-block small path / by
  * the staging pipeline), "host_thread_start_failures" (worker threads of the staging pipeline the system refused to start: the
  * pipeline runs with the threads it has, the calling thread at least). */
 int scv_get_stat(scv_ctx* ctx, const char* key, int64_t* out);

@@ -403,7 +403,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
             if (per_cu < 1) per_cu = 1;
             if (per_cu * W > 16) per_cu = 16 / W > 0 ? 16 / W : 1;
             // (few steps: smaller workgroups on more CUs, scvote_dispatch.h)
-            const int Wl = scv::spread_waves(nsteps, W, ctx->num_cus);
+            const int Wl = scv::spread_waves(nsteps, W, ctx->num_cus, nv <= 16 ? 8 : 4);
             const size_t lds_l = (size_t)(Wl * region_words + tail_words) * sizeof(uint32_t);
             int64_t grid = (nsteps + Wl - 1) / Wl;
             if (grid > (int64_t)ctx->num_cus * per_cu) grid = (int64_t)ctx->num_cus * per_cu;
@@ -892,11 +892,11 @@ int launch_prefix(scv_ctx* ctx, const int32_t* pool, const int32_t* tokens, cons
     const bool want_any_counters = tie || truth_sum || (tokens && tok_sum);
     if (ctx->path == 0 && (ctx->prefix_path == 0 || ctx->prefix_path == 5) && ctx->sort_n_max >= 64 && ctx->fused_counters_max != 0 && rows_aligned &&
         N > 16 && N <= 128 && B <= scv::kMaxSortedB &&
-        // pools of 68 .. 128 votes (scv_sort_prefix2: two sorts, a merge and a 128-vote scan per step) pay ~36 us for a launch of one step per wave:
-        // measured against scv_prefix_pool it wins from ~1e5 pools (2e5: 64 against 84 us, 8e5: 183 against 297; 3e4: 153 against 69 in HOST-mode
+        // pools of 68 .. 128 votes (scv_sort_prefix2: two sorts, a merge and a 128-vote scan per step) pay ~27 us for a launch of one step per wave (36 before round 6's 4-wave workgroups):
+        // measured against scv_prefix_pool it wins from ~5e4 pools (4.9e4: 28.9 against 29.5 us, 6.6e4: 30.1 against 35.2, 2e5: 48 .. 63 against 82; 3e4: 153 against 69 in HOST-mode
         // chunks); with tokens (round 6) the sums come from token steps of the same launch (round 5 tried a second image: 114 against 114 us,
         // and left such calls on scv_prefix_pool); prefix_path = 5 selects it for any number of pools
-        (N <= 64 || P >= 98304 || ctx->prefix_path == 5)) {
+        (N <= 64 || P >= 57344 || ctx->prefix_path == 5)) {
         // prefix_path = 5: the caller PROMISES budgets of that form (a DEVICE-mode call then queues scv_sort_prefix alone; a list that breaks
         // the promise is an error, reported like a domain error at the next synchronisation)
         const bool promised = ctx->prefix_path == 5;

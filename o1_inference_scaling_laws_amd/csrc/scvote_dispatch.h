@@ -17,11 +17,12 @@ struct RegKernel { KernelFn fn; int waves; };   // + the workgroup size (waves) 
 // has wave slots: every SIMD of a CU gets a wave before any gets a second one (two waves of a SIMD in the same VALU-bound step take turns: 4.9 against
 // 3.0 us for the sort of a one-step launch of 64-vote pools) -- but never fewer than one wave per SIMD: every workgroup ends in one device atomic per
 // counter word, ~13 ns each on ONE word whoever sends it (391 one-wave workgroups: 5 us of epilogue; 98 of four waves: 1.3; profiles/r06_sort_prefix_wall.log).
-inline int spread_waves(int64_t nsteps, int waves, int num_cus) {
-    if (nsteps >= (int64_t)num_cus * waves) return waves;
+// Only while that at least halves the workgroup: 7 waves instead of 8 leave three SIMDs with two waves AND add workgroups (1e5 pools of 64 votes: 22.5 against 21.7 us).
+// (least: 4 = one wave per SIMD; 8 for the cheap steps of scv_sort_cells<8 | 16>, where more workgroups cost more than shared SIMDs: 1000 steps of 16 votes 9.6 against 8.9 us)
+inline int spread_waves(int64_t nsteps, int waves, int num_cus, int least = 4) {
     int w = (int)((nsteps + num_cus - 1) / num_cus);
-    if (w < 4) w = 4;
-    return w < waves ? w : waves;
+    if (w < least) w = least;
+    return 2 * w <= waves ? w : waves;
 }
 
 // streaming kernel scv_hist_argmax<log2(copies), threads, unroll, tokens, xtra>.  Instantiated geometries (copies, threads):

@@ -24,6 +24,12 @@
 
 namespace scv {
 
+// Token steps a wave WITHOUT a sort step in the sort's last, partial round takes before any other wave gets one (scv_sort_prefix2<true>): measured
+// 0 .. 4 on 2e5 pools of 128 votes: 80.4 / 80.3 / 74.4 / 77.5 / 78.3 us, equal elsewhere (profiles/r06_prefix_token_steps_ab.log)
+#ifndef SCV_TOK_PASSES
+#define SCV_TOK_PASSES 2
+#endif
+
 // exchanges of the merge phases p' <= pmax of sv_make_network<N>() (the generator's own loops)
 template <int N>
 constexpr int sv_phase_end(int pmax) {
@@ -264,18 +270,12 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
     int32_t cb[NC + 1];
     SP_WALL_START();
     // (tie and acc are adjacent: [NC][TC] words rounded to an even count, then 2 NC 64-bit sums)
-    // A list KNOWN to be this kernel's (a HOST-mode call has read it, a DEVICE-mode caller has promised it): the first copy starts before the classes
-    // are worked out, n_valid travels beside the image instead of in front of it (-1.3 us per launch: profiles/r06_sort_prefix_wall.log).  Otherwise the
-    // verdict comes first: a list this kernel does not serve would wait for an image nobody reads.
-    const bool early = a.budgets_promised != 0;
-    if (early && st < nsteps) { issue(st); issue_truth(st); }
-    if (!sort_prefix_setup_classes<NV, NC>(a, cbeg, ordl, tie, ((NC * TC + 1) & ~1) + 4 * NC, cb)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (a broken promise, error bit 8: no copy may land in LDS this wave no longer owns)
-        return;
-    }
+    if (!sort_prefix_setup_classes<NV, NC>(a, cbeg, ordl, tie, ((NC * TC + 1) & ~1) + 4 * NC, cb)) return;
     SP_WALL(2);
-    // (the load of n_valid has returned -- the verdict needed it --: nothing the compiler would wait for with vmcnt(0) follows the copy)
-    if (!early && st < nsteps) { issue(st); issue_truth(st); }
+    // (the load of n_valid has returned -- the verdict needed it --: nothing the compiler would wait for with vmcnt(0) follows the copy.  Starting the copy
+    // BEFORE the classes for a list the caller has promised was measured in round 6: the wall-clock marks of one launch move by 1.3 us, its hipEvent time does
+    // not, and launches of >= 2 rounds lose 1-2 us -- every wave's n_valid then queues behind 35 MB of images: profiles/r06_prefix_fixed_cost_ab.log)
+    if (st < nsteps) { issue(st); issue_truth(st); }
     // votes the longest budget sees (the domain check looks no further)
     int32_t nmax = 0;
 #pragma unroll
@@ -525,7 +525,9 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
     }
 #endif
     flush_records();
+#ifdef SCV_SP_WALL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     SP_WALL(8);
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
     const bool counters = a.tie_hits || a.truth_sum || (TOK && a.token_sum);
@@ -563,8 +565,8 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
 // sorted values in plain 32-bit arithmetic (run lengths up to 128 do not fit the packed scan's 6-bit field): running (length, best, count, value),
 // 10 VALU per vote, no keys kept.  Per step: phase A = wait, rows A -> registers, the previous step's records leave through the image, copy B,
 // sort A with the block scans, scan 64; phase B = wait, rows B -> registers, copy the next A, sort B, merge, scan 128.  Classes: 0 | 1 + j for 2^j votes, j = 0 .. 6 | 8 = all N votes.
-// A launch of ONE step per wave takes ~36 us (two copies, two sorts, a merge and a 128-vote dependent scan in sequence; scv_prefix_pool: 13 us):
-// the host takes this kernel from ~1e5 pools (2e5: 64 against 84 us, 8e5: 183 against 297).  A token form (a second image: four waves per CU)
+// A launch of ONE step per wave takes ~27 us (two copies, two sorts, a merge and a 128-vote dependent scan in sequence; scv_prefix_pool: 13 us):
+// the host takes this kernel from 57 344 pools (6.6e4: 30 against 35 us, 2e5: 48 .. 63 against 82, 8e5: 168 against 297).  A token form (a second image: four waves per CU)
 // measured equal to scv_prefix_pool at 2e5 pools (114 us both) and was removed: calls with tokens stay on scv_prefix_pool.
 template <int NP>
 __device__ __forceinline__ void sv_flip_files(uint32_t (&A)[NP], uint32_t (&Bv)[NP]) {
@@ -639,9 +641,6 @@ constexpr int sort_prefix2_threads() { return 512; }
 
 // Host contract: 64 < N <= 128, N % 4 == 0, 16-byte aligned bases, B <= kMaxSortedB, every budget 0, a power of two <= 64 or >= N (checked
 // here: a list that is not leaves the launch to the kernel queued behind it), no tokens stream; a.wave_lds_words = 64 * 17 * 4 + 64.
-#ifndef SCV_TOK_PASSES
-#define SCV_TOK_PASSES 2
-#endif
 template <bool TOK>
 __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const AggArgs a) {
     constexpr int NV = 128, NH = 64, NP = 32, RSH = 16;             // votes per lane; per half; packed registers per half; 16-byte slots per half row
@@ -697,13 +696,8 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
 
     int64_t st = wave;
     int32_t cb[NC + 1];
-    const bool early = a.budgets_promised != 0;                      // (as in scv_sort_prefix: a promised list's first copy does not wait for the classes)
-    if (early && st < nsteps) { issue_half(st, 0); issue_truth(st); }
-    if (!sort_prefix_setup_classes<NV, NC>(a, cbeg, ordl, tie, ((NC * TC + 1) & ~1) + 4 * NC, cb)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
-    if (!early && st < nsteps) { issue_half(st, 0); issue_truth(st); }
+    if (!sort_prefix_setup_classes<NV, NC>(a, cbeg, ordl, tie, ((NC * TC + 1) & ~1) + 4 * NC, cb)) return;
+    if (st < nsteps) { issue_half(st, 0); issue_truth(st); }
     int32_t nmax = 0;                                                // votes the longest budget sees (the domain check looks no further)
 #pragma unroll
     for (int c = 1; c < CF; ++c) if (cb[c + 1] > cb[c]) nmax = 1 << (c - 1);

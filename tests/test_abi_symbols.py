@@ -116,11 +116,10 @@ def test_copy_pipelines_keep_their_waits():
     import tempfile
     csrc = os.path.join(REPO, "o1_inference_scaling_laws_amd", "csrc")
     expect = {                                                       # kernel (mangled-name fragment) -> vmcnt waits from its step loop on: (least, most)
-        # (+ 1: the exit of a broken promise waits for the copy it started early -- where the compiler lays that block behind the loop)
-        "scv_sort_prefixILi64ELb0EE": (2, 2), "scv_sort_prefixILi32ELb0EE": (2, 2),      # the top of a step
-        "scv_sort_prefixILi64ELb1EE": (3, 3), "scv_sort_prefixILi32ELb1EE": (3, 3),      # + the step's tokens, behind the sort
-        "scv_sort_prefix2ILb0EE": (2, 3),                                                    # half A, half B
-        "scv_sort_prefix2ILb1EE": (4, 5),                                                    # + the token steps behind the sort: their half A, half B
+        "scv_sort_prefixILi64ELb0EE": (1, 1), "scv_sort_prefixILi32ELb0EE": (1, 1),      # the top of a step
+        "scv_sort_prefixILi64ELb1EE": (2, 2), "scv_sort_prefixILi32ELb1EE": (2, 2),      # + the step's tokens, behind the sort
+        "scv_sort_prefix2ILb0EE": (2, 2),                                                    # half A, half B
+        "scv_sort_prefix2ILb1EE": (4, 4),                                                    # + the token steps behind the sort: their half A, half B
         "scv_sort_cellsILi64ELb0ELb0EE": (3, 5), "scv_sort_cellsILi16ELb0ELb0EE": (3, 5),  # vmcnt(0) / (1) / (2) by the stores left in flight
     }
     with tempfile.TemporaryDirectory() as d:
@@ -135,8 +134,6 @@ def test_copy_pipelines_keep_their_waits():
         assert m, frag
         body = m.group(2)
         assert "scratch_" not in body, frag
-        # (round 6: a list the caller has promised starts its first copy BEFORE the budget classes are worked out -- n_valid then travels beside the
-        # image and the compiler's wait for it is meant; the STEP LOOP is what must stay free of waits and loads the source did not write)
         behind = body[body.index("SCV_STEP_LOOP"):] if "SCV_STEP_LOOP" in body else body[body.index("global_load_lds_dword"):]
         waits = re.findall(r"vmcnt\(\d+\)", behind)
         assert least <= len(waits) <= most, (frag, waits)

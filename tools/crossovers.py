@@ -47,11 +47,11 @@ def main():
             a, b = timed(sh, mine), timed(sh, other)
             lines.append(f"| {what} | {list(sh)} | {a:.1f} | {b:.1f} | {b / a:.2f} |")
             print(lines[-1], flush=True)
-    # prefix budgets: scv_sort_prefix2 from 98 304 pools of 68 .. 128 votes, scv_prefix_pool below
-    for P in (49152, 98304, 196608):
+    # prefix budgets: scv_sort_prefix2 from 57 344 pools of 68 .. 128 votes, scv_prefix_pool below
+    for P in (12288, 24576, 32768, 49152, 65536, 98304, 196608):
         for tok in (False, True):
             a, b = timed((P, 8, 128), {"prefix_path": 5}, prefix=True, tokens=tok), timed((P, 8, 128), {"prefix_path": 4}, prefix=True, tokens=tok)
-            lines.append(f"| prefix budgets over 128-vote pools{' with tokens' if tok else ''}: one sort per problem from 98 304 pools, one pass per problem below | [{P}, 8, 128] | sort {a:.1f} | one pass {b:.1f} | {b / a:.2f} |")
+            lines.append(f"| prefix budgets over 128-vote pools{' with tokens' if tok else ''}: one sort per problem from 57 344 pools, one pass per problem below | [{P}, 8, 128] | sort {a:.1f} | one pass {b:.1f} | {b / a:.2f} |")
             print(lines[-1], flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     open("gpurun_out/crossovers.md", "w").write("\n".join(lines) + "\n")
