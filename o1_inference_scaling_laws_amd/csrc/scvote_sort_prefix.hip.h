@@ -26,6 +26,9 @@ namespace scv {
 
 // Token steps a wave WITHOUT a sort step in the sort's last, partial round takes before any other wave gets one (scv_sort_prefix2<true>): measured
 // 0 .. 4 on 2e5 pools of 128 votes: 80.4 / 80.3 / 74.4 / 77.5 / 78.3 us, equal elsewhere (profiles/r06_prefix_token_steps_ab.log)
+#ifndef SCV_RECORDS_LAST
+#define SCV_RECORDS_LAST 0
+#endif
 #ifndef SCV_TOK_PASSES
 #define SCV_TOK_PASSES 2
 #endif
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
         atomicAdd(&scv_sp_timeline[7], tl_steps);
     }
 #endif
-    flush_records();
+    if (!SCV_RECORDS_LAST) flush_records();
 #ifdef SCV_SP_WALL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -548,6 +551,7 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
         __syncthreads();
         sort_prefix_hand_out_counters<NC, TC, TOK>(a, cbeg, ordl, tie, acc);
     }
+    if (SCV_RECORDS_LAST) flush_records();
 #ifdef SCV_SP_WALL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -890,7 +894,7 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
         Dlive = live_rows;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    flush_records();
+    if (TOK || !SCV_RECORDS_LAST) flush_records();                   // (the token steps need the image)
     if (bad > 1023u) atomicOr(a.err_flag, 1u);
     // ================================ the token sums (round 6) ================================
     // cell_tokens[p][b] = sum of tokens[p][0 .. min(n_valid[b], N) - 1] (o1.py:195 over the budget's prefix), token_sum[b] = its sum over the problems
@@ -998,6 +1002,7 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
         __syncthreads();
         sort_prefix_hand_out_counters<NC, TC, TOK>(a, cbeg, ordl, tie, acc);
     }
+    if (!TOK && SCV_RECORDS_LAST) flush_records();
 }
 
 }  // namespace scv
