@@ -27,7 +27,7 @@ namespace scv {
 // Token steps a wave WITHOUT a sort step in the sort's last, partial round takes before any other wave gets one (scv_sort_prefix2<true>): measured
 // 0 .. 4 on 2e5 pools of 128 votes: 80.4 / 80.3 / 74.4 / 77.5 / 78.3 us, equal elsewhere (profiles/r06_prefix_token_steps_ab.log)
 #ifndef SCV_RECORDS_LAST
-#define SCV_RECORDS_LAST 0
+#define SCV_RECORDS_LAST 1
 #endif
 #ifndef SCV_TOK_PASSES
 #define SCV_TOK_PASSES 2
@@ -365,7 +365,9 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
 #pragma unroll
         for (int r = 0; r < NP; ++r) orv |= R[r];
         if (__any((orv & 0xfc00fc00u) != 0u)) {                      // (rare: o1.py:140 int(extracted_answer) is unbounded; the extractor maps it into the bins)
-            const int32_t seen = live ? nmax : 0;
+            int32_t nm = nmax;
+            asm volatile("" : "+s"(nm));                             // (nmax laundered: hoisted out of this rare branch, its 64 uniform "i < nmax" masks are 128 SGPRs held -- spilled -- across the whole step loop)
+            const int32_t seen = live ? nm : 0;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 bad |= i < seen ? w[i] : 0u;
@@ -604,14 +606,19 @@ __device__ __forceinline__ void sv_merge_bitonic_file(uint32_t (&X)[NP]) {
 // changes; the first run to reach a new maximum is the smallest such value (ascending order), later runs that reach it are counted
 template <int NP>
 __device__ __forceinline__ BlockStats sv_scan_files(const uint32_t (&A)[NP], const uint32_t (&Bv)[NP]) {
-    uint32_t prev = 0xffffffffu, len = 0, best = 0, cnt = 0, minv = 0;
+    // (length, value) of the best run as ONE key, length << 16 | ~value: its maximum is the longest run with the smallest value (the values ascend).  A
+    // select `minv = len > best ? x : minv` per element is off the dependent chain: the compiler sank all 128 of them behind the loop and kept their
+    // masks -- 256 SGPRs, spilled to VGPR lanes and read back: 168 v_writelane + as many v_readlane and their hazard s_nops per step.
+    uint32_t prev = 0xffffffffu, len = 0, best = 0, cnt = 0, bkey = 0;
     auto feed = [&](uint32_t x) {
         len = x == prev ? len + 1u : 1u;
         prev = x;
-        const bool gt = len > best;
-        cnt = gt ? 1u : cnt + (len == best ? 1u : 0u);
-        minv = gt ? x : minv;
-        best = gt ? len : best;
+        const uint32_t cnt_eq = cnt + (len == best ? 1u : 0u);
+        cnt = len > best ? 1u : cnt_eq;
+        best = best > len ? best : len;
+        const uint32_t key = (len << 16) | (x ^ 0xffffu);
+        bkey = bkey > key ? bkey : key;
+        __builtin_amdgcn_sched_barrier(0);                           // (element by element: nothing of the later elements is worked out ahead into registers the kernel does not have)
     };
 #pragma unroll
     for (int r = 0; r < NP; ++r) feed(A[r] & 0xffffu);
@@ -621,24 +628,26 @@ __device__ __forceinline__ BlockStats sv_scan_files(const uint32_t (&A)[NP], con
     for (int r = 0; r < NP; ++r) feed(Bv[r] & 0xffffu);
 #pragma unroll
     for (int r = 0; r < NP; ++r) feed(Bv[r] >> 16);
-    return BlockStats{best, cnt, minv};
+    return BlockStats{best, cnt, (bkey & 0xffffu) ^ 0xffffu};
 }
 
 // ... of the M sorted values in the LOW halves of R[0 .. M - 1], the same way (no key per element held: the 128-vote kernel has no registers for them)
 template <int M, int NP>
 __device__ __forceinline__ BlockStats sv_scan_block_running(const uint32_t (&R)[NP]) {
-    uint32_t prev = 0xffffffffu, len = 0, best = 0, cnt = 0, minv = 0;
+    uint32_t prev = 0xffffffffu, len = 0, best = 0, cnt = 0, bkey = 0;   // (the best run as one key: see sv_scan_files)
 #pragma unroll
     for (int i = 0; i < M; ++i) {
         const uint32_t x = R[i] & 0xffffu;
         len = x == prev ? len + 1u : 1u;
         prev = x;
-        const bool gt = len > best;
-        cnt = gt ? 1u : cnt + (len == best ? 1u : 0u);
-        minv = gt ? x : minv;
-        best = gt ? len : best;
+        const uint32_t cnt_eq = cnt + (len == best ? 1u : 0u);
+        cnt = len > best ? 1u : cnt_eq;
+        best = best > len ? best : len;
+        const uint32_t key = (len << 16) | (x ^ 0xffffu);
+        bkey = bkey > key ? bkey : key;
+        __builtin_amdgcn_sched_barrier(0);
     }
-    return BlockStats{best, cnt, minv};
+    return BlockStats{best, cnt, (bkey & 0xffffu) ^ 0xffffu};
 }
 
 constexpr int sort_prefix2_threads() { return 512; }
@@ -682,6 +691,7 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
         const uint32_t kmax = h ? RSB - 1u : (uint32_t)RSH - 1u, add = h ? 256u : 0u;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the rows of the image's previous content are in registers, staged tables have left)
         uint32_t cr = c0 * rowbytes + add, kq = k0;
+        asm volatile("" : "+v"(cr), "+v"(kq));                       // (walked again by EVERY copy: hoisted out of the step loop, the 2 x 17 offsets were spilled to scratch)
 #pragma unroll
         for (int q = 0; q < (int)PS; ++q) {
             uint32_t o = cr + (kq < kmax ? kq : kmax) * 16u;
@@ -754,6 +764,10 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
 
     asm volatile("; SCV_STEP_LOOP" ::: "memory");
     for (; st < nsteps; st += nwaves) {
+        // (values every step works out again: hoisted out of the loop, what the compiler derives from them -- 16 slot conditions, 16 clamped offsets, the sentinel
+        // constants -- are ~50 SGPRs the kernel does not have: spilled to VGPR lanes and read back inside the step)
+        uint32_t RSB_l = RSB, nB_l = nB;
+        asm volatile("" : "+s"(RSB_l), "+s"(nB_l));
         // ================================ phase A: votes 0 .. 63 ================================
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // half A and the truths have landed (and every older store)
         const int64_t left = a.P - st * 64;
@@ -779,7 +793,9 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
 #pragma unroll
             for (int r = 0; r < NP; ++r) orv |= RA[r];
             if (__any((orv & 0xfc00fc00u) != 0u)) {
-                const int32_t seen = live ? (nmax < NH ? nmax : NH) : 0;
+                int32_t nm = nmax;
+                asm volatile("" : "+s"(nm));
+                const int32_t seen = live ? (nm < NH ? nm : NH) : 0;
 #pragma unroll
                 for (int i = 0; i < NH; ++i) {
                     bad |= i < seen ? w[i] : 0u;
@@ -840,7 +856,7 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
             uint32_t v[NH];
 #pragma unroll
             for (int k = 0; k < RSH; ++k) {
-                const uint32_t kk = (uint32_t)k < RSB ? (uint32_t)k : RSB - 1u;
+                const uint32_t kk = (uint32_t)k < RSB_l ? (uint32_t)k : RSB_l - 1u;
                 const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * kk));
                 v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
             }
@@ -850,7 +866,9 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
 #pragma unroll
             for (int r = 0; r < NP; ++r) orv |= RB[r];
             if (__any((orv & 0xfc00fc00u) != 0u)) {
-                const int32_t seen = live ? (nmax - NH > 0 ? nmax - NH : 0) : 0;
+                int32_t nm = nmax;
+                asm volatile("" : "+s"(nm));
+                const int32_t seen = live ? (nm - NH > 0 ? nm - NH : 0) : 0;
 #pragma unroll
                 for (int i = 0; i < NH; ++i) {
                     bad |= i < seen ? v[i] : 0u;
@@ -859,10 +877,10 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
 #pragma unroll
                 for (int r = 0; r < NP; ++r) RB[r] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(v[r], v[r + NP]));
             }
-            if (want_full) {                                         // (whole slots under a scalar branch: 64 uniform "i < nB" masks cost 128 SGPRs)
+            if (want_full) {                                         // (whole slots under a scalar branch: 64 uniform "i < nB_l" masks cost 128 SGPRs)
 #pragma unroll
                 for (int k = 0; k < RSH; ++k) {
-                    if ((uint32_t)k < RSB) {
+                    if ((uint32_t)k < RSB_l) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) tcB += v[4 * k + e] == tcmp ? 1u : 0u;
                     }
@@ -872,8 +890,8 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
         // the image is free: the next step's half A is copied
         if (st + nwaves < nsteps) { issue_half(st + nwaves, 0); issue_truth(st + nwaves); }
         if (want_full) {
-            if (nB != (uint32_t)NH) {                                // slots behind the row: distinct sentinels behind every vote
-                const uint32_t n2 = nB | (nB << 16);
+            if (nB_l != (uint32_t)NH) {                                // slots behind the row: distinct sentinels behind every vote
+                const uint32_t n2 = nB_l | (nB_l << 16);
 #pragma unroll
                 for (int r = 0; r < NP; ++r)
                     RB[r] = sv_sentinel(RB[r], n2, (uint32_t)(r + 1) | ((uint32_t)(r + NP + 1) << 16),
@@ -919,6 +937,8 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
             int64_t t = step_of(pass);
             if (t < nsteps) issue_half(t, 0, true);
             while (t < nsteps) {
+                uint32_t RSB_t = RSB;
+                asm volatile("" : "+s"(RSB_t));                      // (per step, as in the sort loop: not 16 hoisted slot conditions in SGPRs)
                 const int64_t left = a.P - t * 64;
                 const uint32_t live_rows = left >= 64 ? 64u : (uint32_t)left;
                 const bool live = (uint32_t)lane < live_rows;
@@ -944,7 +964,7 @@ __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                     for (int k = 0; k < RSH; ++k) {
-                        if ((uint32_t)k < RSB) {                     // (whole slots under a scalar branch, as for the votes)
+                        if ((uint32_t)k < RSB_t) {                   // (whole slots under a scalar branch, as for the votes)
                             const scv_v4u q = *reinterpret_cast<lds_v4u*>((uintptr_t)(ra + 16u * k));
                             run += (long long)(int32_t)q.x + (long long)(int32_t)q.y + (long long)(int32_t)q.z + (long long)(int32_t)q.w;
                         }

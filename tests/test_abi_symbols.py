@@ -101,6 +101,10 @@ def test_no_kernel_spills_to_scratch():
     assert 100 <= len(rows) <= 146, len(rows)                        # round 4: pruned from 231 to <= 130; round 6: + scv_reg_cells<8, 3 | 4>, scv_sort_prefix2<true>, scv_one_vote, - scv_merge_partials
     spilled = {r[0]: r[4] for r in rows if r[4]}                     # (round 5: no exception left -- 17..32 votes with tokens on one lane per cell went to scv_reg_cells)
     assert not spilled, spilled
+    # SGPR values kept in VGPR lanes (round 6): the prefix sort kernels had 157 .. 602 of them, read back inside the step loop -- 64 hoisted "i < nmax" masks
+    # of a rare branch, 16 + 16 slot conditions, one select mask per scanned vote; 20 .. 110 are left, none of those in a loop per vote
+    lanes = {r[0]: r[7] for r in rows if r[0].startswith("scv_sort_prefix")}
+    assert len(lanes) == 6 and max(lanes.values()) <= 110 and lanes["scv_sort_prefix2<false>"] <= 64 and lanes["scv_sort_prefix<64, false>"] <= 48, lanes
     head = [r for r in rows if r[0] == "scv_hist_argmax<4, 1024, 4, false, false>"]
     assert head and head[0][1] <= 128 and head[0][4] == 0            # the headline kernel: 16 waves per CU need <= 128 VGPRs
 
