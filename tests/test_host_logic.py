@@ -451,3 +451,24 @@ def test_packed_cell_records_round_trip_on_the_host():
     for f in ("max_count", "truth_count", "n_modes", "min_mode", "hit"):
         assert np.array_equal(got[f].reshape(-1), ref[f]), f
     assert got.dtype == CELL_DTYPE and got.shape == (100, 50)
+
+
+def test_live_traffic_is_not_measured_from_inside_a_profiler(monkeypatch):
+    """bench.py measures roofline.traffic by re-running itself under `rocprofv3 --pmc` (bench.measure_traffic_live).  When bench.py is ITSELF running under
+    rocprofv3 -- the evidence round's kernel trace, anybody's profile of the driver's command -- the profiler's environment would reach the child's profiler:
+    it says so and the committed figure is quoted instead (a warning in the JSON line), it does not start a profiler inside a profiler."""
+    import argparse
+    import importlib
+    import os
+    import shutil
+    bench = importlib.import_module("bench")
+    args = argparse.Namespace(seed=1, dist=1)
+    if not (os.path.exists("/opt/rocm/bin/rocprofv3") or shutil.which("rocprofv3")):
+        pytest.skip("no rocprofv3 here")
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    got, note = bench.measure_traffic_live(args)
+    assert got is None and "under rocprofv3" in note
+    monkeypatch.delenv("ROCPROF_OUTPUT_PATH")
+    monkeypatch.setenv("ROCPROFILER_LIBRARY_CTOR", "1")
+    got, note = bench.measure_traffic_live(args)
+    assert got is None and "under rocprofv3" in note
