@@ -572,8 +572,9 @@ __global__ __launch_bounds__(sort_prefix_threads(NV)) void scv_sort_prefix(const
 // 10 VALU per vote, no keys kept.  Per step: phase A = wait, rows A -> registers, the previous step's records leave through the image, copy B,
 // sort A with the block scans, scan 64; phase B = wait, rows B -> registers, copy the next A, sort B, merge, scan 128.  Classes: 0 | 1 + j for 2^j votes, j = 0 .. 6 | 8 = all N votes.
 // A launch of ONE step per wave takes ~27 us (two copies, two sorts, a merge and a 128-vote dependent scan in sequence; scv_prefix_pool: 13 us):
-// the host takes this kernel from 57 344 pools (6.6e4: 30 against 35 us, 2e5: 48 .. 63 against 82, 8e5: 168 against 297).  A token form (a second image: four waves per CU)
-// measured equal to scv_prefix_pool at 2e5 pools (114 us both) and was removed: calls with tokens stay on scv_prefix_pool.
+// the host takes this kernel from 57 344 pools (6.6e4: 30 against 35 us, 2e5: 48 .. 63 against 82, 8e5: 168 against 297).  With tokens (TOK): the
+// token rows are summed in token steps of their own behind the sort steps -- the waves the sort's partial last round leaves idle take them first (below); a
+// second image for the tokens (four waves per CU) had measured 114 us at 2e5 pools in round 5, a token kernel of its own behind this one 91, the token steps 69.
 template <int NP>
 __device__ __forceinline__ void sv_flip_files(uint32_t (&A)[NP], uint32_t (&Bv)[NP]) {
 #pragma unroll
@@ -653,7 +654,7 @@ __device__ __forceinline__ BlockStats sv_scan_block_running(const uint32_t (&R)[
 constexpr int sort_prefix2_threads() { return 512; }
 
 // Host contract: 64 < N <= 128, N % 4 == 0, 16-byte aligned bases, B <= kMaxSortedB, every budget 0, a power of two <= 64 or >= N (checked
-// here: a list that is not leaves the launch to the kernel queued behind it), no tokens stream; a.wave_lds_words = 64 * 17 * 4 + 64.
+// here: a list that is not leaves the launch to the kernel queued behind it), a.tokens / a.cell_tokens / a.token_sum only for TOK; a.wave_lds_words = 64 * 17 * 4 + 64.
 template <bool TOK>
 __global__ __launch_bounds__(sort_prefix2_threads()) void scv_sort_prefix2(const AggArgs a) {
     constexpr int NV = 128, NH = 64, NP = 32, RSH = 16;             // votes per lane; per half; packed registers per half; 16-byte slots per half row
