@@ -255,12 +255,15 @@ int ensure_cells(scv_ctx* ctx, size_t bytes) {
 constexpr size_t kTicketWords = 8 + scv::kSplitTickets;     // [0 .. 2] the single-launch epilogues | [8 + cell] split-N arrival counters
 
 // split-N scratch: the split cells' histograms and token sums in memory.  All zero whenever no launch is in flight (the workgroup that
-// finishes a cell clears what it read), so it is cleared here once, when it is (re)allocated.
+// finishes a cell clears what it read), so it is cleared here once, when it is (re)allocated -- ON THE CONTEXT'S STREAM: the stream is
+// non-blocking, so a hipMemset (null stream, asynchronous to the host for device memory) is not ordered before the launch that follows and
+// could clear sums the first segments had already added (round 6, found by fuzz seed 155 run as the first split call of a process; until
+// then every test session happened to grow the scratch in an earlier, larger call).
 int ensure_partial(scv_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->d_partial_bytes) return SCV_OK;
     if (ctx->d_partial) { SCV_HIP(hipStreamSynchronize(ctx->stream)); SCV_HIP(hipFree(ctx->d_partial)); ctx->d_partial = nullptr; ctx->d_partial_bytes = 0; }
     SCV_HIP(hipMalloc(&ctx->d_partial, bytes));
-    SCV_HIP(hipMemset(ctx->d_partial, 0, bytes));
+    SCV_HIP(hipMemsetAsync(ctx->d_partial, 0, bytes, ctx->stream));
     ctx->d_partial_bytes = bytes;
     return SCV_OK;
 }
@@ -384,7 +387,7 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         // The reference's own range (N = 1 ... 128, o1.py:267,276).  Rows that are not all 16-byte aligned (N % 4 != 0, unaligned
         // bases) take the linear-image form (dword reads).
         const bool sort_lin = !rows_aligned;
-        const int nv = N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : (N <= 40 ? 40 : (N <= 48 ? 48 : 64))));
+        const int nv = N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 24 ? 24 : (N <= 32 ? 32 : (N <= 40 ? 40 : (N <= 48 ? 48 : (N <= 56 ? 56 : 64))))));
         const RegKernel rk = pick_sort_kernel(nv, tok, sort_lin);
         const int64_t ps = (N / 4) | 1;
         const int64_t image_words = sort_lin ? ((64 * N * 4 + 16 + 1023) >> 10) * 256 : 64 * ps * 4;

@@ -303,7 +303,7 @@ __device__ __forceinline__ int64_t sv_uniform64(int64_t v) { return uniform64(v)
 
 constexpr int sort_cells_threads(int nv) { return nv >= 64 ? 512 : 1024; }
 
-// NV: votes per lane (capacity of the shape: 8 / 16 / 32 / 48 / 64).  Host contract: N % 4 == 0, 4 <= N <= NV, 16-byte aligned
+// NV: votes per lane (capacity of the shape: 8 / 16 / 24 / 32 / 40 / 48 / 56 / 64; NV / 2 a multiple of 4, NV <= 64: the run-length field of a key is 6 bits).  Host contract: N % 4 == 0, 4 <= N <= NV, 16-byte aligned
 // bases, no pool rows; a.wave_lds_words = words of one wave's LDS region (64 * PS * 4, twice that with tokens, + 64 for the cells'
 // truth values; PS = (N / 4) | 1 slots per padded row); the workgroup's LDS = regions | n_valid cache | tie classes | sums.
 //

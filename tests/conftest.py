@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """SCV_TEST_ORDER=reverse | shuffle:<seed>: run the collected tests in another order (round 6: the suite had always run in file order, in
+    which an early DEVICE-mode call bound the engine to torch's stream and hid a race of the split-N scratch: profiles/r06_split_scratch_race.log)."""
+    order = os.environ.get("SCV_TEST_ORDER", "")
+    if order == "reverse":
+        items.reverse()
+    elif order.startswith("shuffle:"):
+        import random
+        random.Random(int(order.split(":", 1)[1])).shuffle(items)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import json

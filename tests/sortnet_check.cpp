@@ -200,6 +200,24 @@ static bool network_sorts_all_01_bitsliced_with_phase_blocks() {
     return badacc == 0;
 }
 
+// ... and the plain form for a wire count that is not a power of two (round 6: the 28-wire lockstep network of the 56-vote shape): all 2^N 0-1 inputs, bit-sliced
+template <int N>
+static bool network_sorts_all_01_bitsliced() {
+    static_assert(N >= 8 && N <= 32, "wires 0 .. 5 enumerate inside a word");
+    static constexpr SvNetwork<N> net = sv_make_network<N>();
+    static const uint64_t low[6] = {0xAAAAAAAAAAAAAAAAull, 0xCCCCCCCCCCCCCCCCull, 0xF0F0F0F0F0F0F0F0ull, 0xFF00FF00FF00FF00ull, 0xFFFF0000FFFF0000ull, 0xFFFFFFFF00000000ull};
+    const uint64_t words = 1ull << (N - 6);
+    uint64_t badacc = 0;
+    for (uint64_t t = 0; t < words; ++t) {
+        uint64_t x[N];
+        for (int i = 0; i < 6; ++i) x[i] = low[i];
+        for (int i = 6; i < N; ++i) x[i] = ((t >> (i - 6)) & 1) ? ~0ull : 0ull;
+        for (int c = 0; c < net.n; ++c) { const uint64_t lo = x[net.a[c]] & x[net.b[c]], hi = x[net.a[c]] | x[net.b[c]]; x[net.a[c]] = lo; x[net.b[c]] = hi; }
+        for (int i = 1; i < N; ++i) badacc |= x[i - 1] & ~x[i];
+    }
+    return badacc == 0;
+}
+
 // scv_sort_prefix2: two sorted 64-element sequences A, B (element i = half i / 32 of register i % 32) -> flip stage across the files, then each
 // file's bitonic merge (the stage between the halves of a register, five lockstep stages): ascending across A, then B.  0-1 principle on
 // the inputs the merge is applied to (two sorted sequences: 65 x 65 pairs of zero counts), exhaustive; then the running 32-bit scan of the
@@ -312,17 +330,19 @@ int main() {
     ok &= network_sorts_all_01<2>() && network_sorts_all_01<4>() && network_sorts_all_01<8>() && network_sorts_all_01<16>();
     ok &= network_sorts_all_01<24>();                                   // the 48-vote shape's lockstep network: exhaustive (2^24 inputs)
     ok &= network_sorts_all_01<20>();                                   // the 40-vote shape's (round 6): exhaustive (2^20 inputs)
+    ok &= network_sorts_all_01<12>();                                   // the 24-vote shape's (round 6): exhaustive
+    ok &= network_sorts_all_01_bitsliced<28>();                         // the 56-vote shape's (round 6): exhaustive, bit-sliced (2^28 inputs)
     ok &= network_sorts_all_01<32>();                                   // (sampled: 2^20 random 0-1 inputs; all 2^32 below, bit-sliced)
     printf("network: %s (exchanges on 4 / 8 / 16 / 24 / 32 wires: %d %d %d %d %d; exhaustive up to 24 wires, 32 sampled here and exhaustive below)\n", ok ? "sorts" : "FAILS", sv_make_network<4>().n,
            sv_make_network<8>().n, sv_make_network<16>().n, sv_make_network<24>().n, sv_make_network<32>().n);
     const bool okv = valley_merge_sorts_all_01_valleys<6>() && valley_merge_sorts_all_01_valleys<12>() && valley_merge_sorts_all_01_valleys<24>() &&
                      valley_merge_sorts_all_01_valleys<16>() && valley_merge_sorts_all_01_valleys<48>() && valley_merge_sorts_all_01_valleys<20>() &&
-                     valley_merge_sorts_all_01_valleys<40>();
+                     valley_merge_sorts_all_01_valleys<40>() && valley_merge_sorts_all_01_valleys<28>() && valley_merge_sorts_all_01_valleys<56>();
     printf("valley merge: %s (exchanges on 24 wires: %d)\n", okv ? "sorts every 0-1 valley" : "FAILS", sv_make_valley_merge<24>().n);
     ok &= okv;
     bool ok2 = packed_count_matches_bruteforce<8>(20000) && packed_count_matches_bruteforce<16>(20000) && packed_count_matches_bruteforce<32>(20000) &&
                packed_count_matches_bruteforce<48>(60000) && packed_count_matches_bruteforce<64>(20000) && packed_count_matches_bruteforce<24>(20000) &&
-               packed_count_matches_bruteforce<40>(60000);
+               packed_count_matches_bruteforce<40>(60000) && packed_count_matches_bruteforce<56>(60000);
     printf("packed sort + scan: %s\n", ok2 ? "equals statistics.multimode" : "DIFFERS");
     const bool ok3 = network_sorts_all_01_bitsliced_with_phase_blocks<32>() && network_sorts_all_01_bitsliced_with_phase_blocks<16>();
     printf("32 wires, all 2^32 inputs, every aligned block of 2 p wires after phase p: %s\n", ok3 ? "sorted" : "FAILS");

@@ -498,7 +498,10 @@ SORT_SHAPES = [(700, 3, 4), (41, 11, 8), (3333, 5, 7), (1000, 3, 16), (777, 2, 1
                (5000, 4, 5), (4000, 3, 20), (2500, 4, 30), (2000, 2, 33), (1500, 3, 48), (1200, 4, 61), (1100, 2, 63), (3000, 4, 64), (1, 1, 64),
                (65, 1, 36), (40, 600, 24), (900, 64, 64),
                # round 4: the 48-vote shape (33 ... 48 votes: 24 packed registers, the halves meet at r = 0), aligned and unaligned rows
-               (2000, 2, 36), (1800, 3, 40), (1700, 2, 44), (900, 3, 45), (1300, 2, 47), (700, 5, 34), (77, 1, 48), (300, 40, 48)]
+               (2000, 2, 36), (1800, 3, 40), (1700, 2, 44), (900, 3, 45), (1300, 2, 47), (700, 5, 34), (77, 1, 48), (300, 40, 48),
+               # round 6: the 24- and 56-vote shapes (17 ... 24 votes used to sort 32 slots, 49 ... 56 votes 64), aligned and unaligned rows
+               (2200, 3, 24), (1900, 2, 21), (1300, 4, 18), (500, 2, 23), (1500, 3, 52), (1100, 2, 56), (900, 3, 53), (800, 5, 49), (77, 1, 56),
+               (200, 70, 56)]
 
 
 @pytest.mark.parametrize("dist", [0, 1, 2, 3, 4, 5])
@@ -689,6 +692,36 @@ def test_split_n_with_many_segments_and_overwrite_mode(hip_engine, segs, shape, 
             hip_engine.sync()
             got = AggregateResult.from_counters(c.cpu().numpy(), P, B, cells_from_torch(cells), ctok.cpu().numpy())
             assert_results_equal(got, oracle(a, tr, tokens=t))
+
+
+def test_split_n_scratch_is_clear_when_it_has_just_grown():
+    """The split cells' histograms in memory must be all zero when the launch starts -- also in the call that (re)allocates them.  Round 6: the
+    clearing memset ran on the NULL stream, which the context's non-blocking stream does not wait for, so the first segments' sums could be
+    cleared again (fuzz seed 155 -- 116 x 4 cells of 211 votes in 40 segments -- failed when it was the first split call of a session; in the
+    full suite an earlier, larger call had always grown the scratch).  Fresh contexts, and within each a sequence of calls that each grow the
+    scratch, every one checked against the oracle; DEVICE-mode calls too (no host staging between the allocation and the launch)."""
+    import torch
+    from o1_inference_scaling_laws_amd.engine import Engine
+    dev = torch.device("cuda:0")
+    for rep in range(8):
+        eng = Engine(timing=False)
+        try:
+            eng.set_option("path", 2)
+            eng.set_option("segs", 40)
+            for P in (3, 9, 29, 116, 128):                           # 12 ... 512 split cells: 48 KiB ... 2 MiB of histograms, each call a new allocation
+                a, t, tr = coracle.synth_fill(P, 4, 211, 155 + rep, 2, want_tokens=True)
+                nv = np.array([123, 44, 33, 204], dtype=np.int32)
+                want = oracle(a, tr, tokens=t, n_valid=nv)
+                if rep % 4 != 3:                                     # HOST mode: the context's own non-blocking stream (a DEVICE-mode call binds torch's)
+                    got = eng.aggregate(a, tr, tokens=t, n_valid=nv)
+                else:
+                    ad, td, trd, nvd = (torch.from_numpy(x).to(dev) for x in (a, t, tr, nv))
+                    c, cells, ctok = eng.aggregate_device(ad, trd, tokens=td, n_valid=nvd)
+                    eng.sync()
+                    got = AggregateResult.from_counters(c.cpu().numpy(), P, 4, cells_from_torch(cells), ctok.cpu().numpy())
+                assert_results_equal(got, want)
+        finally:
+            eng.close()
 
 
 @pytest.mark.parametrize("shape,opts", [((30, 8, 1 << 17), {}), ((30, 8, 1 << 17), {"path": 2, "segs": 3}), ((7, 3, 5000), {"path": 1}),
