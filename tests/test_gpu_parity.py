@@ -508,7 +508,7 @@ SORT_SHAPES = [(700, 3, 4), (41, 11, 8), (3333, 5, 7), (1000, 3, 16), (777, 2, 1
 @pytest.mark.parametrize("shape", SORT_SHAPES, ids=lambda s: "x".join(map(str, s)))
 def test_sorted_cells_one_lane_per_cell(hip_engine, dist, shape):
     """scv_sort_cells (round 3; the reference's own range, o1.py:267,276): one lane per cell, the wave's 64 rows staged through
-    LDS by LDS-DMA, packed 16-bit sort + run-length scan in registers.  Every shape of the kernel (8 / 16 / 32 / 48 / 64 votes
+    LDS by LDS-DMA, packed 16-bit sort + run-length scan in registers.  Every shape of the kernel (8 / 16 / 24 / 32 / 40 / 48 / 56 / 64 votes
     per lane), rows 16-byte aligned (padded image, b128 reads) and not (linear image, dword reads), a cell count that is not a
     multiple of 64, tokens, ragged n_valid incl. 0, narrow value ranges (ties everywhere: runs that cross the halves of the packed
     registers), many budgets (counters in LDS; more budgets than the n_valid cache holds), small forced grids (many steps per
