@@ -256,3 +256,24 @@ def test_random_short_cells_in_device_memory_both_record_forms(hip_engine, seed)
             assert np.array_equal(gc[f], want["cells"][f]), (seed, kind, P, B, N, packed, f)
         if tokens:
             assert np.array_equal(ctok.cpu().numpy(), want["cell_tokens"]), (seed, "cell_tokens")
+
+
+# ---- round 6, last session: every draw as the FIRST call of a fresh context ------------------------------------------------------------------------
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SCV_FUZZ_FIRST", "0")), int(os.environ.get("SCV_FUZZ_FIRST", "0")) + int(os.environ.get("SCV_FUZZ_FRESH_SEEDS", "240"))))
+def test_first_call_of_a_fresh_context_is_bit_exact(seed):
+    """The session-wide engine of the other tests has made thousands of calls by the time a fuzz draw reaches it: its scratch buffers have their final
+    sizes and an early DEVICE-mode call has bound it to torch's stream.  Here every draw (two thirds dense, one third prefix; seeds of their own) is the
+    first call of a context created for it -- every allocation on the launch path happens in the call that is checked, on the context's own
+    non-blocking stream unless the draw is a DEVICE-mode one.  (Written after the split-N scratch's clearing memset was found racing with the launch
+    behind it, profiles/r06_split_scratch_race.log; that race needs a context in mid-session -- 240 + 240 draws here pass on the old library too --
+    so this test is coverage of the first-call paths, not that bug's reproducer.)"""
+    from o1_inference_scaling_laws_amd.engine import Engine
+    eng = Engine(timing=bool(seed & 1))
+    try:
+        if seed % 3 == 2:
+            test_random_prefix_configuration_is_bit_exact(eng, 40_000 + seed)
+        else:
+            test_random_configuration_is_bit_exact(eng, 40_000 + seed)
+    finally:
+        eng.close()
