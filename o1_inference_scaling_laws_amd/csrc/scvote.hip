@@ -396,6 +396,9 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         const int64_t tail_words = (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0) + ((((int64_t)B * (nv + 1) + 1) & ~(int64_t)1) + 4 * (int64_t)B);
         int W = rk.waves;
         while (W > 1 && (W * region_words + tail_words) * 4 > ctx->lds_max) --W;
+#ifdef SCV_SORT_W4
+        if (W > SCV_SORT_W4) W &= ~3;
+#endif
         if ((W * region_words + tail_words) * 4 <= ctx->lds_max && W >= (rk.waves >= 16 ? 4 : 2)) {
             a.wave_lds_words = (int32_t)region_words;
             const size_t lds = (size_t)(W * region_words + tail_words) * sizeof(uint32_t);

@@ -1,3 +1,4 @@
 #!/bin/bash
+# scratch entry point of a gpurun call (gpurun --timeout N -- 'bash tools/_gpu_call.sh'): edited per call
 cd /root/repo
-python tools/memset_async_probe.py 2>&1 | grep -v amdgpu.ids
+bash tools/_driver_like.sh 2>&1 | grep -v amdgpu.ids
