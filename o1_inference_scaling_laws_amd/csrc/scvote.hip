@@ -396,9 +396,10 @@ int launch_aggregate(scv_ctx* ctx, const int32_t* answers, const int32_t* tokens
         const int64_t tail_words = (n_valid && B <= scv::kMaxSortedB ? ((B + 3) & ~3) : 0) + ((((int64_t)B * (nv + 1) + 1) & ~(int64_t)1) + 4 * (int64_t)B);
         int W = rk.waves;
         while (W > 1 && (W * region_words + tail_words) * 4 > ctx->lds_max) --W;
-#ifdef SCV_SORT_W4
-        if (W > SCV_SORT_W4) W &= ~3;
-#endif
+        // whole waves per SIMD: the steps are VALU-bound, so with 14 waves (N = 37 ... 44) two SIMDs carry 4 and set the pace of a round that 12 waves finish as
+        // fast with the other two SIMDs idle a quarter of the time (N = 40 / 44 / 56: 72.1 / 72.7 / 82.4 -> 67.5 / 68.0 / 78.1 us, profiles/r06_sort_waves_ab.log);
+        // not below 8: with tokens 7 / 6 / 5 waves beat 4 by 10-17 % (one wave per SIMD cannot hide its own copy)
+        if (W > 8) W &= ~3;
         if ((W * region_words + tail_words) * 4 <= ctx->lds_max && W >= (rk.waves >= 16 ? 4 : 2)) {
             a.wave_lds_words = (int32_t)region_words;
             const size_t lds = (size_t)(W * region_words + tail_words) * sizeof(uint32_t);
