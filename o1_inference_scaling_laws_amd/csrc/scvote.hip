@@ -257,8 +257,9 @@ constexpr size_t kTicketWords = 8 + scv::kSplitTickets;     // [0 .. 2] the sing
 // split-N scratch: the split cells' histograms and token sums in memory.  All zero whenever no launch is in flight (the workgroup that
 // finishes a cell clears what it read), so it is cleared here once, when it is (re)allocated -- ON THE CONTEXT'S STREAM: the stream is
 // non-blocking, so a hipMemset (null stream, asynchronous to the host for device memory) is not ordered before the launch that follows and
-// could clear sums the first segments had already added (round 6, found by fuzz seed 155 run as the first split call of a process; until
-// then every test session happened to grow the scratch in an earlier, larger call).
+// could clear sums the first segments had already added (round 6: fuzz seeds 116 / 155 -- calls in which the scratch grows -- failed in a test
+// selection without a DEVICE-mode call in front; in the full suite such a call binds the context to torch's null stream early, which ordered the two:
+// profiles/r06_split_scratch_race.log).
 int ensure_partial(scv_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->d_partial_bytes) return SCV_OK;
     if (ctx->d_partial) { SCV_HIP(hipStreamSynchronize(ctx->stream)); SCV_HIP(hipFree(ctx->d_partial)); ctx->d_partial = nullptr; ctx->d_partial_bytes = 0; }
