@@ -175,3 +175,24 @@ def test_every_extern_c_entry_runs_inside_the_exception_guard():
                 seen += 1
                 assert body.lstrip().startswith("return guarded([&]() -> int {") and body.rstrip().endswith("});"), (unit, name)
         assert seen >= (19 if unit == "scvote.hip" else 7), (unit, seen)
+
+
+def test_no_null_stream_memset_or_memcpy_on_the_launch_path():
+    """hipMemset / hipMemcpy (the forms without a stream) run on the NULL stream and, for device memory, return before the device is done; a
+    context's own stream is non-blocking and does not wait for the null stream.  Round 6: the split-N scratch was cleared that way right before a
+    launch and lost sums (profiles/r06_split_scratch_race.log).  The product sources may use the stream-less forms only in scv_create, where a
+    hipDeviceSynchronize follows before the context is handed out."""
+    csrc = os.path.join(REPO, "o1_inference_scaling_laws_amd", "csrc")
+    found = []
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        for i, line in enumerate(open(os.path.join(csrc, f)).read().split("\n"), 1):
+            code = line.split("//")[0]
+            if re.search(r"\bhipMemset\(|\bhipMemcpy\(|\bhipMemsetD\d+\(|\bhipMemcpy(DtoH|HtoD|DtoD)\(", code):
+                found.append((f, i, code.strip()))
+    assert [x[0] for x in found] == ["scvote.hip", "scvote.hip"], found          # d_err and d_tickets at scv_create
+    src = open(os.path.join(csrc, "scvote.hip")).read().split("\n")
+    last = max(i for _, i, _ in found)
+    assert any("hipDeviceSynchronize()" in l for l in src[last - 1: last + 3]), "the memsets of scv_create must be followed by a device synchronisation"
+    assert all("ctx->d_err" in c or "ctx->d_tickets" in c for _, _, c in found), found
